@@ -1,0 +1,576 @@
+"""CPU ORACLE for the PSLD hot path — TEST INFRASTRUCTURE ONLY.
+
+This file is a pure-torch (CPU, eager ATen) *restatement* of the reference's
+algorithm for the path named by BASELINE.json:north_star.  It imports nothing
+from /root/reference and nothing from ``psld_amd``; only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+it, and only as the checker — never as something shipped or measured as the
+product (the product path is the HIP library and fails loudly without it).
+
+Parity status: PINNED.  ``tools/gen_golden.py`` imports the real reference in
+the build container (CPU path of the reference, with the nvcc JIT and the
+missing Lightning/torchvision packages stubbed) and writes
+input/output vectors to ``tests/golden/*.npz``; ``tests/test_oracle_golden.py``
+checks every function below against those vectors.  The reference has no tests
+or golden vectors of its own.
+
+Every function cites the reference file:line it restates (paths relative to
+/root/reference/).  Tensor layout here is the reference's (NCHW, OIHW).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------------------
+# helpers
+# --------------------------------------------------------------------------------------
+def bcast(t: Tensor, like: Tensor) -> Tensor:
+    """main/util.py:13-22 ``reshape``: view a [B] tensor as [B,1,1,1] (no-op if ranks match)."""
+    if t.dim() == like.dim():
+        return t
+    return t.view(-1, *([1] * (like.dim() - 1)))
+
+
+# --------------------------------------------------------------------------------------
+# PSLD SDE  (main/models/sde/psld.py)
+# --------------------------------------------------------------------------------------
+class PSLDOracle:
+    """Scalar parameters + analytic perturbation kernel of the PSLD SDE.
+
+    main/models/sde/psld.py:14-33 (constructor), :38-44 (beta_t / b_t), :46-60 (T/mode/type).
+    """
+
+    def __init__(self, beta_min=8.0, beta_max=8.0, nu=4.01, gamma=0.01, kappa=0.04,
+                 numerical_eps=1e-9, decomp_mode="lower"):
+        assert nu != 0 or gamma != 0
+        assert decomp_mode in ("lower", "upper")
+        self.beta_0, self.beta_1 = beta_min, beta_max
+        self.nu, self.gamma = nu, gamma
+        self.m_inv = (gamma - nu) ** 2 / 4
+        self.m = 1 / self.m_inv
+        self.kappa = kappa
+        self.mm_0 = kappa * self.m
+        self.eps = numerical_eps
+        self.decomp_mode = decomp_mode
+        self.T = 1.0
+
+    @classmethod
+    def from_config(cls, config):
+        s = config.model.sde
+        return cls(s.beta_min, s.beta_max, s.nu, s.gamma, s.kappa, s.numerical_eps, s.decomp_mode)
+
+    @property
+    def mode(self):
+        if self.gamma == 0:
+            return "score_m"
+        if self.nu == 0:
+            return "score_x"
+        return "score_xm"
+
+    # psld.py:38-44
+    def beta_t(self, t):
+        return self.beta_0 + t * (self.beta_1 - self.beta_0)
+
+    def b_t(self, t):
+        return self.beta_0 * t + 0.5 * (t ** 2) * (self.beta_1 - self.beta_0)
+
+    # psld.py:62-84
+    def mean(self, x_0: Tensor, m_0: Tensor, t: Tensor) -> Tensor:
+        lam = (self.nu + self.gamma) / 4
+        b = bcast(self.b_t(t), x_0)
+        a1 = (self.nu - self.gamma) / 4
+        a2 = (self.gamma - self.nu) ** 2 / 8
+        c1 = -0.5
+        c2 = (self.gamma - self.nu) / 4
+        mu_x = a1 * x_0 * b + a2 * m_0 * b + x_0
+        mu_m = c1 * x_0 * b + c2 * m_0 * b + m_0
+        mu = torch.cat([mu_x, mu_m], dim=1)
+        return mu * bcast(torch.exp(-lam * b), mu)
+
+    # psld.py:86-152
+    def cov(self, xx_0, mm_0, t: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+        lam = (self.nu + self.gamma) / 2
+        b = self.b_t(t)
+        b2 = b ** 2
+        sc = torch.exp(-lam * b)
+        isc = torch.exp(lam * b)
+        mi, m, nu, ga = self.m_inv, self.m, self.nu, self.gamma
+        xx = (mi / 4 * b2 * xx_0 + mi ** 2 / 4 * b2 * mm_0 + (nu - ga) / 2 * b * xx_0
+              + (-mi / 2) * b2 + (ga - nu) / 2 * b + (isc - 1) + xx_0) * sc
+        xm = ((ga - nu) / 8 * b2 * xx_0 + mi * (ga - nu) / 8 * b2 * mm_0 + (-1 / 2) * b * xx_0
+              + mi / 2 * b * mm_0 + (nu - ga) / 4 * b2) * sc
+        mm = (1 / 4 * b2 * xx_0 + mi / 4 * b2 * mm_0 + (ga - nu) / 2 * b * mm_0
+              + (-1 / 2) * b2 + m * (nu - ga) / 2 * b + m * (isc - 1) + mm_0) * sc
+        return xx + self.eps, xm, mm + self.eps
+
+    # psld.py:154-186
+    def coeff(self, var):
+        xx, xm, mm = var
+        if self.decomp_mode == "lower":
+            l11 = torch.sqrt(xx)
+            l21 = xm / l11
+            l22 = torch.sqrt(mm - l21 ** 2.0)
+            out = (l11, torch.zeros_like(xx), l21, l22)
+        else:
+            u22 = torch.sqrt(mm)
+            u12 = xm / u22
+            u11 = torch.sqrt(xx - u12 ** 2.0)
+            out = (u11, u12, torch.zeros_like(mm), u22)
+        if any(torch.isnan(c).any() for c in out):
+            raise ValueError("Numerical precision error.")
+        return out
+
+    # psld.py:188-220
+    def inv_coeff(self, var):
+        xx, xm, mm = var
+        det = xx * mm - xm ** 2
+        if self.decomp_mode == "lower":
+            out = (torch.sqrt(1 / xx), -xm / (torch.sqrt(xx) * torch.sqrt(det)),
+                   torch.zeros_like(xx), torch.sqrt(xx / det))
+        else:
+            out = (torch.sqrt(mm / det), torch.zeros_like(mm),
+                   -xm / (torch.sqrt(mm) * torch.sqrt(det)), torch.sqrt(1 / mm))
+        if any(torch.isnan(c).any() for c in out):
+            raise ValueError("Numerical precision error.")
+        return out
+
+    # psld.py:262-287 (+ :222-228)
+    def perturb_data(self, x_0, m_0, xx_0, mm_0, t, eps):
+        mu = self.mean(x_0, m_0, t)
+        var = self.cov(xx_0, mm_0, t)
+        c11, c12, c21, c22 = self.coeff(var)
+        ex, em = torch.chunk(eps, 2, dim=1)
+        nx = bcast(c11, ex) * ex + bcast(c12, em) * em
+        nm = bcast(c21, ex) * ex + bcast(c22, em) * em
+        return mu + torch.cat([nx, nm], dim=1), mu, var
+
+    # psld.py:230-260
+    def get_score(self, eps, xx_0, mm_0, t):
+        c11, c12, c21, c22 = self.inv_coeff(self.cov(xx_0, mm_0, t))
+        f32 = torch.float32
+        if self.decomp_mode == "lower" and self.mode == "score_m":
+            return torch.cat([torch.zeros_like(eps), -bcast(c22, eps).type(f32) * eps], dim=1)
+        if self.decomp_mode == "upper" and self.mode == "score_x":
+            return torch.cat([-bcast(c11, eps).type(f32) * eps, torch.zeros_like(eps)], dim=1)
+        ex, em = torch.chunk(eps, 2, dim=1)
+        sx = -bcast(c11, ex).type(f32) * ex - bcast(c12, em).type(f32) * em
+        sm = -bcast(c21, ex).type(f32) * ex - bcast(c22, em).type(f32) * em
+        return torch.cat([sx, sm], dim=1)
+
+    # psld.py:330-343
+    def sde(self, u, t):
+        x, m = torch.chunk(u, 2, dim=1)
+        beta = bcast(self.beta_t(t), x)
+        fx = 0.5 * beta * (self.m_inv * m - self.gamma * x)
+        fm = 0.5 * beta * (-self.nu * m - x)
+        gx = torch.sqrt(beta * self.gamma) * torch.ones_like(x)
+        gm = torch.sqrt(beta * self.m * self.nu) * torch.ones_like(x)
+        return torch.cat([fx, fm], dim=1), torch.cat([gx, gm], dim=1)
+
+    # psld.py:345-364
+    def reverse_sde(self, u, t, score_fn, probability_flow=False):
+        t = self.T - t
+        f, g = self.sde(u, t)
+        eps_pred = score_fn(u.type(torch.float32), t.type(torch.float32))
+        score = self.get_score(eps_pred, 0, self.mm_0, t)
+        if probability_flow:
+            score = 0.5 * score
+        f_bar = -f + g ** 2 * score
+        g_bar = torch.zeros_like(g) if probability_flow else g
+        return f_bar, g_bar
+
+    # psld.py:366-370
+    def prior_sampling(self, shape, generator=None):
+        px = torch.randn(*shape, generator=generator)
+        pm = torch.randn(*shape, generator=generator) * np.sqrt(self.m)
+        return torch.cat([px, pm], dim=1)
+
+
+# --------------------------------------------------------------------------------------
+# HSM / DSM loss  (main/losses.py:94-130)
+# --------------------------------------------------------------------------------------
+def psld_score_loss(sde: PSLDOracle, x_0: Tensor, t: Tensor, score_fn: Callable, eps: Tensor,
+                    mode: str = "hsm", reduce_mean: bool = True, m_0: Optional[Tensor] = None):
+    """losses.py:94-130.  ``eps`` (and ``m_0`` for DSM) are injected so that the result is
+    deterministic; the reference draws them with ``torch.randn_like``."""
+    if mode == "hsm":
+        m_0 = torch.zeros_like(x_0)          # losses.py:100-102
+        mm_0 = sde.mm_0
+    else:
+        assert m_0 is not None               # losses.py:96-97: sqrt(mm_0)*randn
+        mm_0 = 0.0
+    z_t, _, _ = sde.perturb_data(x_0, m_0, 0, mm_0, t, eps)
+    z_t = z_t.type(torch.float32)            # losses.py:114
+    eps_pred = score_fn(z_t, t.type(torch.float32))
+    ex, em = torch.chunk(eps, 2, dim=1)
+    if sde.mode == "score_m" and sde.decomp_mode == "lower":
+        loss = (em - eps_pred) ** 2          # losses.py:119-121
+    elif sde.mode == "score_x" and sde.decomp_mode == "upper":
+        loss = (ex - eps_pred) ** 2
+    else:
+        loss = (eps - eps_pred) ** 2         # losses.py:125-127
+    return loss.mean() if reduce_mean else loss.sum()
+
+
+# --------------------------------------------------------------------------------------
+# Euler-Maruyama sampler  (main/samplers/sde.py:9-58, main/models/wrapper.py:101-122)
+# --------------------------------------------------------------------------------------
+def sampling_times(T: float, eval_eps: float, n_discrete_steps: int, denoise: bool,
+                   stride_type: str = "uniform") -> Tuple[Tensor, int]:
+    """wrapper.py:52-54 and :101-114: the time grid handed to ``sampler.sample``."""
+    n = n_discrete_steps - 1 if denoise else n_discrete_steps
+    t_final = T - eval_eps
+    ts = torch.linspace(0, t_final, n + 1, dtype=torch.float64)
+    if stride_type == "quadratic":
+        ts = t_final * torch.flip(1 - (ts / t_final) ** 2.0, dims=[0])
+    return ts, n
+
+
+def em_sample(sde: PSLDOracle, score_fn: Callable, batch: Tensor, ts: Tensor, n_steps: int,
+              denoise: bool = True, eps: float = 1e-3,
+              noise: Optional[Sequence[Tensor]] = None) -> Tensor:
+    """samplers/sde.py:38-58.  ``noise[i]`` (float64, shape of x) replaces the reference's
+    ``torch.randn_like(x)`` at step i; ``None`` draws it."""
+    x = batch
+    with torch.no_grad():
+        for i in range(n_steps):
+            dt = bcast(ts[i + 1] - ts[i], x)                       # sde.py:45 -> [1,1,1,1] f64
+            tt = ts[i] * torch.ones(x.shape[0], dtype=torch.float64)  # sde.py:19
+            f, g = sde.reverse_sde(x, tt, score_fn, probability_flow=False)
+            x_mean = x + f * dt                                    # sde.py:23
+            z = noise[i] if noise is not None else torch.randn_like(x)
+            x = x_mean + g * torch.sqrt(dt) * z                    # sde.py:24-25
+            # corrector: identity (samplers/base.py:22-28)
+        if denoise:
+            t_d = torch.tensor(sde.T - eps)                        # sde.py:55: f32 0-d tensor
+            dt = bcast(torch.tensor(eps), x)
+            tt = t_d * torch.ones(x.shape[0], dtype=torch.float64)
+            f, _ = sde.reverse_sde(x, tt, score_fn, probability_flow=False)
+            x = x + f * dt                                         # sde.py:28-36
+    return x
+
+
+# --------------------------------------------------------------------------------------
+# FIR resampling  (song_sde/op/upfirdn2d.py:159-200, song_sde/up_or_down_sampling.py)
+# --------------------------------------------------------------------------------------
+def upfirdn2d(x: Tensor, kernel: Tensor, up: int = 1, down: int = 1,
+              pad: Tuple[int, int] = (0, 0)) -> Tensor:
+    """op/upfirdn2d.py:159-200 (``upfirdn2d_native``): zero-insert upsample, pad (negative pads
+    crop), correlate with the flipped kernel (= convolve), decimate.  x is [N,C,H,W]."""
+    n, c, h, w = x.shape
+    kh, kw = kernel.shape
+    p0, p1 = pad
+    y = x.reshape(n * c, 1, h, w)
+    if up > 1:
+        z = y.new_zeros(n * c, 1, h * up, w * up)
+        z[:, :, ::up, ::up] = y
+        y = z
+    y = F.pad(y, [max(p0, 0), max(p1, 0), max(p0, 0), max(p1, 0)])
+    y = y[:, :, max(-p0, 0): y.shape[2] - max(-p1, 0), max(-p0, 0): y.shape[3] - max(-p1, 0)]
+    y = F.conv2d(y, torch.flip(kernel, [0, 1]).view(1, 1, kh, kw))
+    y = y[:, :, ::down, ::down]
+    return y.reshape(n, c, y.shape[2], y.shape[3])
+
+
+def fir_kernel_2d(k: Sequence[float]) -> np.ndarray:
+    """up_or_down_sampling.py:181-188 ``_setup_kernel``: outer product, normalised, float32."""
+    k = np.asarray(k, dtype=np.float32)
+    if k.ndim == 1:
+        k = np.outer(k, k)
+    k /= np.sum(k)
+    return k
+
+
+def upsample_2d(x, k=(1, 3, 3, 1), factor=2, gain=1):
+    """up_or_down_sampling.py:195-224."""
+    kk = fir_kernel_2d(k) * (gain * factor ** 2)
+    p = kk.shape[0] - factor
+    return upfirdn2d(x, torch.tensor(kk), up=factor, pad=((p + 1) // 2 + factor - 1, p // 2))
+
+
+def downsample_2d(x, k=(1, 3, 3, 1), factor=2, gain=1):
+    """up_or_down_sampling.py:227-257."""
+    kk = fir_kernel_2d(k) * gain
+    p = kk.shape[0] - factor
+    return upfirdn2d(x, torch.tensor(kk), down=factor, pad=((p + 1) // 2, p // 2))
+
+
+def conv_downsample_2d(x, w, k=(1, 3, 3, 1), factor=2, gain=1):
+    """up_or_down_sampling.py:144-178: FIR (no decimation) then stride-``factor`` conv, pad 0."""
+    kk = fir_kernel_2d(k) * gain
+    p = (kk.shape[0] - factor) + (w.shape[-1] - 1)
+    x = upfirdn2d(x, torch.tensor(kk), pad=((p + 1) // 2, p // 2))
+    return F.conv2d(x, w, stride=factor, padding=0)
+
+
+def naive_upsample_2d(x, factor=2):
+    """up_or_down_sampling.py:59-63: nearest-neighbour repeat."""
+    return x.repeat_interleave(factor, dim=2).repeat_interleave(factor, dim=3)
+
+
+def naive_downsample_2d(x, factor=2):
+    """up_or_down_sampling.py:66-69: mean over factor x factor boxes."""
+    n, c, h, w = x.shape
+    return x.reshape(n, c, h // factor, factor, w // factor, factor).mean(dim=(3, 5))
+
+
+# --------------------------------------------------------------------------------------
+# NCSN++ blocks  (song_sde/layerspp.py, song_sde/layers.py)
+# --------------------------------------------------------------------------------------
+def _gn(x, sd, prefix, eps=1e-6):
+    """nn.GroupNorm(num_groups=min(C//4,32), eps=1e-6): layerspp.py:67,219,231; ncsnpp.py:276-280."""
+    c = x.shape[1]
+    return F.group_norm(x, min(c // 4, 32), sd[prefix + ".weight"], sd[prefix + ".bias"], eps)
+
+
+def _nin(x, sd, prefix):
+    """layers.py:531-540: channel-mixing y[b,o,h,w] = sum_c x[b,c,h,w] W[c,o] + b[o]."""
+    y = torch.einsum("bchw,co->bohw", x, sd[prefix + ".W"])
+    return y + sd[prefix + ".b"].view(1, -1, 1, 1)
+
+
+def gaussian_fourier(log_t: Tensor, W: Tensor) -> Tensor:
+    """layerspp.py:39-41: ((x*W)*2)*pi in f32, cat[sin, cos]."""
+    xp = log_t[:, None] * W[None, :] * 2 * np.pi
+    return torch.cat([torch.sin(xp), torch.cos(xp)], dim=-1)
+
+
+def positional_embedding(timesteps: Tensor, dim: int, max_positions=10000) -> Tensor:
+    """layers.py:500-514."""
+    half = dim // 2
+    e = math.log(max_positions) / (half - 1)
+    e = torch.exp(torch.arange(half, dtype=torch.float32) * -e)
+    e = timesteps.float()[:, None] * e[None, :]
+    e = torch.cat([torch.sin(e), torch.cos(e)], dim=1)
+    if dim % 2 == 1:
+        e = F.pad(e, (0, 1))
+    return e
+
+
+def attn_block(x, sd, p, skip_rescale=True):
+    """layerspp.py:75-91 AttnBlockpp.forward."""
+    b, c, h, w = x.shape
+    hn = _gn(x, sd, p + ".GroupNorm_0")
+    q = _nin(hn, sd, p + ".NIN_0")
+    k = _nin(hn, sd, p + ".NIN_1")
+    v = _nin(hn, sd, p + ".NIN_2")
+    wgt = torch.einsum("bchw,bcij->bhwij", q, k) * (int(c) ** (-0.5))
+    wgt = F.softmax(wgt.reshape(b, h, w, h * w), dim=-1).reshape(b, h, w, h, w)
+    hh = torch.einsum("bhwij,bcij->bchw", wgt, v)
+    hh = _nin(hh, sd, p + ".NIN_3")
+    return (x + hh) / np.sqrt(2.0) if skip_rescale else x + hh
+
+
+def resblock_biggan(x, temb, sd, p, up=False, down=False, fir=True, fir_k=(1, 3, 3, 1),
+                    skip_rescale=True, dropout_mask: Optional[Tensor] = None):
+    """layerspp.py:242-274 ResnetBlockBigGANpp.forward.  ``dropout_mask`` (already scaled by
+    1/(1-p)) replaces nn.Dropout; None = eval mode."""
+    out_ch = sd[p + ".Conv_0.weight"].shape[0]
+    in_ch = x.shape[1]
+    h = F.silu(_gn(x, sd, p + ".GroupNorm_0"))
+    if up:
+        if fir:
+            h, x = upsample_2d(h, fir_k), upsample_2d(x, fir_k)
+        else:
+            h, x = naive_upsample_2d(h), naive_upsample_2d(x)
+    elif down:
+        if fir:
+            h, x = downsample_2d(h, fir_k), downsample_2d(x, fir_k)
+        else:
+            h, x = naive_downsample_2d(h), naive_downsample_2d(x)
+    h = F.conv2d(h, sd[p + ".Conv_0.weight"], sd[p + ".Conv_0.bias"], padding=1)
+    if temb is not None:
+        h = h + F.linear(F.silu(temb), sd[p + ".Dense_0.weight"], sd[p + ".Dense_0.bias"])[:, :, None, None]
+    h = F.silu(_gn(h, sd, p + ".GroupNorm_1"))
+    if dropout_mask is not None:
+        h = h * dropout_mask
+    h = F.conv2d(h, sd[p + ".Conv_1.weight"], sd[p + ".Conv_1.bias"], padding=1)
+    if in_ch != out_ch or up or down:
+        x = F.conv2d(x, sd[p + ".Conv_2.weight"], sd[p + ".Conv_2.bias"])
+    return (x + h) / np.sqrt(2.0) if skip_rescale else x + h
+
+
+def pyramid_downsample(x, sd, p, fir=True, fir_k=(1, 3, 3, 1)):
+    """layerspp.Downsample(with_conv=True) forward, layerspp.py:149-163.
+    fir:   up_or_down_sampling.Conv2d(down=True) (:45-56) = conv_downsample_2d + bias.
+    !fir:  pad (0,1,0,1) then 3x3 stride-2 conv pad 0 (layerspp.py:152-154)."""
+    if fir:
+        y = conv_downsample_2d(x, sd[p + ".Conv2d_0.weight"], fir_k)
+        return y + sd[p + ".Conv2d_0.bias"].reshape(1, -1, 1, 1)
+    x = F.pad(x, (0, 1, 0, 1))
+    return F.conv2d(x, sd[p + ".Conv_0.weight"], sd[p + ".Conv_0.bias"], stride=2, padding=0)
+
+
+# --------------------------------------------------------------------------------------
+# NCSN++ forward  (song_sde/ncsnpp.py:287-438), functional over a state_dict
+# --------------------------------------------------------------------------------------
+def ncsnpp_forward(sd: Dict[str, Tensor], config, x: Tensor, time_cond: Tensor,
+                   dropout_masks: Optional[List[Tensor]] = None) -> Tensor:
+    """ncsnpp.py:287-438 for resblock_type='biggan', progressive='none',
+    progressive_input in {'none','residual'}, embedding_type in {'fourier','positional'}.
+
+    ``sd`` holds the reference's parameter names without the wrapper prefix
+    (``all_modules.<i>.<Sub>.<param>``).  ``dropout_masks`` — one pre-scaled mask per
+    ResBlock in call order — replaces nn.Dropout (None = eval).
+    """
+    sf = config.model.score_fn
+    nf, ch_mult, nres = sf.nf, list(sf.ch_mult), sf.num_res_blocks
+    attn_res = list(sf.attn_resolutions)
+    nlev = len(ch_mult)
+    fir, fir_k = sf.fir, tuple(sf.fir_kernel)
+    skip_rescale = sf.skip_rescale
+    assert sf.resblock_type.lower() == "biggan" and sf.progressive.lower() == "none"
+    assert sf.nonlinearity.lower() == "swish"
+    pin = sf.progressive_input.lower()
+    assert pin in ("none", "residual")
+    emb = sf.embedding_type.lower()
+
+    mi = [0]
+    rb = [0]
+
+    def nxt():
+        i = mi[0]
+        mi[0] += 1
+        return f"all_modules.{i}"
+
+    def res(h, temb, **kw):
+        mask = None
+        if dropout_masks is not None:
+            mask = dropout_masks[rb[0]]
+        rb[0] += 1
+        return resblock_biggan(h, temb, sd, nxt(), fir=fir, fir_k=fir_k,
+                               skip_rescale=skip_rescale, dropout_mask=mask, **kw)
+
+    # time embedding: ncsnpp.py:292-313
+    if emb == "fourier":
+        temb = gaussian_fourier(torch.log(time_cond), sd[nxt() + ".W"])
+    else:
+        temb = positional_embedding(time_cond, nf)
+    if sf.noise_cond:
+        p = nxt()
+        temb = F.linear(temb, sd[p + ".weight"], sd[p + ".bias"])
+        p = nxt()
+        temb = F.linear(F.silu(temb), sd[p + ".weight"], sd[p + ".bias"])
+    else:
+        temb = None
+
+    # down path: ncsnpp.py:319-359
+    pyr = x if pin != "none" else None
+    p = nxt()
+    hs = [F.conv2d(x, sd[p + ".weight"], sd[p + ".bias"], padding=1)]
+    for lvl in range(nlev):
+        for _ in range(nres):
+            h = res(hs[-1], temb)
+            if h.shape[-1] in attn_res:
+                h = attn_block(h, sd, nxt(), skip_rescale)
+            hs.append(h)
+        if lvl != nlev - 1:
+            h = res(hs[-1], temb, down=True)
+            if pin == "residual":
+                pyr = pyramid_downsample(pyr, sd, nxt(), fir, fir_k)
+                pyr = (pyr + h) / np.sqrt(2.0) if skip_rescale else pyr + h
+                h = pyr
+            hs.append(h)
+
+    # middle: ncsnpp.py:361-367
+    h = hs[-1]
+    h = res(h, temb)
+    h = attn_block(h, sd, nxt(), skip_rescale)
+    h = res(h, temb)
+
+    # up path: ncsnpp.py:372-420
+    for lvl in reversed(range(nlev)):
+        for _ in range(nres + 1):
+            h = res(torch.cat([h, hs.pop()], dim=1), temb)
+        if h.shape[-1] in attn_res:
+            h = attn_block(h, sd, nxt(), skip_rescale)
+        if lvl != 0:
+            h = res(h, temb, up=True)
+    assert not hs
+
+    # head: ncsnpp.py:427-430
+    h = F.silu(_gn(h, sd, nxt()))
+    p = nxt()
+    h = F.conv2d(h, sd[p + ".weight"], sd[p + ".bias"], padding=1)
+    assert f"all_modules.{mi[0]}.weight" not in sd and f"all_modules.{mi[0]}.W" not in sd
+    return h
+
+
+def count_resblocks(config) -> int:
+    sf = config.model.score_fn
+    nlev = len(sf.ch_mult)
+    return nlev * sf.num_res_blocks + (nlev - 1) + 2 + nlev * (sf.num_res_blocks + 1) + (nlev - 1)
+
+
+# --------------------------------------------------------------------------------------
+# Per-step parameter maintenance (wrapper.py:82-89,128-155; callbacks.py:57-64)
+# --------------------------------------------------------------------------------------
+def clip_grad_norm(grads: Sequence[Tensor], max_norm: float) -> Tuple[List[Tensor], Tensor]:
+    """torch.nn.utils.clip_grad_norm_ (wrapper.py:82-85): total L2 norm, coef = clamp(max/(norm+1e-6), max=1)."""
+    total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g) for g in grads]))
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    return [g * coef for g in grads], total
+
+
+def adam_step(p, g, m, v, step: int, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0):
+    """torch.optim.Adam single-tensor update (wrapper.py:133-139); ``step`` is 1-based.
+    Returns (p, m, v)."""
+    if weight_decay != 0:
+        g = g + weight_decay * p
+    m = beta1 * m + (1 - beta1) * g
+    v = beta2 * v + (1 - beta2) * g * g
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = v.sqrt() / math.sqrt(bc2) + eps
+    p = p - (lr / bc1) * m / denom
+    return p, m, v
+
+
+def warmup_lr(base_lr: float, sched_step: int, warmup: int) -> float:
+    """LambdaLR(min(step/warmup, 1)) (wrapper.py:143-147); ``sched_step`` = number of
+    scheduler.step() calls so far (0 for the first optimizer step)."""
+    return base_lr * (1.0 if warmup == 0 else min(sched_step / warmup, 1.0))
+
+
+def ema_update(target: Tensor, src: Tensor, tau: float) -> Tensor:
+    """callbacks.py:57-64: targ.mul_(tau).add_(src, alpha=1-tau)."""
+    return target * tau + src * (1 - tau)
+
+
+def train_step(sde: PSLDOracle, sd: Dict[str, Tensor], config, x_0, t, eps,
+               adam_state: Dict[str, Tuple[Tensor, Tensor]], step: int,
+               ema_sd: Optional[Dict[str, Tensor]] = None,
+               dropout_masks: Optional[List[Tensor]] = None):
+    """One full HSM training step (wrapper.py:64-91 + callbacks.py:42-64) on CPU with torch
+    autograd as the differentiator.  Mutates sd / adam_state / ema_sd in place; returns
+    (loss, grad_norm, grads)."""
+    oc = config.training.optimizer
+    names = [k for k in sd if not k.endswith(".W") or k.count(".") > 2]  # GFP W is frozen
+    params = {k: sd[k].detach().clone().requires_grad_(True) for k in names}
+    full = dict(sd)
+    full.update(params)
+    loss = psld_score_loss(sde, x_0, t, lambda z, tt: ncsnpp_forward(full, config, z, tt, dropout_masks),
+                           eps, mode=config.training.mode, reduce_mean=config.training.loss.reduce_mean)
+    grads = torch.autograd.grad(loss, [params[k] for k in names])
+    gnorm = None
+    if oc.grad_clip != 0:
+        grads, gnorm = clip_grad_norm(grads, oc.grad_clip)
+    lr = warmup_lr(oc.lr, step - 1, oc.warmup)
+    with torch.no_grad():
+        for k, g in zip(names, grads):
+            m, v = adam_state.get(k, (torch.zeros_like(sd[k]), torch.zeros_like(sd[k])))
+            p, m, v = adam_step(sd[k], g, m, v, step, lr, oc.beta_1, oc.beta_2, oc.eps, oc.weight_decay)
+            sd[k].copy_(p)
+            adam_state[k] = (m, v)
+        if ema_sd is not None:
+            for k in sd:
+                ema_sd[k].copy_(ema_update(ema_sd[k], sd[k], config.training.ema_decay))
+    return loss.detach(), gnorm, dict(zip(names, grads))
