@@ -1,0 +1,220 @@
+/* libpsld_hip — C ABI of the MI355X (gfx950) PSLD hot path.
+ *
+ * Drop-in boundary.  The reference's only native FFI is the pybind module
+ * `upfirdn2d_op.upfirdn2d(...)` (main/models/score_fn/song_sde/op/upfirdn2d.cpp:12-22) and
+ * `fused.fused_bias_act(...)` (op/fused_bias_act.cpp:11-20); everything else on the path is
+ * eager ATen called from Python.  This header is what a maintainer of the reference binds
+ * instead (ctypes stub in INTEGRATION.md): every entry point takes raw device pointers, sizes
+ * and a hipStream_t, never allocates, never synchronises, is re-entrant per stream, and
+ * returns 0 on success (non-zero -> psld_last_error() has the message; the Python side raises
+ * RuntimeError, or ValueError for PSLD_ERR_NUMERIC to mirror psld.py:166-171).
+ *
+ * Activations inside the network are NHWC ("channels-last": [B][H][W][C], C contiguous);
+ * the public tensors (x, eps, samples) stay NCHW like the reference and are converted at the
+ * network boundary by psld_nchw_to_nhwc_f32 / psld_nhwc_to_nchw_f32.
+ */
+#ifndef PSLD_HIP_H
+#define PSLD_HIP_H
+
+#if defined(__HIP__) || defined(__HIPCC__)
+#include <hip/hip_runtime_api.h>
+#else
+typedef struct ihipStream_t* hipStream_t; /* opaque: pass the raw HIP stream handle */
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+
+#define PSLD_ABI_VERSION 1
+#define PSLD_COEFF_STRIDE 12
+
+int psld_version(void);
+const char* psld_last_error(void);
+
+/* ---- fused epilogue of every MFMA tile kernel ------------------------------------------
+ * value = ((alpha * acc + bias[n] + rowbias[m / rows_per_img][n] + residual[m][n]) * out_scale)
+ *         (+ C[m][n] if accumulate)
+ * Used for: conv bias (layers.py:103-109), the time-embedding add `h += Dense_0(act(temb))`
+ * (layerspp.py:262-263), the residual `(x + h) / sqrt(2)` (layerspp.py:271-274, :88-91) and the
+ * attention scale C^-1/2 (layerspp.py:82). */
+typedef struct psld_epilogue {
+    float alpha;
+    const float* bias;
+    const float* rowbias;
+    int ld_rowbias;
+    int rows_per_img;
+    const float* residual;
+    int ld_residual;
+    long long residual_stride_batch;
+    float out_scale;
+    int accumulate;
+} psld_epilogue_t;
+
+/* C[b] = epilogue(op(A[b]) * op(B[b])), fp32 MFMA (v_mfma_f32_32x32x2_f32), batched.
+ * trans_a = 0: A is [M][K] (lda >= K); 1: A is [K][M].   trans_b = 0: B is [K][N]; 1: B is [N][K].
+ * Replaces nn.Linear / NIN / 1x1 conv / attention einsums (layers.py:531-540, layerspp.py:82-87). */
+int psld_gemm_f32(int trans_a, int trans_b, int M, int N, int K,
+                  const float* A, int lda, long long stride_a,
+                  const float* B, int ldb, long long stride_b,
+                  float* C, int ldc, long long stride_c, int batch,
+                  const psld_epilogue_t* epi, hipStream_t stream);
+
+/* slabs[s] = A[ks:ke]^T B[ks:ke] for nsplit K-ranges (weight-gradient GEMMs with K = B*H*W). */
+int psld_gemm_tn_splitk_f32(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                            float* slabs, int nsplit, hipStream_t stream);
+
+/* NHWC implicit-GEMM convolution; input = concat(x1[c1], x2[c2]) along channels (x2 may be
+ * NULL with c2 = 0: the up-path `torch.cat([h, hs.pop()], dim=1)` of ncsnpp.py:374 is never
+ * materialised).  Weights are [cout][kh][kw][c1+c2].
+ * transposed_stride = 1: y[n,oy,ox,:] = sum x[n, oy*stride+ky-pad, ox*stride+kx-pad, :] w[:,ky,kx,:]
+ * transposed_stride = s>1 (data-gradient of a stride-s conv): input index (oy+ky-pad)/s when divisible.
+ * Replaces nn.Conv2d 3x3/1x1 (layers.py:85-109) and F.conv2d(stride=2) of
+ * up_or_down_sampling.py:177. */
+int psld_conv2d_nhwc_f32(const float* x1, int c1, const float* x2, int c2,
+                         int batch, int ih, int iw,
+                         const float* w_ohwi, int cout, int kh, int kw,
+                         int stride, int pad, int transposed_stride,
+                         int oh, int ow, float* y, int ldy,
+                         const psld_epilogue_t* epi, hipStream_t stream);
+
+/* Weight gradient of the convolution above for one input source:
+ * slabs[s][co][tap][col0 + ci] = sum over the s-th range of output pixels of dy[pix][co] * x[pix+tap][ci]. */
+int psld_conv2d_wgrad_nhwc_f32(const float* dy, int lddy, int cout,
+                               const float* x, int cin, int batch, int ih, int iw,
+                               int kh, int kw, int stride, int pad, int oh, int ow,
+                               float* slabs, int cin_total, int col0, int nsplit,
+                               hipStream_t stream);
+
+/* out[perm(i)] = sum_s slabs[s][i]; layout: 0 = keep [co][tap][ci], 1 = write OIHW [co][ci][tap]. */
+int psld_reduce_slabs_f32(const float* slabs, int nsplit, long long n, float* out,
+                          int layout, int cout, int taps, int cin, hipStream_t stream);
+
+/* ---- weight layout (state_dict keeps the reference's OIHW / [in,out] shapes) ------------ */
+/* OIHW -> [co][tap][ci] (forward operand). */
+int psld_pack_oihw_to_ohwi_f32(const float* w, float* out, int cout, int cin, int taps, hipStream_t stream);
+/* OIHW -> [ci][flip(tap)][co] (data-gradient operand: the conv of dy with the flipped, transposed filter). */
+int psld_pack_oihw_to_dgrad_f32(const float* w, float* out, int cout, int cin, int taps, hipStream_t stream);
+
+/* ---- layout at the network boundary -------------------------------------------------------*/
+int psld_nchw_to_nhwc_f32(const float* x, float* y, int batch, int c, int hw, hipStream_t stream);
+int psld_nhwc_to_nchw_f32(const float* x, float* y, int batch, int c, int hw, hipStream_t stream);
+
+/* ---- GroupNorm (+SiLU), NHWC (nn.GroupNorm(min(C//4,32), eps=1e-6) + nn.SiLU:
+ *      layerspp.py:67,219,231,243,264; ncsnpp.py:276-280,427) ------------------------------- */
+/* workspace: psld_gn_workspace_bytes(batch, hw, c, groups). Outputs per-(n,g) mean/rstd and the
+ * per-(n,c) affine scale = rstd*gamma, shift = beta - mean*rstd*gamma. */
+long long psld_gn_workspace_bytes(int batch, int hw, int c, int groups);
+int psld_gn_stats_nhwc_f32(const float* x, int batch, int hw, int c, int groups, float eps,
+                           const float* gamma, const float* beta,
+                           float* mean, float* rstd, float* scale, float* shift,
+                           void* workspace, hipStream_t stream);
+/* y = act(x*scale[n,c] + shift[n,c]); act: 0 = identity, 1 = SiLU. */
+int psld_gn_apply_nhwc_f32(const float* x, const float* scale, const float* shift, float* y,
+                           int batch, int hw, int c, int act, hipStream_t stream);
+/* Backward of y = act(GN(x)): dx, dgamma[C], dbeta[C] (written, not accumulated). */
+int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float* mean, const float* rstd,
+                         const float* gamma, const float* beta, int batch, int hw, int c, int groups,
+                         int act, float* dx, float* dgamma, float* dbeta, int accumulate_dx,
+                         void* workspace, hipStream_t stream);
+
+/* ---- FIR resampling: the replacement of the pybind op upfirdn2d_op.upfirdn2d
+ *      (op/upfirdn2d.cpp:12-22, op/upfirdn2d_kernel.cu:209-369).  Same semantics: zero-insert
+ *      upsample by `up`, pad (negative = crop), convolve with `kernel` (i.e. correlate with the
+ *      flipped kernel), decimate by `down`.  layout 0: NCHW ([N*C][H][W], the reference op's view),
+ *      1: NHWC.  out_h = (in_h*up + pad0 + pad1 - kh)/down + 1.  Backward = same entry with the
+ *      flipped kernel, up<->down swapped and the g_pad of op/upfirdn2d.py:111-116. */
+int psld_upfirdn2d_f32(const float* x, float* y, int batch, int c, int in_h, int in_w,
+                       const float* kernel_host, int kh, int kw,
+                       int up_x, int up_y, int down_x, int down_y,
+                       int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                       int layout, int accumulate, hipStream_t stream);
+/* The (compiled-but-unused) second native op of the reference, for inventory parity:
+ * y = act(x + b[(i / step_b) % size_b]) * scale, act 1 = linear, 3 = leaky-relu(alpha)
+ * (op/fused_bias_act_kernel.cu:18-49, forward only). */
+int psld_fused_bias_act_f32(const float* x, const float* b, float* y, long long n, int size_b, int step_b,
+                            int act, float alpha, float scale, hipStream_t stream);
+
+/* ---- pointwise / reductions ---------------------------------------------------------------*/
+/* y = (a*sa + b*sb) (b may be NULL); accumulate: y += ... */
+int psld_axpby_f32(const float* a, float sa, const float* b, float sb, float* y, long long n,
+                   int accumulate, hipStream_t stream);
+int psld_silu_f32(const float* x, float* y, long long n, hipStream_t stream);
+int psld_silu_bwd_f32(const float* x, const float* dy, float* dx, long long n, hipStream_t stream);
+/* out[b][c] = sum over the hw rows of image b of x[(b*hw+p)*ld + c] (bias / temb-bias gradients). */
+int psld_colsum_f32(const float* x, int ld, int batch, int hw, int c, float* out, hipStream_t stream);
+/* rows of length L: y = softmax(x) ; dx = y * (dy - sum(y*dy)) (layerspp.py:84). */
+int psld_softmax_rows_f32(const float* x, float* y, long long rows, int L, hipStream_t stream);
+int psld_softmax_rows_bwd_f32(const float* y, const float* dy, float* dx, long long rows, int L, hipStream_t stream);
+
+/* ---- time embedding (layerspp.py:39-41, layers.py:500-514) ----------------------------------*/
+/* out[b] = cat[sin(p), cos(p)], p = ((logf(t[b]) * W[e]) * 2) * pi   (use_log = 1, Fourier)
+ *                               p = t[b] * W[e]                      (use_log = 0, positional) */
+int psld_time_embed_f32(const float* t, const float* W, float* out, int batch, int e, int use_log,
+                        hipStream_t stream);
+
+/* ---- PSLD SDE (main/models/sde/psld.py) -----------------------------------------------------*/
+typedef struct psld_sde_params {
+    double beta_0, beta_1, nu, gamma, m_inv, numerical_eps;
+    int decomp_lower;      /* 1 = 'lower' (Cholesky), 0 = 'upper' */
+} psld_sde_params_t;
+
+/* Per-sample f64 scalars of the perturbation kernel, PSLD_COEFF_STRIDE doubles per sample:
+ * [0] = b_t (psld.py:42-44), [1] = exp(-(nu+gamma)/4 * b_t) (psld.py:65-67), [4..7] = c11,c12,c21,c22
+ * of get_coeff (psld.py:154-186), [8..10] = (xx_t, xm_t, mm_t) of _cov (psld.py:86-152).  nan_flag (device int, caller-zeroed) is set to 1 if any
+ * coefficient is NaN (psld.py:166-171 raises ValueError). */
+int psld_perturb_coeffs_f64(const double* t, int batch, const psld_sde_params_t* p,
+                            double xx_0, double mm_0, double* coeffs, int* nan_flag, hipStream_t stream);
+/* u_t = mu_t + L_t eps (psld.py:262-287), NCHW.  x0,m0 [B,C,H,W] f32 (m0 NULL = zeros: HSM),
+ * eps [B,2C,H,W] f32; writes z_t f32 (losses.py:114) and optionally u_t / mu_t f64. */
+int psld_perturb_f32(const float* x0, const float* m0, const float* eps, const double* coeffs,
+                     const psld_sde_params_t* p, int batch, int c, int hw,
+                     float* z_f32, double* u_f64, double* mu_f64, hipStream_t stream);
+/* loss = mean|sum (eps - eps_pred)^2 over n elements (losses.py:118-129); partials workspace
+ * >= psld_reduce_workspace_bytes(n); also writes d(loss)/d(eps_pred) * upstream if grad != NULL. */
+long long psld_reduce_workspace_bytes(long long n);
+int psld_sqerr_loss_f32(const float* eps, const float* eps_pred, long long n, int reduce_mean,
+                        float* loss, float* grad, float grad_scale, void* workspace, hipStream_t stream);
+
+/* One Euler-Maruyama predictor update of the reverse SDE (samplers/sde.py:16-26 +
+ * psld.py:230-260,330-364), NCHW, float64 state:
+ *   f = drift(x, beta), g = diffusion;  score = -L^{-T} eps_pred (f32, coefficients cast to f32);
+ *   f_bar = -f + g^2 * score (x0.5 if probability_flow); x_mean = x + f_bar*dt;
+ *   x = x_mean + g*sqrt(dt)*z   (z NULL -> drift-only "denoise" step, sde.py:28-36)
+ * Also writes x as f32 for the next network call (psld.py:354). */
+typedef struct psld_em_coeffs {
+    double beta;                 /* beta(T - t) */
+    double m_inv, gamma, nu, m;  /* SDE constants */
+    float c11, c12, c21, c22;    /* get_inv_coeff(...) cast to f32 (psld.py:253-258) */
+    double dt;
+    int score_mode;              /* 0 = score_xm (6-ch eps), 1 = score_m lower (3-ch eps -> momentum only),
+                                    2 = score_x upper */
+    int probability_flow;
+} psld_em_coeffs_t;
+int psld_em_step_f64(double* x, const float* eps_pred, const double* z, const psld_em_coeffs_t* k,
+                     int batch, int c, int hw, float* x_f32_out, hipStream_t stream);
+/* reverse_sde outputs themselves (f_bar, g_bar) for callers that want them (psld.py:345-364). */
+int psld_reverse_sde_f64(const double* x, const float* eps_pred, const psld_em_coeffs_t* k,
+                         int batch, int c, int hw, double* f_bar, double* g_bar, hipStream_t stream);
+int psld_f64_to_f32(const double* x, float* y, long long n, hipStream_t stream);
+int psld_f32_to_f64(const float* x, double* y, long long n, hipStream_t stream);
+
+/* ---- per-step parameter maintenance over flat buffers (wrapper.py:82-89,128-155;
+ *      callbacks.py:57-64): 97.6 M parameters in ONE launch each --------------------------------*/
+/* norm_out[0] = sqrt(sum g^2) (double); workspace >= psld_reduce_workspace_bytes(n). */
+int psld_grad_norm_f32(const float* g, long long n, double* norm_out, void* workspace, hipStream_t stream);
+/* clip_coef = min(max_norm / (norm + 1e-6), 1) computed on device from norm_out (no host sync);
+ * g *= clip_coef; Adam (torch.optim.Adam semantics, step is 1-based); optional EMA of p into ema.
+ * max_norm <= 0 disables clipping (norm may be NULL). */
+int psld_adam_ema_f32(float* p, const float* g, float* m, float* v, float* ema, long long n,
+                      const double* norm, float max_norm, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, int step, float ema_tau, int write_clipped_grad,
+                      float* g_mut, hipStream_t stream);
+/* target = target*tau + src*(1-tau) (callbacks.py:62-64). */
+int psld_ema_f32(float* target, const float* src, long long n, float tau, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSLD_HIP_H */

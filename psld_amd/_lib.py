@@ -1,0 +1,137 @@
+"""ctypes binding of libpsld_hip.so (the C ABI declared in include/psld_hip.h).
+
+The product path has NO fallback: if the shared object is missing or a symbol is absent the
+import of the compute path raises.  (Contrast the reference, which JIT-builds its ops at import
+time: op/upfirdn2d.py:10-16.)  The library is built in-tree by ``__graft_entry__.build()`` /
+``make -C psld_amd/csrc`` and travels to the GPU box with the repository snapshot.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpsld_hip.so")
+
+c_f32p = C.c_void_p
+c_f64p = C.c_void_p
+c_stream = C.c_void_p
+c_ll = C.c_longlong
+
+
+class Epilogue(C.Structure):
+    """struct psld_epilogue (include/psld_hip.h)."""
+    _fields_ = [
+        ("alpha", C.c_float),
+        ("bias", C.c_void_p),
+        ("rowbias", C.c_void_p),
+        ("ld_rowbias", C.c_int),
+        ("rows_per_img", C.c_int),
+        ("residual", C.c_void_p),
+        ("ld_residual", C.c_int),
+        ("residual_stride_batch", C.c_longlong),
+        ("out_scale", C.c_float),
+        ("accumulate", C.c_int),
+    ]
+
+
+class SdeParams(C.Structure):
+    """struct psld_sde_params."""
+    _fields_ = [
+        ("beta_0", C.c_double), ("beta_1", C.c_double), ("nu", C.c_double), ("gamma", C.c_double),
+        ("m_inv", C.c_double), ("numerical_eps", C.c_double), ("decomp_lower", C.c_int),
+    ]
+
+
+class EmCoeffs(C.Structure):
+    """struct psld_em_coeffs."""
+    _fields_ = [
+        ("beta", C.c_double), ("m_inv", C.c_double), ("gamma", C.c_double), ("nu", C.c_double),
+        ("m", C.c_double),
+        ("c11", C.c_float), ("c12", C.c_float), ("c21", C.c_float), ("c22", C.c_float),
+        ("dt", C.c_double), ("score_mode", C.c_int), ("probability_flow", C.c_int),
+    ]
+
+
+I, F, D, LL, P = C.c_int, C.c_float, C.c_double, C.c_longlong, C.c_void_p
+EP = C.POINTER(Epilogue)
+
+# name -> (restype, argtypes): every symbol include/psld_hip.h declares
+SIGNATURES = {
+    "psld_version": (I, []),
+    "psld_last_error": (C.c_char_p, []),
+    "psld_gemm_f32": (I, [I, I, I, I, I, P, I, LL, P, I, LL, P, I, LL, I, EP, P]),
+    "psld_gemm_tn_splitk_f32": (I, [I, I, I, P, I, P, I, P, I, P]),
+    "psld_conv2d_nhwc_f32": (I, [P, I, P, I, I, I, I, P, I, I, I, I, I, I, I, I, P, I, EP, P]),
+    "psld_conv2d_wgrad_nhwc_f32": (I, [P, I, I, P, I, I, I, I, I, I, I, I, I, I, P, I, I, I, P]),
+    "psld_reduce_slabs_f32": (I, [P, I, LL, P, I, I, I, I, P]),
+    "psld_pack_oihw_to_ohwi_f32": (I, [P, P, I, I, I, P]),
+    "psld_pack_oihw_to_dgrad_f32": (I, [P, P, I, I, I, P]),
+    "psld_nchw_to_nhwc_f32": (I, [P, P, I, I, I, P]),
+    "psld_nhwc_to_nchw_f32": (I, [P, P, I, I, I, P]),
+    "psld_gn_workspace_bytes": (LL, [I, I, I, I]),
+    "psld_gn_stats_nhwc_f32": (I, [P, I, I, I, I, F, P, P, P, P, P, P, P, P]),
+    "psld_gn_apply_nhwc_f32": (I, [P, P, P, P, I, I, I, I, P]),
+    "psld_gn_bwd_nhwc_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, P, P, P, I, P, P]),
+    "psld_upfirdn2d_f32": (I, [P, P, I, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "psld_fused_bias_act_f32": (I, [P, P, P, LL, I, I, I, F, F, P]),
+    "psld_axpby_f32": (I, [P, F, P, F, P, LL, I, P]),
+    "psld_silu_f32": (I, [P, P, LL, P]),
+    "psld_silu_bwd_f32": (I, [P, P, P, LL, P]),
+    "psld_colsum_f32": (I, [P, I, I, I, I, P, P]),
+    "psld_softmax_rows_f32": (I, [P, P, LL, I, P]),
+    "psld_softmax_rows_bwd_f32": (I, [P, P, P, LL, I, P]),
+    "psld_time_embed_f32": (I, [P, P, P, I, I, I, P]),
+    "psld_perturb_coeffs_f64": (I, [P, I, C.POINTER(SdeParams), D, D, P, P, P]),
+    "psld_perturb_f32": (I, [P, P, P, P, C.POINTER(SdeParams), I, I, I, P, P, P, P]),
+    "psld_reduce_workspace_bytes": (LL, [LL]),
+    "psld_sqerr_loss_f32": (I, [P, P, LL, I, P, P, F, P, P]),
+    "psld_em_step_f64": (I, [P, P, P, C.POINTER(EmCoeffs), I, I, I, P, P]),
+    "psld_reverse_sde_f64": (I, [P, P, C.POINTER(EmCoeffs), I, I, I, P, P, P]),
+    "psld_f64_to_f32": (I, [P, P, LL, P]),
+    "psld_f32_to_f64": (I, [P, P, LL, P]),
+    "psld_grad_norm_f32": (I, [P, LL, P, P, P]),
+    "psld_adam_ema_f32": (I, [P, P, P, P, P, LL, P, F, F, F, F, F, F, I, F, I, P, P]),
+    "psld_ema_f32": (I, [P, P, LL, F, P]),
+}
+
+PSLD_ERR_NUMERIC = 3
+
+_lib = None
+
+
+class PsldHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libpsld_hip.so and bind every declared symbol.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PsldHipError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C psld_amd/csrc`. "
+            "There is no CPU / PyTorch fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise PsldHipError(f"libpsld_hip.so does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = ""):
+    """0 -> ok; PSLD_ERR_NUMERIC -> ValueError (mirrors psld.py:171); anything else -> RuntimeError
+    (mirrors TORCH_CHECK in op/upfirdn2d.cpp:8,15-16)."""
+    if status == 0:
+        return
+    msg = load().psld_last_error().decode("utf-8", "replace")
+    if status == PSLD_ERR_NUMERIC:
+        raise ValueError(msg or "Numerical precision error.")
+    raise RuntimeError(f"libpsld_hip {what} failed (status {status}): {msg}")

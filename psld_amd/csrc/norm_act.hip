@@ -1,0 +1,350 @@
+// GroupNorm(+SiLU) forward / backward on NHWC activations — the HBM-bound part of the U-Net.
+//
+// Reference: nn.GroupNorm(num_groups=min(C//4,32), eps=1e-6) followed by nn.SiLU
+// (song_sde/layerspp.py:219,231,243,264; :67,77 (attention, no act); ncsnpp.py:276-280,427).
+//
+// Thread mapping for every kernel here: a block owns one image `n` and a contiguous chunk of
+// its pixels.  Thread -> (channel quad q = tid % CQ, pixel lane pl = tid / CQ), CQ = C/4, so a
+// wave reads whole 16-byte-per-lane contiguous runs of the NHWC row (coalesced float4).
+// Reductions: per-thread fp32 partials over <= ~64 pixels, then fp64 across threads (LDS) and
+// across chunks (finalize kernel) — deterministic, no global atomics.
+#include "common.h"
+#include "psld_hip.h"
+
+namespace {
+
+constexpr int MAXT = 256;
+constexpr int MAXG = 32;
+
+struct Map {
+    int cq, pl, threads, chunks, chunk_px;
+};
+
+inline Map make_map(int batch, int hw, int c) {
+    Map m;
+    m.cq = c / 4;
+    m.pl = MAXT / m.cq;
+    if (m.pl < 1) m.pl = 1;
+    if (m.pl > hw) m.pl = hw;
+    m.threads = m.cq * m.pl;
+    // aim for >= ~2048 blocks in flight but <= 64 pixels per thread per chunk
+    int chunks = cdiv(2048, batch);
+    int max_chunks = cdiv(hw, m.pl);          // at least one pixel per thread
+    if (chunks > max_chunks) chunks = max_chunks;
+    int min_chunks = cdiv(hw, m.pl * 64);
+    if (chunks < min_chunks) chunks = min_chunks;
+    if (chunks < 1) chunks = 1;
+    m.chunk_px = cdiv(hw, chunks);
+    m.chunks = cdiv(hw, m.chunk_px);
+    return m;
+}
+
+// ---- forward statistics -------------------------------------------------------------------
+__global__ void gn_partial_kernel(const float* __restrict__ x, int hw, int c, int groups, int cq, int pl,
+                                  int chunk_px, int chunks, double* __restrict__ part) {
+    __shared__ double gs[MAXG][2];
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (tid < 2 * MAXG) (&gs[0][0])[tid] = 0.0;
+    __syncthreads();
+    const int q = tid % cq, l = tid / cq;
+    const int p0 = chunk * chunk_px, p1 = min(hw, p0 + chunk_px);
+    const float* base = x + ((long long)n * hw) * c + q * 4;
+    float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    for (int p = p0 + l; p < p1; p += pl) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)p * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s[e] += v[e];
+            ss[e] += v[e] * v[e];
+        }
+    }
+    const int cpg = c / groups;
+    if (cpg % 4 == 0) {
+        const int g = (q * 4) / cpg;
+        atomicAdd(&gs[g][0], (double)s[0] + (double)s[1] + (double)s[2] + (double)s[3]);
+        atomicAdd(&gs[g][1], (double)ss[0] + (double)ss[1] + (double)ss[2] + (double)ss[3]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int g = (q * 4 + e) / cpg;
+            atomicAdd(&gs[g][0], (double)s[e]);
+            atomicAdd(&gs[g][1], (double)ss[e]);
+        }
+    }
+    __syncthreads();
+    if (tid < groups * 2) part[(((long long)n * chunks + chunk) * groups) * 2 + tid] = (&gs[0][0])[tid];
+}
+
+__global__ void gn_finalize_kernel(const double* __restrict__ part, int hw, int c, int groups, int chunks,
+                                   float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ mean, float* __restrict__ rstd,
+                                   float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ float smean[MAXG], srstd[MAXG];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int cpg = c / groups;
+    if (tid < groups) {
+        double s = 0, ss = 0;
+        for (int k = 0; k < chunks; ++k) {
+            const double* pp = part + (((long long)n * chunks + k) * groups + tid) * 2;
+            s += pp[0];
+            ss += pp[1];
+        }
+        const double cnt = (double)cpg * hw;
+        const double mu = s / cnt;
+        double var = ss / cnt - mu * mu;
+        if (var < 0) var = 0;
+        const float m = (float)mu, r = (float)(1.0 / sqrt(var + (double)eps));
+        smean[tid] = m;
+        srstd[tid] = r;
+        mean[n * groups + tid] = m;
+        rstd[n * groups + tid] = r;
+    }
+    __syncthreads();
+    for (int ch = tid; ch < c; ch += blockDim.x) {
+        const int g = ch / cpg;
+        const float sc = srstd[g] * gamma[ch];
+        scale[(long long)n * c + ch] = sc;
+        shift[(long long)n * c + ch] = beta[ch] - smean[g] * sc;
+    }
+}
+
+__global__ void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                const float* __restrict__ shift, float* __restrict__ y, int hw, int c, int cq,
+                                int pl, int chunk_px, int act) {
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int q = threadIdx.x % cq, l = threadIdx.x / cq;
+    const int p0 = chunk * chunk_px, p1 = min(hw, p0 + chunk_px);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + (long long)n * c + q * 4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + (long long)n * c + q * 4);
+    const long long off = ((long long)n * hw) * c + q * 4;
+    for (int p = p0 + l; p < p1; p += pl) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + off + (long long)p * c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float z = v[e] * sc[e] + sh[e];
+            o[e] = act ? silu_f(z) : z;
+        }
+        *reinterpret_cast<f32x4*>(y + off + (long long)p * c) = o;
+    }
+}
+
+// ---- backward -------------------------------------------------------------------------------
+// pass 1: per (n, chunk, channel): s1 = sum dz, s2 = sum dz * xhat      (dz = dy * act'(z))
+__global__ void gn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta, int hw,
+                                      int c, int groups, int cq, int pl, int chunk_px, int chunks, int act,
+                                      float* __restrict__ part) {
+    extern __shared__ float red[];  // [pl][cq][8]
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int q = tid % cq, l = tid / cq;
+    const int p0 = chunk * chunk_px, p1 = min(hw, p0 + chunk_px);
+    const int cpg = c / groups;
+    float mu[4], rs[4], ga[4], be[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int ch = q * 4 + e;
+        const int g = ch / cpg;
+        mu[e] = mean[n * groups + g];
+        rs[e] = rstd[n * groups + g];
+        ga[e] = gamma[ch];
+        be[e] = beta[ch];
+    }
+    const long long off = ((long long)n * hw) * c + q * 4;
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    for (int p = p0 + l; p < p1; p += pl) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off + (long long)p * c);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(dy + off + (long long)p * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (xv[e] - mu[e]) * rs[e];
+            float dz = gv[e];
+            if (act) dz *= dsilu_f(xh * ga[e] + be[e]);
+            s1[e] += dz;
+            s2[e] += dz * xh;
+        }
+    }
+    float* my = red + ((long long)l * cq + q) * 8;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        my[e] = s1[e];
+        my[4 + e] = s2[e];
+    }
+    __syncthreads();
+    // threads 0..cq*8-1 reduce over pixel lanes
+    for (int i = tid; i < cq * 8; i += blockDim.x) {
+        double acc = 0;
+        for (int ll = 0; ll < pl; ++ll) acc += (double)red[(long long)ll * cq * 8 + i];
+        const int qq = i / 8, k = i % 8;
+        const int ch = qq * 4 + (k & 3);
+        // layout [n][chunk][2][c]
+        part[(((long long)n * chunks + chunk) * 2 + (k >> 2)) * c + ch] = (float)acc;
+    }
+}
+
+// pass 2: per image: sum chunks -> s1[n,c], s2[n,c]; group means m1, m2; write coefficient rows
+//   coef[n][0][c] = rstd*gamma  (multiplies dz)
+//   coef[n][1][c] = rstd*m1_g   (subtracted)
+//   coef[n][2][c] = rstd*m2_g   (multiplies xhat, subtracted)
+// and sums[n][2][c] (s1, s2) for the dgamma/dbeta reduction over n.
+__global__ void gn_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ rstd,
+                                       const float* __restrict__ gamma, int hw, int c, int groups, int chunks,
+                                       float* __restrict__ sums, float* __restrict__ coef) {
+    __shared__ double g1[MAXG], g2[MAXG];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int cpg = c / groups;
+    if (tid < MAXG) g1[tid] = g2[tid] = 0.0;
+    __syncthreads();
+    for (int ch = tid; ch < c; ch += blockDim.x) {
+        double a = 0, b = 0;
+        for (int k = 0; k < chunks; ++k) {
+            a += (double)part[(((long long)n * chunks + k) * 2 + 0) * c + ch];
+            b += (double)part[(((long long)n * chunks + k) * 2 + 1) * c + ch];
+        }
+        sums[((long long)n * 2 + 0) * c + ch] = (float)a;
+        sums[((long long)n * 2 + 1) * c + ch] = (float)b;
+        const int g = ch / cpg;
+        atomicAdd(&g1[g], a * (double)gamma[ch]);
+        atomicAdd(&g2[g], b * (double)gamma[ch]);
+    }
+    __syncthreads();
+    const double cnt = (double)cpg * hw;
+    for (int ch = tid; ch < c; ch += blockDim.x) {
+        const int g = ch / cpg;
+        const float r = rstd[n * groups + g];
+        coef[((long long)n * 3 + 0) * c + ch] = r * gamma[ch];
+        coef[((long long)n * 3 + 1) * c + ch] = (float)((double)r * g1[g] / cnt);
+        coef[((long long)n * 3 + 2) * c + ch] = (float)((double)r * g2[g] / cnt);
+    }
+}
+
+__global__ void gn_bwd_param_kernel(const float* __restrict__ sums, int batch, int c, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double a = 0, b = 0;
+    for (int n = 0; n < batch; ++n) {
+        a += (double)sums[((long long)n * 2 + 0) * c + ch];
+        b += (double)sums[((long long)n * 2 + 1) * c + ch];
+    }
+    dbeta[ch] = (float)a;
+    dgamma[ch] = (float)b;
+}
+
+// pass 3: dx = coef0*dz - coef1 - xhat*coef2
+__global__ void gn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ coef, int hw, int c, int groups, int cq, int pl,
+                                    int chunk_px, int act, int accumulate, float* __restrict__ dx) {
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int q = threadIdx.x % cq, l = threadIdx.x / cq;
+    const int p0 = chunk * chunk_px, p1 = min(hw, p0 + chunk_px);
+    const int cpg = c / groups;
+    float mu[4], rs[4], ga[4], be[4], c0[4], c1[4], c2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int ch = q * 4 + e;
+        const int g = ch / cpg;
+        mu[e] = mean[n * groups + g];
+        rs[e] = rstd[n * groups + g];
+        ga[e] = gamma[ch];
+        be[e] = beta[ch];
+        c0[e] = coef[((long long)n * 3 + 0) * c + ch];
+        c1[e] = coef[((long long)n * 3 + 1) * c + ch];
+        c2[e] = coef[((long long)n * 3 + 2) * c + ch];
+    }
+    const long long off = ((long long)n * hw) * c + q * 4;
+    for (int p = p0 + l; p < p1; p += pl) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off + (long long)p * c);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(dy + off + (long long)p * c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (xv[e] - mu[e]) * rs[e];
+            float dz = gv[e];
+            if (act) dz *= dsilu_f(xh * ga[e] + be[e]);
+            o[e] = c0[e] * dz - c1[e] - xh * c2[e];
+        }
+        float* dp = dx + off + (long long)p * c;
+        if (accumulate) {
+            const f32x4 old = *reinterpret_cast<const f32x4*>(dp);
+            o += old;
+        }
+        *reinterpret_cast<f32x4*>(dp) = o;
+    }
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" long long psld_gn_workspace_bytes(int batch, int hw, int c, int groups) {
+    if (batch <= 0 || hw <= 0 || c <= 0 || c % 4) return 0;
+    const Map m = make_map(batch, hw, c);
+    size_t fwd = align256((size_t)batch * m.chunks * groups * 2 * sizeof(double));
+    size_t bwd = align256((size_t)batch * m.chunks * 2 * c * sizeof(float)) +
+                 align256((size_t)batch * 2 * c * sizeof(float)) + align256((size_t)batch * 3 * c * sizeof(float));
+    return (long long)(fwd > bwd ? fwd : bwd);
+}
+
+extern "C" int psld_gn_stats_nhwc_f32(const float* x, int batch, int hw, int c, int groups, float eps,
+                                      const float* gamma, const float* beta, float* mean, float* rstd,
+                                      float* scale, float* shift, void* workspace, hipStream_t stream) {
+    PSLD_CHECK_ARG(x && gamma && beta && mean && rstd && scale && shift && workspace, "psld_gn_stats: null pointer");
+    PSLD_CHECK_ARG(c % 4 == 0 && c / 4 <= MAXT && groups <= MAXG && c % groups == 0,
+                   "psld_gn_stats: unsupported C=%d groups=%d", c, groups);
+    const Map m = make_map(batch, hw, c);
+    double* part = reinterpret_cast<double*>(workspace);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(m.chunks, batch), dim3(m.threads), 0, stream, x, hw, c, groups, m.cq,
+                       m.pl, m.chunk_px, m.chunks, part);
+    PSLD_CHECK_LAUNCH("gn_partial_kernel");
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, stream, part, hw, c, groups, m.chunks, eps,
+                       gamma, beta, mean, rstd, scale, shift);
+    PSLD_CHECK_LAUNCH("gn_finalize_kernel");
+    return PSLD_OK;
+}
+
+extern "C" int psld_gn_apply_nhwc_f32(const float* x, const float* scale, const float* shift, float* y, int batch,
+                                      int hw, int c, int act, hipStream_t stream) {
+    PSLD_CHECK_ARG(x && scale && shift && y, "psld_gn_apply: null pointer");
+    PSLD_CHECK_ARG(c % 4 == 0 && c / 4 <= MAXT, "psld_gn_apply: unsupported C=%d", c);
+    const Map m = make_map(batch, hw, c);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(m.chunks, batch), dim3(m.threads), 0, stream, x, scale, shift, y, hw, c,
+                       m.cq, m.pl, m.chunk_px, act);
+    PSLD_CHECK_LAUNCH("gn_apply_kernel");
+    return PSLD_OK;
+}
+
+extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float* mean, const float* rstd,
+                                    const float* gamma, const float* beta, int batch, int hw, int c, int groups,
+                                    int act, float* dx, float* dgamma, float* dbeta, int accumulate_dx,
+                                    void* workspace, hipStream_t stream) {
+    PSLD_CHECK_ARG(dy && x && mean && rstd && gamma && beta && dx && dgamma && dbeta && workspace,
+                   "psld_gn_bwd: null pointer");
+    PSLD_CHECK_ARG(c % 4 == 0 && c / 4 <= MAXT && groups <= MAXG && c % groups == 0,
+                   "psld_gn_bwd: unsupported C=%d groups=%d", c, groups);
+    const Map m = make_map(batch, hw, c);
+    char* ws = reinterpret_cast<char*>(workspace);
+    float* part = reinterpret_cast<float*>(ws);
+    ws += align256((size_t)batch * m.chunks * 2 * c * sizeof(float));
+    float* sums = reinterpret_cast<float*>(ws);
+    ws += align256((size_t)batch * 2 * c * sizeof(float));
+    float* coef = reinterpret_cast<float*>(ws);
+    const size_t lds = (size_t)m.pl * m.cq * 8 * sizeof(float);
+    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(m.chunks, batch), dim3(m.threads), lds, stream, dy, x, mean, rstd,
+                       gamma, beta, hw, c, groups, m.cq, m.pl, m.chunk_px, m.chunks, act, part);
+    PSLD_CHECK_LAUNCH("gn_bwd_partial_kernel");
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(batch), dim3(256), 0, stream, part, rstd, gamma, hw, c, groups,
+                       m.chunks, sums, coef);
+    PSLD_CHECK_LAUNCH("gn_bwd_finalize_kernel");
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(cdiv(c, 128)), dim3(128), 0, stream, sums, batch, c, dgamma, dbeta);
+    PSLD_CHECK_LAUNCH("gn_bwd_param_kernel");
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(m.chunks, batch), dim3(m.threads), 0, stream, dy, x, mean, rstd,
+                       gamma, beta, coef, hw, c, groups, m.cq, m.pl, m.chunk_px, act, accumulate_dx, dx);
+    PSLD_CHECK_LAUNCH("gn_bwd_apply_kernel");
+    return PSLD_OK;
+}

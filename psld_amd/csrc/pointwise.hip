@@ -1,0 +1,295 @@
+// Bandwidth-bound helpers: layout changes at the network boundary, weight packing, residual /
+// pyramid combines, SiLU on the time embedding, column sums (bias gradients), row softmax
+// (attention) and the Fourier / positional time embedding.
+#include "common.h"
+#include "psld_hip.h"
+
+namespace {
+
+inline int grid_for(long long n, int per_thread = 1) {
+    long long b = (n + 256LL * per_thread - 1) / (256LL * per_thread);
+    if (b > 256LL * 16) b = 256LL * 16;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+#define GRID_STRIDE(i, n) \
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
+
+// ---- layout -----------------------------------------------------------------------------------
+// per image: [C][HW] <-> [HW][C] through a 32x33 LDS tile (coalesced on both sides)
+__global__ void transpose_kernel(const float* __restrict__ x, float* __restrict__ y, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const long long img = blockIdx.z;
+    const float* xp = x + img * rows * cols;
+    float* yp = y + img * rows * cols;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        if (r < rows && c < cols) tile[j][tx] = xp[(long long)r * cols + c];
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (r < rows && c < cols) yp[(long long)c * rows + r] = tile[tx][j];
+    }
+}
+
+// OIHW -> [co][tap][ci]
+__global__ void pack_ohwi_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin, int taps) {
+    const long long n = (long long)cout * cin * taps;
+    GRID_STRIDE(i, n) {
+        const int ci = (int)(i % cin);
+        long long t = i / cin;
+        const int tap = (int)(t % taps);
+        const int co = (int)(t / taps);
+        out[i] = w[((long long)co * cin + ci) * taps + tap];
+    }
+}
+// OIHW -> [ci][taps-1-tap][co]
+__global__ void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin, int taps) {
+    const long long n = (long long)cout * cin * taps;
+    GRID_STRIDE(i, n) {
+        const int co = (int)(i % cout);
+        long long t = i / cout;
+        const int tapf = (int)(t % taps);
+        const int ci = (int)(t / taps);
+        out[i] = w[((long long)co * cin + ci) * taps + (taps - 1 - tapf)];
+    }
+}
+
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nsplit, long long n, float* __restrict__ out,
+                                    int layout, int taps, int cin) {
+    GRID_STRIDE(i, n) {
+        float acc = 0.f;
+        for (int s = 0; s < nsplit; ++s) acc += slabs[(long long)s * n + i];
+        long long o = i;
+        if (layout == 1) {  // [co][tap][ci] -> [co][ci][tap]
+            const int ci = (int)(i % cin);
+            long long t = i / cin;
+            const int tap = (int)(t % taps);
+            const long long co = t / taps;
+            o = (co * cin + ci) * taps + tap;
+        }
+        out[o] = acc;
+    }
+}
+
+// ---- pointwise ----------------------------------------------------------------------------------
+__global__ void axpby_kernel(const float* __restrict__ a, float sa, const float* __restrict__ b, float sb,
+                             float* __restrict__ y, long long n4, long long n, int accumulate) {
+    GRID_STRIDE(i, n4) {
+        f32x4 v = reinterpret_cast<const f32x4*>(a)[i] * sa;
+        if (b) v += reinterpret_cast<const f32x4*>(b)[i] * sb;
+        if (accumulate) v += reinterpret_cast<const f32x4*>(y)[i];
+        reinterpret_cast<f32x4*>(y)[i] = v;
+    }
+    // tail
+    const long long t0 = n4 * 4;
+    GRID_STRIDE(j, n - t0) {
+        const long long i = t0 + j;
+        float v = a[i] * sa;
+        if (b) v += b[i] * sb;
+        if (accumulate) v += y[i];
+        y[i] = v;
+    }
+}
+
+__global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
+    GRID_STRIDE(i, n) y[i] = silu_f(x[i]);
+}
+__global__ void silu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                long long n) {
+    GRID_STRIDE(i, n) dx[i] = dy[i] * dsilu_f(x[i]);
+}
+
+// out[b][c] = sum_p x[(b*hw+p)*ld + c].  grid (chunks_c, batch); block 256 = (cw = 64 columns) x 4 row lanes
+__global__ void colsum_kernel(const float* __restrict__ x, int ld, int hw, int c, float* __restrict__ out) {
+    __shared__ double red[4][64];
+    const int b = blockIdx.y;
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    double acc = 0.0;
+    if (col < c) {
+        const float* p = x + ((long long)b * hw) * ld + col;
+        float part = 0.f;
+        int cnt = 0;
+        for (int r = rl; r < hw; r += 4) {
+            part += p[(long long)r * ld];
+            if (++cnt == 32) {
+                acc += (double)part;
+                part = 0.f;
+                cnt = 0;
+            }
+        }
+        acc += (double)part;
+    }
+    red[rl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rl == 0 && col < c) out[(long long)b * c + col] = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// one wave64 per row
+__global__ void softmax_rows_kernel(const float* __restrict__ x, float* __restrict__ y, long long rows, int L) {
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* xp = x + row * L;
+    float* yp = y + row * L;
+    float mx = -INFINITY;
+    for (int i = lane; i < L; i += 64) mx = fmaxf(mx, xp[i]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int i = lane; i < L; i += 64) {
+        const float e = expf(xp[i] - mx);
+        yp[i] = e;
+        s += e;
+    }
+    s = wave_sum(s);
+    const float inv = 1.0f / s;
+    for (int i = lane; i < L; i += 64) yp[i] *= inv;
+}
+
+__global__ void softmax_rows_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                        float* __restrict__ dx, long long rows, int L) {
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* yp = y + row * L;
+    const float* gp = dy + row * L;
+    float d = 0.f;
+    for (int i = lane; i < L; i += 64) d += yp[i] * gp[i];
+    d = wave_sum(d);
+    for (int i = lane; i < L; i += 64) dx[row * L + i] = yp[i] * (gp[i] - d);
+}
+
+// ---- time embedding ---------------------------------------------------------------------------------
+// Precision-critical: |p| reaches 1e3..1e4 rad, so full-range sinf/cosf (no fast-math) and the
+// reference's multiplication order ((log t * W) * 2) * pi, every product rounded to f32.
+__global__ void time_embed_kernel(const float* __restrict__ t, const float* __restrict__ W, float* __restrict__ out,
+                                  int batch, int e, int use_log) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch * e) return;
+    const int b = i / e, k = i % e;
+    float p;
+    if (use_log) {
+        const float lt = logf(t[b]);
+        p = __fmul_rn(__fmul_rn(__fmul_rn(lt, W[k]), 2.0f), 3.14159265358979323846f);
+    } else {
+        p = __fmul_rn(t[b], W[k]);
+    }
+    out[(long long)b * 2 * e + k] = sinf(p);
+    out[(long long)b * 2 * e + e + k] = cosf(p);
+}
+
+__global__ void f64_to_f32_kernel(const double* __restrict__ x, float* __restrict__ y, long long n) {
+    GRID_STRIDE(i, n) y[i] = (float)x[i];
+}
+__global__ void f32_to_f64_kernel(const float* __restrict__ x, double* __restrict__ y, long long n) {
+    GRID_STRIDE(i, n) y[i] = (double)x[i];
+}
+
+}  // namespace
+
+extern "C" int psld_nchw_to_nhwc_f32(const float* x, float* y, int batch, int c, int hw, hipStream_t stream) {
+    PSLD_CHECK_ARG(x && y && batch > 0 && c > 0 && hw > 0, "psld_nchw_to_nhwc_f32: bad args");
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(hw, 32), cdiv(c, 32), batch), dim3(256), 0, stream, x, y, c, hw);
+    PSLD_CHECK_LAUNCH("psld_nchw_to_nhwc_f32");
+    return PSLD_OK;
+}
+extern "C" int psld_nhwc_to_nchw_f32(const float* x, float* y, int batch, int c, int hw, hipStream_t stream) {
+    PSLD_CHECK_ARG(x && y && batch > 0 && c > 0 && hw > 0, "psld_nhwc_to_nchw_f32: bad args");
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(c, 32), cdiv(hw, 32), batch), dim3(256), 0, stream, x, y, hw, c);
+    PSLD_CHECK_LAUNCH("psld_nhwc_to_nchw_f32");
+    return PSLD_OK;
+}
+
+extern "C" int psld_pack_oihw_to_ohwi_f32(const float* w, float* out, int cout, int cin, int taps, hipStream_t stream) {
+    PSLD_CHECK_ARG(w && out, "psld_pack_oihw_to_ohwi_f32: null pointer");
+    const long long n = (long long)cout * cin * taps;
+    hipLaunchKernelGGL(pack_ohwi_kernel, dim3(grid_for(n)), dim3(256), 0, stream, w, out, cout, cin, taps);
+    PSLD_CHECK_LAUNCH("psld_pack_oihw_to_ohwi_f32");
+    return PSLD_OK;
+}
+extern "C" int psld_pack_oihw_to_dgrad_f32(const float* w, float* out, int cout, int cin, int taps, hipStream_t stream) {
+    PSLD_CHECK_ARG(w && out, "psld_pack_oihw_to_dgrad_f32: null pointer");
+    const long long n = (long long)cout * cin * taps;
+    hipLaunchKernelGGL(pack_dgrad_kernel, dim3(grid_for(n)), dim3(256), 0, stream, w, out, cout, cin, taps);
+    PSLD_CHECK_LAUNCH("psld_pack_oihw_to_dgrad_f32");
+    return PSLD_OK;
+}
+extern "C" int psld_reduce_slabs_f32(const float* slabs, int nsplit, long long n, float* out, int layout, int cout,
+                                     int taps, int cin, hipStream_t stream) {
+    PSLD_CHECK_ARG(slabs && out && nsplit >= 1, "psld_reduce_slabs_f32: bad args");
+    PSLD_CHECK_ARG(layout == 0 || n == (long long)cout * taps * cin, "psld_reduce_slabs_f32: shape mismatch");
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(n)), dim3(256), 0, stream, slabs, nsplit, n, out, layout,
+                       taps, cin);
+    PSLD_CHECK_LAUNCH("psld_reduce_slabs_f32");
+    return PSLD_OK;
+}
+
+extern "C" int psld_axpby_f32(const float* a, float sa, const float* b, float sb, float* y, long long n,
+                              int accumulate, hipStream_t stream) {
+    PSLD_CHECK_ARG(a && y && n >= 0, "psld_axpby_f32: bad args");
+    if (n == 0) return PSLD_OK;
+    const bool al = ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(y) |
+                      (b ? reinterpret_cast<uintptr_t>(b) : 0)) & 15) == 0;
+    const long long n4 = al ? n / 4 : 0;
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n, 4)), dim3(256), 0, stream, a, sa, b, sb, y, n4, n, accumulate);
+    PSLD_CHECK_LAUNCH("psld_axpby_f32");
+    return PSLD_OK;
+}
+extern "C" int psld_silu_f32(const float* x, float* y, long long n, hipStream_t stream) {
+    PSLD_CHECK_ARG(x && y, "psld_silu_f32: null pointer");
+    hipLaunchKernelGGL(silu_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, y, n);
+    PSLD_CHECK_LAUNCH("psld_silu_f32");
+    return PSLD_OK;
+}
+extern "C" int psld_silu_bwd_f32(const float* x, const float* dy, float* dx, long long n, hipStream_t stream) {
+    PSLD_CHECK_ARG(x && dy && dx, "psld_silu_bwd_f32: null pointer");
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, dy, dx, n);
+    PSLD_CHECK_LAUNCH("psld_silu_bwd_f32");
+    return PSLD_OK;
+}
+extern "C" int psld_colsum_f32(const float* x, int ld, int batch, int hw, int c, float* out, hipStream_t stream) {
+    PSLD_CHECK_ARG(x && out && batch > 0 && hw > 0 && c > 0, "psld_colsum_f32: bad args");
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(c, 64), batch), dim3(256), 0, stream, x, ld, hw, c, out);
+    PSLD_CHECK_LAUNCH("psld_colsum_f32");
+    return PSLD_OK;
+}
+extern "C" int psld_softmax_rows_f32(const float* x, float* y, long long rows, int L, hipStream_t stream) {
+    PSLD_CHECK_ARG(x && y && rows >= 0 && L > 0, "psld_softmax_rows_f32: bad args");
+    if (rows == 0) return PSLD_OK;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, y, rows, L);
+    PSLD_CHECK_LAUNCH("psld_softmax_rows_f32");
+    return PSLD_OK;
+}
+extern "C" int psld_softmax_rows_bwd_f32(const float* y, const float* dy, float* dx, long long rows, int L,
+                                         hipStream_t stream) {
+    PSLD_CHECK_ARG(y && dy && dx && rows >= 0 && L > 0, "psld_softmax_rows_bwd_f32: bad args");
+    if (rows == 0) return PSLD_OK;
+    hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, y, dy, dx, rows, L);
+    PSLD_CHECK_LAUNCH("psld_softmax_rows_bwd_f32");
+    return PSLD_OK;
+}
+extern "C" int psld_time_embed_f32(const float* t, const float* W, float* out, int batch, int e, int use_log,
+                                   hipStream_t stream) {
+    PSLD_CHECK_ARG(t && W && out && batch > 0 && e > 0, "psld_time_embed_f32: bad args");
+    hipLaunchKernelGGL(time_embed_kernel, dim3(cdiv((long long)batch * e, 256)), dim3(256), 0, stream, t, W, out,
+                       batch, e, use_log);
+    PSLD_CHECK_LAUNCH("psld_time_embed_f32");
+    return PSLD_OK;
+}
+extern "C" int psld_f64_to_f32(const double* x, float* y, long long n, hipStream_t stream) {
+    PSLD_CHECK_ARG(x && y, "psld_f64_to_f32: null pointer");
+    hipLaunchKernelGGL(f64_to_f32_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, y, n);
+    PSLD_CHECK_LAUNCH("psld_f64_to_f32");
+    return PSLD_OK;
+}
+extern "C" int psld_f32_to_f64(const float* x, double* y, long long n, hipStream_t stream) {
+    PSLD_CHECK_ARG(x && y, "psld_f32_to_f64: null pointer");
+    hipLaunchKernelGGL(f32_to_f64_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, y, n);
+    PSLD_CHECK_LAUNCH("psld_f32_to_f64");
+    return PSLD_OK;
+}

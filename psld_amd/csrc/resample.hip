@@ -1,0 +1,141 @@
+// FIR resampling (upfirdn2d) and the unused-but-inventoried fused_bias_act, for gfx950.
+//
+// Replaces the reference's two JIT-built CUDA ops:
+//   op/upfirdn2d_kernel.cu:49-207 (kernels), :209-369 (host op), bound at op/upfirdn2d.cpp:12-22
+//   op/fused_bias_act_kernel.cu:18-49, bound at op/fused_bias_act.cpp:11-20
+// Semantics follow the CPU path the reference itself uses as ground truth
+// (op/upfirdn2d.py:159-200): zero-insert upsample, pad/crop, correlate with the flipped
+// kernel, decimate.  HBM-bound: each thread produces one float4 of channels (NHWC) or one
+// pixel (NCHW) and reads its <= kh*kw taps through L1/L2 (neighbouring outputs share taps).
+#include "common.h"
+#include "psld_hip.h"
+
+namespace {
+
+constexpr int MAX_TAPS = 64;
+
+struct Fir {
+    float w[MAX_TAPS];  // already flipped: w[ky*kw+kx] = kernel[kh-1-ky][kw-1-kx]
+    int kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0;
+};
+
+// out[oy][ox] = sum_{ky,kx} w[ky][kx] * U[oy*down_y + ky - pad_y0][ox*down_x + kx - pad_x0],
+// U = zero-inserted upsample of the input (U[y*up][x*up] = in[y][x]), zero outside.
+__global__ void upfirdn_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, const Fir f, int batch,
+                                    int c, int in_h, int in_w, int out_h, int out_w, int accumulate) {
+    const int cq = c >> 2;
+    const long long total = (long long)batch * out_h * out_w * cq;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq);
+        long long t = i / cq;
+        const int ox = (int)(t % out_w);
+        t /= out_w;
+        const int oy = (int)(t % out_h);
+        const int n = (int)(t / out_h);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int ky = 0; ky < f.kh; ++ky) {
+            const int py = oy * f.down_y + ky - f.pad_y0;
+            if (py < 0 || py % f.up_y) continue;
+            const int iy = py / f.up_y;
+            if (iy >= in_h) continue;
+            for (int kx = 0; kx < f.kw; ++kx) {
+                const int px = ox * f.down_x + kx - f.pad_x0;
+                if (px < 0 || px % f.up_x) continue;
+                const int ix = px / f.up_x;
+                if (ix >= in_w) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((long long)n * in_h + iy) * in_w + ix) * c + q * 4);
+                acc += v * f.w[ky * f.kw + kx];
+            }
+        }
+        float* op = y + (((long long)n * out_h + oy) * out_w + ox) * c + q * 4;
+        if (accumulate) acc += *reinterpret_cast<const f32x4*>(op);
+        *reinterpret_cast<f32x4*>(op) = acc;
+    }
+}
+
+__global__ void upfirdn_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, const Fir f, int planes,
+                                    int in_h, int in_w, int out_h, int out_w, int accumulate) {
+    const long long total = (long long)planes * out_h * out_w;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % out_w);
+        long long t = i / out_w;
+        const int oy = (int)(t % out_h);
+        const long long pl = t / out_h;
+        const float* xp = x + pl * in_h * in_w;
+        float acc = 0.f;
+        for (int ky = 0; ky < f.kh; ++ky) {
+            const int py = oy * f.down_y + ky - f.pad_y0;
+            if (py < 0 || py % f.up_y) continue;
+            const int iy = py / f.up_y;
+            if (iy >= in_h) continue;
+            for (int kx = 0; kx < f.kw; ++kx) {
+                const int px = ox * f.down_x + kx - f.pad_x0;
+                if (px < 0 || px % f.up_x) continue;
+                const int ix = px / f.up_x;
+                if (ix >= in_w) continue;
+                acc += xp[iy * in_w + ix] * f.w[ky * f.kw + kx];
+            }
+        }
+        if (accumulate) acc += y[i];
+        y[i] = acc;
+    }
+}
+
+__global__ void fused_bias_act_kernel(const float* __restrict__ x, const float* __restrict__ b,
+                                      float* __restrict__ y, long long n, int size_b, int step_b, int act,
+                                      float alpha, float scale) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        float v = x[i];
+        if (b) v += b[(i / step_b) % size_b];
+        if (act == 3) v = v > 0.f ? v : v * alpha;
+        y[i] = v * scale;
+    }
+}
+
+}  // namespace
+
+extern "C" int psld_upfirdn2d_f32(const float* x, float* y, int batch, int c, int in_h, int in_w,
+                                  const float* kernel_host, int kh, int kw, int up_x, int up_y, int down_x,
+                                  int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1, int layout,
+                                  int accumulate, hipStream_t stream) {
+    PSLD_CHECK_ARG(x && y && kernel_host, "psld_upfirdn2d_f32: null pointer");
+    PSLD_CHECK_ARG(kh >= 1 && kw >= 1 && kh * kw <= MAX_TAPS, "psld_upfirdn2d_f32: kernel %dx%d too large", kh, kw);
+    PSLD_CHECK_ARG(up_x >= 1 && up_y >= 1 && down_x >= 1 && down_y >= 1, "psld_upfirdn2d_f32: bad factors");
+    const int out_h = (in_h * up_y + pad_y0 + pad_y1 - kh) / down_y + 1;  // op/upfirdn2d_kernel.cu:237-240
+    const int out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) / down_x + 1;
+    PSLD_CHECK_ARG(out_h > 0 && out_w > 0, "psld_upfirdn2d_f32: empty output");
+    Fir f;
+    f.kh = kh; f.kw = kw; f.up_x = up_x; f.up_y = up_y; f.down_x = down_x; f.down_y = down_y;
+    f.pad_x0 = pad_x0; f.pad_y0 = pad_y0;
+    for (int ky = 0; ky < kh; ++ky)
+        for (int kx = 0; kx < kw; ++kx) f.w[ky * kw + kx] = kernel_host[(kh - 1 - ky) * kw + (kw - 1 - kx)];
+    if (layout == 1) {
+        PSLD_CHECK_ARG(c % 4 == 0, "psld_upfirdn2d_f32: NHWC needs C%%4==0 (C=%d)", c);
+        const long long total = (long long)batch * out_h * out_w * (c / 4);
+        const int blocks = (int)min((long long)cdiv(total, 256), 256LL * 32);
+        hipLaunchKernelGGL(upfirdn_nhwc_kernel, dim3(blocks), dim3(256), 0, stream, x, y, f, batch, c, in_h, in_w,
+                           out_h, out_w, accumulate);
+    } else {
+        const long long total = (long long)batch * c * out_h * out_w;
+        const int blocks = (int)min((long long)cdiv(total, 256), 256LL * 32);
+        hipLaunchKernelGGL(upfirdn_nchw_kernel, dim3(blocks), dim3(256), 0, stream, x, y, f, batch * c, in_h, in_w,
+                           out_h, out_w, accumulate);
+    }
+    PSLD_CHECK_LAUNCH("psld_upfirdn2d_f32");
+    return PSLD_OK;
+}
+
+extern "C" int psld_fused_bias_act_f32(const float* x, const float* b, float* y, long long n, int size_b,
+                                       int step_b, int act, float alpha, float scale, hipStream_t stream) {
+    PSLD_CHECK_ARG(x && y && n >= 0 && (!b || (size_b > 0 && step_b > 0)), "psld_fused_bias_act_f32: bad args");
+    PSLD_CHECK_ARG(act == 1 || act == 3, "psld_fused_bias_act_f32: act must be 1 (linear) or 3 (lrelu)");
+    if (n == 0) return PSLD_OK;
+    const int blocks = (int)min((long long)cdiv(n, 256), 256LL * 32);
+    hipLaunchKernelGGL(fused_bias_act_kernel, dim3(blocks), dim3(256), 0, stream, x, b, y, n, size_b, step_b, act,
+                       alpha, scale);
+    PSLD_CHECK_LAUNCH("psld_fused_bias_act_f32");
+    return PSLD_OK;
+}

@@ -1,0 +1,273 @@
+// PSLD SDE kernels: perturbation kernel p(z_t | x_0), HSM loss, Euler-Maruyama reverse step.
+// Compiled with -ffp-contract=off so that the f32/f64 operation order of the reference's eager
+// elementwise chains is reproduced without fused multiply-adds.
+//
+// Reference: main/models/sde/psld.py:38-44 (b_t, beta_t), :62-84 (_mean), :86-152 (_cov),
+// :154-186 (get_coeff), :188-220 (get_inv_coeff), :230-260 (get_score), :262-287 (perturb_data),
+// :330-364 (sde / reverse_sde); main/losses.py:94-130; main/samplers/sde.py:16-36.
+// All public tensors here are NCHW like the reference ([B, 2C, H, W] state = [x | m]).
+#include "common.h"
+#include "psld_hip.h"
+
+namespace {
+
+constexpr int COEFF_STRIDE = 12;
+
+#define GRID_STRIDE(i, n) \
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
+
+inline int grid_for(long long n) {
+    long long b = (n + 255) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// psld.py:86-152 with the numerical_eps of :152 on the diagonal
+__device__ void psld_cov(const psld_sde_params_t& p, double xx_0, double mm_0, double b, double& xx, double& xm,
+                         double& mm) {
+    const double nu = p.nu, ga = p.gamma, mi = p.m_inv, m = 1.0 / p.m_inv;
+    const double lam = (nu + ga) / 2;
+    const double b2 = b * b;
+    const double sc = exp(-lam * b), isc = exp(lam * b);
+    xx = (mi / 4 * b2 * xx_0 + mi * mi / 4 * b2 * mm_0 + (nu - ga) / 2 * b * xx_0 + (-mi / 2) * b2 +
+          (ga - nu) / 2 * b + (isc - 1) + xx_0) * sc + p.numerical_eps;
+    xm = ((ga - nu) / 8 * b2 * xx_0 + mi * (ga - nu) / 8 * b2 * mm_0 + (-1.0 / 2) * b * xx_0 + mi / 2 * b * mm_0 +
+          (nu - ga) / 4 * b2) * sc;
+    mm = (1.0 / 4 * b2 * xx_0 + mi / 4 * b2 * mm_0 + (ga - nu) / 2 * b * mm_0 + (-1.0 / 2) * b2 +
+          m * (nu - ga) / 2 * b + m * (isc - 1) + mm_0) * sc + p.numerical_eps;
+}
+
+__global__ void perturb_coeffs_kernel(const double* __restrict__ t, int batch, const psld_sde_params_t p,
+                                      double xx_0, double mm_0, double* __restrict__ out, int* __restrict__ nan_flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch) return;
+    const double tt = t[i];
+    const double b = p.beta_0 * tt + 0.5 * (tt * tt) * (p.beta_1 - p.beta_0);  // psld.py:42-44
+    const double sf = exp(-((p.nu + p.gamma) / 4) * b);                        // psld.py:65-67
+    double xx, xm, mm;
+    psld_cov(p, xx_0, mm_0, b, xx, xm, mm);
+    double c11, c12, c21, c22;
+    if (p.decomp_lower) {  // psld.py:160-164
+        c11 = sqrt(xx);
+        c12 = 0.0;
+        c21 = xm / c11;
+        c22 = sqrt(mm - c21 * c21);
+    } else {  // psld.py:174-178
+        c22 = sqrt(mm);
+        c12 = xm / c22;
+        c11 = sqrt(xx - c12 * c12);
+        c21 = 0.0;
+    }
+    if (isnan(c11) || isnan(c12) || isnan(c21) || isnan(c22)) atomicExch(nan_flag, 1);
+    double* o = out + (long long)i * COEFF_STRIDE;
+    o[0] = b; o[1] = sf; o[2] = 0; o[3] = 0;
+    o[4] = c11; o[5] = c12; o[6] = c21; o[7] = c22;
+    o[8] = xx; o[9] = xm; o[10] = mm; o[11] = 0;
+}
+
+// one thread per (b, c, pixel) of the x half; writes both halves
+__global__ void perturb_kernel(const float* __restrict__ x0, const float* __restrict__ m0,
+                               const float* __restrict__ eps, const double* __restrict__ coeffs,
+                               const psld_sde_params_t p, int batch, int c, int hw, float* __restrict__ z,
+                               double* __restrict__ u, double* __restrict__ mu_out) {
+    const long long n = (long long)batch * c * hw;
+    const double A1 = (p.nu - p.gamma) / 4, A2 = (p.gamma - p.nu) * (p.gamma - p.nu) / 8;
+    const double C1 = -0.5, C2 = (p.gamma - p.nu) / 4;
+    GRID_STRIDE(i, n) {
+        const int b = (int)(i / ((long long)c * hw));
+        const long long r = i - (long long)b * c * hw;  // offset inside the half
+        const double* k = coeffs + (long long)b * COEFF_STRIDE;
+        const double bt = k[0], sf = k[1];
+        const double xv = (double)x0[i];
+        const double mv = m0 ? (double)m0[i] : 0.0;
+        // psld.py:76-83
+        const double mu_x = (A1 * xv * bt + A2 * mv * bt + xv) * sf;
+        const double mu_m = (C1 * xv * bt + C2 * mv * bt + mv) * sf;
+        const long long ox = (long long)b * 2 * c * hw + r, om = ox + (long long)c * hw;
+        const double ex = (double)eps[ox], em = (double)eps[om];
+        // psld.py:277-283
+        const double nx = k[4] * ex + k[5] * em;
+        const double nm = k[6] * ex + k[7] * em;
+        const double ux = mu_x + nx, um = mu_m + nm;
+        if (z) { z[ox] = (float)ux; z[om] = (float)um; }
+        if (u) { u[ox] = ux; u[om] = um; }
+        if (mu_out) { mu_out[ox] = mu_x; mu_out[om] = mu_m; }
+    }
+}
+
+// ---- loss ---------------------------------------------------------------------------------------
+__global__ void sqerr_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n,
+                                     double* __restrict__ part, float* __restrict__ grad, float gscale) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    float local = 0.f;
+    int cnt = 0;
+    GRID_STRIDE(i, n) {
+        const float d = a[i] - b[i];
+        local += d * d;
+        if (grad) grad[i] = -gscale * d;   // d/d(b) of (a-b)^2 * (gscale/2)
+        if (++cnt == 16) { acc += (double)local; local = 0.f; cnt = 0; }
+    }
+    acc += (double)local;
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void sqerr_final_kernel(const double* __restrict__ part, int nparts, double denom, float* __restrict__ loss) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 64) acc += part[i];
+    acc = wave_sum_d(acc);
+    if (threadIdx.x == 0) loss[0] = (float)(acc / denom);
+}
+
+// ---- reverse SDE / Euler-Maruyama ---------------------------------------------------------------
+struct RevOut {
+    double fbx, fbm, gx, gm;
+};
+
+__device__ __forceinline__ RevOut reverse_terms(const psld_em_coeffs_t& k, double xv, double mv, float ex, float em,
+                                                bool have_ex) {
+    // psld.py:336-337 drift, :339-340 diffusion
+    const double fx = 0.5 * k.beta * (k.m_inv * mv - k.gamma * xv);
+    const double fm = 0.5 * k.beta * (-k.nu * mv - xv);
+    const double gx = sqrt(k.beta * k.gamma);
+    const double gm = sqrt(k.beta * k.m * k.nu);
+    // psld.py:240-259 score in f32 with f32-cast coefficients
+    float sx, sm;
+    if (k.score_mode == 1) {         // score_m, lower: eps is the momentum part only
+        sx = 0.f;
+        sm = -k.c22 * em;
+    } else if (k.score_mode == 2) {  // score_x, upper
+        sx = -k.c11 * ex;
+        sm = 0.f;
+    } else {
+        sx = -k.c11 * ex - k.c12 * em;
+        sm = -k.c21 * ex - k.c22 * em;
+    }
+    (void)have_ex;
+    if (k.probability_flow) { sx = 0.5f * sx; sm = 0.5f * sm; }
+    RevOut o;
+    o.fbx = -fx + (gx * gx) * (double)sx;   // psld.py:360
+    o.fbm = -fm + (gm * gm) * (double)sm;
+    o.gx = k.probability_flow ? 0.0 : gx;
+    o.gm = k.probability_flow ? 0.0 : gm;
+    return o;
+}
+
+__device__ __forceinline__ void fetch_eps(const float* eps, const psld_em_coeffs_t& k, int b, long long r, int c, int hw,
+                                          float& ex, float& em) {
+    if (k.score_mode == 0) {
+        const long long o = (long long)b * 2 * c * hw + r;
+        ex = eps[o];
+        em = eps[o + (long long)c * hw];
+    } else {
+        const float v = eps[(long long)b * c * hw + r];
+        ex = v;
+        em = v;
+    }
+}
+
+__global__ void em_step_kernel(double* __restrict__ x, const float* __restrict__ eps, const double* __restrict__ z,
+                               const psld_em_coeffs_t k, int batch, int c, int hw, float* __restrict__ xf) {
+    const long long n = (long long)batch * c * hw;
+    const double sdt = sqrt(k.dt);
+    GRID_STRIDE(i, n) {
+        const int b = (int)(i / ((long long)c * hw));
+        const long long r = i - (long long)b * c * hw;
+        const long long ox = (long long)b * 2 * c * hw + r, om = ox + (long long)c * hw;
+        float ex, em;
+        fetch_eps(eps, k, b, r, c, hw, ex, em);
+        const double xv = x[ox], mv = x[om];
+        const RevOut o = reverse_terms(k, xv, mv, ex, em, true);
+        double nx = xv + o.fbx * k.dt;   // samplers/sde.py:23
+        double nm = mv + o.fbm * k.dt;
+        if (z) {                          // samplers/sde.py:24-25
+            nx = nx + o.gx * sdt * z[ox];
+            nm = nm + o.gm * sdt * z[om];
+        }
+        x[ox] = nx;
+        x[om] = nm;
+        if (xf) { xf[ox] = (float)nx; xf[om] = (float)nm; }
+    }
+}
+
+__global__ void reverse_sde_kernel(const double* __restrict__ x, const float* __restrict__ eps,
+                                   const psld_em_coeffs_t k, int batch, int c, int hw, double* __restrict__ fbar,
+                                   double* __restrict__ gbar) {
+    const long long n = (long long)batch * c * hw;
+    GRID_STRIDE(i, n) {
+        const int b = (int)(i / ((long long)c * hw));
+        const long long r = i - (long long)b * c * hw;
+        const long long ox = (long long)b * 2 * c * hw + r, om = ox + (long long)c * hw;
+        float ex, em;
+        fetch_eps(eps, k, b, r, c, hw, ex, em);
+        const RevOut o = reverse_terms(k, x[ox], x[om], ex, em, true);
+        fbar[ox] = o.fbx; fbar[om] = o.fbm;
+        if (gbar) { gbar[ox] = o.gx; gbar[om] = o.gm; }
+    }
+}
+
+}  // namespace
+
+extern "C" long long psld_reduce_workspace_bytes(long long n) {
+    (void)n;
+    return 4096LL * sizeof(double);
+}
+
+extern "C" int psld_perturb_coeffs_f64(const double* t, int batch, const psld_sde_params_t* p, double xx_0,
+                                       double mm_0, double* coeffs, int* nan_flag, hipStream_t stream) {
+    PSLD_CHECK_ARG(t && p && coeffs && nan_flag && batch > 0, "psld_perturb_coeffs_f64: bad args");
+    hipLaunchKernelGGL(perturb_coeffs_kernel, dim3(cdiv(batch, 128)), dim3(128), 0, stream, t, batch, *p, xx_0, mm_0,
+                       coeffs, nan_flag);
+    PSLD_CHECK_LAUNCH("psld_perturb_coeffs_f64");
+    return PSLD_OK;
+}
+
+extern "C" int psld_perturb_f32(const float* x0, const float* m0, const float* eps, const double* coeffs,
+                                   const psld_sde_params_t* p, int batch, int c, int hw, float* z_f32, double* u_f64,
+                                   double* mu_f64, hipStream_t stream) {
+    PSLD_CHECK_ARG(x0 && eps && coeffs && p && batch > 0 && c > 0 && hw > 0, "psld_perturb_f32: bad args");
+    const long long n = (long long)batch * c * hw;
+    hipLaunchKernelGGL(perturb_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x0, m0, eps, coeffs, *p, batch, c, hw,
+                       z_f32, u_f64, mu_f64);
+    PSLD_CHECK_LAUNCH("psld_perturb_f32");
+    return PSLD_OK;
+}
+
+extern "C" int psld_sqerr_loss_f32(const float* eps, const float* eps_pred, long long n, int reduce_mean, float* loss,
+                                   float* grad, float grad_scale, void* workspace, hipStream_t stream) {
+    PSLD_CHECK_ARG(eps && eps_pred && loss && workspace && n > 0, "psld_sqerr_loss_f32: bad args");
+    int blocks = grid_for(n);
+    if (blocks > 4096) blocks = 4096;
+    double* part = reinterpret_cast<double*>(workspace);
+    // d loss / d eps_pred = 2*(pred - eps)/denom * upstream  ==  -(gscale) * (eps - pred)
+    const double denom = reduce_mean ? (double)n : 1.0;
+    const float gs = (float)(2.0 * (double)grad_scale / denom);
+    hipLaunchKernelGGL(sqerr_partial_kernel, dim3(blocks), dim3(256), 0, stream, eps, eps_pred, n, part, grad, gs);
+    PSLD_CHECK_LAUNCH("sqerr_partial_kernel");
+    hipLaunchKernelGGL(sqerr_final_kernel, dim3(1), dim3(64), 0, stream, part, blocks, denom, loss);
+    PSLD_CHECK_LAUNCH("sqerr_final_kernel");
+    return PSLD_OK;
+}
+
+extern "C" int psld_em_step_f64(double* x, const float* eps_pred, const double* z, const psld_em_coeffs_t* k, int batch,
+                                int c, int hw, float* x_f32_out, hipStream_t stream) {
+    PSLD_CHECK_ARG(x && eps_pred && k && batch > 0 && c > 0 && hw > 0, "psld_em_step_f64: bad args");
+    const long long n = (long long)batch * c * hw;
+    hipLaunchKernelGGL(em_step_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, eps_pred, z, *k, batch, c, hw,
+                       x_f32_out);
+    PSLD_CHECK_LAUNCH("psld_em_step_f64");
+    return PSLD_OK;
+}
+
+extern "C" int psld_reverse_sde_f64(const double* x, const float* eps_pred, const psld_em_coeffs_t* k, int batch, int c,
+                                    int hw, double* f_bar, double* g_bar, hipStream_t stream) {
+    PSLD_CHECK_ARG(x && eps_pred && k && f_bar && batch > 0, "psld_reverse_sde_f64: bad args");
+    const long long n = (long long)batch * c * hw;
+    hipLaunchKernelGGL(reverse_sde_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, eps_pred, *k, batch, c, hw,
+                       f_bar, g_bar);
+    PSLD_CHECK_LAUNCH("psld_reverse_sde_f64");
+    return PSLD_OK;
+}

@@ -1,0 +1,473 @@
+// fp32 MFMA tile engine: GEMM (NT / NN / TN), implicit-GEMM convolution (forward and
+// data-gradient) and convolution weight-gradient, all on NHWC activations.
+//
+// Replaces, on the reference's hot path, every dense contraction that the reference runs
+// through ATen: nn.Conv2d 3x3/1x1 (song_sde/layers.py:85-109), NIN (layers.py:531-540),
+// nn.Linear (layerspp.py:225-228, ncsnpp.py:99-105), the attention einsums
+// (layerspp.py:82-87) and the strided pyramid conv (up_or_down_sampling.py:177) — and their
+// autograd backward passes.
+//
+// Design (CDNA4):  one workgroup = 256 threads = 4 wave64, block tile 128x128, K step 32.
+// Each wave owns a 64x64 sub-tile = 2x2 v_mfma_f32_32x32x2_f32 accumulators (64 VGPRs);
+// exact fp32 (k-ordered fmaf chain), so outputs stay within fp32 rounding of the CPU
+// reference.  Operands are staged global -> registers -> LDS (register prefetch of tile
+// k+1 overlaps the 64 MFMAs of tile k).  K-contiguous operands sit in LDS as [row][32+4]
+// and are read as ds_read_b128 (4 k-values per lane per read; lanes 0-31 take k=8j..8j+3,
+// lanes 32-63 take k=8j+4..8j+7 — the k order inside a dot product is free as long as A and
+// B agree); row-contiguous ("MC") operands sit as [k][128] and are read with ds_read_b32.
+// The 36-float row stride makes both the b128 fragment reads and the b128 staging writes
+// bank-conflict free (MI355X LDS: 64 banks, 16-lane groups for b128).
+#include "common.h"
+#include "psld_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int KC_LD = BK + 4;   // K-contiguous LDS image: [128][36]
+constexpr int MC_LD = BM;       // row-contiguous LDS image: [32][128]
+constexpr int NTHREADS = 256;
+
+enum : int { OP_KC = 0, OP_MC = 1, OP_IM2COL = 2, OP_SHIFT = 3 };
+
+struct Operand {
+    const float* p;     // base
+    const float* p2;    // second source (im2col concat) or null
+    long long stride_z; // per-batch element stride
+    int ld;             // leading dimension (elements)
+    int vec;            // 1: float4 loads legal (16B aligned base, ld%4==0, extents %4==0)
+};
+
+struct ConvGeom {
+    int IH, IW, C1, C2, OH, OW, KH, KW, stride, pad, tstride;
+};
+
+struct Epilogue {
+    float alpha;
+    const float* bias;      // [N] or null
+    const float* rowbias;   // [M/rows_per_img][ld_rowbias] or null (time-embedding bias)
+    int ld_rowbias;
+    int rows_per_img;
+    const float* res;       // residual [M][ldres] or null
+    int ldres;
+    long long res_stride_z;
+    float out_scale;
+    int accumulate;         // C += result
+};
+
+struct TileArgs {
+    int M, N, K;
+    Operand A, B;
+    float* C;
+    long long c_stride_z;      // per zb
+    long long c_stride_split;  // per split slab
+    int ldc;
+    int nsplit;
+    int kper;                  // K range per split (multiple of BK)
+    ConvGeom g;
+    Epilogue e;
+};
+
+struct RowInfo {  // im2col row (output pixel) decomposition
+    int img, oy, ox;
+};
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// ---- operand tile -> registers -------------------------------------------------------
+// KC modes (OP_KC, OP_IM2COL): thread (c4 = tid&7, r0 = tid>>3) owns rows r0+32i, k = 4*c4..4*c4+3
+// MC modes (OP_MC, OP_SHIFT):  thread (c  = tid&31, kr = tid>>5) owns k rows kr+8i, m = 4c..4c+3
+template <int MODE>
+__device__ __forceinline__ void load_tile(f32x4 (&r)[4], const Operand& op, const ConvGeom& g,
+                                          const float* base, int row0, int nrows, int k0, int kend,
+                                          const RowInfo (&ri)[4], int tap_z) {
+    const int tid = threadIdx.x;
+    if constexpr (MODE == OP_KC) {
+        const int c4 = tid & 7, r0 = tid >> 3;
+        const int gk = k0 + c4 * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gr = row0 + r0 + 32 * i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gr < nrows && gk < kend) {
+                const float* p = base + (long long)gr * op.ld + gk;
+                if (op.vec) {
+                    v = ld4(p);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (gk + e < kend) v[e] = p[e];
+                }
+            }
+            r[i] = v;
+        }
+    } else if constexpr (MODE == OP_IM2COL) {
+        const int c4 = tid & 7;
+        const int gk = k0 + c4 * 4;
+        const int Ct = g.C1 + g.C2;
+        if (op.vec) {
+            // 4 consecutive k share one tap and one source
+            const int tap = gk / Ct;
+            const int c = gk - tap * Ct;
+            const int ky = tap / g.KW, kx = tap - ky * g.KW;
+            const bool second = c >= g.C1;
+            const float* src = second ? op.p2 : base;
+            const int cs = second ? g.C2 : g.C1;
+            const int cc = second ? c - g.C1 : c;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ri[i].img >= 0 && gk < kend) {
+                    int iy = ri[i].oy * g.stride + ky - g.pad;
+                    int ix = ri[i].ox * g.stride + kx - g.pad;
+                    bool ok = true;
+                    if (g.tstride > 1) {
+                        ok = (iy % g.tstride == 0) && (ix % g.tstride == 0) && iy >= 0 && ix >= 0;
+                        iy /= g.tstride;
+                        ix /= g.tstride;
+                    }
+                    if (ok && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW)
+                        v = ld4(src + ((long long)(ri[i].img * g.IH + iy) * g.IW + ix) * cs + cc);
+                }
+                r[i] = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ri[i].img >= 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = gk + e;
+                        if (k >= kend) continue;
+                        const int tap = k / Ct;
+                        const int c = k - tap * Ct;
+                        const int ky = tap / g.KW, kx = tap - ky * g.KW;
+                        int iy = ri[i].oy * g.stride + ky - g.pad;
+                        int ix = ri[i].ox * g.stride + kx - g.pad;
+                        bool ok = true;
+                        if (g.tstride > 1) {
+                            ok = (iy % g.tstride == 0) && (ix % g.tstride == 0) && iy >= 0 && ix >= 0;
+                            iy /= g.tstride;
+                            ix /= g.tstride;
+                        }
+                        if (ok && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW) {
+                            const bool second = c >= g.C1;
+                            const float* src = second ? op.p2 : base;
+                            const int cs = second ? g.C2 : g.C1;
+                            const int cc = second ? c - g.C1 : c;
+                            v[e] = src[((long long)(ri[i].img * g.IH + iy) * g.IW + ix) * cs + cc];
+                        }
+                    }
+                }
+                r[i] = v;
+            }
+        }
+    } else if constexpr (MODE == OP_MC) {
+        const int c = tid & 31, kr = tid >> 5;
+        const int gm = row0 + c * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gk = k0 + kr + 8 * i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gk < kend && gm < nrows) {
+                const float* p = base + (long long)gk * op.ld + gm;
+                if (op.vec) {
+                    v = ld4(p);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (gm + e < nrows) v[e] = p[e];
+                }
+            }
+            r[i] = v;
+        }
+    } else {  // OP_SHIFT: k indexes OUTPUT pixels of the conv; value = X[img, oy*s+ky-p, ox*s+kx-p, m]
+        const int c = tid & 31, kr = tid >> 5;
+        const int gm = row0 + c * 4;
+        const int ky = tap_z / g.KW, kx = tap_z - ky * g.KW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gk = k0 + kr + 8 * i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gk < kend && gm < nrows) {
+                const int ox = gk % g.OW;
+                const int t = gk / g.OW;
+                const int oy = t % g.OH;
+                const int img = t / g.OH;
+                const int iy = oy * g.stride + ky - g.pad;
+                const int ix = ox * g.stride + kx - g.pad;
+                if (iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW) {
+                    const float* p = base + ((long long)(img * g.IH + iy) * g.IW + ix) * op.ld + gm;
+                    if (op.vec) {
+                        v = ld4(p);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (gm + e < nrows) v[e] = p[e];
+                    }
+                }
+            }
+            r[i] = v;
+        }
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void store_tile(float* lds, const f32x4 (&r)[4]) {
+    const int tid = threadIdx.x;
+    if constexpr (MODE == OP_KC || MODE == OP_IM2COL) {
+        const int c4 = tid & 7, r0 = tid >> 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<f32x4*>(lds + (r0 + 32 * i) * KC_LD + c4 * 4) = r[i];
+    } else {
+        const int c = tid & 31, kr = tid >> 5;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<f32x4*>(lds + (kr + 8 * i) * MC_LD + c * 4) = r[i];
+    }
+}
+
+template <int AMODE, int BMODE>
+__global__ void __launch_bounds__(NTHREADS, 2) tile_kernel(const TileArgs a) {
+    constexpr bool A_KC = (AMODE == OP_KC || AMODE == OP_IM2COL);
+    constexpr bool B_KC = (BMODE == OP_KC || BMODE == OP_IM2COL);
+    __shared__ __attribute__((aligned(16))) float As[A_KC ? BM * KC_LD : BK * MC_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[B_KC ? BN * KC_LD : BK * MC_LD];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int tiles_n = (a.N + BN - 1) / BN;
+    const int tile_m = blockIdx.x / tiles_n;
+    const int tile_n = blockIdx.x - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int z = blockIdx.y;
+    const int split = z % a.nsplit;
+    const int zb = z / a.nsplit;
+    const int kbeg = split * a.kper;
+    const int kend = min(a.K, kbeg + a.kper);
+
+    const float* Abase = a.A.p + (long long)zb * a.A.stride_z;
+    const float* Bbase = a.B.p + (long long)zb * a.B.stride_z;
+
+    RowInfo ri[4];
+    if constexpr (AMODE == OP_IM2COL) {
+        const int r0 = tid >> 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gm = m0 + r0 + 32 * i;
+            if (gm < a.M) {
+                ri[i].ox = gm % a.g.OW;
+                const int t = gm / a.g.OW;
+                ri[i].oy = t % a.g.OH;
+                ri[i].img = t / a.g.OH;
+            } else {
+                ri[i].img = -1;
+                ri[i].oy = ri[i].ox = 0;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ri[i].img = ri[i].oy = ri[i].ox = 0;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+    f32x4 ra[4], rb[4];
+    load_tile<AMODE>(ra, a.A, a.g, Abase, m0, a.M, kbeg, kend, ri, zb);
+    load_tile<BMODE>(rb, a.B, a.g, Bbase, n0, a.N, kbeg, kend, ri, zb);
+    store_tile<AMODE>(As, ra);
+    store_tile<BMODE>(Bs, rb);
+    __syncthreads();
+
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        const bool more = (k0 + BK) < kend;
+        if (more) {
+            load_tile<AMODE>(ra, a.A, a.g, Abase, m0, a.M, k0 + BK, kend, ri, zb);
+            load_tile<BMODE>(rb, a.B, a.g, Bbase, n0, a.N, k0 + BK, kend, ri, zb);
+        }
+#pragma unroll
+        for (int j = 0; j < BK / 8; ++j) {
+            float af[2][4], bf[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if constexpr (A_KC) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(As + (wr * 64 + i * 32 + r) * KC_LD + 8 * j + 4 * h);
+                    af[i][0] = t[0]; af[i][1] = t[1]; af[i][2] = t[2]; af[i][3] = t[3];
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) af[i][s] = As[(8 * j + 4 * h + s) * MC_LD + wr * 64 + i * 32 + r];
+                }
+                if constexpr (B_KC) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(Bs + (wc * 64 + i * 32 + r) * KC_LD + 8 * j + 4 * h);
+                    bf[i][0] = t[0]; bf[i][1] = t[1]; bf[i][2] = t[2]; bf[i][3] = t[3];
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) bf[i][s] = Bs[(8 * j + 4 * h + s) * MC_LD + wc * 64 + i * 32 + r];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[n][s], acc[i][n], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            store_tile<AMODE>(As, ra);
+            store_tile<BMODE>(Bs, rb);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: C/D layout of v_mfma_f32_32x32x2: col = lane&31, row = (v&3) + 8*(v>>2) + 4*(lane>>5)
+    float* Cb = a.C + (long long)zb * a.c_stride_z + (long long)split * a.c_stride_split;
+    const float* Rb = a.e.res ? a.e.res + (long long)zb * a.e.res_stride_z : nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int gn = n0 + wc * 64 + n * 32 + r;
+            if (gn >= a.N) continue;
+            const float bias = a.e.bias ? a.e.bias[gn] : 0.f;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int gm = m0 + wr * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                if (gm >= a.M) continue;
+                float x = acc[i][n][v] * a.e.alpha + bias;
+                if (a.e.rowbias) x += a.e.rowbias[(long long)(gm / a.e.rows_per_img) * a.e.ld_rowbias + gn];
+                if (Rb) x += Rb[(long long)gm * a.e.ldres + gn];
+                x *= a.e.out_scale;
+                float* cp = Cb + (long long)gm * a.ldc + gn;
+                if (a.e.accumulate) x += *cp;
+                *cp = x;
+            }
+        }
+    }
+}
+
+template <int AMODE, int BMODE>
+int launch(const TileArgs& a, int nz, hipStream_t stream, const char* name) {
+    if (a.M <= 0 || a.N <= 0 || nz <= 0) return PSLD_OK;
+    const long long tiles = (long long)cdiv(a.M, BM) * cdiv(a.N, BN);
+    PSLD_CHECK_ARG(tiles < (1LL << 31) && nz * a.nsplit <= 65535, "%s: grid too large", name);
+    dim3 grid((unsigned)tiles, (unsigned)(nz * a.nsplit));
+    hipLaunchKernelGGL((tile_kernel<AMODE, BMODE>), grid, dim3(NTHREADS), 0, stream, a);
+    PSLD_CHECK_LAUNCH(name);
+    return PSLD_OK;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+Epilogue make_epilogue(const psld_epilogue_t* e) {
+    Epilogue o;
+    o.alpha = 1.f; o.bias = nullptr; o.rowbias = nullptr; o.ld_rowbias = 0; o.rows_per_img = 1;
+    o.res = nullptr; o.ldres = 0; o.res_stride_z = 0; o.out_scale = 1.f; o.accumulate = 0;
+    if (e) {
+        o.alpha = e->alpha; o.bias = e->bias; o.rowbias = e->rowbias; o.ld_rowbias = e->ld_rowbias;
+        o.rows_per_img = e->rows_per_img > 0 ? e->rows_per_img : 1;
+        o.res = e->residual; o.ldres = e->ld_residual; o.res_stride_z = e->residual_stride_batch;
+        o.out_scale = e->out_scale; o.accumulate = e->accumulate;
+    }
+    return o;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+extern "C" int psld_gemm_f32(int trans_a, int trans_b, int M, int N, int K,
+                             const float* A, int lda, long long stride_a,
+                             const float* B, int ldb, long long stride_b,
+                             float* C, int ldc, long long stride_c, int batch,
+                             const psld_epilogue_t* epi, hipStream_t stream) {
+    PSLD_CHECK_ARG(A && B && C, "psld_gemm_f32: null pointer");
+    PSLD_CHECK_ARG(M >= 0 && N >= 0 && K > 0 && batch >= 1, "psld_gemm_f32: bad shape %d %d %d x%d", M, N, K, batch);
+    TileArgs a{};
+    a.M = M; a.N = N; a.K = K;
+    a.A = {A, nullptr, stride_a, lda, 0};
+    a.B = {B, nullptr, stride_b, ldb, 0};
+    a.C = C; a.c_stride_z = stride_c; a.c_stride_split = 0; a.ldc = ldc;
+    a.nsplit = 1; a.kper = cdiv(K, BK) * BK;
+    a.e = make_epilogue(epi);
+    // op(A) is M x K.  trans_a == 0: A stored [M][K] (K contiguous);  1: stored [K][M].
+    // op(B) is K x N.  trans_b == 0: B stored [K][N] (N contiguous);  1: stored [N][K].
+    if (!trans_a) a.A.vec = aligned16(A) && lda % 4 == 0 && K % 4 == 0 && stride_a % 4 == 0;
+    else          a.A.vec = aligned16(A) && lda % 4 == 0 && M % 4 == 0 && stride_a % 4 == 0;
+    if (trans_b)  a.B.vec = aligned16(B) && ldb % 4 == 0 && K % 4 == 0 && stride_b % 4 == 0;
+    else          a.B.vec = aligned16(B) && ldb % 4 == 0 && N % 4 == 0 && stride_b % 4 == 0;
+    if (!trans_a && trans_b)  return launch<OP_KC, OP_KC>(a, batch, stream, "psld_gemm_f32[NT]");
+    if (!trans_a && !trans_b) return launch<OP_KC, OP_MC>(a, batch, stream, "psld_gemm_f32[NN]");
+    if (trans_a && !trans_b)  return launch<OP_MC, OP_MC>(a, batch, stream, "psld_gemm_f32[TN]");
+    return launch<OP_MC, OP_KC>(a, batch, stream, "psld_gemm_f32[TT]");
+}
+
+// Split-K TN GEMM into slabs: slabs[s][M][N] = A[ks..ke]^T B[ks..ke]; caller reduces.
+extern "C" int psld_gemm_tn_splitk_f32(int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                                       float* slabs, int nsplit, hipStream_t stream) {
+    PSLD_CHECK_ARG(A && B && slabs && nsplit >= 1, "psld_gemm_tn_splitk_f32: bad args");
+    TileArgs a{};
+    a.M = M; a.N = N; a.K = K;
+    a.A = {A, nullptr, 0, lda, aligned16(A) && lda % 4 == 0 && M % 4 == 0};
+    a.B = {B, nullptr, 0, ldb, aligned16(B) && ldb % 4 == 0 && N % 4 == 0};
+    a.C = slabs; a.c_stride_z = 0; a.c_stride_split = (long long)M * N; a.ldc = N;
+    a.nsplit = nsplit; a.kper = cdiv(cdiv(K, nsplit), BK) * BK;
+    a.e = make_epilogue(nullptr);
+    return launch<OP_MC, OP_MC>(a, 1, stream, "psld_gemm_tn_splitk_f32");
+}
+
+extern "C" int psld_conv2d_nhwc_f32(const float* x1, int c1, const float* x2, int c2,
+                                    int batch, int ih, int iw,
+                                    const float* w_ohwi, int cout, int kh, int kw,
+                                    int stride, int pad, int transposed_stride,
+                                    int oh, int ow, float* y, int ldy,
+                                    const psld_epilogue_t* epi, hipStream_t stream) {
+    PSLD_CHECK_ARG(x1 && w_ohwi && y, "psld_conv2d_nhwc_f32: null pointer");
+    PSLD_CHECK_ARG(c1 > 0 && c2 >= 0 && (c2 == 0 || x2), "psld_conv2d_nhwc_f32: bad channel split");
+    PSLD_CHECK_ARG(stride >= 1 && transposed_stride >= 1, "psld_conv2d_nhwc_f32: bad stride");
+    const int ct = c1 + c2;
+    TileArgs a{};
+    a.M = batch * oh * ow; a.N = cout; a.K = kh * kw * ct;
+    a.A = {x1, x2, 0, 0, 0};
+    a.A.vec = aligned16(x1) && (!x2 || aligned16(x2)) && c1 % 4 == 0 && c2 % 4 == 0;
+    a.B = {w_ohwi, nullptr, 0, a.K, aligned16(w_ohwi) && a.K % 4 == 0};
+    a.C = y; a.ldc = ldy; a.c_stride_z = 0; a.c_stride_split = 0;
+    a.nsplit = 1; a.kper = cdiv(a.K, BK) * BK;
+    a.g = {ih, iw, c1, c2, oh, ow, kh, kw, stride, pad, transposed_stride};
+    a.e = make_epilogue(epi);
+    return launch<OP_IM2COL, OP_KC>(a, 1, stream, "psld_conv2d_nhwc_f32");
+}
+
+// dW slabs: slabs[s][cout][kh*kw][cin_total] restricted to columns [col0, col0+cin) for input x.
+extern "C" int psld_conv2d_wgrad_nhwc_f32(const float* dy, int lddy, int cout,
+                                          const float* x, int cin, int batch, int ih, int iw,
+                                          int kh, int kw, int stride, int pad, int oh, int ow,
+                                          float* slabs, int cin_total, int col0, int nsplit,
+                                          hipStream_t stream) {
+    PSLD_CHECK_ARG(dy && x && slabs && nsplit >= 1, "psld_conv2d_wgrad_nhwc_f32: bad args");
+    TileArgs a{};
+    a.M = cout; a.N = cin; a.K = batch * oh * ow;
+    a.A = {dy, nullptr, 0, lddy, aligned16(dy) && lddy % 4 == 0 && cout % 4 == 0};
+    a.B = {x, nullptr, 0, cin, aligned16(x) && cin % 4 == 0};
+    a.C = slabs + col0;
+    a.ldc = kh * kw * cin_total;
+    a.c_stride_z = cin_total;                                  // tap -> column block
+    a.c_stride_split = (long long)cout * kh * kw * cin_total;  // slab
+    a.nsplit = nsplit; a.kper = cdiv(cdiv(a.K, nsplit), BK) * BK;
+    a.g = {ih, iw, cin, 0, oh, ow, kh, kw, stride, pad, 1};
+    a.e = make_epilogue(nullptr);
+    return launch<OP_MC, OP_SHIFT>(a, kh * kw, stream, "psld_conv2d_wgrad_nhwc_f32");
+}

@@ -1,0 +1,384 @@
+"""Thin Python front-ends of the C ABI: torch tensors in (as device pointers on the current HIP
+stream), nothing else.  PyTorch supplies memory and streams only; every computation below runs in
+libpsld_hip.so.  All tensors must be contiguous CUDA(ROCm) tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Epilogue, EmCoeffs, SdeParams, check
+
+Tensor = torch.Tensor
+INV_SQRT2 = float(1.0 / np.sqrt(2.0))
+
+
+def lib():
+    return _lib.load()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[Tensor]):
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def _chk(t: Tensor, dtype=torch.float32):
+    if not t.is_cuda:
+        raise RuntimeError("psld_amd kernels need device tensors (no CPU fallback)")
+    if t.dtype != dtype or not t.is_contiguous():
+        raise RuntimeError(f"expected contiguous {dtype} tensor, got {t.dtype} contiguous={t.is_contiguous()}")
+    return t
+
+
+def epilogue(alpha: float = 1.0, bias: Optional[Tensor] = None, rowbias: Optional[Tensor] = None,
+             rows_per_img: int = 1, residual: Optional[Tensor] = None, ld_residual: int = 0,
+             residual_stride_batch: int = 0, out_scale: float = 1.0, accumulate: bool = False) -> Epilogue:
+    e = Epilogue()
+    e.alpha = alpha
+    e.bias = _p(bias)
+    e.rowbias = _p(rowbias)
+    e.ld_rowbias = rowbias.shape[-1] if rowbias is not None else 0
+    e.rows_per_img = rows_per_img
+    e.residual = _p(residual)
+    e.ld_residual = ld_residual
+    e.residual_stride_batch = residual_stride_batch
+    e.out_scale = out_scale
+    e.accumulate = 1 if accumulate else 0
+    return e
+
+
+# ------------------------------------------------------------------------------------------------
+# MFMA tile engine
+# ------------------------------------------------------------------------------------------------
+def gemm_raw(ta: int, tb: int, M: int, N: int, K: int, A: Tensor, lda: int, sa: int, B: Tensor, ldb: int,
+             sb: int, Cc: Tensor, ldc: int, sc: int, batch: int = 1, epi: Optional[Epilogue] = None,
+             a_off: int = 0, b_off: int = 0, c_off: int = 0):
+    """C = epilogue(op(A) op(B)); offsets are in elements."""
+    check(lib().psld_gemm_f32(ta, tb, M, N, K, A.data_ptr() + 4 * a_off, lda, sa, B.data_ptr() + 4 * b_off, ldb, sb,
+                              Cc.data_ptr() + 4 * c_off, ldc, sc, batch,
+                              C.byref(epi) if epi is not None else None, _stream()), "psld_gemm_f32")
+
+
+def linear(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    """y[M,N] = x[M,K] w[N,K]^T + bias  (nn.Linear / 1x1 conv with OI weights)."""
+    M, K = x.shape[0], x.shape[-1]
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    gemm_raw(0, 1, M, N, K, x, K, 0, w, K, 0, out, N, 0, 1, epilogue(bias=bias) if bias is not None else None)
+    return out
+
+
+def gemm_tn_splitk(M: int, N: int, K: int, A: Tensor, lda: int, B: Tensor, ldb: int, slabs: Tensor, nsplit: int):
+    check(lib().psld_gemm_tn_splitk_f32(M, N, K, A.data_ptr(), lda, B.data_ptr(), ldb, slabs.data_ptr(), nsplit,
+                                        _stream()), "psld_gemm_tn_splitk_f32")
+
+
+def conv2d_nhwc(x1: Tensor, x2: Optional[Tensor], w_ohwi: Tensor, cout: int, kh: int, kw: int, stride: int, pad: int,
+                tstride: int, oh: int, ow: int, y: Tensor, epi: Optional[Epilogue] = None, ldy: Optional[int] = None):
+    b, ih, iw, c1 = x1.shape
+    c2 = x2.shape[-1] if x2 is not None else 0
+    check(lib().psld_conv2d_nhwc_f32(x1.data_ptr(), c1, _p(x2), c2, b, ih, iw, w_ohwi.data_ptr(), cout, kh, kw,
+                                     stride, pad, tstride, oh, ow, y.data_ptr(), ldy if ldy is not None else cout,
+                                     C.byref(epi) if epi is not None else None, _stream()), "psld_conv2d_nhwc_f32")
+
+
+def conv2d_wgrad_nhwc(dy: Tensor, cout: int, x: Tensor, kh: int, kw: int, stride: int, pad: int, oh: int, ow: int,
+                      slabs: Tensor, cin_total: int, col0: int, nsplit: int):
+    b, ih, iw, cin = x.shape
+    check(lib().psld_conv2d_wgrad_nhwc_f32(dy.data_ptr(), cout, cout, x.data_ptr(), cin, b, ih, iw, kh, kw, stride,
+                                           pad, oh, ow, slabs.data_ptr(), cin_total, col0, nsplit, _stream()),
+          "psld_conv2d_wgrad_nhwc_f32")
+
+
+def reduce_slabs(slabs: Tensor, nsplit: int, n: int, out: Tensor, layout: int = 0, cout: int = 0, taps: int = 0,
+                 cin: int = 0):
+    check(lib().psld_reduce_slabs_f32(slabs.data_ptr(), nsplit, n, out.data_ptr(), layout, cout, taps, cin,
+                                      _stream()), "psld_reduce_slabs_f32")
+
+
+def pack_ohwi(w_oihw: Tensor, out: Tensor):
+    co, ci = w_oihw.shape[0], w_oihw.shape[1]
+    taps = w_oihw.shape[2] * w_oihw.shape[3]
+    check(lib().psld_pack_oihw_to_ohwi_f32(w_oihw.data_ptr(), out.data_ptr(), co, ci, taps, _stream()), "pack_ohwi")
+
+
+def pack_dgrad(w_oihw: Tensor, out: Tensor):
+    co, ci = w_oihw.shape[0], w_oihw.shape[1]
+    taps = w_oihw.shape[2] * w_oihw.shape[3]
+    check(lib().psld_pack_oihw_to_dgrad_f32(w_oihw.data_ptr(), out.data_ptr(), co, ci, taps, _stream()), "pack_dgrad")
+
+
+def nchw_to_nhwc(x: Tensor) -> Tensor:
+    b, c, h, w = x.shape
+    y = torch.empty((b, h, w, c), device=x.device, dtype=torch.float32)
+    check(lib().psld_nchw_to_nhwc_f32(_chk(x).data_ptr(), y.data_ptr(), b, c, h * w, _stream()), "nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x: Tensor) -> Tensor:
+    b, h, w, c = x.shape
+    y = torch.empty((b, c, h, w), device=x.device, dtype=torch.float32)
+    check(lib().psld_nhwc_to_nchw_f32(_chk(x).data_ptr(), y.data_ptr(), b, c, h * w, _stream()), "nhwc_to_nchw")
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+# GroupNorm (+SiLU)
+# ------------------------------------------------------------------------------------------------
+_ws_cache = {}
+
+
+def workspace(nbytes: int, device) -> Tensor:
+    """Grow-only scratch buffer per (device, stream): kernels using it are stream-ordered."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
+    t = _ws_cache.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(int(nbytes), 1 << 20), device=device, dtype=torch.uint8)
+        _ws_cache[key] = t
+    return t
+
+
+class GNStats:
+    __slots__ = ("mean", "rstd", "scale", "shift")
+
+    def __init__(self, b, g, c, device):
+        self.mean = torch.empty((b, g), device=device, dtype=torch.float32)
+        self.rstd = torch.empty((b, g), device=device, dtype=torch.float32)
+        self.scale = torch.empty((b, c), device=device, dtype=torch.float32)
+        self.shift = torch.empty((b, c), device=device, dtype=torch.float32)
+
+
+def gn_groups(c: int) -> int:
+    return min(c // 4, 32)
+
+
+def gn_stats(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-6) -> GNStats:
+    b, h, w, c = x.shape
+    g = gn_groups(c)
+    st = GNStats(b, g, c, x.device)
+    ws = workspace(lib().psld_gn_workspace_bytes(b, h * w, c, g), x.device)
+    check(lib().psld_gn_stats_nhwc_f32(x.data_ptr(), b, h * w, c, g, eps, gamma.data_ptr(), beta.data_ptr(),
+                                       st.mean.data_ptr(), st.rstd.data_ptr(), st.scale.data_ptr(),
+                                       st.shift.data_ptr(), ws.data_ptr(), _stream()), "psld_gn_stats_nhwc_f32")
+    return st
+
+
+def gn_apply(x: Tensor, st: GNStats, act: bool, out: Optional[Tensor] = None) -> Tensor:
+    b, h, w, c = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().psld_gn_apply_nhwc_f32(x.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), out.data_ptr(), b,
+                                       h * w, c, 1 if act else 0, _stream()), "psld_gn_apply_nhwc_f32")
+    return out
+
+
+def gn_bwd(dy: Tensor, x: Tensor, st: GNStats, gamma: Tensor, beta: Tensor, act: bool, dx: Tensor, dgamma: Tensor,
+           dbeta: Tensor, accumulate_dx: bool = False):
+    b, h, w, c = x.shape
+    g = gn_groups(c)
+    ws = workspace(lib().psld_gn_workspace_bytes(b, h * w, c, g), x.device)
+    check(lib().psld_gn_bwd_nhwc_f32(dy.data_ptr(), x.data_ptr(), st.mean.data_ptr(), st.rstd.data_ptr(),
+                                     gamma.data_ptr(), beta.data_ptr(), b, h * w, c, g, 1 if act else 0,
+                                     dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 1 if accumulate_dx else 0,
+                                     ws.data_ptr(), _stream()), "psld_gn_bwd_nhwc_f32")
+
+
+# ------------------------------------------------------------------------------------------------
+# FIR resampling
+# ------------------------------------------------------------------------------------------------
+def _pad4(pad):
+    """(p0, p1) -> same pads on x and y like the reference's public wrapper (op/upfirdn2d.py:145-156);
+    (x0, x1, y0, y1) as the pybind op itself takes them (op/upfirdn2d.cpp:12-22)."""
+    if len(pad) == 2:
+        return (pad[0], pad[1], pad[0], pad[1])
+    return tuple(pad)
+
+
+def upfirdn2d_out_size(in_h, in_w, kh, kw, up, down, pad):
+    px0, px1, py0, py1 = _pad4(pad)
+    return ((in_h * up + py0 + py1 - kh) // down + 1, (in_w * up + px0 + px1 - kw) // down + 1)
+
+
+def upfirdn2d_raw(x: Tensor, kernel: np.ndarray, up: int, down: int, pad, layout: int,
+                  out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """layout 0: x is NCHW; 1: NHWC.  ``kernel`` is a host float32 [kh,kw] array."""
+    k = np.ascontiguousarray(kernel, dtype=np.float32)
+    kh, kw = k.shape
+    px0, px1, py0, py1 = _pad4(pad)
+    if layout == 0:
+        b, c, h, w = x.shape
+    else:
+        b, h, w, c = x.shape
+    oh, ow = upfirdn2d_out_size(h, w, kh, kw, up, down, pad)
+    if out is None:
+        shape = (b, c, oh, ow) if layout == 0 else (b, oh, ow, c)
+        out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    check(lib().psld_upfirdn2d_f32(_chk(x).data_ptr(), out.data_ptr(), b, c, h, w, k.ctypes.data, kh, kw, up, up,
+                                   down, down, px0, px1, py0, py1, layout, 1 if accumulate else 0,
+                                   _stream()), "psld_upfirdn2d_f32")
+    return out
+
+
+def upfirdn2d_bwd_raw(gy: Tensor, kernel: np.ndarray, up: int, down: int, pad, in_hw: Tuple[int, int],
+                      layout: int, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """Gradient w.r.t. the input: the same op with flipped kernel, up<->down and g_pad
+    (op/upfirdn2d.py:31-42,111-116)."""
+    k = np.ascontiguousarray(kernel, dtype=np.float32)
+    kh, kw = k.shape
+    in_h, in_w = in_hw
+    px0, px1, py0, py1 = _pad4(pad)
+    oh, ow = upfirdn2d_out_size(in_h, in_w, kh, kw, up, down, pad)
+    gx0 = kw - px0 - 1
+    gy0 = kh - py0 - 1
+    gx1 = in_w * up - ow * down + px0 - up + 1
+    gy1 = in_h * up - oh * down + py0 - up + 1
+    return upfirdn2d_raw(gy, k[::-1, ::-1], down, up, (gx0, gx1, gy0, gy1), layout, out=out, accumulate=accumulate)
+
+
+# ------------------------------------------------------------------------------------------------
+# pointwise
+# ------------------------------------------------------------------------------------------------
+def axpby(a: Tensor, sa: float, b: Optional[Tensor], sb: float, out: Tensor, accumulate: bool = False):
+    check(lib().psld_axpby_f32(a.data_ptr(), sa, _p(b), sb, out.data_ptr(), a.numel(), 1 if accumulate else 0,
+                               _stream()), "psld_axpby_f32")
+    return out
+
+
+def silu(x: Tensor) -> Tensor:
+    y = torch.empty_like(x)
+    check(lib().psld_silu_f32(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "psld_silu_f32")
+    return y
+
+
+def silu_bwd(x: Tensor, dy: Tensor) -> Tensor:
+    dx = torch.empty_like(x)
+    check(lib().psld_silu_bwd_f32(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), _stream()), "psld_silu_bwd")
+    return dx
+
+
+def colsum(x: Tensor, ld: int, batch: int, hw: int, c: int, out: Tensor):
+    check(lib().psld_colsum_f32(x.data_ptr(), ld, batch, hw, c, out.data_ptr(), _stream()), "psld_colsum_f32")
+    return out
+
+
+def softmax_rows(x: Tensor, out: Tensor, rows: int, L: int):
+    check(lib().psld_softmax_rows_f32(x.data_ptr(), out.data_ptr(), rows, L, _stream()), "psld_softmax_rows_f32")
+
+
+def softmax_rows_bwd(y: Tensor, dy: Tensor, dx: Tensor, rows: int, L: int):
+    check(lib().psld_softmax_rows_bwd_f32(y.data_ptr(), dy.data_ptr(), dx.data_ptr(), rows, L, _stream()),
+          "psld_softmax_rows_bwd_f32")
+
+
+def time_embed(t: Tensor, W: Tensor, use_log: bool) -> Tensor:
+    b, e = t.shape[0], W.shape[0]
+    out = torch.empty((b, 2 * e), device=t.device, dtype=torch.float32)
+    check(lib().psld_time_embed_f32(_chk(t).data_ptr(), W.data_ptr(), out.data_ptr(), b, e, 1 if use_log else 0,
+                                    _stream()), "psld_time_embed_f32")
+    return out
+
+
+def fused_bias_act(x: Tensor, bias: Optional[Tensor], act: int = 3, alpha: float = 0.2, scale: float = 2 ** 0.5):
+    """Inventory parity with op/fused_act.py:86-97 (forward): bias indexed along dim 1."""
+    y = torch.empty_like(x)
+    step_b = 1
+    for d in x.shape[2:]:
+        step_b *= d
+    check(lib().psld_fused_bias_act_f32(_chk(x).data_ptr(), _p(bias), y.data_ptr(), x.numel(),
+                                        bias.numel() if bias is not None else 1, step_b, act, alpha, scale, _stream()),
+          "psld_fused_bias_act_f32")
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+# SDE / loss / sampler / optimiser
+# ------------------------------------------------------------------------------------------------
+COEFF_STRIDE = 12
+
+
+def perturb_coeffs(t: Tensor, params: SdeParams, xx_0: float, mm_0: float, nan_flag: Tensor) -> Tensor:
+    b = t.shape[0]
+    out = torch.empty((b, COEFF_STRIDE), device=t.device, dtype=torch.float64)
+    check(lib().psld_perturb_coeffs_f64(_chk(t, torch.float64).data_ptr(), b, C.byref(params), float(xx_0),
+                                        float(mm_0), out.data_ptr(), nan_flag.data_ptr(), _stream()),
+          "psld_perturb_coeffs_f64")
+    return out
+
+
+def perturb(x0: Tensor, m0: Optional[Tensor], eps: Tensor, coeffs: Tensor, params: SdeParams, want_f32=True,
+            want_f64=False, want_mu=False):
+    b, c, h, w = x0.shape
+    z = torch.empty((b, 2 * c, h, w), device=x0.device, dtype=torch.float32) if want_f32 else None
+    u = torch.empty((b, 2 * c, h, w), device=x0.device, dtype=torch.float64) if want_f64 else None
+    mu = torch.empty((b, 2 * c, h, w), device=x0.device, dtype=torch.float64) if want_mu else None
+    check(lib().psld_perturb_f32(_chk(x0).data_ptr(), _p(m0), _chk(eps).data_ptr(), coeffs.data_ptr(),
+                                 C.byref(params), b, c, h * w, _p(z), _p(u), _p(mu), _stream()), "psld_perturb_f32")
+    return z, u, mu
+
+
+def sqerr_loss(eps: Tensor, eps_pred: Tensor, reduce_mean: bool, want_grad: bool, grad_scale: float = 1.0):
+    n = eps.numel()
+    loss = torch.empty((), device=eps.device, dtype=torch.float32)
+    grad = torch.empty_like(eps_pred) if want_grad else None
+    ws = workspace(lib().psld_reduce_workspace_bytes(n), eps.device)
+    check(lib().psld_sqerr_loss_f32(_chk(eps).data_ptr(), _chk(eps_pred).data_ptr(), n, 1 if reduce_mean else 0,
+                                    loss.data_ptr(), _p(grad), grad_scale, ws.data_ptr(), _stream()),
+          "psld_sqerr_loss_f32")
+    return loss, grad
+
+
+def em_step(x: Tensor, eps_pred: Tensor, z: Optional[Tensor], k: EmCoeffs, x_f32: Optional[Tensor]):
+    b, c2, h, w = x.shape
+    check(lib().psld_em_step_f64(_chk(x, torch.float64).data_ptr(), _chk(eps_pred).data_ptr(), _p(z), C.byref(k), b,
+                                 c2 // 2, h * w, _p(x_f32), _stream()), "psld_em_step_f64")
+
+
+def reverse_sde(x: Tensor, eps_pred: Tensor, k: EmCoeffs):
+    b, c2, h, w = x.shape
+    f = torch.empty_like(x)
+    g = torch.empty_like(x)
+    check(lib().psld_reverse_sde_f64(_chk(x, torch.float64).data_ptr(), _chk(eps_pred).data_ptr(), C.byref(k), b,
+                                     c2 // 2, h * w, f.data_ptr(), g.data_ptr(), _stream()), "psld_reverse_sde_f64")
+    return f, g
+
+
+def f64_to_f32(x: Tensor) -> Tensor:
+    y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    check(lib().psld_f64_to_f32(_chk(x, torch.float64).data_ptr(), y.data_ptr(), x.numel(), _stream()), "f64_to_f32")
+    return y
+
+
+def f32_to_f64(x: Tensor) -> Tensor:
+    y = torch.empty(x.shape, device=x.device, dtype=torch.float64)
+    check(lib().psld_f32_to_f64(_chk(x).data_ptr(), y.data_ptr(), x.numel(), _stream()), "f32_to_f64")
+    return y
+
+
+def grad_norm(g: Tensor, norm_out: Tensor):
+    ws = workspace(lib().psld_reduce_workspace_bytes(g.numel()), g.device)
+    check(lib().psld_grad_norm_f32(g.data_ptr(), g.numel(), norm_out.data_ptr(), ws.data_ptr(), _stream()),
+          "psld_grad_norm_f32")
+
+
+def adam_ema(p: Tensor, g: Tensor, m: Tensor, v: Tensor, ema: Optional[Tensor], norm: Optional[Tensor],
+             max_norm: float, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float, step: int,
+             ema_tau: float, write_clipped_grad: bool = False):
+    check(lib().psld_adam_ema_f32(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(ema), p.numel(),
+                                  _p(norm), max_norm, lr, beta1, beta2, eps, weight_decay, step, ema_tau,
+                                  1 if write_clipped_grad else 0, g.data_ptr() if write_clipped_grad else None,
+                                  _stream()), "psld_adam_ema_f32")
+
+
+def ema(target: Tensor, src: Tensor, tau: float):
+    check(lib().psld_ema_f32(target.data_ptr(), src.data_ptr(), target.numel(), tau, _stream()), "psld_ema_f32")

@@ -1,0 +1,373 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI (psld_amd.ops ->
+libpsld_hip.so) and checked against the CPU oracle / plain torch fp32 on the same seeded inputs.
+Tolerances: fp32 contractions 2e-6..1e-5 rel-L2 (k-ordered fmaf chain vs oneDNN blocking);
+f64 SDE math 1e-12; elementwise fp32 1e-6.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import psld_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from psld_amd import ops as _ops
+    _ops.lib()
+    return _ops
+
+
+def gen(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ---------------------------------------------------------------------------------------------------
+# tile engine
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (256, 256, 256), (200, 72, 100), (6, 130, 54), (1, 1, 4),
+                                   (300, 6, 2304), (129, 257, 36)])
+def test_gemm_layouts(ops, ta, tb, M, N, K):
+    A = gen(*((K, M) if ta else (M, K)), seed=1)
+    B = gen(*((N, K) if tb else (K, N)), seed=2)
+    ref = (A.t() if ta else A).double() @ (B.t() if tb else B).double()
+    Ad, Bd = A.to(DEV), B.to(DEV)
+    Cd = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm_raw(ta, tb, M, N, K, Ad, A.shape[1], 0, Bd, B.shape[1], 0, Cd, N, 0)
+    assert rel_l2(Cd, ref) < 2e-6
+
+
+def test_gemm_asymmetric_identity(ops):
+    """A = I with an asymmetric B catches a transposed C write (cdna guide §3)."""
+    n = 64
+    A = torch.eye(n)
+    B = torch.arange(n * n, dtype=torch.float32).reshape(n, n) / 7.0
+    Cd = torch.zeros(n, n, device=DEV)
+    ops.gemm_raw(0, 0, n, n, n, A.to(DEV), n, 0, B.to(DEV), n, 0, Cd, n, 0)
+    assert torch.equal(Cd.cpu(), B)
+
+
+def test_gemm_batched_epilogue(ops):
+    b, M, N, K = 3, 70, 96, 40
+    A, B = gen(b, M, K, seed=3), gen(b, N, K, seed=4)
+    bias, res = gen(N, seed=5), gen(b, M, N, seed=6)
+    rowb = gen(b * 7, N, seed=7)  # rows_per_img = 10 -> M/10 = 7 images per batch entry
+    ref = 0.5 * torch.einsum("bmk,bnk->bmn", A.double(), B.double()) + bias.double()
+    ref = ref + rowb[:7].double().repeat_interleave(10, dim=0)[None]
+    ref = (ref + res.double()) * 0.7
+    Cd = torch.ones(b, M, N, device=DEV)
+    ref = ref + 1.0
+    rb = rowb.to(DEV)
+    e = ops.epilogue(alpha=0.5, bias=bias.to(DEV), rowbias=rb, rows_per_img=10, residual=res.to(DEV), ld_residual=N,
+                     residual_stride_batch=M * N, out_scale=0.7, accumulate=True)
+    ops.gemm_raw(0, 1, M, N, K, A.to(DEV), K, M * K, B.to(DEV), K, N * K, Cd, N, M * N, b, e)
+    assert rel_l2(Cd, ref) < 2e-6
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(b=2, c1=32, c2=0, co=64, s=8, k=3, stride=1, pad=1),
+    dict(b=2, c1=64, c2=32, co=64, s=8, k=3, stride=1, pad=1),     # concat of two sources
+    dict(b=3, c1=32, c2=0, co=32, s=16, k=1, stride=1, pad=0),     # 1x1
+    dict(b=2, c1=6, c2=0, co=32, s=16, k=3, stride=1, pad=1),      # stem (scalar gather path)
+    dict(b=2, c1=64, c2=0, co=6, s=16, k=3, stride=1, pad=1),      # head (N=6)
+    dict(b=2, c1=32, c2=0, co=32, s=9, k=3, stride=2, pad=0),      # pyramid stride-2 pad-0
+    dict(b=1, c1=256, c2=256, co=256, s=8, k=3, stride=1, pad=1),  # north-star K=4608
+])
+def test_conv_forward(ops, cfg):
+    b, c1, c2, co, s, k = cfg["b"], cfg["c1"], cfg["c2"], cfg["co"], cfg["s"], cfg["k"]
+    stride, pad = cfg["stride"], cfg["pad"]
+    x = gen(b, c1 + c2, s, s, seed=10)
+    w = gen(co, c1 + c2, k, k, seed=11, scale=0.1)
+    bias = gen(co, seed=12)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), stride=stride, padding=pad)
+    oh = ref.shape[2]
+    x1 = _nhwc(x[:, :c1]).to(DEV)
+    x2 = _nhwc(x[:, c1:]).to(DEV) if c2 else None
+    wp = torch.empty(co, k * k, c1 + c2, device=DEV)
+    ops.pack_ohwi(w.to(DEV), wp)
+    assert torch.equal(wp.cpu(), w.permute(0, 2, 3, 1).reshape(co, k * k, c1 + c2))
+    y = torch.full((b, oh, oh, co), float("nan"), device=DEV)
+    ops.conv2d_nhwc(x1, x2, wp, co, k, k, stride, pad, 1, oh, oh, y, ops.epilogue(bias=bias.to(DEV)))
+    assert rel_l2(y.permute(0, 3, 1, 2), ref) < 3e-6
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(b=2, ci=32, co=64, s=8, k=3, stride=1, pad=1),
+    dict(b=2, ci=32, co=32, s=9, k=3, stride=2, pad=0),
+    dict(b=2, ci=64, co=6, s=8, k=3, stride=1, pad=1),   # head: dy has 6 channels (scalar path)
+    dict(b=2, ci=32, co=64, s=8, k=1, stride=1, pad=0),
+])
+def test_conv_dgrad_and_wgrad(ops, cfg):
+    b, ci, co, s, k, stride, pad = (cfg[n] for n in ("b", "ci", "co", "s", "k", "stride", "pad"))
+    x = gen(b, ci, s, s, seed=20).requires_grad_(True)
+    w = gen(co, ci, k, k, seed=21, scale=0.1).requires_grad_(True)
+    y = F.conv2d(x.double(), w.double(), stride=stride, padding=pad)
+    gy = gen(*y.shape, seed=22)
+    y.backward(gy.double())
+    oh = y.shape[2]
+    gyd = _nhwc(gy).to(DEV)
+    # dgrad = conv of dy with the flipped / transposed filter
+    wd = torch.empty(ci, k * k, co, device=DEV)
+    ops.pack_dgrad(w.detach().to(DEV), wd)
+    dx = torch.full((b, s, s, ci), float("nan"), device=DEV)
+    ops.conv2d_nhwc(gyd, None, wd, ci, k, k, 1, k - 1 - pad, stride, s, s, dx)
+    assert rel_l2(dx.permute(0, 3, 1, 2), x.grad) < 3e-6
+    # wgrad through split-K slabs, reduced straight into OIHW
+    nsplit = 3
+    slabs = torch.full((nsplit, co, k * k, ci), float("nan"), device=DEV)
+    ops.conv2d_wgrad_nhwc(gyd, co, _nhwc(x.detach()).to(DEV), k, k, stride, pad, oh, oh, slabs, ci, 0, nsplit)
+    dw = torch.empty(co, ci, k, k, device=DEV)
+    ops.reduce_slabs(slabs, nsplit, co * k * k * ci, dw, layout=1, cout=co, taps=k * k, cin=ci)
+    assert rel_l2(dw, w.grad) < 3e-6
+
+
+def test_gemm_tn_splitk(ops):
+    M, N, K = 64, 96, 1000
+    A, B = gen(K, M, seed=30), gen(K, N, seed=31)
+    slabs = torch.empty(4, M, N, device=DEV)
+    ops.gemm_tn_splitk(M, N, K, A.to(DEV), M, B.to(DEV), N, slabs, 4)
+    out = torch.empty(M, N, device=DEV)
+    ops.reduce_slabs(slabs, 4, M * N, out)
+    assert rel_l2(out, A.double().t() @ B.double()) < 2e-6
+
+
+# ---------------------------------------------------------------------------------------------------
+# GroupNorm + SiLU
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("b,c,s", [(2, 32, 8), (3, 64, 16), (2, 128, 32), (2, 256, 16), (1, 384, 8), (2, 512, 8)])
+@pytest.mark.parametrize("act", [True, False])
+def test_groupnorm_fwd_bwd(ops, b, c, s, act):
+    x = (gen(b, c, s, s, seed=40) * 1.5 + 0.3).requires_grad_(True)
+    gamma = (1 + 0.2 * gen(c, seed=41)).requires_grad_(True)
+    beta = (0.1 * gen(c, seed=42)).requires_grad_(True)
+    g = min(c // 4, 32)
+    y = F.group_norm(x.double(), g, gamma.double(), beta.double(), 1e-6)
+    if act:
+        y = F.silu(y)
+    gy = gen(*y.shape, seed=43)
+    y.backward(gy.double())
+    xd = _nhwc(x.detach()).to(DEV)
+    gd, bd = gamma.detach().to(DEV), beta.detach().to(DEV)
+    st = ops.gn_stats(xd, gd, bd)
+    yd = ops.gn_apply(xd, st, act)
+    assert rel_l2(yd.permute(0, 3, 1, 2), y) < 2e-6
+    dx = torch.full_like(xd, float("nan"))
+    dg, db = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    ops.gn_bwd(_nhwc(gy).to(DEV), xd, st, gd, bd, act, dx, dg, db)
+    assert rel_l2(dx.permute(0, 3, 1, 2), x.grad) < 1e-5
+    assert rel_l2(dg, gamma.grad) < 1e-5 and rel_l2(db, beta.grad) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------
+# FIR resampling (the reference's native op)
+# ---------------------------------------------------------------------------------------------------
+def test_upfirdn2d_golden(ops, golden):
+    g = golden("fir.npz")
+    x, k = torch.from_numpy(g["x"]), g["kasym"]
+    for i, (up, dn, p0, p1) in enumerate(g["cases"]):
+        y = ops.upfirdn2d_raw(x.to(DEV), k, int(up), int(dn), (int(p0), int(p1)), layout=0)
+        np.testing.assert_allclose(y.cpu().numpy(), g[f"y_{i}"], rtol=0, atol=3e-6)
+    x2 = torch.from_numpy(g["x2"])
+    k2 = O.fir_kernel_2d((1, 3, 3, 1))
+    up = ops.upfirdn2d_raw(_nhwc(x2).to(DEV), k2 * 4, 2, 1, (2, 1), layout=1)
+    np.testing.assert_allclose(up.permute(0, 3, 1, 2).cpu().numpy(), g["up2"], atol=2e-6)
+    dn = ops.upfirdn2d_raw(_nhwc(x2).to(DEV), k2, 1, 2, (1, 1), layout=1)
+    np.testing.assert_allclose(dn.permute(0, 3, 1, 2).cpu().numpy(), g["down2"], atol=2e-6)
+
+
+@pytest.mark.parametrize("up,down,pad", [(2, 1, (2, 1)), (1, 2, (1, 1)), (1, 1, (2, 2)), (3, 2, (0, 3))])
+def test_upfirdn2d_backward(ops, up, down, pad):
+    x = gen(2, 8, 9, 7, seed=50).requires_grad_(True)
+    k = torch.tensor([[1.0, 2.0, -1.0], [0.5, 3.0, 0.25], [-2.0, 1.5, 4.0], [0.1, 0.2, 0.3]])
+    y = O.upfirdn2d(x, k, up, down, pad)
+    gy = gen(*y.shape, seed=51)
+    y.backward(gy)
+    for layout in (0, 1):
+        gyd = (gy if layout == 0 else _nhwc(gy)).to(DEV)
+        dx = ops.upfirdn2d_bwd_raw(gyd, k.numpy(), up, down, pad, (9, 7), layout)
+        if layout == 1:
+            dx = dx.permute(0, 3, 1, 2)
+        assert dx.shape == x.shape
+        np.testing.assert_allclose(dx.cpu().numpy(), x.grad.numpy(), rtol=0, atol=5e-6)
+
+
+def test_fused_bias_act(ops):
+    x, b = gen(2, 5, 4, 4, seed=52), gen(5, seed=53)
+    ref = F.leaky_relu(x + b.view(1, -1, 1, 1), 0.2) * 2 ** 0.5   # op/fused_act.py:86-94
+    y = ops.fused_bias_act(x.to(DEV), b.to(DEV))
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), rtol=1e-6, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------------------------
+# pointwise / reductions
+# ---------------------------------------------------------------------------------------------------
+def test_layout_roundtrip(ops):
+    x = gen(3, 6, 5, 7, seed=60)
+    y = ops.nchw_to_nhwc(x.to(DEV))
+    assert torch.equal(y.cpu(), _nhwc(x))
+    assert torch.equal(ops.nhwc_to_nchw(y).cpu(), x)
+    x = gen(2, 70, 9, 9, seed=61)
+    assert torch.equal(ops.nhwc_to_nchw(ops.nchw_to_nhwc(x.to(DEV))).cpu(), x)
+
+
+def test_pointwise_and_reductions(ops):
+    a, b = gen(1003, seed=62), gen(1003, seed=63)
+    out = torch.ones(1003, device=DEV)
+    ops.axpby(a.to(DEV), 0.5, b.to(DEV), -2.0, out, accumulate=True)
+    np.testing.assert_allclose(out.cpu().numpy(), (a * 0.5 + b * -2.0 + 1).numpy(), rtol=1e-6, atol=1e-6)
+    x = gen(4096, seed=64) * 3
+    np.testing.assert_allclose(ops.silu(x.to(DEV)).cpu().numpy(), F.silu(x).numpy(), rtol=2e-6, atol=1e-7)
+    xr = x.clone().requires_grad_(True)
+    F.silu(xr).backward(torch.ones_like(xr) * 1.5)
+    np.testing.assert_allclose(ops.silu_bwd(x.to(DEV), torch.full((4096,), 1.5, device=DEV)).cpu().numpy(),
+                               xr.grad.numpy(), rtol=3e-6, atol=1e-7)
+    m = gen(3 * 50, 70, seed=65)
+    cs = torch.empty(3, 70, device=DEV)
+    ops.colsum(m.to(DEV), 70, 3, 50, 70, cs)
+    assert rel_l2(cs, m.double().reshape(3, 50, 70).sum(1)) < 1e-6
+    for L in (64, 256, 100):
+        s = gen(37, L, seed=66) * 4
+        y = torch.empty(37, L, device=DEV)
+        ops.softmax_rows(s.to(DEV), y, 37, L)
+        ref = F.softmax(s.double(), dim=-1)
+        assert rel_l2(y, ref) < 1e-6
+        gy = gen(37, L, seed=67)
+        dx = torch.empty(37, L, device=DEV)
+        ops.softmax_rows_bwd(y, gy.to(DEV), dx, 37, L)
+        refdx = ref * (gy.double() - (ref * gy.double()).sum(-1, keepdim=True))
+        assert rel_l2(dx, refdx) < 1e-5
+
+
+def test_time_embedding(ops, golden):
+    g = golden("layers.npz")
+    t = torch.from_numpy(g["gfp.t"])
+    from tests.synth import synth_tensor
+    W = synth_tensor("W", (128,), torch.Generator().manual_seed(190))
+    y = ops.time_embed(t.to(DEV), W.to(DEV), True)
+    ref = torch.from_numpy(g["gfp.y"])
+    # arguments reach ~1e4 rad: 1 ulp of logf moves sin/cos by ~1e-3 there; typical error is far lower
+    assert (y.cpu() - ref).abs().max().item() < 2e-3
+    assert rel_l2(y, ref) < 2e-4
+    tt = torch.tensor([3.0, 999.0])
+    freq = torch.exp(torch.arange(16, dtype=torch.float32) * -(math.log(10000) / 15))
+    y = ops.time_embed(tt.to(DEV), freq.to(DEV), False)
+    assert rel_l2(y, O.positional_embedding(tt, 32)) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------
+# SDE kernels vs golden vectors of the reference
+# ---------------------------------------------------------------------------------------------------
+def _params(ops, nu=4.01, gamma=0.01, lower=True):
+    from psld_amd._lib import SdeParams
+    p = SdeParams()
+    p.beta_0, p.beta_1, p.nu, p.gamma = 8.0, 8.0, nu, gamma
+    p.m_inv = (gamma - nu) ** 2 / 4
+    p.numerical_eps = 1e-9
+    p.decomp_lower = 1 if lower else 0
+    return p
+
+
+def test_perturb_coeffs_golden(ops, golden):
+    g = golden("sde_coeffs.npz")
+    ts = torch.from_numpy(g["t"]).to(DEV)
+    for i, (nu, ga) in enumerate(g["pairs"]):
+        for dm in ("lower", "upper"):
+            p = _params(ops, float(nu), float(ga), dm == "lower")
+            flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+            mm0 = 0.04 / p.m_inv
+            co = ops.perturb_coeffs(ts, p, 0.0, mm0, flag).cpu().numpy()
+            assert flag.item() == 0
+            np.testing.assert_allclose(co[:, 8:11].T, g[f"cov_{i}"], rtol=1e-12)
+            np.testing.assert_allclose(co[:, 4:8].T, g[f"coeff_{dm}_{i}"], rtol=1e-11, atol=1e-300)
+
+
+def test_perturb_nan_flag(ops):
+    p = _params(ops)
+    p.numerical_eps = -1.0   # forces sqrt of a negative at t ~ 0
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.perturb_coeffs(torch.tensor([1e-5], dtype=torch.float64, device=DEV), p, 0.0, 0.01, flag)
+    assert flag.item() == 1
+
+
+def test_perturb_and_em_golden(ops, golden):
+    from psld_amd._lib import EmCoeffs
+    g = golden("sde_perturb.npz")
+    p = _params(ops)
+    sde = O.PSLDOracle()
+    x0, eps, t = (torch.from_numpy(g[k]).to(DEV) for k in ("x0", "eps", "t"))
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    co = ops.perturb_coeffs(t, p, 0.0, sde.mm_0, flag)
+    z, u, mu = ops.perturb(x0, None, eps, co, p, want_f64=True, want_mu=True)
+    np.testing.assert_allclose(u.cpu().numpy(), g["u_hsm"], rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(mu.cpu().numpy(), g["mu_hsm"], rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(z.cpu().numpy(), g["u_hsm"].astype(np.float32), rtol=1.2e-7, atol=1e-9)
+    co = ops.perturb_coeffs(torch.from_numpy(g["t_dsm"]).to(DEV), p, 0.0, 0.0, flag)
+    _, u, _ = ops.perturb(x0, torch.from_numpy(g["m0"]).to(DEV), eps, co, p, want_f64=True)
+    np.testing.assert_allclose(u.cpu().numpy(), g["u_dsm"], rtol=1e-13, atol=1e-15)
+    # reverse SDE with the fake score of the golden file, one sample at a time (scalar t per launch)
+    uu = torch.from_numpy(g["u"])
+    tt = torch.from_numpy(g["t"])
+    for pf, tag in ((0, ""), (1, "_pf")):
+        for i in range(uu.shape[0]):
+            ti = tt[i:i + 1]
+            epsp = (0.1 * uu[i:i + 1].float() + ti.float().view(-1, 1, 1, 1))
+            c11, c12, c21, c22 = sde.inv_coeff(sde.cov(0.0, sde.mm_0, ti))
+            k = EmCoeffs()
+            k.beta = float(sde.beta_t(ti)); k.m_inv, k.gamma, k.nu, k.m = sde.m_inv, sde.gamma, sde.nu, sde.m
+            k.c11, k.c12, k.c21, k.c22 = (float(c.float()) for c in (c11, c12, c21, c22))
+            k.dt = 0.0; k.score_mode = 0; k.probability_flow = pf
+            f, gb = ops.reverse_sde(uu[i:i + 1].to(DEV), epsp.to(DEV), k)
+            np.testing.assert_allclose(f.cpu().numpy(), g["f_bar" + tag][i:i + 1], rtol=1e-12, atol=1e-14)
+            np.testing.assert_allclose(gb.cpu().numpy(), g["g_bar" + tag][i:i + 1], rtol=1e-14)
+
+
+def test_sqerr_loss(ops):
+    a, b = gen(4, 6, 16, 16, seed=70), gen(4, 6, 16, 16, seed=71)
+    loss, grad = ops.sqerr_loss(a.to(DEV), b.to(DEV), True, True, grad_scale=1.0)
+    br = b.clone().requires_grad_(True)
+    ref = ((a - br) ** 2).mean()
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-6 * ref.item()
+    assert rel_l2(grad, br.grad) < 1e-6
+    loss, _ = ops.sqerr_loss(a.to(DEV), b.to(DEV), False, False)
+    assert abs(loss.item() - ((a - b) ** 2).sum().item()) < 1e-6 * loss.item()
+
+
+def test_adam_clip_ema(ops):
+    n = 100003
+    p, g = gen(n, seed=80), gen(n, seed=81) * 0.01
+    m, v, ema = torch.zeros(n), torch.zeros(n), p.clone()
+    pd, gd, md, vd, ed = (t.to(DEV).clone() for t in (p, g, m, v, ema))
+    norm = torch.zeros(1, dtype=torch.float64, device=DEV)
+    pr, mr, vr, er = p.clone(), m.clone(), v.clone(), ema.clone()
+    for step in (1, 2, 3):
+        ops.grad_norm(gd, norm)
+        ops.adam_ema(pd, gd, md, vd, ed, norm, 1.0, 2e-4, 0.9, 0.999, 1e-8, 0.0, step, 0.9999)
+        (gc,), tot = O.clip_grad_norm([g], 1.0)
+        assert abs(norm.item() - tot.item()) < 1e-5 * tot.item()
+        pr, mr, vr = O.adam_step(pr, gc, mr, vr, step, 2e-4)
+        er = O.ema_update(er, pr, 0.9999)
+    np.testing.assert_allclose(pd.cpu().numpy(), pr.numpy(), rtol=0, atol=2e-7)
+    np.testing.assert_allclose(ed.cpu().numpy(), er.numpy(), rtol=0, atol=2e-7)
+    assert rel_l2(md, mr) < 1e-5 and rel_l2(vd, vr) < 1e-5
+    t2 = gen(n, seed=82).to(DEV)
+    ref = O.ema_update(t2.cpu(), pd.cpu(), 0.99)
+    ops.ema(t2, pd, 0.99)
+    np.testing.assert_allclose(t2.cpu().numpy(), ref.numpy(), rtol=0, atol=1e-7)
