@@ -208,11 +208,12 @@ int psld_grad_norm_f32(const float* g, long long n, double* norm_out, void* work
  * g *= clip_coef; Adam (torch.optim.Adam semantics, step is 1-based); optional EMA of p into ema.
  * max_norm <= 0 disables clipping (norm may be NULL). */
 int psld_adam_ema_f32(float* p, const float* g, float* m, float* v, float* ema, long long n,
-                      const double* norm, float max_norm, float lr, float beta1, float beta2,
-                      float eps, float weight_decay, int step, float ema_tau, int write_clipped_grad,
+                      const double* norm, double max_norm, double lr, double beta1, double beta2,
+                      double eps, double weight_decay, int step, double ema_tau, int write_clipped_grad,
                       float* g_mut, hipStream_t stream);
-/* target = target*tau + src*(1-tau) (callbacks.py:62-64). */
-int psld_ema_f32(float* target, const float* src, long long n, float tau, hipStream_t stream);
+/* target = target*tau + src*(1-tau) (callbacks.py:62-64); hyper-parameters are doubles so that
+ * (1 - tau), (1 - beta) are formed in double and rounded once, as torch does for python floats. */
+int psld_ema_f32(float* target, const float* src, long long n, double tau, hipStream_t stream);
 
 #ifdef __cplusplus
 }

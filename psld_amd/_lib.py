@@ -91,8 +91,8 @@ SIGNATURES = {
     "psld_f64_to_f32": (I, [P, P, LL, P]),
     "psld_f32_to_f64": (I, [P, P, LL, P]),
     "psld_grad_norm_f32": (I, [P, LL, P, P, P]),
-    "psld_adam_ema_f32": (I, [P, P, P, P, P, LL, P, F, F, F, F, F, F, I, F, I, P, P]),
-    "psld_ema_f32": (I, [P, P, LL, F, P]),
+    "psld_adam_ema_f32": (I, [P, P, P, P, P, LL, P, D, D, D, D, D, D, I, D, I, P, P]),
+    "psld_ema_f32": (I, [P, P, LL, D, P]),
 }
 
 PSLD_ERR_NUMERIC = 3

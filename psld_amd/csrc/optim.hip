@@ -45,7 +45,9 @@ __global__ void norm_final_kernel(const double* __restrict__ part, int nparts, d
 }
 
 struct AdamArgs {
-    float lr, beta1, beta2, eps, wd, step_size, inv_sqrt_bc2, max_norm, tau;
+    // (1-beta) and (1-tau) are formed in double on the host and then rounded to f32, exactly as
+    // torch does for python-float scalars (1 - 0.999 -> f32(0.001), not 1.0f - 0.999f).
+    float beta2, eps, wd, step_size, inv_sqrt_bc2, max_norm, tau, omb1, omb2, omtau;
 };
 
 // torch.optim.Adam (single-tensor form): m.lerp_(g, 1-b1); v = v*b2 + (1-b2) g*g;
@@ -64,19 +66,20 @@ __global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__
         float pi = p[i];
         if (a.wd != 0.f) gi += a.wd * pi;
         float mi = m[i], vi = v[i];
-        mi = mi + (gi - mi) * (1.0f - a.beta1);
-        vi = vi * a.beta2 + (1.0f - a.beta2) * gi * gi;
+        mi = mi + (gi - mi) * a.omb1;
+        vi = vi * a.beta2 + a.omb2 * gi * gi;
         const float denom = sqrtf(vi) * a.inv_sqrt_bc2 + a.eps;
         pi = pi - a.step_size * (mi / denom);
         p[i] = pi;
         m[i] = mi;
         v[i] = vi;
-        if (ema) ema[i] = ema[i] * a.tau + pi * (1.0f - a.tau);
+        if (ema) ema[i] = ema[i] * a.tau + pi * a.omtau;
     }
 }
 
-__global__ void ema_kernel(float* __restrict__ target, const float* __restrict__ src, long long n, float tau) {
-    GRID_STRIDE(i, n) target[i] = target[i] * tau + src[i] * (1.0f - tau);
+__global__ void ema_kernel(float* __restrict__ target, const float* __restrict__ src, long long n, float tau,
+                           float omtau) {
+    GRID_STRIDE(i, n) target[i] = target[i] * tau + src[i] * omtau;
 }
 
 }  // namespace
@@ -95,17 +98,18 @@ extern "C" int psld_grad_norm_f32(const float* g, long long n, double* norm_out,
 }
 
 extern "C" int psld_adam_ema_f32(float* p, const float* g, float* m, float* v, float* ema, long long n,
-                                 const double* norm, float max_norm, float lr, float beta1, float beta2, float eps,
-                                 float weight_decay, int step, float ema_tau, int write_clipped_grad, float* g_mut,
-                                 hipStream_t stream) {
+                                 const double* norm, double max_norm, double lr, double beta1, double beta2,
+                                 double eps, double weight_decay, int step, double ema_tau, int write_clipped_grad,
+                                 float* g_mut, hipStream_t stream) {
     PSLD_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "psld_adam_ema_f32: bad args");
     PSLD_CHECK_ARG(max_norm <= 0.f || norm, "psld_adam_ema_f32: clipping needs the norm buffer");
     AdamArgs a;
-    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
-    a.step_size = (float)((double)lr / bc1);
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+    a.beta2 = (float)beta2; a.eps = (float)eps; a.wd = (float)weight_decay;
+    a.omb1 = (float)(1.0 - beta1); a.omb2 = (float)(1.0 - beta2);
+    a.step_size = (float)(lr / bc1);
     a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-    a.max_norm = max_norm; a.tau = ema_tau;
+    a.max_norm = (float)max_norm; a.tau = (float)ema_tau; a.omtau = (float)(1.0 - ema_tau);
     long long b = (n + 1023) / 1024;
     if (b > 256 * 16) b = 256 * 16;
     hipLaunchKernelGGL(adam_ema_kernel, dim3((int)b), dim3(256), 0, stream, p, g, m, v, ema, n, norm, a,
@@ -114,11 +118,12 @@ extern "C" int psld_adam_ema_f32(float* p, const float* g, float* m, float* v, f
     return PSLD_OK;
 }
 
-extern "C" int psld_ema_f32(float* target, const float* src, long long n, float tau, hipStream_t stream) {
+extern "C" int psld_ema_f32(float* target, const float* src, long long n, double tau, hipStream_t stream) {
     PSLD_CHECK_ARG(target && src && n > 0, "psld_ema_f32: bad args");
     long long b = (n + 1023) / 1024;
     if (b > 256 * 16) b = 256 * 16;
-    hipLaunchKernelGGL(ema_kernel, dim3((int)b), dim3(256), 0, stream, target, src, n, tau);
+    hipLaunchKernelGGL(ema_kernel, dim3((int)b), dim3(256), 0, stream, target, src, n, (float)tau,
+                       (float)(1.0 - tau));
     PSLD_CHECK_LAUNCH("ema_kernel");
     return PSLD_OK;
 }

@@ -54,6 +54,7 @@ def epilogue(alpha: float = 1.0, bias: Optional[Tensor] = None, rowbias: Optiona
     e.residual_stride_batch = residual_stride_batch
     e.out_scale = out_scale
     e.accumulate = 1 if accumulate else 0
+    e._keep = (bias, rowbias, residual)  # the struct holds raw pointers: keep the tensors alive
     return e
 
 

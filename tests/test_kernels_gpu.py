@@ -326,7 +326,7 @@ def test_perturb_and_em_golden(ops, golden):
     tt = torch.from_numpy(g["t"])
     for pf, tag in ((0, ""), (1, "_pf")):
         for i in range(uu.shape[0]):
-            ti = tt[i:i + 1]
+            ti = sde.T - tt[i:i + 1]            # psld.py:348: the reverse SDE lives on T - t
             epsp = (0.1 * uu[i:i + 1].float() + ti.float().view(-1, 1, 1, 1))
             c11, c12, c21, c22 = sde.inv_coeff(sde.cov(0.0, sde.mm_0, ti))
             k = EmCoeffs()
@@ -364,8 +364,8 @@ def test_adam_clip_ema(ops):
         assert abs(norm.item() - tot.item()) < 1e-5 * tot.item()
         pr, mr, vr = O.adam_step(pr, gc, mr, vr, step, 2e-4)
         er = O.ema_update(er, pr, 0.9999)
-    np.testing.assert_allclose(pd.cpu().numpy(), pr.numpy(), rtol=0, atol=2e-7)
-    np.testing.assert_allclose(ed.cpu().numpy(), er.numpy(), rtol=0, atol=2e-7)
+    np.testing.assert_allclose(pd.cpu().numpy(), pr.numpy(), rtol=5e-7, atol=2e-7)
+    np.testing.assert_allclose(ed.cpu().numpy(), er.numpy(), rtol=5e-7, atol=2e-7)
     assert rel_l2(md, mr) < 1e-5 and rel_l2(vd, vr) < 1e-5
     t2 = gen(n, seed=82).to(DEV)
     ref = O.ema_update(t2.cpu(), pd.cpu(), 0.99)
