@@ -87,9 +87,9 @@ int psld_conv2d_wgrad_nhwc_f32(const float* dy, int lddy, int cout,
                                float* slabs, int cin_total, int col0, int nsplit,
                                hipStream_t stream);
 
-/* out[perm(i)] = sum_s slabs[s][i]; layout: 0 = keep [co][tap][ci], 1 = write OIHW [co][ci][tap]. */
+/* out[perm(i)] = alpha * sum_s slabs[s][i]; layout: 0 = keep [co][tap][ci], 1 = write OIHW [co][ci][tap]. */
 int psld_reduce_slabs_f32(const float* slabs, int nsplit, long long n, float* out,
-                          int layout, int cout, int taps, int cin, hipStream_t stream);
+                          int layout, int cout, int taps, int cin, float alpha, hipStream_t stream);
 
 /* ---- weight layout (state_dict keeps the reference's OIHW / [in,out] shapes) ------------ */
 /* OIHW -> [co][tap][ci] (forward operand). */
@@ -110,13 +110,18 @@ int psld_gn_stats_nhwc_f32(const float* x, int batch, int hw, int c, int groups,
                            const float* gamma, const float* beta,
                            float* mean, float* rstd, float* scale, float* shift,
                            void* workspace, hipStream_t stream);
-/* y = act(x*scale[n,c] + shift[n,c]); act: 0 = identity, 1 = SiLU. */
+/* y = dropout(act(x*scale[n,c] + shift[n,c])); act: 0 = identity, 1 = SiLU.  Dropout
+ * (nn.Dropout, layerspp.py:265): element i of the NHWC tensor is kept iff
+ * psld_dropout_keep(seed, i, p) (counter-based hash, reproducible in the backward pass, no mask
+ * tensor) and scaled by 1/(1-p); drop_p = 0 disables it. */
 int psld_gn_apply_nhwc_f32(const float* x, const float* scale, const float* shift, float* y,
-                           int batch, int hw, int c, int act, hipStream_t stream);
+                           int batch, int hw, int c, int act, float drop_p, unsigned long long seed,
+                           hipStream_t stream);
 /* Backward of y = act(GN(x)): dx, dgamma[C], dbeta[C] (written, not accumulated). */
 int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float* mean, const float* rstd,
                          const float* gamma, const float* beta, int batch, int hw, int c, int groups,
-                         int act, float* dx, float* dgamma, float* dbeta, int accumulate_dx,
+                         int act, float drop_p, unsigned long long seed,
+                         float* dx, float* dgamma, float* dbeta, int accumulate_dx,
                          void* workspace, hipStream_t stream);
 
 /* ---- FIR resampling: the replacement of the pybind op upfirdn2d_op.upfirdn2d
@@ -142,8 +147,12 @@ int psld_axpby_f32(const float* a, float sa, const float* b, float sb, float* y,
                    int accumulate, hipStream_t stream);
 int psld_silu_f32(const float* x, float* y, long long n, hipStream_t stream);
 int psld_silu_bwd_f32(const float* x, const float* dy, float* dx, long long n, hipStream_t stream);
-/* out[b][c] = sum over the hw rows of image b of x[(b*hw+p)*ld + c] (bias / temb-bias gradients). */
-int psld_colsum_f32(const float* x, int ld, int batch, int hw, int c, float* out, hipStream_t stream);
+/* out[b][c] = alpha * sum over the hw rows of image b of x[(b*hw+p)*ld + c] (bias / temb-bias gradients). */
+int psld_colsum_f32(const float* x, int ld, int batch, int hw, int c, float* out, float alpha,
+                    hipStream_t stream);
+/* dst[r][0:cols] (+)= src[r][0:cols] with row strides: channel concat (ncsnpp.py:374) and its split. */
+int psld_copy2d_f32(const float* src, int ld_src, float* dst, int ld_dst, long long rows, int cols,
+                    int accumulate, hipStream_t stream);
 /* rows of length L: y = softmax(x) ; dx = y * (dy - sum(y*dy)) (layerspp.py:84). */
 int psld_softmax_rows_f32(const float* x, float* y, long long rows, int L, hipStream_t stream);
 int psld_softmax_rows_bwd_f32(const float* y, const float* dy, float* dx, long long rows, int L, hipStream_t stream);

@@ -64,21 +64,22 @@ SIGNATURES = {
     "psld_gemm_tn_splitk_f32": (I, [I, I, I, P, I, P, I, P, I, P]),
     "psld_conv2d_nhwc_f32": (I, [P, I, P, I, I, I, I, P, I, I, I, I, I, I, I, I, P, I, EP, P]),
     "psld_conv2d_wgrad_nhwc_f32": (I, [P, I, I, P, I, I, I, I, I, I, I, I, I, I, P, I, I, I, P]),
-    "psld_reduce_slabs_f32": (I, [P, I, LL, P, I, I, I, I, P]),
+    "psld_reduce_slabs_f32": (I, [P, I, LL, P, I, I, I, I, F, P]),
     "psld_pack_oihw_to_ohwi_f32": (I, [P, P, I, I, I, P]),
     "psld_pack_oihw_to_dgrad_f32": (I, [P, P, I, I, I, P]),
     "psld_nchw_to_nhwc_f32": (I, [P, P, I, I, I, P]),
     "psld_nhwc_to_nchw_f32": (I, [P, P, I, I, I, P]),
     "psld_gn_workspace_bytes": (LL, [I, I, I, I]),
     "psld_gn_stats_nhwc_f32": (I, [P, I, I, I, I, F, P, P, P, P, P, P, P, P]),
-    "psld_gn_apply_nhwc_f32": (I, [P, P, P, P, I, I, I, I, P]),
-    "psld_gn_bwd_nhwc_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, P, P, P, I, P, P]),
+    "psld_gn_apply_nhwc_f32": (I, [P, P, P, P, I, I, I, I, F, C.c_ulonglong, P]),
+    "psld_gn_bwd_nhwc_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, F, C.c_ulonglong, P, P, P, I, P, P]),
     "psld_upfirdn2d_f32": (I, [P, P, I, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "psld_fused_bias_act_f32": (I, [P, P, P, LL, I, I, I, F, F, P]),
     "psld_axpby_f32": (I, [P, F, P, F, P, LL, I, P]),
     "psld_silu_f32": (I, [P, P, LL, P]),
     "psld_silu_bwd_f32": (I, [P, P, P, LL, P]),
-    "psld_colsum_f32": (I, [P, I, I, I, I, P, P]),
+    "psld_colsum_f32": (I, [P, I, I, I, I, P, F, P]),
+    "psld_copy2d_f32": (I, [P, I, P, I, LL, I, I, P]),
     "psld_softmax_rows_f32": (I, [P, P, LL, I, P]),
     "psld_softmax_rows_bwd_f32": (I, [P, P, P, LL, I, P]),
     "psld_time_embed_f32": (I, [P, P, P, I, I, I, P]),

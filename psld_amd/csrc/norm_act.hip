@@ -111,22 +111,26 @@ __global__ void gn_finalize_kernel(const double* __restrict__ part, int hw, int 
 
 __global__ void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                 const float* __restrict__ shift, float* __restrict__ y, int hw, int c, int cq,
-                                int pl, int chunk_px, int act) {
+                                int pl, int chunk_px, int act, float drop_p, unsigned long long seed) {
     const int n = blockIdx.y, chunk = blockIdx.x;
     const int q = threadIdx.x % cq, l = threadIdx.x / cq;
     const int p0 = chunk * chunk_px, p1 = min(hw, p0 + chunk_px);
     const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + (long long)n * c + q * 4);
     const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + (long long)n * c + q * 4);
     const long long off = ((long long)n * hw) * c + q * 4;
+    const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     for (int p = p0 + l; p < p1; p += pl) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + off + (long long)p * c);
+        const long long idx = off + (long long)p * c;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + idx);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float z = v[e] * sc[e] + sh[e];
-            o[e] = act ? silu_f(z) : z;
+            float a = act ? silu_f(z) : z;
+            if (drop_p > 0.f) a = psld_dropout_keep(seed, (unsigned long long)(idx + e), drop_p) ? a * keep_scale : 0.f;
+            o[e] = a;
         }
-        *reinterpret_cast<f32x4*>(y + off + (long long)p * c) = o;
+        *reinterpret_cast<f32x4*>(y + idx) = o;
     }
 }
 
@@ -136,7 +140,7 @@ __global__ void gn_bwd_partial_kernel(const float* __restrict__ dy, const float*
                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                       const float* __restrict__ gamma, const float* __restrict__ beta, int hw,
                                       int c, int groups, int cq, int pl, int chunk_px, int chunks, int act,
-                                      float* __restrict__ part) {
+                                      float drop_p, unsigned long long seed, float* __restrict__ part) {
     extern __shared__ float red[];  // [pl][cq][8]
     const int n = blockIdx.y, chunk = blockIdx.x;
     const int tid = threadIdx.x;
@@ -155,13 +159,16 @@ __global__ void gn_bwd_partial_kernel(const float* __restrict__ dy, const float*
     }
     const long long off = ((long long)n * hw) * c + q * 4;
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     for (int p = p0 + l; p < p1; p += pl) {
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off + (long long)p * c);
-        const f32x4 gv = *reinterpret_cast<const f32x4*>(dy + off + (long long)p * c);
+        const long long idx = off + (long long)p * c;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + idx);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(dy + idx);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float xh = (xv[e] - mu[e]) * rs[e];
             float dz = gv[e];
+            if (drop_p > 0.f) dz = psld_dropout_keep(seed, (unsigned long long)(idx + e), drop_p) ? dz * keep_scale : 0.f;
             if (act) dz *= dsilu_f(xh * ga[e] + be[e]);
             s1[e] += dz;
             s2[e] += dz * xh;
@@ -239,7 +246,8 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                     const float* __restrict__ coef, int hw, int c, int groups, int cq, int pl,
-                                    int chunk_px, int act, int accumulate, float* __restrict__ dx) {
+                                    int chunk_px, int act, float drop_p, unsigned long long seed, int accumulate,
+                                    float* __restrict__ dx) {
     const int n = blockIdx.y, chunk = blockIdx.x;
     const int q = threadIdx.x % cq, l = threadIdx.x / cq;
     const int p0 = chunk * chunk_px, p1 = min(hw, p0 + chunk_px);
@@ -258,18 +266,21 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
         c2[e] = coef[((long long)n * 3 + 2) * c + ch];
     }
     const long long off = ((long long)n * hw) * c + q * 4;
+    const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     for (int p = p0 + l; p < p1; p += pl) {
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off + (long long)p * c);
-        const f32x4 gv = *reinterpret_cast<const f32x4*>(dy + off + (long long)p * c);
+        const long long idx = off + (long long)p * c;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + idx);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(dy + idx);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float xh = (xv[e] - mu[e]) * rs[e];
             float dz = gv[e];
+            if (drop_p > 0.f) dz = psld_dropout_keep(seed, (unsigned long long)(idx + e), drop_p) ? dz * keep_scale : 0.f;
             if (act) dz *= dsilu_f(xh * ga[e] + be[e]);
             o[e] = c0[e] * dz - c1[e] - xh * c2[e];
         }
-        float* dp = dx + off + (long long)p * c;
+        float* dp = dx + idx;
         if (accumulate) {
             const f32x4 old = *reinterpret_cast<const f32x4*>(dp);
             o += old;
@@ -309,20 +320,21 @@ extern "C" int psld_gn_stats_nhwc_f32(const float* x, int batch, int hw, int c, 
 }
 
 extern "C" int psld_gn_apply_nhwc_f32(const float* x, const float* scale, const float* shift, float* y, int batch,
-                                      int hw, int c, int act, hipStream_t stream) {
+                                      int hw, int c, int act, float drop_p, unsigned long long seed,
+                                      hipStream_t stream) {
     PSLD_CHECK_ARG(x && scale && shift && y, "psld_gn_apply: null pointer");
     PSLD_CHECK_ARG(c % 4 == 0 && c / 4 <= MAXT, "psld_gn_apply: unsupported C=%d", c);
     const Map m = make_map(batch, hw, c);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(m.chunks, batch), dim3(m.threads), 0, stream, x, scale, shift, y, hw, c,
-                       m.cq, m.pl, m.chunk_px, act);
+                       m.cq, m.pl, m.chunk_px, act, drop_p, seed);
     PSLD_CHECK_LAUNCH("gn_apply_kernel");
     return PSLD_OK;
 }
 
 extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float* mean, const float* rstd,
                                     const float* gamma, const float* beta, int batch, int hw, int c, int groups,
-                                    int act, float* dx, float* dgamma, float* dbeta, int accumulate_dx,
-                                    void* workspace, hipStream_t stream) {
+                                    int act, float drop_p, unsigned long long seed, float* dx, float* dgamma,
+                                    float* dbeta, int accumulate_dx, void* workspace, hipStream_t stream) {
     PSLD_CHECK_ARG(dy && x && mean && rstd && gamma && beta && dx && dgamma && dbeta && workspace,
                    "psld_gn_bwd: null pointer");
     PSLD_CHECK_ARG(c % 4 == 0 && c / 4 <= MAXT && groups <= MAXG && c % groups == 0,
@@ -336,7 +348,7 @@ extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float
     float* coef = reinterpret_cast<float*>(ws);
     const size_t lds = (size_t)m.pl * m.cq * 8 * sizeof(float);
     hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(m.chunks, batch), dim3(m.threads), lds, stream, dy, x, mean, rstd,
-                       gamma, beta, hw, c, groups, m.cq, m.pl, m.chunk_px, m.chunks, act, part);
+                       gamma, beta, hw, c, groups, m.cq, m.pl, m.chunk_px, m.chunks, act, drop_p, seed, part);
     PSLD_CHECK_LAUNCH("gn_bwd_partial_kernel");
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(batch), dim3(256), 0, stream, part, rstd, gamma, hw, c, groups,
                        m.chunks, sums, coef);
@@ -344,7 +356,7 @@ extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float
     hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(cdiv(c, 128)), dim3(128), 0, stream, sums, batch, c, dgamma, dbeta);
     PSLD_CHECK_LAUNCH("gn_bwd_param_kernel");
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(m.chunks, batch), dim3(m.threads), 0, stream, dy, x, mean, rstd,
-                       gamma, beta, coef, hw, c, groups, m.cq, m.pl, m.chunk_px, act, accumulate_dx, dx);
+                       gamma, beta, coef, hw, c, groups, m.cq, m.pl, m.chunk_px, act, drop_p, seed, accumulate_dx, dx);
     PSLD_CHECK_LAUNCH("gn_bwd_apply_kernel");
     return PSLD_OK;
 }

@@ -60,10 +60,11 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, float* __restrict
 }
 
 __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nsplit, long long n, float* __restrict__ out,
-                                    int layout, int taps, int cin) {
+                                    int layout, int taps, int cin, float alpha) {
     GRID_STRIDE(i, n) {
         float acc = 0.f;
         for (int s = 0; s < nsplit; ++s) acc += slabs[(long long)s * n + i];
+        acc *= alpha;
         long long o = i;
         if (layout == 1) {  // [co][tap][ci] -> [co][ci][tap]
             const int ci = (int)(i % cin);
@@ -96,6 +97,20 @@ __global__ void axpby_kernel(const float* __restrict__ a, float sa, const float*
     }
 }
 
+// strided 2-D copy: dst[r*ld_dst + c] (+)= src[r*ld_src + c], cols % 4 == 0 (channel concat / split)
+__global__ void copy2d_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int ld_dst,
+                              long long rows, int cols4, int accumulate) {
+    const long long n = rows * cols4;
+    GRID_STRIDE(i, n) {
+        const long long r = i / cols4;
+        const int c = (int)(i - r * cols4) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(src + r * ld_src + c);
+        float* d = dst + r * ld_dst + c;
+        if (accumulate) v += *reinterpret_cast<const f32x4*>(d);
+        *reinterpret_cast<f32x4*>(d) = v;
+    }
+}
+
 __global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
     GRID_STRIDE(i, n) y[i] = silu_f(x[i]);
 }
@@ -105,7 +120,8 @@ __global__ void silu_bwd_kernel(const float* __restrict__ x, const float* __rest
 }
 
 // out[b][c] = sum_p x[(b*hw+p)*ld + c].  grid (chunks_c, batch); block 256 = (cw = 64 columns) x 4 row lanes
-__global__ void colsum_kernel(const float* __restrict__ x, int ld, int hw, int c, float* __restrict__ out) {
+__global__ void colsum_kernel(const float* __restrict__ x, int ld, int hw, int c, float* __restrict__ out,
+                              float alpha) {
     __shared__ double red[4][64];
     const int b = blockIdx.y;
     const int col = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -127,7 +143,7 @@ __global__ void colsum_kernel(const float* __restrict__ x, int ld, int hw, int c
     }
     red[rl][threadIdx.x & 63] = acc;
     __syncthreads();
-    if (rl == 0 && col < c) out[(long long)b * c + col] = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (rl == 0 && col < c) out[(long long)b * c + col] = (float)((red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) * (double)alpha);
 }
 
 // one wave64 per row
@@ -220,11 +236,11 @@ extern "C" int psld_pack_oihw_to_dgrad_f32(const float* w, float* out, int cout,
     return PSLD_OK;
 }
 extern "C" int psld_reduce_slabs_f32(const float* slabs, int nsplit, long long n, float* out, int layout, int cout,
-                                     int taps, int cin, hipStream_t stream) {
+                                     int taps, int cin, float alpha, hipStream_t stream) {
     PSLD_CHECK_ARG(slabs && out && nsplit >= 1, "psld_reduce_slabs_f32: bad args");
     PSLD_CHECK_ARG(layout == 0 || n == (long long)cout * taps * cin, "psld_reduce_slabs_f32: shape mismatch");
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(n)), dim3(256), 0, stream, slabs, nsplit, n, out, layout,
-                       taps, cin);
+                       taps, cin, alpha);
     PSLD_CHECK_LAUNCH("psld_reduce_slabs_f32");
     return PSLD_OK;
 }
@@ -240,6 +256,18 @@ extern "C" int psld_axpby_f32(const float* a, float sa, const float* b, float sb
     PSLD_CHECK_LAUNCH("psld_axpby_f32");
     return PSLD_OK;
 }
+extern "C" int psld_copy2d_f32(const float* src, int ld_src, float* dst, int ld_dst, long long rows, int cols,
+                               int accumulate, hipStream_t stream) {
+    PSLD_CHECK_ARG(src && dst && rows >= 0 && cols > 0, "psld_copy2d_f32: bad args");
+    PSLD_CHECK_ARG(cols % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 &&
+                       ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0,
+                   "psld_copy2d_f32: needs 16-byte aligned rows (cols=%d ld=%d/%d)", cols, ld_src, ld_dst);
+    if (rows == 0) return PSLD_OK;
+    hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for(rows * (cols / 4))), dim3(256), 0, stream, src, ld_src, dst,
+                       ld_dst, rows, cols / 4, accumulate);
+    PSLD_CHECK_LAUNCH("psld_copy2d_f32");
+    return PSLD_OK;
+}
 extern "C" int psld_silu_f32(const float* x, float* y, long long n, hipStream_t stream) {
     PSLD_CHECK_ARG(x && y, "psld_silu_f32: null pointer");
     hipLaunchKernelGGL(silu_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, y, n);
@@ -252,9 +280,10 @@ extern "C" int psld_silu_bwd_f32(const float* x, const float* dy, float* dx, lon
     PSLD_CHECK_LAUNCH("psld_silu_bwd_f32");
     return PSLD_OK;
 }
-extern "C" int psld_colsum_f32(const float* x, int ld, int batch, int hw, int c, float* out, hipStream_t stream) {
+extern "C" int psld_colsum_f32(const float* x, int ld, int batch, int hw, int c, float* out, float alpha,
+                               hipStream_t stream) {
     PSLD_CHECK_ARG(x && out && batch > 0 && hw > 0 && c > 0, "psld_colsum_f32: bad args");
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(c, 64), batch), dim3(256), 0, stream, x, ld, hw, c, out);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(c, 64), batch), dim3(256), 0, stream, x, ld, hw, c, out, alpha);
     PSLD_CHECK_LAUNCH("psld_colsum_f32");
     return PSLD_OK;
 }

@@ -1,0 +1,67 @@
+"""HSM / DSM score-matching loss with the reference's interface (main/losses.py:69-130).
+
+``PSLDScoreLoss(config, sde).forward(x_0, t, score_fn, eps=None) -> scalar`` with an autograd graph
+through ``score_fn``.  Perturbation, the f64->f32 casts and the squared-error reduction (+ its
+gradient) are libpsld_hip kernels; ``torch.randn`` draws eps exactly as the reference does.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .registry import get_module, register_module
+
+
+class _SqErr(torch.autograd.Function):
+    """loss = mean|sum (target - pred)^2; the kernel also emits d loss / d pred."""
+
+    @staticmethod
+    def forward(ctx, pred, target, reduce_mean):
+        loss, grad = ops.sqerr_loss(target, pred.contiguous(), reduce_mean, want_grad=True)
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None   # g is the 0-d upstream gradient (1.0 for loss.backward())
+
+
+@register_module(category="losses", name="psld_score_loss")
+class PSLDScoreLoss(nn.Module):
+    def __init__(self, config, sde):
+        super().__init__()
+        assert config.training.loss.weighting in ["fid"]
+        assert config.training.mode in ["hsm", "dsm"]
+        assert isinstance(sde, get_module("sde", "psld"))
+        self.sde = sde
+        self.l_type = config.training.loss.l_type
+        self.weighting = config.training.loss.weighting
+        self.mode = config.training.mode
+        self.decomp_mode = config.model.sde.decomp_mode
+        self.reduce_strategy = "mean" if config.training.loss.reduce_mean else "sum"
+
+    def forward(self, x_0, t, score_fn, eps=None):
+        sde = self.sde
+        # losses.py:96-102: DSM samples the momentum, HSM marginalises it
+        if self.mode == "hsm":
+            m_0, mm_0 = None, sde.mm_0
+        else:
+            m_0, mm_0 = np.sqrt(sde.mm_0) * torch.randn_like(x_0), 0.0
+        if eps is None:
+            eps = torch.randn(x_0.shape[0], 2 * x_0.shape[1], *x_0.shape[2:], device=x_0.device)
+        assert eps.shape[1] == 2 * x_0.shape[1]
+        eps = eps.contiguous()
+        z_t = sde.perturb_f32(x_0, m_0, 0, mm_0, t, eps)                # losses.py:113-114
+        t32 = ops.f64_to_f32(t.contiguous()) if t.dtype == torch.float64 else t.float()
+        eps_pred = score_fn(z_t, t32)                                   # losses.py:115
+        if sde.mode == "score_m" and self.decomp_mode == "lower":      # losses.py:118-127
+            target = torch.chunk(eps, 2, dim=1)[1].contiguous()
+        elif sde.mode == "score_x" and self.decomp_mode == "upper":
+            target = torch.chunk(eps, 2, dim=1)[0].contiguous()
+        else:
+            target = eps
+        assert eps_pred.shape == target.shape
+        return _SqErr.apply(eps_pred, target, self.reduce_strategy == "mean")

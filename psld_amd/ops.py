@@ -103,8 +103,8 @@ def conv2d_wgrad_nhwc(dy: Tensor, cout: int, x: Tensor, kh: int, kw: int, stride
 
 
 def reduce_slabs(slabs: Tensor, nsplit: int, n: int, out: Tensor, layout: int = 0, cout: int = 0, taps: int = 0,
-                 cin: int = 0):
-    check(lib().psld_reduce_slabs_f32(slabs.data_ptr(), nsplit, n, out.data_ptr(), layout, cout, taps, cin,
+                 cin: int = 0, alpha: float = 1.0):
+    check(lib().psld_reduce_slabs_f32(slabs.data_ptr(), nsplit, n, out.data_ptr(), layout, cout, taps, cin, alpha,
                                       _stream()), "psld_reduce_slabs_f32")
 
 
@@ -175,23 +175,24 @@ def gn_stats(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-6) -> GNSta
     return st
 
 
-def gn_apply(x: Tensor, st: GNStats, act: bool, out: Optional[Tensor] = None) -> Tensor:
+def gn_apply(x: Tensor, st: GNStats, act: bool, out: Optional[Tensor] = None, drop_p: float = 0.0,
+             seed: int = 0) -> Tensor:
     b, h, w, c = x.shape
     if out is None:
         out = torch.empty_like(x)
     check(lib().psld_gn_apply_nhwc_f32(x.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), out.data_ptr(), b,
-                                       h * w, c, 1 if act else 0, _stream()), "psld_gn_apply_nhwc_f32")
+                                       h * w, c, 1 if act else 0, drop_p, seed, _stream()), "psld_gn_apply_nhwc_f32")
     return out
 
 
 def gn_bwd(dy: Tensor, x: Tensor, st: GNStats, gamma: Tensor, beta: Tensor, act: bool, dx: Tensor, dgamma: Tensor,
-           dbeta: Tensor, accumulate_dx: bool = False):
+           dbeta: Tensor, accumulate_dx: bool = False, drop_p: float = 0.0, seed: int = 0):
     b, h, w, c = x.shape
     g = gn_groups(c)
     ws = workspace(lib().psld_gn_workspace_bytes(b, h * w, c, g), x.device)
     check(lib().psld_gn_bwd_nhwc_f32(dy.data_ptr(), x.data_ptr(), st.mean.data_ptr(), st.rstd.data_ptr(),
                                      gamma.data_ptr(), beta.data_ptr(), b, h * w, c, g, 1 if act else 0,
-                                     dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 1 if accumulate_dx else 0,
+                                     drop_p, seed, dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 1 if accumulate_dx else 0,
                                      ws.data_ptr(), _stream()), "psld_gn_bwd_nhwc_f32")
 
 
@@ -268,9 +269,15 @@ def silu_bwd(x: Tensor, dy: Tensor) -> Tensor:
     return dx
 
 
-def colsum(x: Tensor, ld: int, batch: int, hw: int, c: int, out: Tensor):
-    check(lib().psld_colsum_f32(x.data_ptr(), ld, batch, hw, c, out.data_ptr(), _stream()), "psld_colsum_f32")
+def colsum(x: Tensor, ld: int, batch: int, hw: int, c: int, out: Tensor, alpha: float = 1.0):
+    check(lib().psld_colsum_f32(x.data_ptr(), ld, batch, hw, c, out.data_ptr(), alpha, _stream()), "psld_colsum_f32")
     return out
+
+
+def copy2d(src: Tensor, ld_src: int, dst: Tensor, ld_dst: int, rows: int, cols: int, accumulate: bool = False,
+           src_off: int = 0, dst_off: int = 0):
+    check(lib().psld_copy2d_f32(src.data_ptr() + 4 * src_off, ld_src, dst.data_ptr() + 4 * dst_off, ld_dst, rows, cols,
+                                1 if accumulate else 0, _stream()), "psld_copy2d_f32")
 
 
 def softmax_rows(x: Tensor, out: Tensor, rows: int, L: int):

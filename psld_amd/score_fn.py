@@ -1,0 +1,855 @@
+"""NCSN++ score network on MI355X: the reference's module surface, a HIP executor underneath.
+
+Surface kept from the reference:
+  * ``NCSNpp(config)`` registered as ``score_fn/ncsnpp`` (ncsnpp.py:35-39), ``forward(x, time_cond)``
+    with ``x: f32[B,C,H,W]`` (NCHW) and ``time_cond: f32[B]`` -> ``f32[B,out_ch,H,W]`` (ncsnpp.py:287,438);
+  * an ``nn.Module`` whose ``state_dict()`` has exactly the reference's keys, shapes and order
+    (``all_modules.<i>.<Sub>.<param>``; conv weights OIHW, ``NIN.W`` as [in,out],
+    ``GaussianFourierProjection.W`` frozen) so published checkpoints load with ``strict=True``;
+  * ``deepcopy`` works (train_sde.py:41), parameters are ordinary ``nn.Parameter``s usable by any
+    optimizer / EMA loop, gradients arrive in ``p.grad`` after ``loss.backward()``.
+
+What is different underneath: no eager ATen graph.  ``forward`` runs a fixed program of
+libpsld_hip kernels over NHWC activations; with grad enabled the whole network is ONE
+``torch.autograd.Function`` whose backward replays a hand-written tape (dgrad / wgrad / GN-bwd
+kernels) and writes parameter gradients straight into one flat fp32 buffer (``p.grad`` are views
+of it), which is what the fused clip+Adam+EMA kernel and the RCCL bucket reducer consume.
+
+Supported config branches = the ones the north-star configs take: resblock_type
+'biggan', progressive 'none', progressive_input 'none' | 'residual', embedding 'fourier' |
+'positional', fir True | False, nonlinearity 'swish'.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .registry import register_module
+
+Tensor = torch.Tensor
+_ALIGN = 64  # floats: every parameter starts on a 256-byte boundary inside the flat buffers
+
+
+# ----------------------------------------------------------------------------------------------
+# initialisers (song_sde/layers.py:39-76)
+# ----------------------------------------------------------------------------------------------
+def default_init(shape, scale: float = 1.0) -> Tensor:
+    """variance_scaling(scale, 'fan_avg', 'uniform') with in_axis=1, out_axis=0; scale 0 -> 1e-10."""
+    scale = 1e-10 if scale == 0 else scale
+    rf = float(np.prod(shape)) / shape[1] / shape[0]
+    fan_in, fan_out = shape[1] * rf, shape[0] * rf
+    variance = scale / ((fan_in + fan_out) / 2)
+    return (torch.rand(*shape) * 2.0 - 1.0) * math.sqrt(3 * variance)
+
+
+# ----------------------------------------------------------------------------------------------
+# parameter holders with the reference's attribute names
+# ----------------------------------------------------------------------------------------------
+class GaussianFourierProjection(nn.Module):
+    """layerspp.py:32-41: fixed random frequencies, requires_grad=False."""
+
+    def __init__(self, embedding_size=256, scale=1.0):
+        super().__init__()
+        self.W = nn.Parameter(torch.randn(embedding_size) * scale, requires_grad=False)
+
+
+class _Affine(nn.Module):
+    """weight / bias holder: nn.Linear ([out,in]), nn.Conv2d (OIHW), nn.GroupNorm ([C])."""
+
+    def __init__(self, weight: Tensor, bias: Tensor):
+        super().__init__()
+        self.weight = nn.Parameter(weight)
+        self.bias = nn.Parameter(bias)
+
+
+def _linear(in_dim, out_dim):
+    return _Affine(default_init((out_dim, in_dim)), torch.zeros(out_dim))  # ncsnpp.py:99-105
+
+
+def _conv(in_ch, out_ch, k, init_scale=1.0):
+    return _Affine(default_init((out_ch, in_ch, k, k), init_scale), torch.zeros(out_ch))  # layers.py:85-109
+
+
+def _groupnorm(ch):
+    return _Affine(torch.ones(ch), torch.zeros(ch))
+
+
+class NIN(nn.Module):
+    """layers.py:531-540: W is [in, out]."""
+
+    def __init__(self, in_dim, num_units, init_scale=0.1):
+        super().__init__()
+        self.W = nn.Parameter(default_init((in_dim, num_units), init_scale))
+        self.b = nn.Parameter(torch.zeros(num_units))
+
+
+class ResnetBlockBigGANpp(nn.Module):
+    """layerspp.py:212-240 (parameters); forward lives in the executor below."""
+
+    def __init__(self, in_ch, out_ch=None, temb_dim=None, up=False, down=False, dropout=0.1, init_scale=0.0):
+        super().__init__()
+        out_ch = out_ch if out_ch else in_ch
+        self.GroupNorm_0 = _groupnorm(in_ch)
+        self.Conv_0 = _conv(in_ch, out_ch, 3)
+        if temb_dim is not None:
+            self.Dense_0 = _linear(temb_dim, out_ch)
+        self.GroupNorm_1 = _groupnorm(out_ch)
+        self.Dropout_0 = nn.Dropout(dropout)  # parameter-free; the rate is read by the executor
+        self.Conv_1 = _conv(out_ch, out_ch, 3, init_scale)
+        self.has_shortcut = in_ch != out_ch or up or down
+        if self.has_shortcut:
+            self.Conv_2 = _conv(in_ch, out_ch, 1)
+        self.in_ch, self.out_ch, self.up, self.down = in_ch, out_ch, up, down
+
+
+class AttnBlockpp(nn.Module):
+    """layerspp.py:62-73."""
+
+    def __init__(self, channels, init_scale=0.0):
+        super().__init__()
+        self.GroupNorm_0 = _groupnorm(channels)
+        self.NIN_0 = NIN(channels, channels)
+        self.NIN_1 = NIN(channels, channels)
+        self.NIN_2 = NIN(channels, channels)
+        self.NIN_3 = NIN(channels, channels, init_scale=init_scale)
+        self.channels = channels
+
+
+class Downsample(nn.Module):
+    """layerspp.py:129-147 with with_conv=True: fir -> up_or_down_sampling.Conv2d named Conv2d_0,
+    else conv3x3(stride 2, pad 0) named Conv_0."""
+
+    def __init__(self, in_ch, out_ch, fir):
+        super().__init__()
+        if fir:
+            self.Conv2d_0 = _conv(in_ch, out_ch, 3)
+        else:
+            self.Conv_0 = _conv(in_ch, out_ch, 3)
+        self.fir, self.in_ch, self.out_ch = fir, in_ch, out_ch
+
+    @property
+    def conv(self):
+        return self.Conv2d_0 if self.fir else self.Conv_0
+
+
+# ----------------------------------------------------------------------------------------------
+# executor
+# ----------------------------------------------------------------------------------------------
+class _Node:
+    __slots__ = ("v", "g")
+
+    def __init__(self, v):
+        self.v = v
+        self.g = None
+
+
+def _gbuf(node: _Node):
+    """Gradient buffer of a node and whether it already holds a partial sum."""
+    if node.g is None:
+        node.g = torch.empty_like(node.v)
+        return node.g, False
+    return node.g, True
+
+
+def _fir_kernel(k) -> np.ndarray:
+    k = np.asarray(k, dtype=np.float32)
+    k = np.outer(k, k)
+    k /= np.sum(k)
+    return k
+
+
+class _Exec:
+    """One forward (and, if ``record``, the tape of its backward) over NHWC tensors."""
+
+    def __init__(self, net: "NCSNpp", record: bool):
+        self.net = net
+        self.tape = [] if record else None
+        self.record = record
+        sf = net.sf
+        self.s = ops.INV_SQRT2 if sf.skip_rescale else 1.0
+        self.drop_p = float(sf.dropout) if net.training else 0.0  # nn.Dropout: active in train mode
+        self.seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if self.drop_p > 0 else 0
+        self.n_drop = 0
+        fk = tuple(sf.fir_kernel) if sf.fir else (1, 1)
+        self.k_down = _fir_kernel(fk)
+        self.k_up = self.k_down * 4.0
+        p = self.k_down.shape[0] - 2
+        self.pad_up = ((p + 1) // 2 + 1, p // 2)       # up_or_down_sampling.py:222-224
+        self.pad_down = ((p + 1) // 2, p // 2)         # :255-257
+        self.temb_act: Optional[_Node] = None
+        self.watermark = None  # callable(flat_offset) for the DDP reducer
+
+    # -- helpers ------------------------------------------------------------------------------
+    def push(self, fn, module=None):
+        if self.tape is not None:
+            self.tape.append((fn, module))
+
+    def g(self, p: nn.Parameter) -> Tensor:
+        return self.net._grad_view(p)
+
+    def wgrad(self, dy: Tensor, x: Tensor, conv: _Affine, k: int, stride: int, pad: int, alpha: float = 1.0,
+              cin_total: Optional[int] = None, col0: int = 0, slabs=None, nsplit=None, finish=True):
+        b, oh, ow, cout = dy.shape
+        cin = x.shape[-1]
+        cin_total = cin_total or cin
+        taps = k * k
+        n = cout * taps * cin_total
+        if nsplit is None:
+            tiles = ((cout + 127) // 128) * ((cin + 127) // 128) * taps
+            kk = b * oh * ow
+            nsplit = max(1, min((768 + tiles - 1) // tiles, (kk + 255) // 256))
+        if slabs is None:
+            slabs = ops.workspace(4 * n * nsplit, dy.device)
+        ops.conv2d_wgrad_nhwc(dy, cout, x, k, k, stride, pad, oh, ow, slabs, cin_total, col0, nsplit)
+        if finish:
+            ops.reduce_slabs(slabs, nsplit, n, self.g(conv.weight), layout=1, cout=cout, taps=taps, cin=cin_total,
+                             alpha=alpha)
+        return slabs, nsplit
+
+    def bias_grad(self, dy: Tensor, out: Tensor, alpha: float = 1.0, per_image: Optional[Tensor] = None):
+        b = dy.shape[0]
+        c = dy.shape[-1]
+        hw = dy.numel() // (b * c)
+        tmp = per_image if per_image is not None else torch.empty((b, c), device=dy.device, dtype=torch.float32)
+        ops.colsum(dy, c, b, hw, c, tmp)
+        ops.colsum(tmp, c, 1, b, c, out, alpha)
+        return tmp
+
+    def dgrad(self, dy: Tensor, conv: _Affine, k: int, stride: int, pad: int, ih: int, iw: int, out: Tensor,
+              alpha: float = 1.0, accumulate: bool = False):
+        cin = conv.weight.shape[1]
+        wd = self.net._packed(conv, dgrad=True)
+        epi = ops.epilogue(alpha=alpha, accumulate=accumulate) if (alpha != 1.0 or accumulate) else None
+        ops.conv2d_nhwc(dy, None, wd, cin, k, k, 1, k - 1 - pad, stride, ih, iw, out, epi)
+
+    def resample(self, x: Tensor, up: bool) -> Tensor:
+        if up:
+            return ops.upfirdn2d_raw(x, self.k_up, 2, 1, self.pad_up, layout=1)
+        return ops.upfirdn2d_raw(x, self.k_down, 1, 2, self.pad_down, layout=1)
+
+    def resample_bwd(self, gy: Tensor, up: bool, in_hw, out: Tensor, accumulate: bool):
+        if up:
+            ops.upfirdn2d_bwd_raw(gy, self.k_up, 2, 1, self.pad_up, in_hw, 1, out=out, accumulate=accumulate)
+        else:
+            ops.upfirdn2d_bwd_raw(gy, self.k_down, 1, 2, self.pad_down, in_hw, 1, out=out, accumulate=accumulate)
+
+    # -- time embedding (ncsnpp.py:289-313) ------------------------------------------------------
+    def time_embedding(self, t: Tensor):
+        net = self.net
+        mods = net.all_modules
+        i = 0
+        if net.embedding_type == "fourier":
+            emb = ops.time_embed(t, mods[0].W, True)
+            i = 1
+        else:
+            emb = ops.time_embed(t, net._pos_freq(t.device), False)
+        if not net.noise_cond:
+            self.temb_act = None
+            return i
+        l1, l2 = mods[i], mods[i + 1]
+        t1 = ops.linear(emb, l1.weight, l1.bias)
+        s1 = ops.silu(t1)
+        temb = ops.linear(s1, l2.weight, l2.bias)
+        st = _Node(ops.silu(temb))
+        self.temb_act = st
+        b = t.shape[0]
+
+        def bwd():
+            if st.g is None:
+                return
+            dtemb = ops.silu_bwd(temb, st.g)
+            n2, k2 = l2.weight.shape
+            ops.gemm_raw(1, 0, n2, k2, b, dtemb, n2, 0, s1, k2, 0, self.g(l2.weight), k2, 0)
+            ops.colsum(dtemb, n2, 1, b, n2, self.g(l2.bias))
+            ds1 = torch.empty_like(s1)
+            ops.gemm_raw(0, 0, b, k2, n2, dtemb, n2, 0, l2.weight, k2, 0, ds1, k2, 0)
+            dt1 = ops.silu_bwd(t1, ds1)
+            n1, k1 = l1.weight.shape
+            ops.gemm_raw(1, 0, n1, k1, b, dt1, n1, 0, emb, k1, 0, self.g(l1.weight), k1, 0)
+            ops.colsum(dt1, n1, 1, b, n1, self.g(l1.bias))
+
+        self.push(bwd, l1)
+        return i + 2
+
+    # -- ResnetBlockBigGANpp.forward (layerspp.py:242-274) -------------------------------------------
+    def resblock(self, x: _Node, mod: ResnetBlockBigGANpp) -> _Node:
+        net, s = self.net, self.s
+        b, h, w, cin = x.v.shape
+        cout = mod.out_ch
+        up, down = mod.up, mod.down
+        gn0, gn1 = mod.GroupNorm_0, mod.GroupNorm_1
+        st0 = ops.gn_stats(x.v, gn0.weight, gn0.bias)
+        a0 = ops.gn_apply(x.v, st0, True)
+        if up or down:
+            a0r = self.resample(a0, up)
+            xr = self.resample(x.v, up)
+            del a0
+        else:
+            a0r, xr = a0, x.v
+        ho, wo = a0r.shape[1], a0r.shape[2]
+        tp = None
+        if self.temb_act is not None:
+            tp = ops.linear(self.temb_act.v, mod.Dense_0.weight, mod.Dense_0.bias)
+        h1 = torch.empty((b, ho, wo, cout), device=x.v.device, dtype=torch.float32)
+        ops.conv2d_nhwc(a0r, None, net._packed(mod.Conv_0), cout, 3, 3, 1, 1, 1, ho, wo, h1,
+                        ops.epilogue(bias=mod.Conv_0.bias, rowbias=tp, rows_per_img=ho * wo))
+        st1 = ops.gn_stats(h1, gn1.weight, gn1.bias)
+        drop_p, seed = 0.0, 0
+        if self.drop_p > 0:
+            drop_p = self.drop_p
+            self.n_drop += 1
+            seed = (self.seed + self.n_drop * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF
+        a1 = ops.gn_apply(h1, st1, True, drop_p=drop_p, seed=seed)
+        out = torch.empty((b, ho, wo, cout), device=x.v.device, dtype=torch.float32)
+        if mod.has_shortcut:
+            ops.conv2d_nhwc(xr, None, mod.Conv_2.weight, cout, 1, 1, 1, 0, 1, ho, wo, out,
+                            ops.epilogue(bias=mod.Conv_2.bias))
+            res = out
+        else:
+            res = xr
+        ops.conv2d_nhwc(a1, None, net._packed(mod.Conv_1), cout, 3, 3, 1, 1, 1, ho, wo, out,
+                        ops.epilogue(bias=mod.Conv_1.bias, residual=res, ld_residual=cout, out_scale=s))
+        on = _Node(out)
+        if not self.record:
+            return on
+        temb_act = self.temb_act
+        xr_saved = xr if mod.has_shortcut else None
+
+        def bwd():
+            dout = on.g
+            on.g = None
+            # Conv_1 (the 1/sqrt(2) of skip_rescale is folded into alpha)
+            self.wgrad(dout, a1, mod.Conv_1, 3, 1, 1, alpha=s)
+            self.bias_grad(dout, self.g(mod.Conv_1.bias), alpha=s)
+            da1 = torch.empty_like(a1)
+            self.dgrad(dout, mod.Conv_1, 3, 1, 1, ho, wo, da1, alpha=s)
+            dh1 = torch.empty_like(h1)
+            ops.gn_bwd(da1, h1, st1, gn1.weight, gn1.bias, True, dh1, self.g(gn1.weight), self.g(gn1.bias),
+                       drop_p=drop_p, seed=seed)
+            del da1
+            # Conv_0 + time-embedding bias
+            self.wgrad(dh1, a0r, mod.Conv_0, 3, 1, 1)
+            dtp = self.bias_grad(dh1, self.g(mod.Conv_0.bias))
+            if temb_act is not None:
+                d0 = mod.Dense_0
+                kd = d0.weight.shape[1]
+                ops.colsum(dtp, cout, 1, b, cout, self.g(d0.bias))
+                ops.gemm_raw(1, 0, cout, kd, b, dtp, cout, 0, temb_act.v, kd, 0, self.g(d0.weight), kd, 0)
+                gb, acc = _gbuf(temb_act)
+                ops.gemm_raw(0, 0, b, kd, cout, dtp, cout, 0, d0.weight, kd, 0, gb, kd, 0,
+                             epi=ops.epilogue(accumulate=True) if acc else None)
+            da0r = torch.empty_like(a0r)
+            self.dgrad(dh1, mod.Conv_0, 3, 1, 1, ho, wo, da0r)
+            del dh1
+            xg, acc = _gbuf(x)
+            if mod.has_shortcut:
+                c2 = mod.Conv_2
+                self.wgrad(dout, xr_saved, c2, 1, 1, 0, alpha=s)
+                self.bias_grad(dout, self.g(c2.bias), alpha=s)
+                m = b * ho * wo
+                if up or down:
+                    dxr = torch.empty((b, ho, wo, cin), device=dout.device, dtype=torch.float32)
+                    ops.gemm_raw(0, 0, m, cin, cout, dout, cout, 0, c2.weight, cin, 0, dxr, cin, 0,
+                                 epi=ops.epilogue(alpha=s))
+                    self.resample_bwd(dxr, up, (h, w), xg, acc)
+                    del dxr
+                else:
+                    ops.gemm_raw(0, 0, m, cin, cout, dout, cout, 0, c2.weight, cin, 0, xg, cin, 0,
+                                 epi=ops.epilogue(alpha=s, accumulate=acc))
+            else:
+                ops.axpby(dout, s, None, 0.0, xg, accumulate=acc)
+            if up or down:
+                da0 = torch.empty((b, h, w, cin), device=dout.device, dtype=torch.float32)
+                self.resample_bwd(da0r, up, (h, w), da0, False)
+            else:
+                da0 = da0r
+            ops.gn_bwd(da0, x.v, st0, gn0.weight, gn0.bias, True, xg, self.g(gn0.weight), self.g(gn0.bias),
+                       accumulate_dx=True)
+
+        self.push(bwd, mod)
+        return on
+
+    # -- AttnBlockpp.forward (layerspp.py:75-91) -----------------------------------------------------
+    def attn(self, x: _Node, mod: AttnBlockpp) -> _Node:
+        s = self.s
+        b, h, w, c = x.v.shape
+        hw = h * w
+        m = b * hw
+        dev = x.v.device
+        gn = mod.GroupNorm_0
+        st = ops.gn_stats(x.v, gn.weight, gn.bias)
+        hn = ops.gn_apply(x.v, st, False)
+        qkv = []
+        for nin in (mod.NIN_0, mod.NIN_1, mod.NIN_2):
+            y = torch.empty((b, hw, c), device=dev, dtype=torch.float32)
+            ops.gemm_raw(0, 0, m, c, c, hn, c, 0, nin.W, c, 0, y, c, 0, epi=ops.epilogue(bias=nin.b))
+            qkv.append(y)
+        q, k, v = qkv
+        scale = float(int(c) ** (-0.5))
+        p = torch.empty((b, hw, hw), device=dev, dtype=torch.float32)
+        ops.gemm_raw(0, 1, hw, hw, c, q, c, hw * c, k, c, hw * c, p, hw, hw * hw, b, ops.epilogue(alpha=scale))
+        ops.softmax_rows(p, p, b * hw, hw)
+        ho = torch.empty((b, hw, c), device=dev, dtype=torch.float32)
+        ops.gemm_raw(0, 0, hw, c, hw, p, hw, hw * hw, v, c, hw * c, ho, c, hw * c, b)
+        out = torch.empty_like(x.v)
+        n3 = mod.NIN_3
+        ops.gemm_raw(0, 0, m, c, c, ho, c, 0, n3.W, c, 0, out, c, 0,
+                     epi=ops.epilogue(bias=n3.b, residual=x.v, ld_residual=c, out_scale=s))
+        on = _Node(out)
+        if not self.record:
+            return on
+
+        def nin_wgrad(a_in: Tensor, dy: Tensor, nin: NIN, alpha: float):
+            # dW[in,out] = a_in^T dy  (K = B*HW -> split-K slabs)
+            nsplit = max(1, min(768 // max(1, ((c + 127) // 128) ** 2), (m + 255) // 256))
+            slabs = ops.workspace(4 * c * c * nsplit, dev)
+            ops.gemm_tn_splitk(c, c, m, a_in, c, dy, c, slabs, nsplit)
+            ops.reduce_slabs(slabs, nsplit, c * c, self.g(nin.W), alpha=alpha)
+            self.bias_grad(dy.view(b, hw, 1, c), self.g(nin.b), alpha=alpha)
+
+        def bwd():
+            dout = on.g
+            on.g = None
+            nin_wgrad(ho, dout, n3, s)
+            dho = torch.empty_like(ho)
+            ops.gemm_raw(0, 1, m, c, c, dout, c, 0, n3.W, c, 0, dho, c, 0, epi=ops.epilogue(alpha=s))
+            # dP = dho v^T ; dv = P^T dho
+            dp = torch.empty_like(p)
+            ops.gemm_raw(0, 1, hw, hw, c, dho, c, hw * c, v, c, hw * c, dp, hw, hw * hw, b)
+            dv = torch.empty_like(v)
+            ops.gemm_raw(1, 0, hw, c, hw, p, hw, hw * hw, dho, c, hw * c, dv, c, hw * c, b)
+            ds = dp
+            ops.softmax_rows_bwd(p, dp, ds, b * hw, hw)
+            dq = torch.empty_like(q)
+            ops.gemm_raw(0, 0, hw, c, hw, ds, hw, hw * hw, k, c, hw * c, dq, c, hw * c, b, ops.epilogue(alpha=scale))
+            dk = dho  # reuse
+            ops.gemm_raw(1, 0, hw, c, hw, ds, hw, hw * hw, q, c, hw * c, dk, c, hw * c, b, ops.epilogue(alpha=scale))
+            dhn = torch.empty_like(hn)
+            first = True
+            for nin, d in ((mod.NIN_0, dq), (mod.NIN_1, dk), (mod.NIN_2, dv)):
+                nin_wgrad(hn, d, nin, 1.0)
+                ops.gemm_raw(0, 1, m, c, c, d, c, 0, nin.W, c, 0, dhn, c, 0,
+                             epi=None if first else ops.epilogue(accumulate=True))
+                first = False
+            xg, acc = _gbuf(x)
+            ops.axpby(dout, s, None, 0.0, xg, accumulate=acc)
+            ops.gn_bwd(dhn, x.v, st, gn.weight, gn.bias, False, xg, self.g(gn.weight), self.g(gn.bias),
+                       accumulate_dx=True)
+
+        self.push(bwd, mod)
+        return on
+
+    # -- progressive_input == 'residual' (ncsnpp.py:350-357; layerspp.py:149-163) ---------------------
+    def pyramid(self, pyr, h: _Node, mod: Downsample, first: bool) -> _Node:
+        """pyr: NCHW input tensor (first level) or the previous combined node (NHWC)."""
+        s = self.s
+        conv = mod.conv
+        cout = mod.out_ch
+        if mod.fir:
+            k = _fir_kernel(self.net.sf.fir_kernel)
+            pad = (2, 2)  # up_or_down_sampling.py:173-176: p = (4-2) + (3-1)
+            if first:
+                xf = ops.nchw_to_nhwc(ops.upfirdn2d_raw(pyr, k, 1, 1, pad, layout=0))
+            else:
+                xf = ops.upfirdn2d_raw(pyr.v, k, 1, 1, pad, layout=1)
+        else:
+            raise NotImplementedError("progressive_input='residual' with fir=False is not on the north-star path")
+        b, fh, fw, cin = xf.shape
+        oh, ow = (fh - 3) // 2 + 1, (fw - 3) // 2 + 1
+        out = torch.empty((b, oh, ow, cout), device=xf.device, dtype=torch.float32)
+        ops.conv2d_nhwc(xf, None, self.net._packed(conv), cout, 3, 3, 2, 0, 1, oh, ow, out,
+                        ops.epilogue(bias=conv.bias, residual=h.v, ld_residual=cout, out_scale=s))
+        on = _Node(out)
+        if not self.record:
+            return on
+
+        def bwd():
+            dout = on.g
+            on.g = None
+            hg, acc = _gbuf(h)
+            ops.axpby(dout, s, None, 0.0, hg, accumulate=acc)
+            self.wgrad(dout, xf, conv, 3, 2, 0, alpha=s)
+            self.bias_grad(dout, self.g(conv.bias), alpha=s)
+            if not first:
+                dxf = torch.empty_like(xf)
+                self.dgrad(dout, conv, 3, 2, 0, fh, fw, dxf, alpha=s)
+                pg, pacc = _gbuf(pyr)
+                ops.upfirdn2d_bwd_raw(dxf, k, 1, 1, pad, (pyr.v.shape[1], pyr.v.shape[2]), 1, out=pg, accumulate=pacc)
+
+        self.push(bwd, mod)
+        return on
+
+    def concat(self, a: _Node, bnode: _Node) -> _Node:
+        """torch.cat([h, hs.pop()], dim=1) (ncsnpp.py:374) in NHWC."""
+        b, h, w, c1 = a.v.shape
+        c2 = bnode.v.shape[-1]
+        rows = b * h * w
+        cat = torch.empty((b, h, w, c1 + c2), device=a.v.device, dtype=torch.float32)
+        ops.copy2d(a.v, c1, cat, c1 + c2, rows, c1)
+        ops.copy2d(bnode.v, c2, cat, c1 + c2, rows, c2, dst_off=c1)
+        cn = _Node(cat)
+        if self.record:
+            def bwd():
+                g = cn.g
+                cn.g = None
+                ga, acc = _gbuf(a)
+                ops.copy2d(g, c1 + c2, ga, c1, rows, c1, accumulate=acc)
+                gb, acc = _gbuf(bnode)
+                ops.copy2d(g, c1 + c2, gb, c2, rows, c2, accumulate=acc, src_off=c1)
+
+            self.push(bwd)
+        return cn
+
+    # -- whole network (ncsnpp.py:287-438) --------------------------------------------------------------
+    def run(self, x: Tensor, t: Tensor) -> Tensor:
+        net = self.net
+        mods = net.all_modules
+        mi = self.time_embedding(t)
+        pin = net.progressive_input
+        x_nhwc = ops.nchw_to_nhwc(x)
+        stem = mods[mi]
+        mi += 1
+        b, hh, ww, _ = x_nhwc.shape
+        h0 = torch.empty((b, hh, ww, stem.weight.shape[0]), device=x.device, dtype=torch.float32)
+        ops.conv2d_nhwc(x_nhwc, None, net._packed(stem), stem.weight.shape[0], 3, 3, 1, 1, 1, hh, ww, h0,
+                        ops.epilogue(bias=stem.bias))
+        n0 = _Node(h0)
+        if self.record:
+            def stem_bwd():
+                self.wgrad(n0.g, x_nhwc, stem, 3, 1, 1)
+                self.bias_grad(n0.g, self.g(stem.bias))
+                n0.g = None
+
+            self.push(stem_bwd, stem)
+        hs: List[_Node] = [n0]
+        pyr = x
+        first_pyr = True
+        for lvl in range(net.num_resolutions):
+            for _ in range(net.num_res_blocks):
+                hnode = self.resblock(hs[-1], mods[mi])
+                mi += 1
+                if hnode.v.shape[2] in net.attn_resolutions:
+                    hnode = self.attn(hnode, mods[mi])
+                    mi += 1
+                hs.append(hnode)
+            if lvl != net.num_resolutions - 1:
+                hnode = self.resblock(hs[-1], mods[mi])
+                mi += 1
+                if pin == "residual":
+                    hnode = self.pyramid(pyr, hnode, mods[mi], first_pyr)
+                    mi += 1
+                    pyr = hnode
+                    first_pyr = False
+                hs.append(hnode)
+        hnode = hs[-1]
+        hnode = self.resblock(hnode, mods[mi]); mi += 1
+        hnode = self.attn(hnode, mods[mi]); mi += 1
+        hnode = self.resblock(hnode, mods[mi]); mi += 1
+        for lvl in reversed(range(net.num_resolutions)):
+            for _ in range(net.num_res_blocks + 1):
+                hnode = self.resblock(self.concat(hnode, hs.pop()), mods[mi])
+                mi += 1
+            if hnode.v.shape[2] in net.attn_resolutions:
+                hnode = self.attn(hnode, mods[mi])
+                mi += 1
+            if lvl != 0:
+                hnode = self.resblock(hnode, mods[mi])
+                mi += 1
+        assert not hs
+        gnf, head = mods[mi], mods[mi + 1]
+        assert mi + 2 == len(mods)
+        stf = ops.gn_stats(hnode.v, gnf.weight, gnf.bias)
+        af = ops.gn_apply(hnode.v, stf, True)
+        oc = head.weight.shape[0]
+        y = torch.empty((b, hh, ww, oc), device=x.device, dtype=torch.float32)
+        ops.conv2d_nhwc(af, None, net._packed(head), oc, 3, 3, 1, 1, 1, hh, ww, y, ops.epilogue(bias=head.bias))
+        if self.record:
+            last = hnode
+            self.head_grad = _Node(y)
+            hg = self.head_grad
+
+            def head_bwd():
+                dy = hg.g
+                self.wgrad(dy, af, head, 3, 1, 1)
+                self.bias_grad(dy, self.g(head.bias))
+                daf = torch.empty_like(af)
+                self.dgrad(dy, head, 3, 1, 1, hh, ww, daf)
+                xg, acc = _gbuf(last)
+                ops.gn_bwd(daf, last.v, stf, gnf.weight, gnf.bias, True, xg, self.g(gnf.weight), self.g(gnf.bias),
+                           accumulate_dx=acc)
+
+            self.push(head_bwd, gnf)
+        return ops.nhwc_to_nchw(y)
+
+    def backward(self, grad_out_nchw: Tensor):
+        net = self.net
+        self.head_grad.g = ops.nchw_to_nhwc(grad_out_nchw.contiguous())
+        for fn, module in reversed(self.tape):
+            fn()
+            if module is not None and self.watermark is not None:
+                self.watermark(net._module_offset(module))
+        self.tape = None
+
+
+class _NCSNppFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, t, anchor, net):
+        ex = _Exec(net, record=True)
+        ex.watermark = net._watermark_hook
+        y = ex.run(x, t)
+        ctx.ex = ex
+        ctx.net = net
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        ex, net = ctx.ex, ctx.net
+        ctx.ex = None
+        net._begin_backward()
+        ex.backward(gy)
+        net._end_backward()
+        return None, None, None, None
+
+
+@register_module(category="score_fn", name="ncsnpp")
+class NCSNpp(nn.Module):
+    """NCSN++ (ncsnpp.py:35-285 for the module list; forward in ``_Exec.run``)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config.model
+        sf = self.sf = config.model.score_fn
+        if sf.nonlinearity.lower() != "swish":
+            raise NotImplementedError("only nonlinearity='swish' is on the north-star path")
+        if sf.resblock_type.lower() != "biggan" or sf.progressive.lower() != "none":
+            raise NotImplementedError("only resblock_type='biggan', progressive='none' are supported")
+        self.nf = nf = sf.nf
+        ch_mult = list(sf.ch_mult)
+        self.num_res_blocks = nres = sf.num_res_blocks
+        self.attn_resolutions = list(sf.attn_resolutions)
+        self.num_resolutions = nlev = len(ch_mult)
+        self.all_resolutions = [config.data.image_size // (2 ** i) for i in range(nlev)]
+        self.noise_cond = sf.noise_cond
+        self.skip_rescale = sf.skip_rescale
+        self.progressive_input = pin = sf.progressive_input.lower()
+        self.embedding_type = emb = sf.embedding_type.lower()
+        if pin not in ("none", "residual"):
+            raise NotImplementedError("progressive_input must be 'none' or 'residual'")
+        if emb not in ("fourier", "positional"):
+            raise ValueError(f"embedding type {emb} unknown.")
+        init_scale = sf.init_scale
+        dropout = sf.dropout
+        fir = sf.fir
+
+        modules: List[nn.Module] = []
+        if emb == "fourier":
+            assert config.training.continuous, "Fourier features are only used for continuous training."
+            modules.append(GaussianFourierProjection(embedding_size=nf, scale=sf.fourier_scale))
+            embed_dim = 2 * nf
+        else:
+            embed_dim = nf
+        if self.noise_cond:
+            modules.append(_linear(embed_dim, nf * 4))
+            modules.append(_linear(nf * 4, nf * 4))
+        temb_dim = nf * 4 if self.noise_cond else None
+        rb = lambda **kw: ResnetBlockBigGANpp(temb_dim=temb_dim, dropout=dropout, init_scale=init_scale, **kw)
+
+        channels = sf.in_ch
+        input_pyramid_ch = channels
+        modules.append(_conv(channels, nf, 3))
+        hs_c = [nf]
+        in_ch = nf
+        for lvl in range(nlev):
+            for _ in range(nres):
+                out_ch = nf * ch_mult[lvl]
+                modules.append(rb(in_ch=in_ch, out_ch=out_ch))
+                in_ch = out_ch
+                if self.all_resolutions[lvl] in self.attn_resolutions:
+                    modules.append(AttnBlockpp(in_ch, init_scale))
+                hs_c.append(in_ch)
+            if lvl != nlev - 1:
+                modules.append(rb(in_ch=in_ch, down=True))
+                if pin == "residual":
+                    modules.append(Downsample(input_pyramid_ch, in_ch, fir))
+                    input_pyramid_ch = in_ch
+                hs_c.append(in_ch)
+        in_ch = hs_c[-1]
+        modules.append(rb(in_ch=in_ch))
+        modules.append(AttnBlockpp(in_ch, init_scale))
+        modules.append(rb(in_ch=in_ch))
+        for lvl in reversed(range(nlev)):
+            for _ in range(nres + 1):
+                out_ch = nf * ch_mult[lvl]
+                modules.append(rb(in_ch=in_ch + hs_c.pop(), out_ch=out_ch))
+                in_ch = out_ch
+            if self.all_resolutions[lvl] in self.attn_resolutions:
+                modules.append(AttnBlockpp(in_ch, init_scale))
+            if lvl != 0:
+                modules.append(rb(in_ch=in_ch, up=True))
+        assert not hs_c
+        modules.append(_groupnorm(in_ch))
+        modules.append(_conv(in_ch, sf.out_ch, 3, init_scale))
+        self.all_modules = nn.ModuleList(modules)
+
+        # executor state (never part of state_dict)
+        self._flat: Optional[Tensor] = None
+        self._flat_grad: Optional[Tensor] = None
+        self._offsets = None
+        self._pack_cache = {}
+        self._pack_key = None
+        self._epoch = 0
+        self._anchor = None
+        self._reducer = None
+        self._posfreq = None
+        self._module_offs = None
+
+    # ---- flat parameter / gradient storage ----------------------------------------------------------
+    def _layout(self):
+        offs, off = {}, 0
+        for p in self.parameters():
+            offs[id(p)] = off
+            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        return offs, off
+
+    def flatten_parameters(self) -> Tensor:
+        """Make every parameter a view into one contiguous fp32 buffer (idempotent).  Needed by the
+        fused optimiser / EMA / all-reduce; deepcopy() and .to() are followed by a re-flatten."""
+        params = list(self.parameters())
+        dev = params[0].device
+        offs, total = self._layout()
+        flat = self._flat
+        ok = flat is not None and flat.device == dev and flat.numel() == total and all(
+            p.data_ptr() == flat.data_ptr() + 4 * offs[id(p)] for p in params)
+        if not ok:
+            flat = torch.zeros(total, device=dev, dtype=torch.float32)
+            for p in params:
+                o = offs[id(p)]
+                flat[o:o + p.numel()].copy_(p.data.reshape(-1))
+                p.data = flat[o:o + p.numel()].view(p.shape)
+            self._flat = flat
+            self._flat_grad = None
+            self._pack_cache.clear()
+            self._epoch += 1
+        self._offsets = offs
+        self._module_offs = None
+        return self._flat
+
+    def flat_grad(self) -> Tensor:
+        self.flatten_parameters()
+        if self._flat_grad is None or self._flat_grad.device != self._flat.device or \
+                self._flat_grad.numel() != self._flat.numel():
+            self._flat_grad = torch.zeros_like(self._flat)
+        return self._flat_grad
+
+    def _grad_view(self, p: nn.Parameter) -> Tensor:
+        o = self._offsets[id(p)]
+        return self._flat_grad[o:o + p.numel()].view(p.shape)
+
+    def _module_offset(self, module: nn.Module) -> int:
+        if self._module_offs is None:
+            self._module_offs = {}
+            for m in self.all_modules:
+                ps = list(m.parameters())
+                if ps:
+                    self._module_offs[id(m)] = min(self._offsets[id(p)] for p in ps)
+        return self._module_offs.get(id(module), 0)
+
+    def weights_changed(self):
+        """Call after writing parameters through raw pointers (fused optimiser / EMA kernels)."""
+        self._epoch += 1
+
+    def _packed(self, conv: _Affine, dgrad: bool = False) -> Tensor:
+        """[co][tap][ci] (forward) or [ci][flip tap][co] (data-gradient) copy of an OIHW weight,
+        cached until the weights change."""
+        w = conv.weight
+        key = (id(w), dgrad)
+        ent = self._pack_cache.get(key)
+        stamp = (self._epoch, w._version, w.data_ptr())
+        if ent is not None and ent[0] == stamp:
+            return ent[1]
+        co, ci, kh, kw = w.shape
+        out = ent[1] if ent is not None and ent[1].device == w.device else \
+            torch.empty((ci, kh * kw, co) if dgrad else (co, kh * kw, ci), device=w.device, dtype=torch.float32)
+        (ops.pack_dgrad if dgrad else ops.pack_ohwi)(w.detach(), out)
+        self._pack_cache[key] = (stamp, out)
+        return out
+
+    def _pos_freq(self, device):
+        if self._posfreq is None or self._posfreq.device != device:
+            half = self.nf // 2
+            e = math.log(10000) / (half - 1)                                   # layers.py:500-507
+            self._posfreq = torch.exp(torch.arange(half, dtype=torch.float32) * -e).to(device)
+        return self._posfreq
+
+    # ---- backward bookkeeping ------------------------------------------------------------------------
+    def _begin_backward(self):
+        self.flat_grad()
+        if self._reducer is not None:
+            self._reducer.begin(self._flat_grad)
+
+    def _watermark_hook(self, offset: int):
+        if self._reducer is not None:
+            self._reducer.ready_from(offset)
+
+    def _end_backward(self):
+        if self._reducer is not None:
+            self._reducer.finish()
+        for p in self.parameters():
+            if not p.requires_grad:
+                continue
+            gv = self._grad_view(p)
+            if p.grad is None or p.grad.data_ptr() == gv.data_ptr():
+                p.grad = gv
+            else:
+                p.grad.add_(gv)  # caller kept a foreign .grad tensor: accumulate like autograd would
+
+    def set_reducer(self, reducer):
+        """Attach a gradient reducer (psld_amd.ddp.BucketReducer) fed during backward."""
+        self._reducer = reducer
+
+    # ---- forward -----------------------------------------------------------------------------------------
+    def forward(self, x: Tensor, time_cond: Tensor) -> Tensor:
+        if not x.is_cuda:
+            raise RuntimeError("psld_amd.NCSNpp runs on MI355X only: the HIP extension has no CPU fallback "
+                               "(use oracle/psld_oracle.py as the CPU checker)")
+        if x.dtype != torch.float32 or time_cond.dtype != torch.float32:
+            raise RuntimeError("NCSNpp expects float32 x and time_cond (ncsnpp.py:287; psld.py:354)")
+        ops.lib()
+        x = x.contiguous()
+        t = time_cond.contiguous()
+        self.flatten_parameters()
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if x.requires_grad:
+            raise NotImplementedError("gradient w.r.t. the network input is not on the hot path")
+        if need_grad:
+            self.flat_grad()
+            if self._anchor is None or self._anchor.device != x.device:
+                self._anchor = torch.zeros(1, device=x.device, requires_grad=True)
+            return _NCSNppFn.apply(x, t, self._anchor, self)
+        with torch.no_grad():
+            return _Exec(self, record=False).run(x, t)
+
+    def __deepcopy__(self, memo):
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        skip = {"_flat", "_flat_grad", "_pack_cache", "_anchor", "_reducer", "_offsets", "_module_offs", "_posfreq"}
+        for k, v in self.__dict__.items():
+            if k in skip:
+                continue
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        new._flat = new._flat_grad = new._offsets = new._anchor = new._reducer = new._posfreq = None
+        new._module_offs = None
+        new._pack_cache = {}
+        new._pack_key = None
+        new._epoch = 0
+        # detach copied params from the source's flat buffer (they are re-flattened on first use)
+        for p in new.parameters():
+            p.data = p.data.clone()
+        return new

@@ -1,0 +1,134 @@
+"""``SDEWrapper``: the reference's Lightning module surface (main/models/wrapper.py:12-155).
+
+Same constructor signature, same ``training_step`` / ``predict_step`` / ``configure_optimizers``
+semantics.  With pytorch_lightning installed it IS a ``pl.LightningModule`` (train_sde.py:57-60,
+eval/sample.py:62-69 work unchanged); on boxes without Lightning (this image) a minimal base class
+supplies ``optimizers()/lr_schedulers()/manual_backward()/log()`` and ``psld_amd.trainer`` drives it.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .optim import FusedAdam
+from .registry import get_module, register_module
+
+try:  # pragma: no cover - Lightning is not in the offline image
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+    HAVE_LIGHTNING = True
+except Exception:  # noqa: BLE001
+    HAVE_LIGHTNING = False
+
+    class _Base(nn.Module):
+        """The slice of LightningModule that wrapper.py uses (manual optimisation)."""
+
+        def __init__(self):
+            super().__init__()
+            self.global_rank = 0
+            self._optim = None
+            self._sched = None
+            self.logged = {}
+
+        @property
+        def device(self):
+            return next(self.parameters()).device
+
+        def _ensure_optim(self):
+            if self._optim is None:
+                cfg = self.configure_optimizers()
+                self._optim = cfg["optimizer"]
+                self._sched = cfg["lr_scheduler"]["scheduler"]
+
+        def optimizers(self):
+            self._ensure_optim()
+            return self._optim
+
+        def lr_schedulers(self):
+            self._ensure_optim()
+            return self._sched
+
+        def manual_backward(self, loss):
+            loss.backward()
+
+        def log(self, name, value, **kw):
+            self.logged[name] = value
+
+
+@register_module(category="pl_modules", name="sde_wrapper")
+class SDEWrapper(_Base):
+    def __init__(self, config, sde, score_fn, ema_score_fn=None, criterion=None, sampler_cls=None,
+                 corrector_fn=None):
+        super().__init__()
+        self.config = config
+        self.score_fn = score_fn
+        self.ema_score_fn = ema_score_fn
+        self.sde = sde
+        self.criterion = criterion
+        self.train_eps = self.config.training.train_eps
+        self.sampler = None
+        if sampler_cls is not None:
+            self.sampler = sampler_cls(
+                self.config, self.sde,
+                self.ema_score_fn if config.evaluation.sample_from == "target" else self.score_fn,
+                corrector_fn=corrector_fn)
+        self.eval_eps = self.config.evaluation.eval_eps
+        self.denoise = self.config.evaluation.denoise
+        n = self.config.evaluation.n_discrete_steps
+        self.n_discrete_steps = n - 1 if self.denoise else n           # wrapper.py:52-54
+        self.val_eps = self.config.evaluation.eval_eps
+        self.stride_type = self.config.evaluation.stride_type
+        self.automatic_optimization = False
+        self.fuse_ema = False   # set True to fold the EMA update into the optimiser kernel
+
+    def forward(self):
+        pass
+
+    def training_step(self, batch, batch_idx):
+        optim = self.optimizers()
+        lr_sched = self.lr_schedulers()
+        x_0 = batch
+        t_ = torch.rand(x_0.shape[0], device=x_0.device, dtype=torch.float64)   # wrapper.py:72-73
+        t = t_ * (self.sde.T - self.train_eps) + self.train_eps
+        loss = self.criterion(x_0, t, self.score_fn)
+        optim.zero_grad()
+        self.manual_backward(loss)
+        gc = self.config.training.optimizer.grad_clip
+        fused = isinstance(getattr(optim, "optimizer", optim), FusedAdam)
+        if gc != 0 and not fused:
+            torch.nn.utils.clip_grad_norm_(self.score_fn.parameters(), gc)   # wrapper.py:82-85
+        optim.step()                  # FusedAdam: norm + clip + Adam (+EMA) in two launches
+        lr_sched.step()
+        self.log("loss", loss, prog_bar=True)
+        return loss
+
+    def on_predict_start(self):
+        seed = self.config.evaluation.seed
+        torch.manual_seed(seed + self.global_rank)                        # wrapper.py:93-99
+
+    def sampling_times(self, device):
+        t_final = self.sde.T - self.eval_eps
+        ts = torch.linspace(0, t_final, self.n_discrete_steps + 1, device=device, dtype=torch.float64)
+        if self.stride_type == "quadratic":
+            ts = t_final * torch.flip(1 - (ts / t_final) ** 2.0, dims=[0])
+        return ts
+
+    def predict_step(self, batch, batch_idx, dataloader_idx=None):
+        ts = self.sampling_times(batch.device)                           # wrapper.py:101-114
+        return self.sampler.sample(batch, ts, self.n_discrete_steps, denoise=self.denoise, eps=self.eval_eps)
+
+    def configure_optimizers(self):
+        oc = self.config.training.optimizer
+        if oc.name != "Adam":
+            raise NotImplementedError(f"Optimizer {oc.name} not supported yet!")
+        optimizer = FusedAdam(self.score_fn, lr=oc.lr, betas=(oc.beta_1, oc.beta_2), eps=oc.eps,
+                              weight_decay=oc.weight_decay, grad_clip=oc.grad_clip,
+                              ema_module=self.ema_score_fn if self.fuse_ema else None,
+                              ema_decay=self.config.training.ema_decay)
+        if oc.warmup == 0:
+            lr_lambda = lambda step: 1.0
+        else:
+            lr_lambda = lambda step: min(step / oc.warmup, 1.0)          # wrapper.py:143-147
+        scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda)
+        return {"optimizer": optimizer,
+                "lr_scheduler": {"scheduler": scheduler, "interval": "step", "strict": False}}

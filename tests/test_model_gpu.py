@@ -1,0 +1,274 @@
+"""GPU parity of the product path (psld_amd.* -> libpsld_hip.so) against the golden vectors of the
+reference and against the CPU oracle on the same seeded inputs.
+
+Tolerances (BASELINE.json: outputs within 1e-4 rel-L2 of the CPU reference): network outputs and
+sampler states are asserted at 2e-5 / 1e-4; gradients at 1e-4; optimiser state after 3 steps at 1e-4.
+"""
+import copy
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import psld_oracle as O
+from psld_amd import config as C
+from tests.conftest import GOLDEN
+from tests.synth import synth_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+T = torch.from_numpy
+
+
+def rel_l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def _meta():
+    with open(os.path.join(GOLDEN, "net_meta.json")) as fh:
+        return json.load(fh)
+
+
+def _cfg(name):
+    from tests.test_oracle_golden import _net_cfg
+    return _net_cfg(name)
+
+
+def _build(name, train=False):
+    import psld_amd
+    psld_amd.import_modules_into_registry()
+    from psld_amd.registry import get_module
+    meta = _meta()[name]
+    cfg = _cfg(name)
+    net = get_module("score_fn", "ncsnpp")(cfg)
+    sd = synth_state_dict([(k, tuple(s)) for k, s in meta["keys"]], meta["seed"])
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV)
+    net.train(train)
+    return net, cfg, sd
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_ablation", "tiny_out3", "c10_sota", "celeba64"])
+def test_network_forward_matches_reference(golden, name):
+    net, cfg, _ = _build(name)
+    g = golden(f"net_{name}.npz")
+    with torch.no_grad():
+        y = net(T(g["x"]).to(DEV), T(g["t"]).to(DEV))
+    assert y.shape == g["y"].shape and y.dtype == torch.float32
+    err = rel_l2(y, T(g["y"]))
+    print(f"{name}: rel-L2 vs reference = {err:.3e}")
+    assert err < 2e-5
+
+
+def test_native_library_is_what_ran():
+    """The HIP shared object must be mapped into this process (no silent eager fallback)."""
+    from psld_amd import _lib
+    _lib.load()
+    with open("/proc/self/maps") as fh:
+        assert "libpsld_hip.so" in fh.read()
+
+
+def test_cpu_tensor_fails_loudly():
+    net, cfg, _ = _build("tiny")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.zeros(1, 6, 16, 16), torch.ones(1))
+
+
+def test_state_dict_roundtrip_and_deepcopy():
+    net, cfg, sd = _build("tiny")
+    out = net.state_dict()
+    assert list(out.keys()) == list(sd.keys())
+    for k in sd:
+        assert torch.equal(out[k].cpu(), sd[k]), k
+    ema = copy.deepcopy(net)
+    x = torch.randn(2, 6, 16, 16, device=DEV)
+    t = torch.rand(2, device=DEV) * 0.9 + 0.05
+    with torch.no_grad():
+        assert torch.equal(net(x, t), ema(x, t))
+    # the copy owns its storage
+    with torch.no_grad():
+        next(iter(ema.parameters())).add_(1.0)
+    assert not torch.equal(next(iter(ema.parameters())), next(iter(net.parameters())))
+
+
+def test_hsm_loss_and_gradients(golden):
+    from psld_amd.registry import get_module
+    net, cfg, _ = _build("tiny", train=True)
+    g = golden("loss_tiny.npz")
+    sde = get_module("sde", "psld")(cfg)
+    crit = get_module("losses", "psld_score_loss")(cfg, sde)
+    x0, eps, t = T(g["x0"]).to(DEV), T(g["eps"]).to(DEV), T(g["t"]).to(DEV)
+    loss = crit(x0, t, net, eps=eps)
+    assert abs(loss.item() - float(g["loss"])) < 2e-5 * abs(float(g["loss"]))
+    loss.backward()
+    pd = dict(net.named_parameters())
+    norms = dict(zip(g["grad_norm_keys"].tolist(), g["grad_norms"].tolist()))
+    worst = 0.0
+    for k, p in pd.items():
+        if not p.requires_grad:
+            assert p.grad is None
+            continue
+        assert p.grad is not None, k
+        gn = p.grad.double().norm().item()
+        assert abs(gn - norms[k]) <= 2e-4 * norms[k] + 1e-9, (k, gn, norms[k])
+    for k in g.files:
+        if k.startswith("g:"):
+            e = rel_l2(pd[k[2:]].grad, T(g[k]))
+            worst = max(worst, e)
+            assert e < 1e-4, (k, e)
+    total = torch.linalg.vector_norm(torch.stack([p.grad.double().norm() for p in pd.values() if p.grad is not None]))
+    assert abs(total.item() - float(g["total_norm"])) < 1e-4 * float(g["total_norm"])
+    print(f"worst selected-grad rel-L2 = {worst:.3e}")
+    # DSM branch: same momentum draw as losses.py:96
+    cfg_d = _cfg("tiny")
+    cfg_d.training.mode = "dsm"
+    crit_d = get_module("losses", "psld_score_loss")(cfg_d, sde)
+    import unittest.mock as mock
+    m0 = T(g["dsm_m0_unit"]).to(DEV)
+    with mock.patch("torch.randn_like", lambda x_, **kw: m0), torch.no_grad():
+        ld = crit_d(x0, t.clamp(min=1e-3), net, eps=eps)
+    assert abs(ld.item() - float(g["loss_dsm"])) < 2e-5 * abs(float(g["loss_dsm"]))
+
+
+def test_three_training_steps(golden):
+    """criterion -> backward -> fused clip+Adam -> LambdaLR -> EMA, vs the reference's
+    torch.optim.Adam / clip_grad_norm_ / EMAWeightUpdate run (tools/gen_golden.py §I)."""
+    from psld_amd.registry import get_module
+    from psld_amd.optim import EMAWeightUpdate, FusedAdam
+    net, cfg, sd0 = _build("tiny", train=True)
+    g = golden("train_tiny.npz")
+    ema = copy.deepcopy(net)
+    for p in ema.parameters():
+        p.requires_grad = False
+    sde = get_module("sde", "psld")(cfg)
+    crit = get_module("losses", "psld_score_loss")(cfg, sde)
+    oc = cfg.training.optimizer
+    opt = FusedAdam(net, lr=oc.lr, betas=(oc.beta_1, oc.beta_2), eps=oc.eps, weight_decay=oc.weight_decay,
+                    grad_clip=oc.grad_clip)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: min(s / oc.warmup, 1.0))
+    cb = EMAWeightUpdate(cfg.training.ema_decay)
+    for step in range(3):
+        loss = crit(T(g[f"x0_{step}"]).to(DEV), T(g[f"t_{step}"]).to(DEV), net, eps=T(g[f"eps_{step}"]).to(DEV))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        sched.step()
+        cb.update_weights(net, ema)
+        assert abs(loss.item() - g["losses"][step]) < 1e-4 * abs(g["losses"][step]), step
+        assert abs(opt.grad_norm.item() - g["grad_norms"][step]) < 2e-4 * g["grad_norms"][step]
+    pd, ed = dict(net.named_parameters()), dict(ema.named_parameters())
+    for k, dn in zip(g["keys"].tolist(), g["param_delta_norms"]):
+        d = (pd[k].detach().cpu() - sd0[k]).double().norm().item()
+        assert abs(d - dn) <= 2e-2 * dn + 1e-9, (k, d, dn)
+    for k in g.files:
+        if k.startswith("p:"):
+            np.testing.assert_allclose(pd[k[2:]].detach().cpu().numpy(), g[k], rtol=0, atol=5e-6)
+        if k.startswith("e:"):
+            np.testing.assert_allclose(ed[k[2:]].detach().cpu().numpy(), g[k], rtol=0, atol=2e-7)
+
+
+def test_wrapper_training_step_runs():
+    import psld_amd
+    psld_amd.import_modules_into_registry()
+    from psld_amd.registry import get_module
+    cfg = C.tiny()
+    cfg.model.score_fn.dropout = 0.15
+    torch.manual_seed(0)
+    net = get_module("score_fn", "ncsnpp")(cfg).to(DEV)
+    ema = copy.deepcopy(net)
+    sde = get_module("sde", "psld")(cfg)
+    crit = get_module("losses", "psld_score_loss")(cfg, sde)
+    wr = get_module("pl_modules", "sde_wrapper")(cfg, sde, net, ema_score_fn=ema, criterion=crit)
+    before = net.flatten_parameters().clone()
+    x0 = torch.rand(4, 3, 16, 16, device=DEV) * 2 - 1
+    losses = [wr.training_step(x0, i).item() for i in range(3)]
+    assert all(np.isfinite(losses))
+    assert not torch.equal(before, net.flatten_parameters())
+
+
+@pytest.mark.parametrize("tag", ["3_uniform", "3_quadratic", "10_uniform", "10_quadratic"])
+def test_em_sampler_matches_reference(golden, tag):
+    from psld_amd.registry import get_module
+    net, cfg, _ = _build("tiny")
+    g = golden("em_tiny.npz")
+    sde = get_module("sde", "psld")(cfg)
+    seen = []
+
+    def score_fn(u, tt):
+        assert u.dtype == torch.float32 and tt.dtype == torch.float32
+        seen.append(tt[0].item())
+        return net(u, tt)
+
+    sampler = get_module("samplers", "em_sde")(cfg, sde, score_fn)
+    noise = T(g[f"noise_{tag}"]).to(DEV)
+    sampler.noise_fn = lambda i, x: noise[i]
+    n_disc, stride = tag.split("_")
+    cfg.evaluation.n_discrete_steps = int(n_disc)
+    cfg.evaluation.stride_type = stride
+    wr = get_module("pl_modules", "sde_wrapper")(cfg, sde, net, ema_score_fn=net, sampler_cls=None)
+    ts = wr.sampling_times(DEV)
+    np.testing.assert_array_equal(ts.cpu().numpy(), g[f"ts_{tag}"])
+    x = sampler.sample(T(g[f"batch_{tag}"]).to(DEV), ts, wr.n_discrete_steps, denoise=True, eps=cfg.evaluation.eval_eps)
+    assert x.dtype == torch.float64
+    err = rel_l2(x, T(g[f"x_{tag}"]))
+    print(f"EM {tag}: rel-L2 = {err:.3e}")
+    assert err < 1e-4
+    np.testing.assert_array_equal(np.array(seen, dtype=np.float32), g[f"seen_t_{tag}"])
+
+
+def test_sde_interface_matches_oracle(golden):
+    from psld_amd.registry import get_module
+    cfg = C.c10_sota()
+    sde = get_module("sde", "psld")(cfg)
+    ref = O.PSLDOracle.from_config(cfg)
+    assert sde.T == 1.0 and sde.mode == "score_xm" and sde.type == "psld-score_xm"
+    assert abs(sde.mm_0 - ref.mm_0) < 1e-15 and abs(sde.m_inv - 4.0) < 1e-12
+    g = golden("sde_perturb.npz")
+    x0, eps, t = T(g["x0"]).to(DEV), T(g["eps"]).to(DEV), T(g["t"]).to(DEV)
+    u, mu, var = sde.perturb_data(x0, torch.zeros_like(x0), 0, sde.mm_0, t, eps=eps)
+    assert u.dtype == torch.float64
+    np.testing.assert_allclose(u.cpu().numpy(), g["u_hsm"], rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(mu.cpu().numpy(), g["mu_hsm"], rtol=1e-13, atol=1e-15)
+    sc = sde.get_score(T(g["eps_score"]).to(DEV), 0, sde.mm_0, t)
+    assert sc.dtype == torch.float32
+    np.testing.assert_allclose(sc.cpu().numpy(), g["score"], rtol=2e-7, atol=1e-9)
+    with pytest.raises(ValueError, match="Numerical precision error"):
+        bad = get_module("sde", "psld")(cfg)
+        bad._params.numerical_eps = -1.0
+        bad.perturb_data(x0, None, 0, bad.mm_0, torch.full((4,), 1e-5, dtype=torch.float64, device=DEV), eps=eps)
+    # reverse_sde through the generic (reference-shaped) entry point, uniform t
+    uu = T(g["u"])[:1].to(DEV)
+    fake = lambda a, b: 0.1 * a + b.view(-1, 1, 1, 1)
+    fb, gb = sde.reverse_sde(uu, T(g["t"])[:1].to(DEV), fake)
+    np.testing.assert_allclose(fb.cpu().numpy(), g["f_bar"][:1], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(gb.cpu().numpy(), g["g_bar"][:1], rtol=1e-14)
+    f, gg = sde.sde(uu, T(g["t"])[:1].to(DEV))
+    np.testing.assert_allclose(f.cpu().numpy(), g["f"][:1], rtol=1e-12, atol=1e-14)
+
+
+def test_dropout_mask_statistics_and_gradient_consistency():
+    """In-kernel counter-based dropout: keep rate ~ 1-p, and forward/backward use the same mask
+    (checked against the oracle fed with the mask extracted from the kernel)."""
+    from psld_amd import ops
+    b, c, s, p = 2, 64, 16, 0.15
+    x = torch.randn(b, s, s, c, device=DEV)
+    gamma, beta = torch.ones(c, device=DEV), torch.full((c,), 3.0, device=DEV)
+    st = ops.gn_stats(x, gamma, beta)
+    y = ops.gn_apply(x, st, True, drop_p=p, seed=1234)
+    y0 = ops.gn_apply(x, st, True)
+    keep = (y != 0)
+    rate = keep.float().mean().item()
+    assert abs(rate - (1 - p)) < 0.01
+    torch.testing.assert_close(y[keep], (y0 / (1 - p))[keep], rtol=1e-6, atol=1e-7)
+    gy = torch.randn_like(x)
+    dx = torch.empty_like(x)
+    dg, db = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    ops.gn_bwd(gy, x, st, gamma, beta, True, dx, dg, db, drop_p=p, seed=1234)
+    xr = x.detach().cpu().permute(0, 3, 1, 2).double().requires_grad_(True)
+    mask = (keep.cpu().permute(0, 3, 1, 2).double() / (1 - p))
+    yr = torch.nn.functional.silu(torch.nn.functional.group_norm(xr, 16, gamma.cpu().double(), beta.cpu().double(), 1e-6)) * mask
+    yr.backward(gy.cpu().permute(0, 3, 1, 2).double())
+    assert rel_l2(dx.permute(0, 3, 1, 2), xr.grad) < 1e-5
