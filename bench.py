@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""Headline benchmark: HSM training images/sec of the CIFAR-10 PSLD NCSN++ (C10-SOTA) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 128]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = the reference's full training step (main/models/wrapper.py:64-91 + callbacks.py:42-64):
+t ~ U[eps,1] -> PSLD perturb -> NCSN++ forward -> HSM loss -> backward (-> RCCL bucketed all-reduce
+when N>1) -> global-norm clip -> Adam -> LambdaLR -> EMA, dropout 0.15 on, fp32, per-GPU batch 128,
+synthetic CIFAR-shaped data resident in HBM.  Prints ONE JSON line (rank 0).
+
+roofline: the dominant kernel is the fp32-MFMA implicit-GEMM tile kernel (conv forward + data
+gradient); every launch in the timed region is bracketed by HIP events on its own stream, and
+achieved = sum(2*M*N*K) / sum(duration).  cpu_baseline: the CPU oracle (a port of the reference's
+CPU path, pinned to its golden vectors) timed on this host for one B=16 train step (N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
+
+
+class ConvProbe:
+    """HIP-event timing of every conv tile-kernel launch (installed around ops.conv2d_nhwc)."""
+
+    def __init__(self, ops):
+        self.ops = ops
+        self.orig = ops.conv2d_nhwc
+        self.records = []
+        self.enabled = False
+
+    def install(self):
+        probe = self
+
+        def wrapped(x1, x2, w, cout, kh, kw, stride, pad, tstride, oh, ow, y, epi=None, ldy=None):
+            if not probe.enabled:
+                return probe.orig(x1, x2, w, cout, kh, kw, stride, pad, tstride, oh, ow, y, epi, ldy)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            probe.orig(x1, x2, w, cout, kh, kw, stride, pad, tstride, oh, ow, y, epi, ldy)
+            e.record()
+            cin = x1.shape[-1] + (x2.shape[-1] if x2 is not None else 0)
+            flops = 2.0 * x1.shape[0] * oh * ow * cout * kh * kw * cin
+            if tstride > 1:
+                flops /= tstride * tstride      # structural zeros of the strided data-gradient
+            probe.records.append((s, e, flops))
+
+        self.ops.conv2d_nhwc = wrapped
+
+    def summary(self):
+        if not self.records:
+            return None
+        ms = sum(s.elapsed_time(e) for s, e, _ in self.records)
+        fl = sum(f for _, _, f in self.records)
+        return {"launches": len(self.records), "total_ms": ms, "total_flop": fl,
+                "avg_us": 1e3 * ms / len(self.records), "tflops": fl / (ms * 1e-3) / 1e12}
+
+
+def cpu_baseline(cfg, batch=16):
+    """Oracle (kind 'port') on the host cores: one full HSM train step at B=16 (configs[0])."""
+    from oracle import psld_oracle as O
+    from psld_amd.score_fn import NCSNpp
+    from tests.synth import synth_inputs
+    torch.manual_seed(0)
+    net = NCSNpp(cfg)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    sde = O.PSLDOracle.from_config(cfg)
+    x0, eps, t = synth_inputs(batch, 3, cfg.data.image_size, seed=0)
+    g = torch.Generator().manual_seed(1)
+    p = cfg.model.score_fn.dropout
+    masks = None
+    if p > 0:
+        # one pre-scaled Bernoulli mask per ResBlock (shape of its GroupNorm_1 output)
+        shapes = []
+        hook_sd = sd
+        with torch.no_grad():
+            rec = []
+            orig = O.resblock_biggan
+
+            def spy(x, temb, sdd, pfx, **kw):
+                out = orig(x, temb, sdd, pfx, **{k: v for k, v in kw.items() if k != "dropout_mask"})
+                rec.append(out.shape)
+                return out
+
+            O.resblock_biggan = spy
+            try:
+                O.ncsnpp_forward(hook_sd, cfg, torch.zeros(1, 6, cfg.data.image_size, cfg.data.image_size),
+                                 torch.ones(1) * 0.5)
+            finally:
+                O.resblock_biggan = orig
+            shapes = rec
+        masks = [(torch.rand(batch, *s[1:], generator=g) >= p).float() / (1 - p) for s in shapes]
+    t0 = time.perf_counter()
+    O.train_step(sde, sd, cfg, x0, t, eps, {}, 1, ema_sd={k: v.clone() for k, v in sd.items()},
+                 dropout_masks=masks)
+    dt = time.perf_counter() - t0
+    return {"value": batch / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 HSM train step (fwd+bwd+clip+Adam+EMA), B={batch}, C10-SOTA NCSN++, fp32, "
+                      f"{dt:.1f} s on {torch.get_num_threads()} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probe", action="store_true")
+    ap.add_argument("--bucket-mb", type=int, default=64)
+    args = ap.parse_args()
+
+    import psld_amd
+    from psld_amd import config as C, ops
+    from psld_amd.ddp import BucketReducer, init_distributed
+    from psld_amd.optim import EMAWeightUpdate
+    from psld_amd.registry import get_module
+    import torch.distributed as dist
+
+    rank, local, world = init_distributed()
+    assert world == max(1, args.gpus) or world == 1, (world, args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    psld_amd.import_modules_into_registry()
+    ops.lib()
+
+    cfg = C.c10_sota()
+    cfg.training.batch_size = args.batch
+    torch.manual_seed(cfg.training.seed)                      # same seed on every rank (train_sde.py:29)
+    net = get_module("score_fn", "ncsnpp")(cfg).to(dev).train()
+    ema = copy.deepcopy(net)
+    for p in ema.parameters():
+        p.requires_grad = False
+    sde = get_module("sde", "psld")(cfg)
+    sde.check_nan = True
+    crit = get_module("losses", "psld_score_loss")(cfg, sde)
+    wrapper = get_module("pl_modules", "sde_wrapper")(cfg, sde, net, ema_score_fn=ema, criterion=crit)
+    ema_cb = EMAWeightUpdate(cfg.training.ema_decay)
+    if world > 1:
+        net.set_reducer(BucketReducer(bucket_bytes=args.bucket_mb << 20))
+    g = torch.Generator(device=dev).manual_seed(rank)         # per-rank data
+    data = [torch.rand(args.batch, 3, 32, 32, device=dev, generator=g) * 2 - 1 for _ in range(4)]
+
+    def step(i):
+        loss = wrapper.training_step(data[i % len(data)], i)
+        ema_cb.on_train_batch_end(None, wrapper)
+        return loss
+
+    probe = ConvProbe(ops)
+    if not args.no_probe:
+        probe.install()
+    for i in range(args.warmup):
+        step(i)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    probe.enabled = not args.no_probe
+    t0 = time.perf_counter()
+    last = None
+    for i in range(args.steps):
+        last = step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    probe.enabled = False
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss_val = float(last.item())
+
+    if rank == 0:
+        total_imgs = world * args.batch * args.steps
+        out = {
+            "metric": "train images/sec, CIFAR-10 PSLD (6ch 32x32) NCSN++ HSM step",
+            "value": total_imgs / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C10-SOTA NCSN++ (nf=128, ch_mult=[2,2,2], nres=8, attn@16, fir, fourier, "
+                                   "dropout 0.15) full HSM train step: perturb+fwd+loss+bwd+clip+Adam+EMA",
+                       "per_gpu_batch": args.batch, "global_batch": world * args.batch,
+                       "parallelism": f"dp{world}", "image": "6x32x32"},
+            "images_per_sec_per_gpu": total_imgs / dt / world,
+            "final_loss": loss_val,
+        }
+        ps = probe.summary()
+        if ps is not None:
+            out["roofline"] = {"bound": "mfma", "kernel": "tile_kernel<IM2COL,KC> (conv3x3/1x1 fwd + dgrad)",
+                               "achieved": ps["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ps["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "launches": ps["launches"], "avg_launch_us": ps["avg_us"],
+                               "share_of_step": ps["total_ms"] / (1e3 * dt)}
+        else:
+            out["roofline"] = None
+        step_flops = 229.4e9 * args.batch                       # train step = 3 x 76.46 GFLOP/img
+        out["whole_step_tflops_per_gpu"] = step_flops * args.steps / dt / 1e12
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(C.c10_sota())
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": repr(e)}
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,104 @@
+"""N>1 path on CPU: two processes, gloo backend, the same BucketReducer that runs over RCCL on the
+GPU box.  (1) bucketed mean all-reduce driven by backward watermarks; (2) data-parallel gradient
+equality: mean of per-rank oracle gradients == single-process large-batch gradient."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from psld_amd.ddp import BucketReducer, shard_range
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _init(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+
+
+def _worker_buckets(rank, world, port, q):
+    _init(rank, world, port)
+    n = 1000
+    flat = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    red = BucketReducer(bucket_bytes=4 * 256)          # 256-element buckets -> 4 buckets
+    red.begin(flat)
+    for off in (900, 600, 512, 300, 0):                # watermarks as the backward tape would report them
+        red.ready_from(off)
+        launched_so_far = list(red.launched)
+        # a bucket is only launched once everything inside it is final
+        assert all(lo >= off for lo, _ in launched_so_far), (off, launched_so_far)
+    red.finish()
+    expect = torch.arange(n, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
+    ok = torch.allclose(flat, expect) and red.launched == [(768, 1000), (512, 768), (256, 512), (0, 256)]
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def _worker_grads(rank, world, port, q):
+    _init(rank, world, port)
+    from oracle import psld_oracle as O
+    from psld_amd import config as C
+    from psld_amd.score_fn import NCSNpp
+    from tests.synth import synth_inputs, synth_state_dict
+    cfg = C.tiny(image_size=8, nf=16, ch_mult=(1,), num_res_blocks=1, attn_resolutions=(8,))
+    net = NCSNpp(cfg)
+    keys = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    sd = synth_state_dict(keys, 5)
+    sde = O.PSLDOracle.from_config(cfg)
+    x0, eps, t = synth_inputs(4, 3, 8, seed=9)
+
+    def grads(sl):
+        p = {k: v.clone().requires_grad_(k != "all_modules.0.W") for k, v in sd.items()}
+        loss = O.psld_score_loss(sde, x0[sl], t[sl], lambda z, tt: O.ncsnpp_forward(p, cfg, z, tt), eps[sl])
+        loss.backward()
+        return {k: v.grad for k, v in p.items() if v.grad is not None}
+
+    lo, hi = shard_range(4, rank, world)
+    mine = grads(slice(lo, hi))
+    names = list(mine.keys())
+    sizes = [mine[k].numel() for k in names]
+    flat = torch.cat([mine[k].reshape(-1) for k in names])
+    red = BucketReducer(bucket_bytes=4 * 4096)
+    red.begin(flat)
+    off = flat.numel()
+    for s in reversed(sizes):                           # reverse module order, like the tape
+        off -= s
+        red.ready_from(off)
+    red.finish()
+    full = grads(slice(0, 4))
+    ref = torch.cat([full[k].reshape(-1) for k in names])
+    err = ((flat - ref).norm() / ref.norm()).item()
+    q.put((rank, err < 1e-5))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("worker", [_worker_buckets, _worker_grads])
+def test_two_process_gloo(worker):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]
+
+
+def test_shard_range_partitions_samples():
+    n, world = 50000, 8
+    spans = [shard_range(n, r, world) for r in range(world)]
+    assert spans[0][0] == 0 and spans[-1][1] == n
+    assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+    assert shard_range(5, 7, 8) == (5, 5)
