@@ -369,6 +369,302 @@ int launch(const TileArgs& a, int nz, hipStream_t stream, const char* name) {
     return PSLD_OK;
 }
 
+
+// =======================================================================================
+// FAST specialisation: the hot shapes (every operand float4-addressable, K % 32 == 0 per
+// split, conv channels % 32 == 0, no transposed stride).  Differences from the generic kernel:
+//   * double-buffered LDS, ONE barrier per K-step (loads of tile k+1 in flight under the MFMAs
+//     of tile k, their ds_writes go to the other buffer);
+//   * branch-free loaders (clamped address + select instead of exec-masked branches);
+//   * conv K order = (channel chunk, tap, channel-in-chunk): the 9 taps of one 32-channel chunk
+//     are consecutive K-steps, so 8 of 9 gathers re-hit the same cache lines in L1/L2;
+//   * wgrad pixel decomposition by shifts (OH, OW powers of two).
+// =======================================================================================
+// 16 bytes of zeros: out-of-range lanes load from here, so no select (and no early vmcnt wait) is needed
+__device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+
+struct FastGeom {
+    int taps, ow_shift, oh_shift, ct_chunks;  // ct_chunks = (C1+C2)/32
+    const float* zero;                        // 16 B of zeros in global memory (filled by launch_fast)
+};
+
+template <int MODE>
+__device__ __forceinline__ void fast_load(f32x4 (&r)[4], const Operand& op, const ConvGeom& g, const FastGeom& fg,
+                                          const float* base, int row0, int nrows, int kstep, int kend,
+                                          const RowInfo (&ri)[4], int tap_z, const float* zp) {
+    const int tid = threadIdx.x;
+    if constexpr (MODE == OP_KC) {
+        const int c4 = tid & 7, r0 = tid >> 3;
+        const int gk = kstep * BK + c4 * 4;
+        const bool kok = gk < kend;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gr = row0 + r0 + 32 * i;
+            const bool ok = kok && gr < nrows;
+            r[i] = ld4(ok ? base + ((long long)gr * op.ld + gk) : zp);
+        }
+    } else if constexpr (MODE == OP_IM2COL) {
+        const int c4 = tid & 7;
+        const int chunk = kstep / fg.taps;          // wave-uniform
+        const int tap = kstep - chunk * fg.taps;
+        const int ky = tap / g.KW, kx = tap - ky * g.KW;
+        const int c0 = chunk * BK;
+        const bool second = c0 >= g.C1;
+        const float* src = second ? op.p2 : base;
+        const int cs = second ? g.C2 : g.C1;
+        const int cc = (second ? c0 - g.C1 : c0) + c4 * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int iy = ri[i].oy * g.stride + ky - g.pad;
+            const int ix = ri[i].ox * g.stride + kx - g.pad;
+            const bool ok = ri[i].img >= 0 && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
+            r[i] = ld4(ok ? src + (((long long)(ri[i].img * g.IH + iy) * g.IW + ix) * cs + cc) : zp);
+        }
+    } else if constexpr (MODE == OP_MC) {
+        const int c = tid & 31, kr = tid >> 5;
+        const int gm = row0 + c * 4;
+        const bool mok = gm < nrows;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gk = kstep * BK + kr + 8 * i;
+            const bool ok = mok && gk < kend;
+            r[i] = ld4(ok ? base + ((long long)gk * op.ld + gm) : zp);
+        }
+    } else {  // OP_SHIFT
+        const int c = tid & 31, kr = tid >> 5;
+        const int gm = row0 + c * 4;
+        const bool mok = gm < nrows;
+        const int ky = tap_z / g.KW, kx = tap_z - ky * g.KW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gk = kstep * BK + kr + 8 * i;
+            const int ox = gk & (g.OW - 1);
+            const int t = gk >> fg.ow_shift;
+            const int oy = t & (g.OH - 1);
+            const int img = t >> fg.oh_shift;
+            const int iy = oy * g.stride + ky - g.pad;
+            const int ix = ox * g.stride + kx - g.pad;
+            const bool ok = mok && gk < kend && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
+            r[i] = ld4(ok ? base + (((long long)(img * g.IH + iy) * g.IW + ix) * op.ld + gm) : zp);
+        }
+    }
+}
+
+template <int AMODE, int BMODE>
+__global__ void __launch_bounds__(NTHREADS, 2) tile_kernel_fast(const TileArgs a, const FastGeom fg) {
+    constexpr bool A_KC = (AMODE == OP_KC || AMODE == OP_IM2COL);
+    constexpr bool B_KC = (BMODE == OP_KC || BMODE == OP_IM2COL);
+    constexpr int A_SZ = A_KC ? BM * KC_LD : BK * MC_LD;
+    constexpr int B_SZ = B_KC ? BN * KC_LD : BK * MC_LD;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As0 = smem;
+    float* Bs0 = smem + 2 * A_SZ;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int tiles_n = (a.N + BN - 1) / BN;
+    const int tile_m = blockIdx.x / tiles_n;
+    const int tile_n = blockIdx.x - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int z = blockIdx.y;
+    const int split = z % a.nsplit;
+    const int zb = z / a.nsplit;
+    const int kbeg = split * a.kper;
+    const int kend = min(a.K, kbeg + a.kper);
+    const int ks0 = kbeg / BK;
+    const int nks = (kend - kbeg + BK - 1) / BK;
+
+    const float* Abase = a.A.p + (long long)zb * a.A.stride_z;
+    const float* Bbase = a.B.p + (long long)zb * a.B.stride_z;
+    // opaque pointer to 16 bytes of zeros (laundered so the compiler cannot fold the loads back into
+    // selects, which would force a vmcnt(0) wait ahead of the MFMA block)
+    const float* zp = fg.zero;
+
+    RowInfo ri[4];
+    if constexpr (AMODE == OP_IM2COL) {
+        const int r0 = tid >> 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gm = m0 + r0 + 32 * i;
+            if (gm < a.M) {
+                ri[i].ox = gm % a.g.OW;
+                const int t = gm / a.g.OW;
+                ri[i].oy = t % a.g.OH;
+                ri[i].img = t / a.g.OH;
+            } else {
+                ri[i].img = -1;
+                ri[i].oy = ri[i].ox = 0;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ri[i].img = ri[i].oy = ri[i].ox = 0;
+    }
+
+    // B operand of a conv: weights [N][tap][Ct] -> column of K-step ks is tap*Ct + chunk*32
+    auto b_kstep_col = [&](int ks) -> int {
+        if constexpr (AMODE == OP_IM2COL) {
+            const int chunk = ks / fg.taps;
+            const int tap = ks - chunk * fg.taps;
+            return tap * (fg.ct_chunks * BK) + chunk * BK;
+        } else {
+            return ks * BK;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+    f32x4 ra[4], rb[4];
+    auto load_b = [&](int ks) {
+        if constexpr (BMODE == OP_KC && AMODE == OP_IM2COL) {
+            // weights: plain KC load at a remapped column
+            const int c4 = tid & 7, r0 = tid >> 3;
+            const int col = b_kstep_col(ks) + c4 * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int gr = n0 + r0 + 32 * i;
+                const bool ok = gr < a.N;
+                rb[i] = ld4(ok ? Bbase + ((long long)gr * a.B.ld + col) : zp);
+            }
+        } else {
+            fast_load<BMODE>(rb, a.B, a.g, fg, Bbase, n0, a.N, ks, kend, ri, zb, zp);
+        }
+    };
+
+    fast_load<AMODE>(ra, a.A, a.g, fg, Abase, m0, a.M, ks0, kend, ri, zb, zp);
+    load_b(ks0);
+    store_tile<AMODE>(As0, ra);
+    store_tile<BMODE>(Bs0, rb);
+    __syncthreads();
+
+    int cur = 0;
+    for (int it = 0; it < nks; ++it) {
+        const bool more = (it + 1) < nks;
+        if (more) {
+            fast_load<AMODE>(ra, a.A, a.g, fg, Abase, m0, a.M, ks0 + it + 1, kend, ri, zb, zp);
+            load_b(ks0 + it + 1);
+        }
+        const float* As = As0 + cur * A_SZ;
+        const float* Bs = Bs0 + cur * B_SZ;
+        // fragment reads for 8 k-values (4 MFMA k-pairs) at a time, software-pipelined one group ahead
+        float af[2][2][4], bf[2][2][4];
+        auto read_frags = [&](int j, float (&fa)[2][4], float (&fb)[2][4]) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if constexpr (A_KC) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(As + (wr * 64 + i * 32 + r) * KC_LD + 8 * j + 4 * h);
+                    fa[i][0] = t[0]; fa[i][1] = t[1]; fa[i][2] = t[2]; fa[i][3] = t[3];
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) fa[i][s] = As[(8 * j + 4 * h + s) * MC_LD + wr * 64 + i * 32 + r];
+                }
+                if constexpr (B_KC) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(Bs + (wc * 64 + i * 32 + r) * KC_LD + 8 * j + 4 * h);
+                    fb[i][0] = t[0]; fb[i][1] = t[1]; fb[i][2] = t[2]; fb[i][3] = t[3];
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) fb[i][s] = Bs[(8 * j + 4 * h + s) * MC_LD + wc * 64 + i * 32 + r];
+                }
+            }
+        };
+        read_frags(0, af[0], bf[0]);
+#pragma unroll
+        for (int j = 0; j < BK / 8; ++j) {
+            if (j + 1 < BK / 8) read_frags(j + 1, af[(j + 1) & 1], bf[(j + 1) & 1]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j & 1][i][s], bf[j & 1][n][s], acc[i][n], 0, 0, 0);
+        }
+        if (more) {
+            store_tile<AMODE>(As0 + (cur ^ 1) * A_SZ, ra);
+            store_tile<BMODE>(Bs0 + (cur ^ 1) * B_SZ, rb);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    float* Cb = a.C + (long long)zb * a.c_stride_z + (long long)split * a.c_stride_split;
+    const float* Rb = a.e.res ? a.e.res + (long long)zb * a.e.res_stride_z : nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int gn = n0 + wc * 64 + n * 32 + r;
+            if (gn >= a.N) continue;
+            const float bias = a.e.bias ? a.e.bias[gn] : 0.f;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int gm = m0 + wr * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                if (gm >= a.M) continue;
+                float x = acc[i][n][v] * a.e.alpha + bias;
+                if (a.e.rowbias) x += a.e.rowbias[(long long)(gm / a.e.rows_per_img) * a.e.ld_rowbias + gn];
+                if (Rb) x += Rb[(long long)gm * a.e.ldres + gn];
+                x *= a.e.out_scale;
+                float* cp = Cb + (long long)gm * a.ldc + gn;
+                if (a.e.accumulate) x += *cp;
+                *cp = x;
+            }
+        }
+    }
+}
+
+inline int ilog2_exact(int v) {
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return s;
+}
+
+template <int AMODE, int BMODE>
+int launch_fast(const TileArgs& a, FastGeom fg, int nz, hipStream_t stream, const char* name) {
+    static const float* zero_dev = nullptr;
+    if (!zero_dev) {
+        void* zptr = nullptr;
+        hipError_t e = hipGetSymbolAddress(&zptr, HIP_SYMBOL(g_zero_page));
+        if (e != hipSuccess || !zptr) {
+            psld_set_error("%s: hipGetSymbolAddress failed: %s", name, hipGetErrorString(e));
+            return PSLD_ERR_LAUNCH;
+        }
+        zero_dev = static_cast<const float*>(zptr);
+    }
+    fg.zero = zero_dev;
+    constexpr bool A_KC = (AMODE == OP_KC || AMODE == OP_IM2COL);
+    constexpr bool B_KC = (BMODE == OP_KC || BMODE == OP_IM2COL);
+    constexpr int A_SZ = A_KC ? BM * KC_LD : BK * MC_LD;
+    constexpr int B_SZ = B_KC ? BN * KC_LD : BK * MC_LD;
+    constexpr size_t LDS = (size_t)2 * (A_SZ + B_SZ) * sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_kernel_fast<AMODE, BMODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        if (e != hipSuccess) {
+            psld_set_error("%s: hipFuncSetAttribute failed: %s", name, hipGetErrorString(e));
+            return PSLD_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    const long long tiles = (long long)cdiv(a.M, BM) * cdiv(a.N, BN);
+    PSLD_CHECK_ARG(tiles < (1LL << 31) && nz * a.nsplit <= 65535, "%s: grid too large", name);
+    dim3 grid((unsigned)tiles, (unsigned)(nz * a.nsplit));
+    hipLaunchKernelGGL((tile_kernel_fast<AMODE, BMODE>), grid, dim3(NTHREADS), LDS, stream, a, fg);
+    PSLD_CHECK_LAUNCH(name);
+    return PSLD_OK;
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 Epilogue make_epilogue(const psld_epilogue_t* e) {
@@ -409,6 +705,13 @@ extern "C" int psld_gemm_f32(int trans_a, int trans_b, int M, int N, int K,
     else          a.A.vec = aligned16(A) && lda % 4 == 0 && M % 4 == 0 && stride_a % 4 == 0;
     if (trans_b)  a.B.vec = aligned16(B) && ldb % 4 == 0 && K % 4 == 0 && stride_b % 4 == 0;
     else          a.B.vec = aligned16(B) && ldb % 4 == 0 && N % 4 == 0 && stride_b % 4 == 0;
+    const bool fastok = a.A.vec && a.B.vec && K % BK == 0 && M > 0 && N > 0;
+    FastGeom fg{1, 0, 0, 0, nullptr};
+    if (fastok) {
+        if (!trans_a && trans_b)  return launch_fast<OP_KC, OP_KC>(a, fg, batch, stream, "psld_gemm_f32[NT,fast]");
+        if (!trans_a && !trans_b) return launch_fast<OP_KC, OP_MC>(a, fg, batch, stream, "psld_gemm_f32[NN,fast]");
+        if (trans_a && !trans_b)  return launch_fast<OP_MC, OP_MC>(a, fg, batch, stream, "psld_gemm_f32[TN,fast]");
+    }
     if (!trans_a && trans_b)  return launch<OP_KC, OP_KC>(a, batch, stream, "psld_gemm_f32[NT]");
     if (!trans_a && !trans_b) return launch<OP_KC, OP_MC>(a, batch, stream, "psld_gemm_f32[NN]");
     if (trans_a && !trans_b)  return launch<OP_MC, OP_MC>(a, batch, stream, "psld_gemm_f32[TN]");
@@ -426,6 +729,10 @@ extern "C" int psld_gemm_tn_splitk_f32(int M, int N, int K, const float* A, int 
     a.C = slabs; a.c_stride_z = 0; a.c_stride_split = (long long)M * N; a.ldc = N;
     a.nsplit = nsplit; a.kper = cdiv(cdiv(K, nsplit), BK) * BK;
     a.e = make_epilogue(nullptr);
+    if (a.A.vec && a.B.vec && M > 0 && N > 0) {
+        FastGeom fg{1, 0, 0, 0, nullptr};
+        return launch_fast<OP_MC, OP_MC>(a, fg, 1, stream, "psld_gemm_tn_splitk_f32[fast]");
+    }
     return launch<OP_MC, OP_MC>(a, 1, stream, "psld_gemm_tn_splitk_f32");
 }
 
@@ -448,6 +755,10 @@ extern "C" int psld_conv2d_nhwc_f32(const float* x1, int c1, const float* x2, in
     a.nsplit = 1; a.kper = cdiv(a.K, BK) * BK;
     a.g = {ih, iw, c1, c2, oh, ow, kh, kw, stride, pad, transposed_stride};
     a.e = make_epilogue(epi);
+    if (a.A.vec && a.B.vec && c1 % BK == 0 && c2 % BK == 0 && transposed_stride == 1 && a.M > 0) {
+        FastGeom fg{kh * kw, 0, 0, ct / BK, nullptr};
+        return launch_fast<OP_IM2COL, OP_KC>(a, fg, 1, stream, "psld_conv2d_nhwc_f32[fast]");
+    }
     return launch<OP_IM2COL, OP_KC>(a, 1, stream, "psld_conv2d_nhwc_f32");
 }
 
@@ -469,5 +780,10 @@ extern "C" int psld_conv2d_wgrad_nhwc_f32(const float* dy, int lddy, int cout,
     a.nsplit = nsplit; a.kper = cdiv(cdiv(a.K, nsplit), BK) * BK;
     a.g = {ih, iw, cin, 0, oh, ow, kh, kw, stride, pad, 1};
     a.e = make_epilogue(nullptr);
+    const int ows = ilog2_exact(ow), ohs = ilog2_exact(oh);
+    if (a.A.vec && a.B.vec && ows >= 0 && ohs >= 0 && cout > 0 && cin > 0) {
+        FastGeom fg{kh * kw, ows, ohs, 0, nullptr};
+        return launch_fast<OP_MC, OP_SHIFT>(a, fg, kh * kw, stream, "psld_conv2d_wgrad_nhwc_f32[fast]");
+    }
     return launch<OP_MC, OP_SHIFT>(a, kh * kw, stream, "psld_conv2d_wgrad_nhwc_f32");
 }

@@ -156,6 +156,23 @@ def _gbuf(node: _Node):
     return node.g, True
 
 
+_RESIDENT_BLOCKS = 512  # 256 CUs x 2 workgroups (64-72 KB LDS each) of the tile kernels
+
+
+def _pick_nsplit(tiles: int, k: int) -> int:
+    """Split-K factor of a weight-gradient GEMM: fill whole rounds of resident workgroups (a 1.5-round
+    grid wastes a quarter of the machine) while keeping >= 256 K per split."""
+    max_split = max(1, k // 256)
+    best, best_eff = 1, 0.0
+    for ns in range(1, min(max_split, 64) + 1):
+        blocks = tiles * ns
+        rounds = -(-blocks // _RESIDENT_BLOCKS)
+        eff = blocks / (rounds * _RESIDENT_BLOCKS)
+        if eff > best_eff + 0.02:
+            best, best_eff = ns, eff
+    return best
+
+
 def _fir_kernel(k) -> np.ndarray:
     k = np.asarray(k, dtype=np.float32)
     k = np.outer(k, k)
@@ -201,8 +218,7 @@ class _Exec:
         n = cout * taps * cin_total
         if nsplit is None:
             tiles = ((cout + 127) // 128) * ((cin + 127) // 128) * taps
-            kk = b * oh * ow
-            nsplit = max(1, min((768 + tiles - 1) // tiles, (kk + 255) // 256))
+            nsplit = _pick_nsplit(tiles, b * oh * ow)
         if slabs is None:
             slabs = ops.workspace(4 * n * nsplit, dy.device)
         ops.conv2d_wgrad_nhwc(dy, cout, x, k, k, stride, pad, oh, ow, slabs, cin_total, col0, nsplit)
@@ -406,7 +422,7 @@ class _Exec:
 
         def nin_wgrad(a_in: Tensor, dy: Tensor, nin: NIN, alpha: float):
             # dW[in,out] = a_in^T dy  (K = B*HW -> split-K slabs)
-            nsplit = max(1, min(768 // max(1, ((c + 127) // 128) ** 2), (m + 255) // 256))
+            nsplit = _pick_nsplit(((c + 127) // 128) ** 2, m)
             slabs = ops.workspace(4 * c * c * nsplit, dev)
             ops.gemm_tn_splitk(c, c, m, a_in, c, dy, c, slabs, nsplit)
             ops.reduce_slabs(slabs, nsplit, c * c, self.g(nin.W), alpha=alpha)
