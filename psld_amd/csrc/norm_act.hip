@@ -228,17 +228,22 @@ __global__ void gn_bwd_finalize_kernel(const float* __restrict__ part, const flo
     }
 }
 
+// dbeta[c] = sum_n s1[n,c], dgamma[c] = sum_n s2[n,c]: grid (C/64, 2), 64 columns x 4 batch lanes
 __global__ void gn_bwd_param_kernel(const float* __restrict__ sums, int batch, int c, float* __restrict__ dgamma,
                                     float* __restrict__ dbeta) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
-    double a = 0, b = 0;
-    for (int n = 0; n < batch; ++n) {
-        a += (double)sums[((long long)n * 2 + 0) * c + ch];
-        b += (double)sums[((long long)n * 2 + 1) * c + ch];
+    __shared__ double red[4][64];
+    const int which = blockIdx.y;
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int lane = threadIdx.x >> 6;
+    double acc = 0.0;
+    if (col < c)
+        for (int n = lane; n < batch; n += 4) acc += (double)sums[((long long)n * 2 + which) * c + col];
+    red[lane][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (lane == 0 && col < c) {
+        const float v = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+        (which ? dgamma : dbeta)[col] = v;
     }
-    dbeta[ch] = (float)a;
-    dgamma[ch] = (float)b;
 }
 
 // pass 3: dx = coef0*dz - coef1 - xhat*coef2
@@ -353,7 +358,7 @@ extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(batch), dim3(256), 0, stream, part, rstd, gamma, hw, c, groups,
                        m.chunks, sums, coef);
     PSLD_CHECK_LAUNCH("gn_bwd_finalize_kernel");
-    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(cdiv(c, 128)), dim3(128), 0, stream, sums, batch, c, dgamma, dbeta);
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(cdiv(c, 64), 2), dim3(256), 0, stream, sums, batch, c, dgamma, dbeta);
     PSLD_CHECK_LAUNCH("gn_bwd_param_kernel");
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(m.chunks, batch), dim3(m.threads), 0, stream, dy, x, mean, rstd,
                        gamma, beta, coef, hw, c, groups, m.cq, m.pl, m.chunk_px, act, drop_p, seed, accumulate_dx, dx);

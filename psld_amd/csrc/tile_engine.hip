@@ -388,17 +388,17 @@ struct FastGeom {
     const float* zero;                        // 16 B of zeros in global memory (filled by launch_fast)
 };
 
-template <int MODE>
-__device__ __forceinline__ void fast_load(f32x4 (&r)[4], const Operand& op, const ConvGeom& g, const FastGeom& fg,
+template <int MODE, int NR>
+__device__ __forceinline__ void fast_load(f32x4 (&r)[NR], const Operand& op, const ConvGeom& g, const FastGeom& fg,
                                           const float* base, int row0, int nrows, int kstep, int kend,
-                                          const RowInfo (&ri)[4], int tap_z, const float* zp) {
+                                          const RowInfo (&ri)[NR], int tap_z, const float* zp) {
     const int tid = threadIdx.x;
     if constexpr (MODE == OP_KC) {
         const int c4 = tid & 7, r0 = tid >> 3;
         const int gk = kstep * BK + c4 * 4;
         const bool kok = gk < kend;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NR; ++i) {
             const int gr = row0 + r0 + 32 * i;
             const bool ok = kok && gr < nrows;
             r[i] = ld4(ok ? base + ((long long)gr * op.ld + gk) : zp);
@@ -414,7 +414,7 @@ __device__ __forceinline__ void fast_load(f32x4 (&r)[4], const Operand& op, cons
         const int cs = second ? g.C2 : g.C1;
         const int cc = (second ? c0 - g.C1 : c0) + c4 * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NR; ++i) {
             const int iy = ri[i].oy * g.stride + ky - g.pad;
             const int ix = ri[i].ox * g.stride + kx - g.pad;
             const bool ok = ri[i].img >= 0 && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
@@ -450,11 +450,23 @@ __device__ __forceinline__ void fast_load(f32x4 (&r)[4], const Operand& op, cons
     }
 }
 
-template <int AMODE, int BMODE>
+template <int NR>
+__device__ __forceinline__ void store_kc_rows(float* lds, const f32x4 (&r)[NR]) {
+    const int tid = threadIdx.x;
+    const int c4 = tid & 7, r0 = tid >> 3;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) *reinterpret_cast<f32x4*>(lds + (r0 + 32 * i) * KC_LD + c4 * 4) = r[i];
+}
+
+// TBM = 128 (default) or 64 (small-M layers: the 8x8 convs give only 128 tiles of 128 rows for 256 CUs).
+template <int AMODE, int BMODE, int TBM>
 __global__ void __launch_bounds__(NTHREADS, 2) tile_kernel_fast(const TileArgs a, const FastGeom fg) {
     constexpr bool A_KC = (AMODE == OP_KC || AMODE == OP_IM2COL);
     constexpr bool B_KC = (BMODE == OP_KC || BMODE == OP_IM2COL);
-    constexpr int A_SZ = A_KC ? BM * KC_LD : BK * MC_LD;
+    static_assert(TBM == 128 || (TBM == 64 && A_KC), "TBM=64 needs a K-contiguous A operand");
+    constexpr int MI = TBM / 64;          // 32-row MFMA tiles per wave along M
+    constexpr int NRA = A_KC ? TBM / 32 : 4;  // A rows (KC) or k-rows (MC) staged per thread
+    constexpr int A_SZ = A_KC ? TBM * KC_LD : BK * MC_LD;
     constexpr int B_SZ = B_KC ? BN * KC_LD : BK * MC_LD;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As0 = smem;
@@ -466,9 +478,17 @@ __global__ void __launch_bounds__(NTHREADS, 2) tile_kernel_fast(const TileArgs a
     const int r = lane & 31, h = lane >> 5;
 
     const int tiles_n = (a.N + BN - 1) / BN;
-    const int tile_m = blockIdx.x / tiles_n;
-    const int tile_n = blockIdx.x - tile_m * tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so give
+    // every XCD a contiguous run of tiles — the N-tiles of one M-tile and neighbouring M-tiles (halo
+    // rows) then share one L2.  Bijective form (cdna guide T1) for any grid size.
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = bid & 7;
+        bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    }
+    const int tile_m = bid / tiles_n;
+    const int tile_n = bid - tile_m * tiles_n;
+    const int m0 = tile_m * TBM, n0 = tile_n * BN;
 
     const int z = blockIdx.y;
     const int split = z % a.nsplit;
@@ -484,11 +504,11 @@ __global__ void __launch_bounds__(NTHREADS, 2) tile_kernel_fast(const TileArgs a
     // selects, which would force a vmcnt(0) wait ahead of the MFMA block)
     const float* zp = fg.zero;
 
-    RowInfo ri[4];
+    RowInfo ri[NRA];
     if constexpr (AMODE == OP_IM2COL) {
         const int r0 = tid >> 3;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NRA; ++i) {
             const int gm = m0 + r0 + 32 * i;
             if (gm < a.M) {
                 ri[i].ox = gm % a.g.OW;
@@ -502,8 +522,11 @@ __global__ void __launch_bounds__(NTHREADS, 2) tile_kernel_fast(const TileArgs a
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ri[i].img = ri[i].oy = ri[i].ox = 0;
+        for (int i = 0; i < NRA; ++i) ri[i].img = ri[i].oy = ri[i].ox = 0;
     }
+    RowInfo rib[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rib[i].img = rib[i].oy = rib[i].ox = 0;
 
     // B operand of a conv: weights [N][tap][Ct] -> column of K-step ks is tap*Ct + chunk*32
     auto b_kstep_col = [&](int ks) -> int {
@@ -516,15 +539,19 @@ __global__ void __launch_bounds__(NTHREADS, 2) tile_kernel_fast(const TileArgs a
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
-    f32x4 ra[4], rb[4];
+    f32x4 ra[NRA], rb[4];
+    auto store_a = [&](float* dst) {
+        if constexpr (A_KC) store_kc_rows<NRA>(dst, ra);
+        else store_tile<AMODE>(dst, ra);
+    };
     auto load_b = [&](int ks) {
         if constexpr (BMODE == OP_KC && AMODE == OP_IM2COL) {
             // weights: plain KC load at a remapped column
@@ -537,13 +564,13 @@ __global__ void __launch_bounds__(NTHREADS, 2) tile_kernel_fast(const TileArgs a
                 rb[i] = ld4(ok ? Bbase + ((long long)gr * a.B.ld + col) : zp);
             }
         } else {
-            fast_load<BMODE>(rb, a.B, a.g, fg, Bbase, n0, a.N, ks, kend, ri, zb, zp);
+            fast_load<BMODE, 4>(rb, a.B, a.g, fg, Bbase, n0, a.N, ks, kend, rib, zb, zp);
         }
     };
 
-    fast_load<AMODE>(ra, a.A, a.g, fg, Abase, m0, a.M, ks0, kend, ri, zb, zp);
+    fast_load<AMODE, NRA>(ra, a.A, a.g, fg, Abase, m0, a.M, ks0, kend, ri, zb, zp);
     load_b(ks0);
-    store_tile<AMODE>(As0, ra);
+    store_a(As0);
     store_tile<BMODE>(Bs0, rb);
     __syncthreads();
 
@@ -551,23 +578,26 @@ __global__ void __launch_bounds__(NTHREADS, 2) tile_kernel_fast(const TileArgs a
     for (int it = 0; it < nks; ++it) {
         const bool more = (it + 1) < nks;
         if (more) {
-            fast_load<AMODE>(ra, a.A, a.g, fg, Abase, m0, a.M, ks0 + it + 1, kend, ri, zb, zp);
+            fast_load<AMODE, NRA>(ra, a.A, a.g, fg, Abase, m0, a.M, ks0 + it + 1, kend, ri, zb, zp);
             load_b(ks0 + it + 1);
         }
         const float* As = As0 + cur * A_SZ;
         const float* Bs = Bs0 + cur * B_SZ;
         // fragment reads for 8 k-values (4 MFMA k-pairs) at a time, software-pipelined one group ahead
-        float af[2][2][4], bf[2][2][4];
-        auto read_frags = [&](int j, float (&fa)[2][4], float (&fb)[2][4]) {
+        float af[2][MI][4], bf[2][2][4];
+        auto read_frags = [&](int j, float (&fa)[MI][4], float (&fb)[2][4]) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < MI; ++i) {
                 if constexpr (A_KC) {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(As + (wr * 64 + i * 32 + r) * KC_LD + 8 * j + 4 * h);
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(As + (wr * (TBM / 2) + i * 32 + r) * KC_LD + 8 * j + 4 * h);
                     fa[i][0] = t[0]; fa[i][1] = t[1]; fa[i][2] = t[2]; fa[i][3] = t[3];
                 } else {
 #pragma unroll
                     for (int s = 0; s < 4; ++s) fa[i][s] = As[(8 * j + 4 * h + s) * MC_LD + wr * 64 + i * 32 + r];
                 }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
                 if constexpr (B_KC) {
                     const f32x4 t = *reinterpret_cast<const f32x4*>(Bs + (wc * 64 + i * 32 + r) * KC_LD + 8 * j + 4 * h);
                     fb[i][0] = t[0]; fb[i][1] = t[1]; fb[i][2] = t[2]; fb[i][3] = t[3];
@@ -584,13 +614,13 @@ __global__ void __launch_bounds__(NTHREADS, 2) tile_kernel_fast(const TileArgs a
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int n = 0; n < 2; ++n)
                         acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j & 1][i][s], bf[j & 1][n][s], acc[i][n], 0, 0, 0);
         }
         if (more) {
-            store_tile<AMODE>(As0 + (cur ^ 1) * A_SZ, ra);
+            store_a(As0 + (cur ^ 1) * A_SZ);
             store_tile<BMODE>(Bs0 + (cur ^ 1) * B_SZ, rb);
         }
         __syncthreads();
@@ -600,7 +630,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) tile_kernel_fast(const TileArgs a
     float* Cb = a.C + (long long)zb * a.c_stride_z + (long long)split * a.c_stride_split;
     const float* Rb = a.e.res ? a.e.res + (long long)zb * a.e.res_stride_z : nullptr;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const int gn = n0 + wc * 64 + n * 32 + r;
@@ -608,7 +638,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) tile_kernel_fast(const TileArgs a
             const float bias = a.e.bias ? a.e.bias[gn] : 0.f;
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                const int gm = m0 + wr * 64 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                const int gm = m0 + wr * (TBM / 2) + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
                 if (gm >= a.M) continue;
                 float x = acc[i][n][v] * a.e.alpha + bias;
                 if (a.e.rowbias) x += a.e.rowbias[(long long)(gm / a.e.rows_per_img) * a.e.ld_rowbias + gn];
@@ -629,7 +659,7 @@ inline int ilog2_exact(int v) {
     return s;
 }
 
-template <int AMODE, int BMODE>
+template <int AMODE, int BMODE, int TBM = 128>
 int launch_fast(const TileArgs& a, FastGeom fg, int nz, hipStream_t stream, const char* name) {
     static const float* zero_dev = nullptr;
     if (!zero_dev) {
@@ -644,12 +674,12 @@ int launch_fast(const TileArgs& a, FastGeom fg, int nz, hipStream_t stream, cons
     fg.zero = zero_dev;
     constexpr bool A_KC = (AMODE == OP_KC || AMODE == OP_IM2COL);
     constexpr bool B_KC = (BMODE == OP_KC || BMODE == OP_IM2COL);
-    constexpr int A_SZ = A_KC ? BM * KC_LD : BK * MC_LD;
+    constexpr int A_SZ = A_KC ? TBM * KC_LD : BK * MC_LD;
     constexpr int B_SZ = B_KC ? BN * KC_LD : BK * MC_LD;
     constexpr size_t LDS = (size_t)2 * (A_SZ + B_SZ) * sizeof(float);
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_kernel_fast<AMODE, BMODE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_kernel_fast<AMODE, BMODE, TBM>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         if (e != hipSuccess) {
             psld_set_error("%s: hipFuncSetAttribute failed: %s", name, hipGetErrorString(e));
@@ -657,10 +687,10 @@ int launch_fast(const TileArgs& a, FastGeom fg, int nz, hipStream_t stream, cons
         }
         configured = true;
     }
-    const long long tiles = (long long)cdiv(a.M, BM) * cdiv(a.N, BN);
+    const long long tiles = (long long)cdiv(a.M, TBM) * cdiv(a.N, BN);
     PSLD_CHECK_ARG(tiles < (1LL << 31) && nz * a.nsplit <= 65535, "%s: grid too large", name);
     dim3 grid((unsigned)tiles, (unsigned)(nz * a.nsplit));
-    hipLaunchKernelGGL((tile_kernel_fast<AMODE, BMODE>), grid, dim3(NTHREADS), LDS, stream, a, fg);
+    hipLaunchKernelGGL((tile_kernel_fast<AMODE, BMODE, TBM>), grid, dim3(NTHREADS), LDS, stream, a, fg);
     PSLD_CHECK_LAUNCH(name);
     return PSLD_OK;
 }
@@ -708,6 +738,9 @@ extern "C" int psld_gemm_f32(int trans_a, int trans_b, int M, int N, int K,
     const bool fastok = a.A.vec && a.B.vec && K % BK == 0 && M > 0 && N > 0;
     FastGeom fg{1, 0, 0, 0, nullptr};
     if (fastok) {
+        const bool small = (long long)cdiv(M, BM) * cdiv(N, BN) * batch <= 256;
+        if (!trans_a && trans_b && small && M > 64)
+            return launch_fast<OP_KC, OP_KC, 64>(a, fg, batch, stream, "psld_gemm_f32[NT,fast64]");
         if (!trans_a && trans_b)  return launch_fast<OP_KC, OP_KC>(a, fg, batch, stream, "psld_gemm_f32[NT,fast]");
         if (!trans_a && !trans_b) return launch_fast<OP_KC, OP_MC>(a, fg, batch, stream, "psld_gemm_f32[NN,fast]");
         if (trans_a && !trans_b)  return launch_fast<OP_MC, OP_MC>(a, fg, batch, stream, "psld_gemm_f32[TN,fast]");
@@ -757,6 +790,8 @@ extern "C" int psld_conv2d_nhwc_f32(const float* x1, int c1, const float* x2, in
     a.e = make_epilogue(epi);
     if (a.A.vec && a.B.vec && c1 % BK == 0 && c2 % BK == 0 && transposed_stride == 1 && a.M > 0) {
         FastGeom fg{kh * kw, 0, 0, ct / BK, nullptr};
+        if ((long long)cdiv(a.M, BM) * cdiv(a.N, BN) <= 256 && a.M > 64)
+            return launch_fast<OP_IM2COL, OP_KC, 64>(a, fg, 1, stream, "psld_conv2d_nhwc_f32[fast64]");
         return launch_fast<OP_IM2COL, OP_KC>(a, fg, 1, stream, "psld_conv2d_nhwc_f32[fast]");
     }
     return launch<OP_IM2COL, OP_KC>(a, 1, stream, "psld_conv2d_nhwc_f32");

@@ -164,7 +164,7 @@ def _pick_nsplit(tiles: int, k: int) -> int:
     grid wastes a quarter of the machine) while keeping >= 256 K per split."""
     max_split = max(1, k // 256)
     best, best_eff = 1, 0.0
-    for ns in range(1, min(max_split, 64) + 1):
+    for ns in range(1, min(max_split, 128) + 1):
         blocks = tiles * ns
         rounds = -(-blocks // _RESIDENT_BLOCKS)
         eff = blocks / (rounds * _RESIDENT_BLOCKS)
