@@ -111,6 +111,31 @@ def cpu_baseline(cfg, batch=16):
                       f"{dt:.1f} s on {torch.get_num_threads()} threads"}
 
 
+def sampling_probe(cfg, ema_net, sde, dev, batch, steps):
+    """Second half of BASELINE.json's metric: EM reverse-SDE sampling (configs[4]: 1000 steps, 512/GPU).
+    Times `steps` full predictor updates (network forward + fused EM kernel) of the EMA network in eval
+    mode and extrapolates the 50k-sample wall-clock for 8 GPUs (ceil(50000/(8*512)) = 13 batches/GPU)."""
+    from psld_amd.registry import get_module
+    ema_net.eval()
+    sampler = get_module("samplers", "em_sde")(cfg, sde, ema_net)
+    x = sde.prior_sampling((batch, 3, 32, 32), device=dev)
+    n = 1000
+    ts = torch.linspace(0, sde.T - cfg.evaluation.eval_eps, n, device=dev, dtype=torch.float64)
+    with torch.no_grad():
+        sampler.sample(x, ts[:2], 1, denoise=False)          # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sampler.sample(x, ts[: steps + 1], steps, denoise=False)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    ema_net.train()
+    batches = -(-50000 // (8 * batch))
+    return {"batch_per_gpu": batch, "ms_per_em_step": 1e3 * dt, "network_evals_per_s": batch / dt,
+            "fwd_tflops": 76.46e9 * batch / dt / 1e12,
+            "est_50k_samples_1000_steps_8gpu_s": batches * 1000 * dt,
+            "note": "measured on 1 GPU; 8-GPU figure assumes the collective-free sharding of SURVEY 8(e)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,6 +145,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--bucket-mb", type=int, default=64)
+    ap.add_argument("--sample-batch", type=int, default=512, help="per-GPU batch of the EM sampling probe (0 = skip)")
+    ap.add_argument("--sample-steps", type=int, default=4)
     args = ap.parse_args()
 
     import psld_amd
@@ -212,6 +239,8 @@ def main():
             out["roofline"] = None
         step_flops = 229.4e9 * args.batch                       # train step = 3 x 76.46 GFLOP/img
         out["whole_step_tflops_per_gpu"] = step_flops * args.steps / dt / 1e12
+        if world == 1 and args.sample_batch > 0:
+            out["sampling"] = sampling_probe(cfg, ema, sde, dev, args.sample_batch, args.sample_steps)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(C.c10_sota())

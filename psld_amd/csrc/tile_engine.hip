@@ -404,10 +404,12 @@ __device__ __forceinline__ void fast_load(f32x4 (&r)[NR], const Operand& op, con
             r[i] = ld4(ok ? base + ((long long)gr * op.ld + gk) : zp);
         }
     } else if constexpr (MODE == OP_IM2COL) {
+        // ri[i].img = bit mask of valid taps (0 for rows beyond M), ri[i].oy = pixel index of tap (0,0)
         const int c4 = tid & 7;
         const int chunk = kstep / fg.taps;          // wave-uniform
         const int tap = kstep - chunk * fg.taps;
         const int ky = tap / g.KW, kx = tap - ky * g.KW;
+        const int dpix = ky * g.IW + kx;
         const int c0 = chunk * BK;
         const bool second = c0 >= g.C1;
         const float* src = second ? op.p2 : base;
@@ -415,10 +417,8 @@ __device__ __forceinline__ void fast_load(f32x4 (&r)[NR], const Operand& op, con
         const int cc = (second ? c0 - g.C1 : c0) + c4 * 4;
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            const int iy = ri[i].oy * g.stride + ky - g.pad;
-            const int ix = ri[i].ox * g.stride + kx - g.pad;
-            const bool ok = ri[i].img >= 0 && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
-            r[i] = ld4(ok ? src + (((long long)(ri[i].img * g.IH + iy) * g.IW + ix) * cs + cc) : zp);
+            const bool ok = (ri[i].img >> tap) & 1;
+            r[i] = ld4(ok ? src + ((long long)(ri[i].oy + dpix) * cs + cc) : zp);
         }
     } else if constexpr (MODE == OP_MC) {
         const int c = tid & 31, kr = tid >> 5;
@@ -510,14 +510,23 @@ __global__ void __launch_bounds__(NTHREADS, 2) tile_kernel_fast(const TileArgs a
 #pragma unroll
         for (int i = 0; i < NRA; ++i) {
             const int gm = m0 + r0 + 32 * i;
+            ri[i].img = 0;
+            ri[i].oy = 0;
+            ri[i].ox = 0;
             if (gm < a.M) {
-                ri[i].ox = gm % a.g.OW;
+                const int ox = gm % a.g.OW;
                 const int t = gm / a.g.OW;
-                ri[i].oy = t % a.g.OH;
-                ri[i].img = t / a.g.OH;
-            } else {
-                ri[i].img = -1;
-                ri[i].oy = ri[i].ox = 0;
+                const int oy = t % a.g.OH;
+                const int img = t / a.g.OH;
+                const int iy0 = oy * a.g.stride - a.g.pad, ix0 = ox * a.g.stride - a.g.pad;
+                unsigned mask = 0;
+                for (int ky = 0; ky < a.g.KH; ++ky)
+                    for (int kx = 0; kx < a.g.KW; ++kx) {
+                        const int iy = iy0 + ky, ix = ix0 + kx;
+                        if (iy >= 0 && iy < a.g.IH && ix >= 0 && ix < a.g.IW) mask |= 1u << (ky * a.g.KW + kx);
+                    }
+                ri[i].img = (int)mask;
+                ri[i].oy = (img * a.g.IH + iy0) * a.g.IW + ix0;   // pixel index of tap (0,0); only used when valid
             }
         }
     } else {
@@ -629,19 +638,25 @@ __global__ void __launch_bounds__(NTHREADS, 2) tile_kernel_fast(const TileArgs a
 
     float* Cb = a.C + (long long)zb * a.c_stride_z + (long long)split * a.c_stride_split;
     const float* Rb = a.e.res ? a.e.res + (long long)zb * a.e.res_stride_z : nullptr;
+    const bool rb_uniform = a.e.rowbias && (a.e.rows_per_img % 32 == 0);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
+        const int row_base = m0 + wr * (TBM / 2) + i * 32;          // wave-uniform, 32-aligned
+        const int img_u = rb_uniform ? row_base / a.e.rows_per_img : 0;
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const int gn = n0 + wc * 64 + n * 32 + r;
             if (gn >= a.N) continue;
-            const float bias = a.e.bias ? a.e.bias[gn] : 0.f;
+            float bias = a.e.bias ? a.e.bias[gn] : 0.f;
+            // time-embedding bias: one value per (image, channel); a 32-row tile never straddles images
+            if (rb_uniform) bias += a.e.rowbias[(long long)img_u * a.e.ld_rowbias + gn];
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                const int gm = m0 + wr * (TBM / 2) + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                const int gm = row_base + (v & 3) + 8 * (v >> 2) + 4 * h;
                 if (gm >= a.M) continue;
                 float x = acc[i][n][v] * a.e.alpha + bias;
-                if (a.e.rowbias) x += a.e.rowbias[(long long)(gm / a.e.rows_per_img) * a.e.ld_rowbias + gn];
+                if (a.e.rowbias && !rb_uniform)
+                    x += a.e.rowbias[(long long)(gm / a.e.rows_per_img) * a.e.ld_rowbias + gn];
                 if (Rb) x += Rb[(long long)gm * a.e.ldres + gn];
                 x *= a.e.out_scale;
                 float* cp = Cb + (long long)gm * a.ldc + gn;
@@ -788,7 +803,7 @@ extern "C" int psld_conv2d_nhwc_f32(const float* x1, int c1, const float* x2, in
     a.nsplit = 1; a.kper = cdiv(a.K, BK) * BK;
     a.g = {ih, iw, c1, c2, oh, ow, kh, kw, stride, pad, transposed_stride};
     a.e = make_epilogue(epi);
-    if (a.A.vec && a.B.vec && c1 % BK == 0 && c2 % BK == 0 && transposed_stride == 1 && a.M > 0) {
+    if (a.A.vec && a.B.vec && c1 % BK == 0 && c2 % BK == 0 && transposed_stride == 1 && a.M > 0 && kh * kw <= 31) {
         FastGeom fg{kh * kw, 0, 0, ct / BK, nullptr};
         if ((long long)cdiv(a.M, BM) * cdiv(a.N, BN) <= 256 && a.M > 64)
             return launch_fast<OP_IM2COL, OP_KC, 64>(a, fg, 1, stream, "psld_conv2d_nhwc_f32[fast64]");
