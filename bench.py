@@ -156,7 +156,8 @@ def main():
     from psld_amd.registry import get_module
     import torch.distributed as dist
 
-    rank, local, world = init_distributed()
+    force_pg = os.environ.get("PSLD_FORCE_PG", "0") == "1"   # 1-GPU rehearsal of the RCCL path
+    rank, local, world = init_distributed(force=force_pg)
     assert world == max(1, args.gpus) or world == 1, (world, args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
@@ -177,8 +178,8 @@ def main():
     crit = get_module("losses", "psld_score_loss")(cfg, sde)
     wrapper = get_module("pl_modules", "sde_wrapper")(cfg, sde, net, ema_score_fn=ema, criterion=crit)
     ema_cb = EMAWeightUpdate(cfg.training.ema_decay)
-    if world > 1:
-        net.set_reducer(BucketReducer(bucket_bytes=args.bucket_mb << 20))
+    if world > 1 or force_pg:
+        net.set_reducer(BucketReducer(bucket_bytes=args.bucket_mb << 20, force_collective=force_pg))
     g = torch.Generator(device=dev).manual_seed(rank)         # per-rank data
     data = [torch.rand(args.batch, 3, 32, 32, device=dev, generator=g) * 2 - 1 for _ in range(4)]
 
@@ -195,8 +196,8 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        if world > 1 or force_pg:
+            dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
     fence()
@@ -249,8 +250,8 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
+    if world > 1 or force_pg:
+        dist.barrier(device_ids=[local])
         dist.destroy_process_group()
 
 

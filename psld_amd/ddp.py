@@ -22,12 +22,13 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
-    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun); returns (rank, local_rank, world)."""
+def init_distributed(backend: Optional[str] = None, force: bool = False) -> Tuple[int, int, int]:
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun); returns (rank, local_rank, world).
+    ``force`` creates the process group even for world size 1."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -39,11 +40,15 @@ def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
 
 
 class BucketReducer:
-    def __init__(self, process_group=None, bucket_bytes: int = 64 << 20, average: bool = True):
+    def __init__(self, process_group=None, bucket_bytes: int = 64 << 20, average: bool = True,
+                 force_collective: bool = False):
         self.pg = process_group
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.average = average
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # force_collective: issue the collectives even for a single-rank group (exercises the RCCL +
+        # side-stream path on a 1-GPU box)
+        self.force = force_collective and dist.is_initialized()
         self._flat = None
         self._bounds: List[Tuple[int, int]] = []
         self._next = -1
@@ -64,7 +69,7 @@ class BucketReducer:
 
     def _launch(self, lo: int, hi: int):
         self.launched.append((lo, hi))
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         view = self._flat[lo:hi]
         if self._flat.is_cuda:
@@ -94,7 +99,7 @@ class BucketReducer:
             lo, hi = self._bounds[self._next]
             self._launch(lo, hi)
             self._next -= 1
-        if self._flat is not None and self._flat.is_cuda and self.world > 1:
+        if self._flat is not None and self._flat.is_cuda and (self.world > 1 or self.force):
             for w in self._works:
                 w.wait()
             torch.cuda.current_stream().wait_stream(self._side)

@@ -274,3 +274,35 @@ def test_dropout_mask_statistics_and_gradient_consistency():
     yr = torch.nn.functional.silu(torch.nn.functional.group_norm(xr, 16, gamma.cpu().double(), beta.cpu().double(), 1e-6)) * mask
     yr.backward(gy.cpu().permute(0, 3, 1, 2).double())
     assert rel_l2(dx.permute(0, 3, 1, 2), xr.grad) < 1e-5
+
+
+def test_rccl_bucket_reducer_single_rank():
+    """The real RCCL + side-stream path on one GPU: a single-rank 'nccl' process group with the
+    collectives forced.  Gradients must equal the reducer-free run bit for bit (mean over 1 rank)."""
+    import socket
+    import torch.distributed as dist
+    from psld_amd.ddp import BucketReducer
+    from psld_amd.registry import get_module
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        net, cfg, _ = _build("tiny", train=True)
+        sde = get_module("sde", "psld")(cfg)
+        crit = get_module("losses", "psld_score_loss")(cfg, sde)
+        g = np.load(os.path.join(GOLDEN, "loss_tiny.npz"))
+        x0, eps, t = T(g["x0"]).to(DEV), T(g["eps"]).to(DEV), T(g["t"]).to(DEV)
+        crit(x0, t, net, eps=eps).backward()
+        ref = net.flat_grad().clone()
+        red = BucketReducer(bucket_bytes=1 << 18, force_collective=True)
+        net.set_reducer(red)
+        crit(x0, t, net, eps=eps).backward()
+        torch.cuda.synchronize()
+        assert len(red.launched) >= 8
+        assert red.launched[0][1] == ref.numel() and red.launched[-1][0] == 0     # end of buffer first
+        assert all(red.launched[i][0] == red.launched[i + 1][1] for i in range(len(red.launched) - 1))
+        assert torch.equal(net.flat_grad(), ref)
+    finally:
+        dist.destroy_process_group()
