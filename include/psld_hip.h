@@ -148,7 +148,9 @@ int psld_axpby_f32(const float* a, float sa, const float* b, float sb, float* y,
 int psld_silu_f32(const float* x, float* y, long long n, hipStream_t stream);
 int psld_silu_bwd_f32(const float* x, const float* dy, float* dx, long long n, hipStream_t stream);
 /* out[b][c] = alpha * sum over the hw rows of image b of x[(b*hw+p)*ld + c] (bias / temb-bias gradients). */
+long long psld_colsum_workspace_bytes(int batch, int hw, int c);
 int psld_colsum_f32(const float* x, int ld, int batch, int hw, int c, float* out, float alpha,
+                    void* workspace /* >= psld_colsum_workspace_bytes, NULL = slow scalar path */,
                     hipStream_t stream);
 /* dst[r][0:cols] (+)= src[r][0:cols] with row strides: channel concat (ncsnpp.py:374) and its split. */
 int psld_copy2d_f32(const float* src, int ld_src, float* dst, int ld_dst, long long rows, int cols,

@@ -78,7 +78,8 @@ SIGNATURES = {
     "psld_axpby_f32": (I, [P, F, P, F, P, LL, I, P]),
     "psld_silu_f32": (I, [P, P, LL, P]),
     "psld_silu_bwd_f32": (I, [P, P, P, LL, P]),
-    "psld_colsum_f32": (I, [P, I, I, I, I, P, F, P]),
+    "psld_colsum_workspace_bytes": (LL, [I, I, I]),
+    "psld_colsum_f32": (I, [P, I, I, I, I, P, F, P, P]),
     "psld_copy2d_f32": (I, [P, I, P, I, LL, I, I, P]),
     "psld_softmax_rows_f32": (I, [P, P, LL, I, P]),
     "psld_softmax_rows_bwd_f32": (I, [P, P, P, LL, I, P]),

@@ -119,7 +119,38 @@ __global__ void silu_bwd_kernel(const float* __restrict__ x, const float* __rest
     GRID_STRIDE(i, n) dx[i] = dy[i] * dsilu_f(x[i]);
 }
 
-// out[b][c] = sum_p x[(b*hw+p)*ld + c].  grid (chunks_c, batch); block 256 = (cw = 64 columns) x 4 row lanes
+// out[b][c] = alpha * sum_p x[(b*hw+p)*ld + c].
+// Vector path (c % 4 == 0, 16-B aligned): block = (channel quads) x (pixel lanes) like the GroupNorm
+// kernels, grid (chunks, batch); per-thread fp32 partials over <= 64 rows, fp64 across lanes; chunk
+// partials are combined by colsum_final_kernel (deterministic, no atomics).
+__global__ void colsum_partial_kernel(const float* __restrict__ x, int ld, int hw, int c, int cq, int pl,
+                                      int chunk_px, int chunks, double* __restrict__ part) {
+    extern __shared__ double red[];  // [pl][cq*4]
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int q = threadIdx.x % cq, l = threadIdx.x / cq;
+    const int p0 = chunk * chunk_px, p1 = min(hw, p0 + chunk_px);
+    const float* base = x + ((long long)b * hw) * ld + q * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int p = p0 + l; p < p1; p += pl) acc += *reinterpret_cast<const f32x4*>(base + (long long)p * ld);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[(long long)l * cq * 4 + q * 4 + e] = (double)acc[e];
+    __syncthreads();
+    for (int i = threadIdx.x; i < cq * 4; i += blockDim.x) {
+        double t = 0.0;
+        for (int ll = 0; ll < pl; ++ll) t += red[(long long)ll * cq * 4 + i];
+        part[((long long)b * chunks + chunk) * c + i] = t;
+    }
+}
+__global__ void colsum_final_kernel(const double* __restrict__ part, int chunks, int c, float* __restrict__ out,
+                                    float alpha) {
+    const int b = blockIdx.y;
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= c) return;
+    double t = 0.0;
+    for (int k = 0; k < chunks; ++k) t += part[((long long)b * chunks + k) * c + col];
+    out[(long long)b * c + col] = (float)(t * (double)alpha);
+}
+// scalar fallback: grid (c/64, batch); block 256 = 64 columns x 4 row lanes
 __global__ void colsum_kernel(const float* __restrict__ x, int ld, int hw, int c, float* __restrict__ out,
                               float alpha) {
     __shared__ double red[4][64];
@@ -280,9 +311,35 @@ extern "C" int psld_silu_bwd_f32(const float* x, const float* dy, float* dx, lon
     PSLD_CHECK_LAUNCH("psld_silu_bwd_f32");
     return PSLD_OK;
 }
+extern "C" long long psld_colsum_workspace_bytes(int batch, int hw, int c) {
+    return (long long)batch * 64 * c * sizeof(double) + 256;
+}
 extern "C" int psld_colsum_f32(const float* x, int ld, int batch, int hw, int c, float* out, float alpha,
-                               hipStream_t stream) {
+                               void* workspace, hipStream_t stream) {
     PSLD_CHECK_ARG(x && out && batch > 0 && hw > 0 && c > 0, "psld_colsum_f32: bad args");
+    const bool vec = workspace && c % 4 == 0 && ld % 4 == 0 && c / 4 <= 256 && hw >= 8 &&
+                     (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    if (vec) {
+        const int cq = c / 4;
+        int pl = 256 / cq;
+        if (pl < 1) pl = 1;
+        if (pl > hw) pl = hw;
+        int chunks = cdiv(1024, batch);
+        const int max_chunks = cdiv(hw, pl * 4);
+        if (chunks > max_chunks) chunks = max_chunks;
+        if (chunks > 64) chunks = 64;
+        if (chunks < 1) chunks = 1;
+        const int chunk_px = cdiv(hw, chunks);
+        chunks = cdiv(hw, chunk_px);
+        double* part = reinterpret_cast<double*>(workspace);
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(chunks, batch), dim3(cq * pl), (size_t)pl * cq * 4 * sizeof(double),
+                           stream, x, ld, hw, c, cq, pl, chunk_px, chunks, part);
+        PSLD_CHECK_LAUNCH("colsum_partial_kernel");
+        hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(c, 128), batch), dim3(128), 0, stream, part, chunks, c, out,
+                           alpha);
+        PSLD_CHECK_LAUNCH("colsum_final_kernel");
+        return PSLD_OK;
+    }
     hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(c, 64), batch), dim3(256), 0, stream, x, ld, hw, c, out, alpha);
     PSLD_CHECK_LAUNCH("psld_colsum_f32");
     return PSLD_OK;

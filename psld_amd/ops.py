@@ -270,7 +270,9 @@ def silu_bwd(x: Tensor, dy: Tensor) -> Tensor:
 
 
 def colsum(x: Tensor, ld: int, batch: int, hw: int, c: int, out: Tensor, alpha: float = 1.0):
-    check(lib().psld_colsum_f32(x.data_ptr(), ld, batch, hw, c, out.data_ptr(), alpha, _stream()), "psld_colsum_f32")
+    ws = workspace(lib().psld_colsum_workspace_bytes(batch, hw, c), x.device)
+    check(lib().psld_colsum_f32(x.data_ptr(), ld, batch, hw, c, out.data_ptr(), alpha, ws.data_ptr(), _stream()),
+          "psld_colsum_f32")
     return out
 
 
