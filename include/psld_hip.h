@@ -208,6 +208,17 @@ int psld_em_step_f64(double* x, const float* eps_pred, const double* z, const ps
 /* reverse_sde outputs themselves (f_bar, g_bar) for callers that want them (psld.py:345-364). */
 int psld_reverse_sde_f64(const double* x, const float* eps_pred, const psld_em_coeffs_t* k,
                          int batch, int c, int hw, double* f_bar, double* g_bar, hipStream_t stream);
+/* Symmetric-splitting (SSCS) sampler, SURVEY.md 8(f) rank 1 (samplers/sde.py:227-370):
+ * analytic half step u <- M u + L z (M = exp-scaled 2x2 mean matrix of :236-263, L = factor of the
+ * transition covariance :265-291 through get_coeff) and the Euler score step of :313-329. */
+typedef struct psld_sscs_coeffs {
+    double a_xx, a_xm, a_mx, a_mm;
+    double c11, c12, c21, c22;
+} psld_sscs_coeffs_t;
+int psld_sscs_analytic_f64(double* x, const double* z, const psld_sscs_coeffs_t* k,
+                           int batch, int c, int hw, float* x_f32_out, hipStream_t stream);
+int psld_sscs_score_step_f64(double* x, const float* eps_pred, const psld_em_coeffs_t* k,
+                             int batch, int c, int hw, hipStream_t stream);
 int psld_f64_to_f32(const double* x, float* y, long long n, hipStream_t stream);
 int psld_f32_to_f64(const float* x, double* y, long long n, hipStream_t stream);
 

@@ -53,6 +53,11 @@ class EmCoeffs(C.Structure):
     ]
 
 
+class SscsCoeffs(C.Structure):
+    """struct psld_sscs_coeffs."""
+    _fields_ = [(n, C.c_double) for n in ("a_xx", "a_xm", "a_mx", "a_mm", "c11", "c12", "c21", "c22")]
+
+
 I, F, D, LL, P = C.c_int, C.c_float, C.c_double, C.c_longlong, C.c_void_p
 EP = C.POINTER(Epilogue)
 
@@ -90,6 +95,8 @@ SIGNATURES = {
     "psld_sqerr_loss_f32": (I, [P, P, LL, I, P, P, F, P, P]),
     "psld_em_step_f64": (I, [P, P, P, C.POINTER(EmCoeffs), I, I, I, P, P]),
     "psld_reverse_sde_f64": (I, [P, P, C.POINTER(EmCoeffs), I, I, I, P, P, P]),
+    "psld_sscs_analytic_f64": (I, [P, P, C.POINTER(SscsCoeffs), I, I, I, P, P]),
+    "psld_sscs_score_step_f64": (I, [P, P, C.POINTER(EmCoeffs), I, I, I, P]),
     "psld_f64_to_f32": (I, [P, P, LL, P]),
     "psld_f32_to_f64": (I, [P, P, LL, P]),
     "psld_grad_norm_f32": (I, [P, LL, P, P, P]),

@@ -209,7 +209,66 @@ __global__ void reverse_sde_kernel(const double* __restrict__ x, const float* __
     }
 }
 
+// ---- symmetric-splitting sampler (samplers/sde.py:227-370) ----------------------------------------
+// analytic half step: u' = M u + L z with host-computed 2x2 mean matrix (incl. exp scaling) and
+// Cholesky factor of the transition covariance (sde.py:236-311)
+__global__ void sscs_analytic_kernel(double* __restrict__ x, const double* __restrict__ z, const psld_sscs_coeffs_t k,
+                                     int batch, int c, int hw, float* __restrict__ xf) {
+    const long long n = (long long)batch * c * hw;
+    GRID_STRIDE(i, n) {
+        const int b = (int)(i / ((long long)c * hw));
+        const long long r = i - (long long)b * c * hw;
+        const long long ox = (long long)b * 2 * c * hw + r, om = ox + (long long)c * hw;
+        const double xv = x[ox], mv = x[om];
+        const double zx = z[ox], zm = z[om];
+        const double nx = (k.a_xx * xv + k.a_xm * mv) + (k.c11 * zx + k.c12 * zm);
+        const double nm = (k.a_mx * xv + k.a_mm * mv) + (k.c21 * zx + k.c22 * zm);
+        x[ox] = nx;
+        x[om] = nm;
+        if (xf) { xf[ox] = (float)nx; xf[om] = (float)nm; }
+    }
+}
+
+// score step (sde.py:313-329): x += dt*gamma*beta*(score_x + x);  m += dt*m*nu*beta*(score_m + m_inv*m)
+__global__ void sscs_score_kernel(double* __restrict__ x, const float* __restrict__ eps, const psld_em_coeffs_t k,
+                                  int batch, int c, int hw) {
+    const long long n = (long long)batch * c * hw;
+    GRID_STRIDE(i, n) {
+        const int b = (int)(i / ((long long)c * hw));
+        const long long r = i - (long long)b * c * hw;
+        const long long ox = (long long)b * 2 * c * hw + r, om = ox + (long long)c * hw;
+        float ex, em;
+        fetch_eps(eps, k, b, r, c, hw, ex, em);
+        float sx, sm;
+        if (k.score_mode == 1) { sx = 0.f; sm = -k.c22 * em; }
+        else if (k.score_mode == 2) { sx = -k.c11 * ex; sm = 0.f; }
+        else { sx = -k.c11 * ex - k.c12 * em; sm = -k.c21 * ex - k.c22 * em; }
+        const double xv = x[ox], mv = x[om];
+        x[ox] = xv + k.dt * k.gamma * k.beta * ((double)sx + xv);
+        x[om] = mv + k.dt * k.m * k.nu * k.beta * ((double)sm + k.m_inv * mv);
+    }
+}
+
 }  // namespace
+
+extern "C" int psld_sscs_analytic_f64(double* x, const double* z, const psld_sscs_coeffs_t* k, int batch, int c,
+                                      int hw, float* x_f32_out, hipStream_t stream) {
+    PSLD_CHECK_ARG(x && z && k && batch > 0 && c > 0 && hw > 0, "psld_sscs_analytic_f64: bad args");
+    const long long n = (long long)batch * c * hw;
+    hipLaunchKernelGGL(sscs_analytic_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, z, *k, batch, c, hw,
+                       x_f32_out);
+    PSLD_CHECK_LAUNCH("psld_sscs_analytic_f64");
+    return PSLD_OK;
+}
+
+extern "C" int psld_sscs_score_step_f64(double* x, const float* eps_pred, const psld_em_coeffs_t* k, int batch,
+                                        int c, int hw, hipStream_t stream) {
+    PSLD_CHECK_ARG(x && eps_pred && k && batch > 0 && c > 0 && hw > 0, "psld_sscs_score_step_f64: bad args");
+    const long long n = (long long)batch * c * hw;
+    hipLaunchKernelGGL(sscs_score_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, eps_pred, *k, batch, c, hw);
+    PSLD_CHECK_LAUNCH("psld_sscs_score_step_f64");
+    return PSLD_OK;
+}
 
 extern "C" long long psld_reduce_workspace_bytes(long long n) {
     (void)n;

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import Epilogue, EmCoeffs, SdeParams, check
+from ._lib import Epilogue, EmCoeffs, SdeParams, SscsCoeffs, check
 
 Tensor = torch.Tensor
 INV_SQRT2 = float(1.0 / np.sqrt(2.0))
@@ -361,6 +361,18 @@ def reverse_sde(x: Tensor, eps_pred: Tensor, k: EmCoeffs):
     check(lib().psld_reverse_sde_f64(_chk(x, torch.float64).data_ptr(), _chk(eps_pred).data_ptr(), C.byref(k), b,
                                      c2 // 2, h * w, f.data_ptr(), g.data_ptr(), _stream()), "psld_reverse_sde_f64")
     return f, g
+
+
+def sscs_analytic(x: Tensor, z: Tensor, k: SscsCoeffs, x_f32: Optional[Tensor]):
+    b, c2, h, w = x.shape
+    check(lib().psld_sscs_analytic_f64(_chk(x, torch.float64).data_ptr(), _chk(z, torch.float64).data_ptr(),
+                                       C.byref(k), b, c2 // 2, h * w, _p(x_f32), _stream()), "psld_sscs_analytic_f64")
+
+
+def sscs_score_step(x: Tensor, eps_pred: Tensor, k: EmCoeffs):
+    b, c2, h, w = x.shape
+    check(lib().psld_sscs_score_step_f64(_chk(x, torch.float64).data_ptr(), _chk(eps_pred).data_ptr(), C.byref(k), b,
+                                         c2 // 2, h * w, _stream()), "psld_sscs_score_step_f64")
 
 
 def f64_to_f32(x: Tensor) -> Tensor:

@@ -100,3 +100,89 @@ class EulerMaruyamaSampler(Sampler):
                 dt_d = float(np.float32(eps))
                 self._step(x64, x32, t_d, dt_d, None)
         return x64
+
+
+@register_module(category="samplers", name="sscs_sde")
+class SSCSSampler(Sampler):
+    """Symmetric-splitting CLD sampler (samplers/sde.py:227-370): per step two analytic Ornstein-
+    Uhlenbeck half steps (closed-form mean matrix + Cholesky noise, one fused kernel each) around
+    one Euler score step (one network call + one fused kernel).  Same surface and noise-draw order
+    as the reference (two ``randn_like`` per step, one unused draw in the denoising step)."""
+
+    def __init__(self, config, sde, score_fn, corrector_fn=None):
+        super().__init__(config, sde, score_fn, corrector_fn=corrector_fn)
+        self.noise_fn = None   # test hook: callable(draw_index, x) -> float64 noise
+
+    # host-side scalars (python doubles) ----------------------------------------------------------
+    def _analytic_coeffs(self, t: float, dt: float):
+        import math
+        from ._lib import SscsCoeffs
+        sde = self.sde
+        db = sde.b_t(sde.T - (t + dt)) - sde.b_t(sde.T - t)              # sde.py:241
+        nu, ga, m, mi = sde.nu, sde.gamma, sde.m, sde.m_inv
+        sf = math.exp(((nu + ga) / 4) * db)                               # :245-246
+        a1, a2, c1, c2 = (nu - ga) / 4, -((ga - nu) ** 2) / 8, 0.5, (ga - nu) / 4
+        k = SscsCoeffs()
+        k.a_xx, k.a_xm = (1 - a1 * db) * sf, (-a2 * db) * sf              # :255
+        k.a_mx, k.a_mm = (-c1 * db) * sf, (1 - c2 * db) * sf              # :257
+        db2 = db * db
+        lam = (nu + ga) / 2
+        sc, isc = math.exp(lam * db), math.exp(-lam * db)                 # :271-272
+        xx = ((-mi / 2) * db2 - ((ga - nu) / 2) * db + (isc - 1)) * sc + sde.eps
+        xm = (((ga - nu) / 4) * db2) * sc
+        mm = ((-1 / 2) * db2 - (m * (nu - ga) / 2) * db + m * (isc - 1)) * sc + sde.eps
+        try:                                                              # psld.py:154-186
+            if sde.decomp_mode == "lower":
+                l11 = math.sqrt(xx)
+                l21 = xm / l11
+                k.c11, k.c12, k.c21, k.c22 = l11, 0.0, l21, math.sqrt(mm - l21 ** 2)
+            else:
+                u22 = math.sqrt(mm)
+                u12 = xm / u22
+                k.c11, k.c12, k.c21, k.c22 = math.sqrt(xx - u12 ** 2), u12, 0.0, u22
+        except ValueError:
+            raise ValueError("Numerical precision error.")
+        return k
+
+    def predictor_update_fn(self, u, t, dt):
+        raise NotImplementedError("use sample(); the fused kernels update the state in place")
+
+    def sample(self, batch, ts, n_discrete_steps, denoise=True, eps=1e-3):
+        if not batch.is_cuda:
+            raise RuntimeError("psld_amd sampler needs device tensors (no CPU fallback)")
+        sde = self.sde
+        self.nfe = n_discrete_steps
+        tl = ts.detach().to(torch.float64).cpu().tolist()
+        x32 = batch.to(torch.float32).contiguous().clone()
+        x64 = ops.f32_to_f64(x32) if batch.dtype != torch.float64 else batch.contiguous().clone()
+        draws = [0]
+
+        def noise():
+            i = draws[0]
+            draws[0] += 1
+            z = self.noise_fn(i, x64) if self.noise_fn is not None else torch.randn_like(x64)
+            return z.contiguous()
+
+        with torch.no_grad():
+            for i in range(n_discrete_steps):
+                t, dt = tl[i], tl[i + 1] - tl[i]
+                ka = self._analytic_coeffs(t, dt / 2)
+                ops.sscs_analytic(x64, noise(), ka, x32)                  # sde.py:333
+                t_rev = sde.T - t
+                t32 = torch.full((x64.shape[0],), float(np.float32(t_rev)), device=x64.device, dtype=torch.float32)
+                eps_pred = self.score_fn(x32, t32)
+                ops.sscs_score_step(x64, eps_pred.contiguous(), sde.em_coeffs(t_rev, dt))   # :334
+                ops.sscs_analytic(x64, noise(), ka, x32)                  # :335
+                if self.corrector_fn is not None:
+                    x64, _ = self.corrector_update_fn(x64, ts[i], dt)
+                    x64 = x64.contiguous()
+                    x32 = ops.f64_to_f32(x64)
+            if denoise:                                                   # sde.py:363-368, :340-351
+                t_d = float(np.float32(sde.T - eps))
+                dt_d = float(np.float32(eps))
+                t_rev = sde.T - t_d
+                t32 = torch.full((x64.shape[0],), float(np.float32(t_rev)), device=x64.device, dtype=torch.float32)
+                eps_pred = self.score_fn(x32, t32)
+                noise()                                                    # drawn and discarded by the reference
+                ops.em_step(x64, eps_pred.contiguous(), None, sde.em_coeffs(t_rev, dt_d), x32)
+        return x64

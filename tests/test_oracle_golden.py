@@ -259,3 +259,19 @@ def test_em_sampler(golden, tag):
     assert x.dtype == torch.float64
     assert rel_l2(x, T(g[f"x_{tag}"])) < 1e-6
     np.testing.assert_array_equal(torch.stack(seen).numpy(), g[f"seen_t_{tag}"])
+
+
+@pytest.mark.parametrize("tag", ["xm_3", "xm_6", "m_3", "m_6"])
+def test_sscs_sampler(golden, tag):
+    """symmetric-splitting sampler, default (score_xm) and gamma=0 (score_m, out_ch=3)."""
+    g = golden("sscs_tiny.npz")
+    name = "tiny" if tag.startswith("xm") else "tiny_out3"
+    cfg = _net_cfg(name)
+    meta = _net_meta()[name]
+    sd = synth_state_dict([(k, tuple(s)) for k, s in meta["keys"]], meta["seed"])
+    sde = O.PSLDOracle.from_config(cfg)
+    n = int(tag.split("_")[1]) - 1
+    x = O.sscs_sample(sde, lambda u, t: O.ncsnpp_forward(sd, cfg, u, t), T(g[f"batch_{tag}"]), T(g[f"ts_{tag}"]), n,
+                      True, cfg.evaluation.eval_eps, noise=list(T(g[f"noise_{tag}"])))
+    assert x.dtype == torch.float64
+    assert rel_l2(x, T(g[f"x_{tag}"])) < 1e-12

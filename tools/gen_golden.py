@@ -329,6 +329,35 @@ def main():
             out[f"seen_t_{tag}"] = torch.stack([s[0] for s in seen_t])
             assert xf.dtype == torch.float64
     save("em_tiny.npz", **out)
+
+    # ------------------------------------------------------------------ J. SSCS sampler (8(f) rank 1)
+    print("SSCS sampler (tiny)")
+    SSCS = get("samplers", "sscs_sde")
+    out = {}
+    for cname, ccfg, seed in (("xm", C.tiny(), 1000), ("m", tiny3, 1020)):
+        sde_c = PSLD(ccfg)
+        net = NCSNpp(ccfg)
+        load_synth(net, seed)
+        net.eval()
+        sampler = SSCS(ccfg, sde_c, net)
+        for n_disc in (3, 6):
+            g = torch.Generator().manual_seed(70 + n_disc)
+            batch = torch.cat([torch.randn(2, 3, 16, 16, generator=g),
+                               torch.randn(2, 3, 16, 16, generator=g) * np.sqrt(sde_c.m)], dim=1)
+            n = n_disc - 1
+            tsx = torch.linspace(0, sde_c.T - ccfg.evaluation.eval_eps, n + 1, dtype=torch.float64)
+            noises = [torch.randn(2, 6, 16, 16, generator=g, dtype=torch.float64) for _ in range(2 * n + 1)]
+            it = iter(noises)
+            orig = torch.randn_like
+            torch.randn_like = lambda x_, **kw: next(it).to(x_.dtype)
+            try:
+                xf = sampler.sample(batch, tsx, n, denoise=True, eps=ccfg.evaluation.eval_eps)
+            finally:
+                torch.randn_like = orig
+            tag = f"{cname}_{n_disc}"
+            out[f"batch_{tag}"], out[f"noise_{tag}"], out[f"x_{tag}"], out[f"ts_{tag}"] = batch, torch.stack(noises), xf, tsx
+            assert xf.dtype == torch.float64
+    save("sscs_tiny.npz", **out)
     print("done")
 
 
