@@ -157,7 +157,13 @@ def main():
     import torch.distributed as dist
 
     force_pg = os.environ.get("PSLD_FORCE_PG", "0") == "1"   # 1-GPU rehearsal of the RCCL path
-    rank, local, world = init_distributed(force=force_pg)
+    # PSLD_DIST_BACKEND=gloo + PSLD_SHARE_GPU=1: rehearsal of the N>1 code path with several ranks on ONE
+    # GPU (RCCL needs one device per rank; gloo stages through the host)
+    backend = os.environ.get("PSLD_DIST_BACKEND") or None
+    share_gpu = os.environ.get("PSLD_SHARE_GPU", "0") == "1"
+    rank, local, world = init_distributed(backend=backend, force=force_pg)
+    if share_gpu:
+        local = 0
     assert world == max(1, args.gpus) or world == 1, (world, args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
@@ -197,7 +203,7 @@ def main():
     def fence():
         torch.cuda.synchronize()
         if world > 1 or force_pg:
-            dist.barrier(device_ids=[local])
+            dist.barrier(device_ids=[local]) if dist.get_backend() == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
     fence()
@@ -210,7 +216,7 @@ def main():
     dt = time.perf_counter() - t0
     probe.enabled = False
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     loss_val = float(last.item())
@@ -251,7 +257,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if world > 1 or force_pg:
-        dist.barrier(device_ids=[local])
+        dist.barrier(device_ids=[local]) if dist.get_backend() == "nccl" else dist.barrier()
         dist.destroy_process_group()
 
 

@@ -72,7 +72,7 @@ class BucketReducer:
         if self.world == 1 and not self.force:
             return
         view = self._flat[lo:hi]
-        if self._flat.is_cuda:
+        if self._flat.is_cuda and dist.get_backend(self.pg) == "nccl":
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self._side.wait_event(ev)
@@ -83,6 +83,8 @@ class BucketReducer:
                     view.mul_(1.0 / self.world)
             self._works.append(w)
         else:
+            if self._flat.is_cuda:
+                torch.cuda.current_stream().synchronize()   # gloo reads the buffer from the host side
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)
             if self.average:
                 view.mul_(1.0 / self.world)
@@ -99,7 +101,7 @@ class BucketReducer:
             lo, hi = self._bounds[self._next]
             self._launch(lo, hi)
             self._next -= 1
-        if self._flat is not None and self._flat.is_cuda and (self.world > 1 or self.force):
+        if self._flat is not None and self._flat.is_cuda and (self.world > 1 or self.force) and self._works:
             for w in self._works:
                 w.wait()
             torch.cuda.current_stream().wait_stream(self._side)

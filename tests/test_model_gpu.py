@@ -373,3 +373,54 @@ def test_training_overfits_fixed_batch():
         losses.append(loss.item())
     assert np.isfinite(losses).all()
     assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
+
+
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from psld_amd.ddp import BucketReducer, shard_range
+        from psld_amd.registry import get_module
+        from tests.synth import synth_inputs
+        net, cfg, _ = _build("tiny", train=True)
+        sde = get_module("sde", "psld")(cfg)
+        crit = get_module("losses", "psld_score_loss")(cfg, sde)
+        x0, eps, t = (v.to(DEV) for v in synth_inputs(4, 3, 16, seed=77))
+        if rank == 0:   # single-process large-batch reference, before the reducer is attached
+            crit(x0, t, net, eps=eps).backward()
+            ref = net.flat_grad().clone()
+        red = BucketReducer(bucket_bytes=1 << 17)
+        net.set_reducer(red)
+        lo, hi = shard_range(4, rank, world)
+        crit(x0[lo:hi].contiguous(), t[lo:hi].contiguous(), net, eps=eps[lo:hi].contiguous()).backward()
+        torch.cuda.synchronize()
+        g = net.flat_grad()
+        if rank == 0:
+            err = ((g - ref).double().norm() / ref.double().norm()).item()
+            q.put((rank, err, len(red.launched)))
+        else:
+            q.put((rank, 0.0, len(red.launched)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_gradients_two_ranks_one_gpu():
+    """DP semantics with the real HIP backward + BucketReducer: 2 gloo ranks share this GPU, each takes
+    half of a batch of 4; the bucket-averaged flat gradient equals the full-batch gradient."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][1] < 2e-5, res
+    assert res[0][2] >= 4 and res[0][2] == res[1][2]
