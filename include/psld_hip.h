@@ -219,6 +219,14 @@ int psld_sscs_analytic_f64(double* x, const double* z, const psld_sscs_coeffs_t*
                            int batch, int c, int hw, float* x_f32_out, hipStream_t stream);
 int psld_sscs_score_step_f64(double* x, const float* eps_pred, const psld_em_coeffs_t* k,
                              int batch, int c, int hw, hipStream_t stream);
+/* Edges of the path.  Writer: position half of the f64 [B,c_total,H,W] state ->
+ * uint8 [B,H,W,c] = trunc(clip((x*0.5+0.5)*255, 0, 255)) (callbacks.py:103-107, util.py:147-158).
+ * Loader: uint8 [B,H,W,c] -> f32 [B,c,H,W] = img/127.5-1 (norm) or img/255, optional per-image
+ * horizontal flip (util.py:25-30, datasets/cifar10.py:33-46). */
+int psld_samples_to_uint8(const double* x, unsigned char* out, int batch, int c, int c_total, int hw,
+                          int denorm, hipStream_t stream);
+int psld_uint8_to_images_f32(const unsigned char* img, float* out, const unsigned char* flip,
+                             int batch, int c, int h, int w, int norm, hipStream_t stream);
 int psld_f64_to_f32(const double* x, float* y, long long n, hipStream_t stream);
 int psld_f32_to_f64(const float* x, double* y, long long n, hipStream_t stream);
 

@@ -586,6 +586,27 @@ def count_resblocks(config) -> int:
 
 
 # --------------------------------------------------------------------------------------
+# Edges of the path
+# --------------------------------------------------------------------------------------
+def samples_to_uint8(prediction: Tensor, is_augmented: bool = True, denorm: bool = True) -> np.ndarray:
+    """callbacks.py:103-107 + util.py:124-158 (save_as_images up to the PIL call): [B,H,W,C] uint8."""
+    samples = prediction.cpu()
+    if is_augmented:
+        samples, _ = torch.chunk(samples, 2, dim=1)
+    if denorm:
+        samples = samples * 0.5 + 0.5
+    arr = samples.permute(0, 2, 3, 1).contiguous().detach().numpy()
+    return (arr * 255).clip(0, 255).astype(np.uint8)
+
+
+def images_to_tensor(img_u8: np.ndarray, norm: bool = True) -> Tensor:
+    """util.py:25-30 (data_scaler; np.float is float64) + datasets/cifar10.py:43: [B,H,W,C] uint8 -> f32 [B,C,H,W]."""
+    a = np.asarray(img_u8).astype(np.float64)
+    a = a / 127.5 - 1.0 if norm else a / 255.0
+    return torch.tensor(a).permute(0, 3, 1, 2).float()
+
+
+# --------------------------------------------------------------------------------------
 # Per-step parameter maintenance (wrapper.py:82-89,128-155; callbacks.py:57-64)
 # --------------------------------------------------------------------------------------
 def clip_grad_norm(grads: Sequence[Tensor], max_norm: float) -> Tuple[List[Tensor], Tensor]:

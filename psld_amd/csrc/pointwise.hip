@@ -230,6 +230,43 @@ __global__ void time_embed_kernel(const float* __restrict__ t, const float* __re
     out[(long long)b * 2 * e + e + k] = cosf(p);
 }
 
+// ---- edges of the hot path -------------------------------------------------
+// Sample writer (callbacks.py:103-107 + util.py:147-158): keep the position half of the [B,2C,H,W]
+// f64 state, x*0.5+0.5 (denorm), *255, clip to [0,255], truncate to uint8, NCHW -> NHWC for the encoder.
+__global__ void samples_to_u8_kernel(const double* __restrict__ x, unsigned char* __restrict__ out, int batch,
+                                     int c, int c_total, int hw, int denorm) {
+    const long long n = (long long)batch * hw * c;
+    GRID_STRIDE(i, n) {
+        const int ch = (int)(i % c);
+        long long t = i / c;
+        const int p = (int)(t % hw);
+        const int b = (int)(t / hw);
+        double v = x[((long long)b * c_total + ch) * hw + p];
+        if (denorm) v = v * 0.5 + 0.5;
+        v = v * 255.0;
+        v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+        out[i] = (unsigned char)v;
+    }
+}
+// Data loader (util.py:25-30 + datasets/cifar10.py:33-46): uint8 HWC -> float32 CHW,
+// (img / 127.5) - 1 (norm) or img / 255, evaluated in double then rounded to f32 like the reference;
+// optional per-image horizontal flip (the RandomHorizontalFlip transform of util.py:80-113).
+__global__ void u8_to_images_kernel(const unsigned char* __restrict__ img, float* __restrict__ out,
+                                    const unsigned char* __restrict__ flip, int batch, int c, int h, int w, int norm) {
+    const long long n = (long long)batch * c * h * w;
+    GRID_STRIDE(i, n) {
+        const int xw = (int)(i % w);
+        long long t = i / w;
+        const int y = (int)(t % h);
+        t /= h;
+        const int ch = (int)(t % c);
+        const int b = (int)(t / c);
+        const int sx = (flip && flip[b]) ? (w - 1 - xw) : xw;
+        const double u = (double)img[(((long long)b * h + y) * w + sx) * c + ch];
+        out[i] = (float)(norm ? (u / 127.5) - 1.0 : u / 255.0);
+    }
+}
+
 __global__ void f64_to_f32_kernel(const double* __restrict__ x, float* __restrict__ y, long long n) {
     GRID_STRIDE(i, n) y[i] = (float)x[i];
 }
@@ -365,6 +402,22 @@ extern "C" int psld_time_embed_f32(const float* t, const float* W, float* out, i
     hipLaunchKernelGGL(time_embed_kernel, dim3(cdiv((long long)batch * e, 256)), dim3(256), 0, stream, t, W, out,
                        batch, e, use_log);
     PSLD_CHECK_LAUNCH("psld_time_embed_f32");
+    return PSLD_OK;
+}
+extern "C" int psld_samples_to_uint8(const double* x, unsigned char* out, int batch, int c, int c_total, int hw,
+                                     int denorm, hipStream_t stream) {
+    PSLD_CHECK_ARG(x && out && batch > 0 && c > 0 && c_total >= c && hw > 0, "psld_samples_to_uint8: bad args");
+    hipLaunchKernelGGL(samples_to_u8_kernel, dim3(grid_for((long long)batch * c * hw)), dim3(256), 0, stream, x, out,
+                       batch, c, c_total, hw, denorm);
+    PSLD_CHECK_LAUNCH("psld_samples_to_uint8");
+    return PSLD_OK;
+}
+extern "C" int psld_uint8_to_images_f32(const unsigned char* img, float* out, const unsigned char* flip, int batch,
+                                        int c, int h, int w, int norm, hipStream_t stream) {
+    PSLD_CHECK_ARG(img && out && batch > 0 && c > 0 && h > 0 && w > 0, "psld_uint8_to_images_f32: bad args");
+    hipLaunchKernelGGL(u8_to_images_kernel, dim3(grid_for((long long)batch * c * h * w)), dim3(256), 0, stream, img,
+                       out, flip, batch, c, h, w, norm);
+    PSLD_CHECK_LAUNCH("psld_uint8_to_images_f32");
     return PSLD_OK;
 }
 extern "C" int psld_f64_to_f32(const double* x, float* y, long long n, hipStream_t stream) {

@@ -375,6 +375,26 @@ def sscs_score_step(x: Tensor, eps_pred: Tensor, k: EmCoeffs):
                                          c2 // 2, h * w, _stream()), "psld_sscs_score_step_f64")
 
 
+def samples_to_uint8(samples: Tensor, is_augmented: bool = True, denorm: bool = True) -> Tensor:
+    """[B,2C,H,W] f64 sampler output -> uint8 [B,H,W,C] ready for the PNG encoder (SimpleImageWriter,
+    callbacks.py:88-124): 16x less device->host traffic than copying the f64 state."""
+    b, ct, h, w = samples.shape
+    c = ct // 2 if is_augmented else ct
+    out = torch.empty((b, h, w, c), device=samples.device, dtype=torch.uint8)
+    check(lib().psld_samples_to_uint8(_chk(samples, torch.float64).data_ptr(), out.data_ptr(), b, c, ct, h * w,
+                                      1 if denorm else 0, _stream()), "psld_samples_to_uint8")
+    return out
+
+
+def uint8_to_images(img: Tensor, norm: bool = True, flip: Optional[Tensor] = None) -> Tensor:
+    """uint8 [B,H,W,C] -> f32 [B,C,H,W] in [-1,1] (util.data_scaler + CIFAR10Dataset.__getitem__)."""
+    b, h, w, c = img.shape
+    out = torch.empty((b, c, h, w), device=img.device, dtype=torch.float32)
+    check(lib().psld_uint8_to_images_f32(_chk(img, torch.uint8).data_ptr(), out.data_ptr(), _p(flip), b, c, h, w,
+                                         1 if norm else 0, _stream()), "psld_uint8_to_images_f32")
+    return out
+
+
 def f64_to_f32(x: Tensor) -> Tensor:
     y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
     check(lib().psld_f64_to_f32(_chk(x, torch.float64).data_ptr(), y.data_ptr(), x.numel(), _stream()), "f64_to_f32")

@@ -371,3 +371,27 @@ def test_adam_clip_ema(ops):
     ref = O.ema_update(t2.cpu(), pd.cpu(), 0.99)
     ops.ema(t2, pd, 0.99)
     np.testing.assert_allclose(t2.cpu().numpy(), ref.numpy(), rtol=0, atol=1e-7)
+
+
+def test_writer_and_loader_edges(ops, golden):
+    """bit-exact against the reference's own outputs (tests/golden/edges.npz: PNGs
+    written by save_as_images read back; data_scaler tensors) and against the oracle on more inputs."""
+    ge = golden("edges.npz")
+    np.testing.assert_array_equal(ops.samples_to_uint8(torch.from_numpy(ge["pred"]).to(DEV)).cpu().numpy(), ge["u8"])
+    assert torch.equal(ops.uint8_to_images(torch.from_numpy(ge["img"]).to(DEV)).cpu(), torch.from_numpy(ge["tens"]))
+    g = torch.Generator().manual_seed(90)
+    x = torch.randn(5, 6, 16, 16, generator=g, dtype=torch.float64) * 0.8
+    x[0, 0, 0, :4] = torch.tensor([-1.0, 1.0, 0.0, 0.999999])          # clip edges
+    u8 = ops.samples_to_uint8(x.to(DEV))
+    np.testing.assert_array_equal(u8.cpu().numpy(), O.samples_to_uint8(x))
+    raw = ops.samples_to_uint8(x.to(DEV), is_augmented=False, denorm=False)
+    np.testing.assert_array_equal(raw.cpu().numpy(), O.samples_to_uint8(x, False, False))
+    img = torch.randint(0, 256, (4, 32, 32, 3), generator=g, dtype=torch.uint8)
+    t = ops.uint8_to_images(img.to(DEV))
+    assert torch.equal(t.cpu(), O.images_to_tensor(img.numpy()))
+    flip = torch.tensor([1, 0, 1, 0], dtype=torch.uint8)
+    tf = ops.uint8_to_images(img.to(DEV), flip=flip.to(DEV))
+    ref = O.images_to_tensor(img.numpy())
+    ref[0], ref[2] = ref[0].flip(-1), ref[2].flip(-1)
+    assert torch.equal(tf.cpu(), ref)
+    assert torch.equal(ops.uint8_to_images(img.to(DEV), norm=False).cpu(), O.images_to_tensor(img.numpy(), False))

@@ -275,3 +275,11 @@ def test_sscs_sampler(golden, tag):
                       True, cfg.evaluation.eval_eps, noise=list(T(g[f"noise_{tag}"])))
     assert x.dtype == torch.float64
     assert rel_l2(x, T(g[f"x_{tag}"])) < 1e-12
+
+
+def test_writer_loader_edges(golden):
+    """vectors produced by the reference's save_as_images (PNG read back) and data_scaler."""
+    g = golden("edges.npz")
+    np.testing.assert_array_equal(O.samples_to_uint8(T(g["pred"])), g["u8"])
+    assert torch.equal(O.images_to_tensor(g["img"]), T(g["tens"]))
+    assert torch.equal(O.images_to_tensor(g["img"], norm=False), T(g["tens01"]))

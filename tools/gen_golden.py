@@ -358,6 +358,24 @@ def main():
             out[f"batch_{tag}"], out[f"noise_{tag}"], out[f"x_{tag}"], out[f"ts_{tag}"] = batch, torch.stack(noises), xf, tsx
             assert xf.dtype == torch.float64
     save("sscs_tiny.npz", **out)
+
+    # ------------------------------------------------------------------ K. writer / loader edges (8(f) rank 3)
+    print("writer / loader edges")
+    import tempfile
+    from PIL import Image
+    g = torch.Generator().manual_seed(90)
+    pred = torch.randn(5, 6, 16, 16, generator=g, dtype=torch.float64) * 0.8
+    pred[0, 0, 0, :4] = torch.tensor([-1.0, 1.0, 0.0, 0.999999])
+    with tempfile.TemporaryDirectory() as td:
+        samples, _ = torch.chunk(pred.cpu(), 2, dim=1)                     # callbacks.py:103-107
+        util.save_as_images(samples, file_name=os.path.join(td, "o"), denorm=True)
+        u8 = np.stack([np.asarray(Image.open(os.path.join(td, f"o_{i}.png"))) for i in range(5)])
+    img = torch.randint(0, 256, (4, 32, 32, 3), generator=g, dtype=torch.uint8).numpy()
+    if not hasattr(np, "float"):
+        np.float = float                                                    # util.py:27 predates numpy 1.24
+    tens = torch.stack([torch.tensor(util.data_scaler(im, norm=True)).permute(2, 0, 1).float() for im in img])
+    tens01 = torch.stack([torch.tensor(util.data_scaler(im, norm=False)).permute(2, 0, 1).float() for im in img])
+    save("edges.npz", pred=pred, u8=u8, img=img, tens=tens, tens01=tens01)
     print("done")
 
 
