@@ -424,3 +424,40 @@ def test_data_parallel_gradients_two_ranks_one_gpu():
         assert p.exitcode == 0
     assert res[0][1] < 2e-5, res
     assert res[0][2] >= 4 and res[0][2] == res[1][2]
+
+
+@pytest.mark.parametrize("name", ["c10_sota", "celeba64"])
+def test_full_size_network_gradients_against_live_oracle(name):
+    """North-star scale backward: every parameter gradient of the 97.6 M (C10-SOTA) / 62.8 M (CelebA-64)
+    network vs torch autograd through the oracle on this box's CPU (same weights, inputs, t, eps)."""
+    from psld_amd.registry import get_module
+    net, cfg, sd = _build(name, train=True)
+    cfg.model.score_fn.dropout = 0.0
+    net.sf.dropout = 0.0
+    sde = get_module("sde", "psld")(cfg)
+    crit = get_module("losses", "psld_score_loss")(cfg, sde)
+    from tests.synth import synth_inputs
+    b = 2 if name == "c10_sota" else 1
+    x0, eps, t = synth_inputs(b, 3, cfg.data.image_size, seed=321)
+    loss = crit(x0.to(DEV), t.to(DEV), net, eps=eps.to(DEV))
+    loss.backward()
+    torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+    osd = {k: v.clone().requires_grad_(k != "all_modules.0.W") for k, v in sd.items()}
+    oloss = O.psld_score_loss(O.PSLDOracle.from_config(cfg), x0, t, lambda z, tt: O.ncsnpp_forward(osd, cfg, z, tt), eps)
+    oloss.backward()
+    assert abs(loss.item() - oloss.item()) < 2e-5 * abs(oloss.item())
+    total = torch.stack([v.grad.double().norm() for v in osd.values() if v.grad is not None]).norm().item()
+    worst, worst_k = 0.0, None
+    num = den = 0.0
+    for k, p in net.named_parameters():
+        if p.grad is None:
+            continue
+        a, bb = p.grad.double().cpu(), osd[k].grad.double()
+        e = ((a - bb).norm() / (bb.norm() + 1e-4 * total)).item()
+        num += float((a - bb).pow(2).sum())
+        den += float(bb.pow(2).sum())
+        if e > worst:
+            worst, worst_k = e, k
+    print(f"{name}: loss {loss.item():.6f}; global grad rel-L2 {np.sqrt(num / den):.3e}; worst tensor {worst:.3e} ({worst_k})")
+    assert np.sqrt(num / den) < 2e-5
+    assert worst < 1e-4, (worst, worst_k)
