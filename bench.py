@@ -236,10 +236,19 @@ def main():
             "final_loss": loss_val,
         }
         ps = probe.summary()
+        traffic = None
+        try:   # HBM bytes of the dominant launch shape from the committed PMC passes (profiles/r01/pmc_traffic.json)
+            with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as fh:
+                traffic = json.load(fh)["traffic_bytes"]
+        except Exception:  # noqa: BLE001
+            traffic = None
         if ps is not None:
             out["roofline"] = {"bound": "mfma", "kernel": "tile_kernel<IM2COL,KC> (conv3x3/1x1 fwd + dgrad)",
                                "achieved": ps["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ps["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "frac": ps["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                               "traffic_note": "HBM bytes/launch of the conv3x3 256->256 @32x32 B=128 launch "
+                                               "(PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01/pmc_traffic.json); "
+                                               "algorithmic 270.8 MB",
                                "launches": ps["launches"], "avg_launch_us": ps["avg_us"],
                                "share_of_step": ps["total_ms"] / (1e3 * dt)}
         else:

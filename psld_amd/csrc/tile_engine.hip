@@ -482,7 +482,19 @@ __global__ void __launch_bounds__(NTHREADS, 2) tile_kernel_fast(const TileArgs a
     // every XCD a contiguous run of tiles — the N-tiles of one M-tile and neighbouring M-tiles (halo
     // rows) then share one L2.  Bijective form (cdna guide T1) for any grid size.
     int bid = blockIdx.x;
-    {
+    int z = blockIdx.y;
+    if constexpr (BMODE == OP_SHIFT) {
+        // weight gradient: the tiles x taps blocks of one split-K range read the same dY / x pixels;
+        // keep them on one XCD (shared L2) by swizzling the LINEAR block id, split slowest.
+        const int per_z = gridDim.x;
+        const int nwg = per_z * gridDim.y, lin = blockIdx.y * per_z + blockIdx.x;
+        const int q = nwg >> 3, rem = nwg & 7, xcd = lin & 7;
+        const int vid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (lin >> 3);
+        bid = vid % per_z;
+        const int zz = vid / per_z;               // = split * taps + tap
+        const int ntap = gridDim.y / a.nsplit;
+        z = (zz % ntap) * a.nsplit + zz / ntap;   // back to the (zb = tap, split) packing used below
+    } else {
         const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = bid & 7;
         bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
     }
@@ -490,7 +502,6 @@ __global__ void __launch_bounds__(NTHREADS, 2) tile_kernel_fast(const TileArgs a
     const int tile_n = bid - tile_m * tiles_n;
     const int m0 = tile_m * TBM, n0 = tile_n * BN;
 
-    const int z = blockIdx.y;
     const int split = z % a.nsplit;
     const int zb = z / a.nsplit;
     const int kbeg = split * a.kper;
