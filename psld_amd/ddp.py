@@ -55,6 +55,7 @@ class BucketReducer:
         self._side = None
         self._works = []
         self.launched: List[Tuple[int, int]] = []   # (lo, hi) in launch order (inspected by tests)
+        self.producer_streams = []   # extra streams that write gradients (the network's wgrad stream)
 
     def begin(self, flat_grad: torch.Tensor):
         self._flat = flat_grad
@@ -76,6 +77,10 @@ class BucketReducer:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self._side.wait_event(ev)
+            for ps in self.producer_streams:
+                pe = torch.cuda.Event()
+                pe.record(ps)
+                self._side.wait_event(pe)
             with torch.cuda.stream(self._side):
                 w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
                 if self.average:
@@ -85,6 +90,8 @@ class BucketReducer:
         else:
             if self._flat.is_cuda:
                 torch.cuda.current_stream().synchronize()   # gloo reads the buffer from the host side
+                for ps in self.producer_streams:
+                    ps.synchronize()
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)
             if self.average:
                 view.mul_(1.0 / self.world)
