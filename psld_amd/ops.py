@@ -22,8 +22,27 @@ def lib():
     return _lib.load()
 
 
+_stream_cache = []   # stack of raw HIP stream handles pinned by stream_scope()
+
+
 def _stream() -> int:
+    if _stream_cache:
+        return _stream_cache[-1]
     return torch.cuda.current_stream().cuda_stream
+
+
+class stream_scope:
+    """Pins the raw handle of torch's current stream for the duration of a forward / backward pass so
+    that each of the ~1400 launches does not pay a `torch.cuda.current_stream()` lookup.  Nested scopes
+    (side streams) push their own handle."""
+
+    def __enter__(self):
+        _stream_cache.append(torch.cuda.current_stream().cuda_stream)
+        return self
+
+    def __exit__(self, *exc):
+        _stream_cache.pop()
+        return False
 
 
 def _p(t: Optional[Tensor]):

@@ -221,7 +221,7 @@ class _Exec:
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         self.side.wait_event(ev)
-        with torch.cuda.stream(self.side):
+        with torch.cuda.stream(self.side), ops.stream_scope():
             fn()
         for t in tensors:
             if t is not None:
@@ -557,6 +557,10 @@ class _Exec:
 
     # -- whole network (ncsnpp.py:287-438) --------------------------------------------------------------
     def run(self, x: Tensor, t: Tensor) -> Tensor:
+        with ops.stream_scope():
+            return self._run(x, t)
+
+    def _run(self, x: Tensor, t: Tensor) -> Tensor:
         net = self.net
         mods = net.all_modules
         mi = self.time_embedding(t)
@@ -646,6 +650,10 @@ class _Exec:
         return ops.nhwc_to_nchw(y)
 
     def backward(self, grad_out_nchw: Tensor):
+        with ops.stream_scope():
+            self._backward(grad_out_nchw)
+
+    def _backward(self, grad_out_nchw: Tensor):
         net = self.net
         self.head_grad.g = ops.nchw_to_nhwc(grad_out_nchw.contiguous())
         for fn, module in reversed(self.tape):
@@ -771,6 +779,8 @@ class NCSNpp(nn.Module):
         # per-kernel HIP-event timings are not inflated by a concurrent MFMA kernel)
         import os as _os
         self.overlap_wgrad = _os.environ.get("PSLD_OVERLAP_WGRAD", "0") == "1"
+        self._plist = None
+        self._gviews = None
         self._side = None
 
     def _side_stream(self):
@@ -780,9 +790,15 @@ class NCSNpp(nn.Module):
         return self._side
 
     # ---- flat parameter / gradient storage ----------------------------------------------------------
+    def _params(self) -> List[nn.Parameter]:
+        """Cached parameter list (the module structure never changes after construction)."""
+        if self._plist is None:
+            self._plist = list(self.parameters())
+        return self._plist
+
     def _layout(self):
         offs, off = {}, 0
-        for p in self.parameters():
+        for p in self._params():
             offs[id(p)] = off
             off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         return offs, off
@@ -790,10 +806,17 @@ class NCSNpp(nn.Module):
     def flatten_parameters(self) -> Tensor:
         """Make every parameter a view into one contiguous fp32 buffer (idempotent).  Needed by the
         fused optimiser / EMA / all-reduce; deepcopy() and .to() are followed by a re-flatten."""
-        params = list(self.parameters())
+        params = self._params()
+        flat = self._flat
+        if flat is not None:
+            # fast validation: first, middle and last parameter still point into the flat buffer
+            offs = self._offsets
+            base = flat.data_ptr()
+            probe = (params[0], params[len(params) // 2], params[-1])
+            if all(q.data_ptr() == base + 4 * offs[id(q)] for q in probe):
+                return flat
         dev = params[0].device
         offs, total = self._layout()
-        flat = self._flat
         ok = flat is not None and flat.device == dev and flat.numel() == total and all(
             p.data_ptr() == flat.data_ptr() + 4 * offs[id(p)] for p in params)
         if not ok:
@@ -804,6 +827,7 @@ class NCSNpp(nn.Module):
                 p.data = flat[o:o + p.numel()].view(p.shape)
             self._flat = flat
             self._flat_grad = None
+            self._gviews = None
             self._pack_cache.clear()
             self._epoch += 1
         self._offsets = offs
@@ -815,11 +839,18 @@ class NCSNpp(nn.Module):
         if self._flat_grad is None or self._flat_grad.device != self._flat.device or \
                 self._flat_grad.numel() != self._flat.numel():
             self._flat_grad = torch.zeros_like(self._flat)
+            self._gviews = None
         return self._flat_grad
 
     def _grad_view(self, p: nn.Parameter) -> Tensor:
-        o = self._offsets[id(p)]
-        return self._flat_grad[o:o + p.numel()].view(p.shape)
+        gv = self._gviews
+        if gv is None:
+            gv = self._gviews = {}
+            fg = self._flat_grad
+            for q in self._params():
+                o = self._offsets[id(q)]
+                gv[id(q)] = fg[o:o + q.numel()].view(q.shape)
+        return gv[id(p)]
 
     def _module_offset(self, module: nn.Module) -> int:
         if self._module_offs is None:
@@ -871,7 +902,7 @@ class NCSNpp(nn.Module):
     def _end_backward(self):
         if self._reducer is not None:
             self._reducer.finish()
-        for p in self.parameters():
+        for p in self._params():
             if not p.requires_grad:
                 continue
             gv = self._grad_view(p)
@@ -895,7 +926,7 @@ class NCSNpp(nn.Module):
         x = x.contiguous()
         t = time_cond.contiguous()
         self.flatten_parameters()
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._params())
         if x.requires_grad:
             raise NotImplementedError("gradient w.r.t. the network input is not on the hot path")
         if need_grad:
@@ -912,13 +943,14 @@ class NCSNpp(nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         skip = {"_flat", "_flat_grad", "_pack_cache", "_anchor", "_reducer", "_offsets", "_module_offs", "_posfreq",
-                "_side"}
+                "_side", "_plist", "_gviews"}
         for k, v in self.__dict__.items():
             if k in skip:
                 continue
             new.__dict__[k] = copy.deepcopy(v, memo)
         new._flat = new._flat_grad = new._offsets = new._anchor = new._reducer = new._posfreq = new._side = None
         new._module_offs = None
+        new._plist = new._gviews = None
         new._pack_cache = {}
         new._pack_key = None
         new._epoch = 0
