@@ -227,6 +227,16 @@ int psld_samples_to_uint8(const double* x, unsigned char* out, int batch, int c,
                           int denorm, hipStream_t stream);
 int psld_uint8_to_images_f32(const unsigned char* img, float* out, const unsigned char* flip,
                              int batch, int c, int h, int w, int norm, hipStream_t stream);
+/* Adaptive Runge-Kutta building blocks for the black-box probability-flow ODE sampler (SURVEY 8(f)
+ * rank 2, samplers/ode.py:40-76; the reference round-trips every RHS evaluation through host numpy via
+ * torchdiffeq's scipy bridge).  v / coef are HOST arrays of nv <= 8 device pointers / doubles.
+ *   out = base + sum_j coef[j]*v[j]            (base may be NULL; optional f32 copy)
+ *   out[0] = sum_i ((sum_j coef[j]*v[j][i]) / (atol + rtol*max(|p_i|,|q_i|)))^2   (device scalar) */
+int psld_lincomb_f64(double* out, const double* base, const double* const* v, const double* coef, int nv,
+                     long long n, float* out_f32, hipStream_t stream);
+int psld_scaled_norm_sq_f64(const double* const* v, const double* coef, int nv, const double* p,
+                            const double* q, double atol, double rtol, long long n, double* out,
+                            void* workspace /* >= psld_reduce_workspace_bytes(n) */, hipStream_t stream);
 int psld_f64_to_f32(const double* x, float* y, long long n, hipStream_t stream);
 int psld_f32_to_f64(const float* x, double* y, long long n, hipStream_t stream);
 

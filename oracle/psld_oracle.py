@@ -334,6 +334,42 @@ def sscs_sample(sde: PSLDOracle, score_fn: Callable, batch: Tensor, ts: Tensor, 
 
 
 # --------------------------------------------------------------------------------------
+# Black-box probability-flow ODE sampler (main/samplers/ode.py:9-76) -- SURVEY.md 8(f) rank 2
+# PARITY UNPINNED for this function: torchdiffeq==0.2.3 (Pipfile:8) is neither vendored nor installed,
+# so its ``method="scipy_solver"`` bridge (torchdiffeq/_impl/scipy_wrapper.py, published source) is
+# restated here: y0 and every (t, y) handed to the RHS are cast to y0's dtype (float32), the
+# integration itself is scipy.integrate.solve_ivp(method="RK45") in float64, the solution is cast back
+# to float32.  The RHS (reverse_sde with probability_flow=True) IS pinned (tests/golden/sde_perturb.npz).
+# --------------------------------------------------------------------------------------
+def bbode_sample(sde: PSLDOracle, score_fn: Callable, batch: Tensor, rtol: float, atol: float,
+                 eps: float = 1e-3, denoise: bool = True, solver: str = "RK45"):
+    from scipy.integrate import solve_ivp
+    shape, dtype = batch.shape, batch.dtype
+    nfe = [0]
+
+    def np_func(t, y):
+        tt = torch.tensor(t).to(dtype)
+        yy = torch.reshape(torch.tensor(y).to(dtype), shape)
+        with torch.no_grad():
+            vec_t = torch.ones(shape[0], dtype=torch.float64) * tt          # ode.py:43
+            f, _ = sde.reverse_sde(yy, vec_t, score_fn, probability_flow=True)
+        nfe[0] += 1
+        return f.detach().numpy().reshape(-1)
+
+    t = np.array([0.0, sde.T - eps])                                         # ode.py:50-52
+    sol = solve_ivp(np_func, [t.min(), t.max()], batch.detach().numpy().reshape(-1), t_eval=t, method=solver,
+                    rtol=rtol, atol=atol)
+    x = torch.tensor(sol.y).T.to(dtype).reshape(-1, *shape)[-1]             # ode.py:64
+    if denoise:                                                              # ode.py:66-75, :35-38
+        with torch.no_grad():
+            tt = torch.ones(shape[0], dtype=torch.float64) * (sde.T - eps)
+            f, _ = sde.reverse_sde(x, tt, score_fn, probability_flow=True)
+            x = x + f * eps
+        nfe[0] += 1
+    return x, nfe[0]
+
+
+# --------------------------------------------------------------------------------------
 # FIR resampling  (song_sde/op/upfirdn2d.py:159-200, song_sde/up_or_down_sampling.py)
 # --------------------------------------------------------------------------------------
 def upfirdn2d(x: Tensor, kernel: Tensor, up: int = 1, down: int = 1,

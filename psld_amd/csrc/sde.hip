@@ -249,7 +249,77 @@ __global__ void sscs_score_kernel(double* __restrict__ x, const float* __restric
     }
 }
 
+// ---- adaptive RK45 building blocks (black-box probability-flow ODE sampler, samplers/ode.py) ---------
+struct RkArgs {
+    const double* v[8];
+    double c[8];
+    int nv;
+};
+// out = base + sum_j c_j v_j  (base may be null); optional f32 copy for the next network call
+__global__ void rk_lincomb_kernel(double* __restrict__ out, const double* __restrict__ base, const RkArgs a,
+                                  long long n, float* __restrict__ out32) {
+    GRID_STRIDE(i, n) {
+        double acc = base ? base[i] : 0.0;
+#pragma unroll 8
+        for (int j = 0; j < a.nv; ++j) acc += a.c[j] * a.v[j][i];
+        out[i] = acc;
+        if (out32) out32[i] = (float)acc;
+    }
+}
+// partial sums of ((sum_j c_j v_j) / (atol + rtol * max(|p|,|q|)))^2
+__global__ void rk_scaled_sq_kernel(const RkArgs a, const double* __restrict__ p, const double* __restrict__ q,
+                                    double atol, double rtol, long long n, double* __restrict__ part) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    GRID_STRIDE(i, n) {
+        double e = 0.0;
+#pragma unroll 8
+        for (int j = 0; j < a.nv; ++j) e += a.c[j] * a.v[j][i];
+        const double sc = atol + rtol * fmax(fabs(p[i]), fabs(q[i]));
+        const double r = e / sc;
+        acc += r * r;
+    }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void rk_final_kernel(const double* __restrict__ part, int nparts, double* __restrict__ out) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 64) acc += part[i];
+    acc = wave_sum_d(acc);
+    if (threadIdx.x == 0) out[0] = acc;
+}
+
 }  // namespace
+
+extern "C" int psld_lincomb_f64(double* out, const double* base, const double* const* v, const double* coef, int nv,
+                                long long n, float* out_f32, hipStream_t stream) {
+    PSLD_CHECK_ARG(out && v && coef && nv >= 0 && nv <= 8 && n > 0, "psld_lincomb_f64: bad args");
+    RkArgs a{};
+    a.nv = nv;
+    for (int j = 0; j < nv; ++j) { a.v[j] = v[j]; a.c[j] = coef[j]; }
+    hipLaunchKernelGGL(rk_lincomb_kernel, dim3(grid_for(n)), dim3(256), 0, stream, out, base, a, n, out_f32);
+    PSLD_CHECK_LAUNCH("psld_lincomb_f64");
+    return PSLD_OK;
+}
+
+extern "C" int psld_scaled_norm_sq_f64(const double* const* v, const double* coef, int nv, const double* p,
+                                       const double* q, double atol, double rtol, long long n, double* out,
+                                       void* workspace, hipStream_t stream) {
+    PSLD_CHECK_ARG(v && coef && nv >= 1 && nv <= 8 && p && q && out && workspace && n > 0,
+                   "psld_scaled_norm_sq_f64: bad args");
+    RkArgs a{};
+    a.nv = nv;
+    for (int j = 0; j < nv; ++j) { a.v[j] = v[j]; a.c[j] = coef[j]; }
+    const int blocks = grid_for(n);
+    double* part = reinterpret_cast<double*>(workspace);
+    hipLaunchKernelGGL(rk_scaled_sq_kernel, dim3(blocks), dim3(256), 0, stream, a, p, q, atol, rtol, n, part);
+    PSLD_CHECK_LAUNCH("rk_scaled_sq_kernel");
+    hipLaunchKernelGGL(rk_final_kernel, dim3(1), dim3(64), 0, stream, part, blocks, out);
+    PSLD_CHECK_LAUNCH("rk_final_kernel");
+    return PSLD_OK;
+}
 
 extern "C" int psld_sscs_analytic_f64(double* x, const double* z, const psld_sscs_coeffs_t* k, int batch, int c,
                                       int hw, float* x_f32_out, hipStream_t stream) {

@@ -414,6 +414,29 @@ def uint8_to_images(img: Tensor, norm: bool = True, flip: Optional[Tensor] = Non
     return out
 
 
+def _ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+def lincomb(out: Tensor, base: Optional[Tensor], vs: Sequence[Tensor], coefs: Sequence[float],
+            out_f32: Optional[Tensor] = None):
+    """out = base + sum_j coefs[j] * vs[j] (float64), optional f32 copy."""
+    cf = (C.c_double * len(coefs))(*[float(c) for c in coefs])
+    check(lib().psld_lincomb_f64(out.data_ptr(), _p(base), _ptr_array(vs), cf, len(vs), out.numel(), _p(out_f32),
+                                 _stream()), "psld_lincomb_f64")
+    return out
+
+
+def scaled_norm_sq(vs: Sequence[Tensor], coefs: Sequence[float], p: Tensor, q: Tensor, atol: float, rtol: float,
+                   out: Tensor):
+    cf = (C.c_double * len(coefs))(*[float(c) for c in coefs])
+    ws = workspace(lib().psld_reduce_workspace_bytes(p.numel()), p.device)
+    check(lib().psld_scaled_norm_sq_f64(_ptr_array(vs), cf, len(vs), p.data_ptr(), q.data_ptr(), atol, rtol, p.numel(),
+                                        out.data_ptr(), ws.data_ptr(), _stream()), "psld_scaled_norm_sq_f64")
+    return out
+
+
 def f64_to_f32(x: Tensor) -> Tensor:
     y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
     check(lib().psld_f64_to_f32(_chk(x, torch.float64).data_ptr(), y.data_ptr(), x.numel(), _stream()), "f64_to_f32")

@@ -186,3 +186,127 @@ class SSCSSampler(Sampler):
                 noise()                                                    # drawn and discarded by the reference
                 ops.em_step(x64, eps_pred.contiguous(), None, sde.em_coeffs(t_rev, dt_d), x32)
         return x64
+
+
+@register_module(category="samplers", name="bb_ode")
+class BBODESampler(Sampler):
+    """Black-box probability-flow ODE sampler (samplers/ode.py:9-76) with the adaptive RK45 on the device.
+
+    The reference hands the ODE to ``torchdiffeq.odeint(method="scipy_solver")``, i.e. scipy's
+    ``solve_ivp(RK45)`` on the host: every function evaluation copies the state device -> numpy ->
+    device.  Here the Dormand-Prince stages, the error norm and the step update are fused kernels on
+    float64 device buffers; only the scalar error norm comes back per step.  The step controller follows
+    scipy's RK45 (safety 0.9, factors [0.2, 10], `select_initial_step`), and like torchdiffeq's bridge
+    the RHS sees the state and the time rounded to float32."""
+
+    C = (0.0, 1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0)
+    A = ((), (1 / 5,), (3 / 40, 9 / 40), (44 / 45, -56 / 15, 32 / 9),
+         (19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729),
+         (9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656))
+    B = (35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84)
+    E = (-71 / 57600, 0.0, 71 / 16695, -71 / 1920, 17253 / 339200, -22 / 525, 1 / 40)
+
+    def __init__(self, config, sde, score_fn, corrector_fn=None):
+        super().__init__(config, sde, score_fn, corrector_fn=corrector_fn)
+        self.nfe = 0
+        self.rtol = config.evaluation.sampler.rtol
+        self.atol = config.evaluation.sampler.atol
+        self.solver_opts = {"solver": config.evaluation.sampler.solver}
+        if self.solver_opts["solver"] != "RK45":
+            raise NotImplementedError("device-side BB-ODE implements scipy's RK45 (the solver every script uses)")
+        self._counter = 0
+
+    @property
+    def n_steps(self):
+        return self.nfe
+
+    @property
+    def mean_nfe(self):
+        if self._counter != 0:
+            return self.nfe / self._counter
+        raise ValueError("Run .sample() to compute mean_nfe")
+
+    def predictor_update_fn(self, x, t, dt):
+        pass
+
+    def _rhs(self, t: float, y64, y32, shape):
+        """f(t, y) = reverse_sde(..., probability_flow=True)[0] on float32-rounded (t, y) (ode.py:41-45)."""
+        self.nfe += 1
+        t32 = float(np.float32(t))
+        f, _ = self.sde.reverse_sde(y32.view(shape), t32, self.score_fn, probability_flow=True)
+        return f.view(-1)
+
+    def sample(self, batch, ts=None, n_discrete_steps=None, denoise=True, eps=1e-3):
+        if not batch.is_cuda:
+            raise RuntimeError("psld_amd sampler needs device tensors (no CPU fallback)")
+        import math
+        sde, rtol, atol = self.sde, float(self.rtol), float(self.atol)
+        self._counter += 1
+        shape = batch.shape
+        dev = batch.device
+        y32 = batch.to(torch.float32).contiguous().clone().view(-1)
+        y = ops.f32_to_f64(y32)
+        n = y.numel()
+        t, t_bound = 0.0, sde.T - eps
+        acc = torch.zeros(1, dtype=torch.float64, device=dev)
+
+        def norm(vs, cs, p, q):
+            ops.scaled_norm_sq(vs, cs, p, q, atol, rtol, acc)
+            return math.sqrt(float(acc.item()) / n)
+
+        with torch.no_grad():
+            f = self._rhs(t, y, y32, shape)
+            # scipy select_initial_step (order 4)
+            d0 = norm([y], [1.0], y, y)
+            d1 = norm([f], [1.0], y, y)
+            h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+            h0 = min(h0, t_bound - t)
+            y1 = torch.empty_like(y)
+            y1_32 = torch.empty_like(y32)
+            ops.lincomb(y1, y, [f], [h0], y1_32)
+            f1 = self._rhs(t + h0, y1, y1_32, shape)
+            d2 = norm([f1, f], [1.0, -1.0], y, y) / h0
+            h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** (1 / 5)
+            h_abs = min(100 * h0, h1, t_bound - t)
+            K = [f] + [None] * 6
+            ys, ys32 = torch.empty_like(y), torch.empty_like(y32)
+            y_new, y_new32 = torch.empty_like(y), torch.empty_like(y32)
+            while t < t_bound:
+                min_step = 10 * abs(np.nextafter(t, np.inf) - t)
+                h_abs = max(h_abs, min_step)
+                rejected = False
+                while True:
+                    if h_abs < min_step:
+                        raise RuntimeError("BB-ODE: required step size is less than spacing between numbers")
+                    t_new = t + h_abs
+                    if t_new - t_bound > 0:
+                        t_new = t_bound
+                    h = t_new - t
+                    h_abs = abs(h)
+                    for s in range(1, 6):                                     # scipy rk_step
+                        ops.lincomb(ys, y, K[:s], [a * h for a in self.A[s]], ys32)
+                        K[s] = self._rhs(t + self.C[s] * h, ys, ys32, shape)
+                    ops.lincomb(y_new, y, K[:6], [b * h for b in self.B], y_new32)
+                    K[6] = self._rhs(t + h, y_new, y_new32, shape)
+                    err = norm(K, [e * h for e in self.E], y, y_new)
+                    if err < 1:
+                        factor = 10.0 if err == 0 else min(10.0, 0.9 * err ** -0.2)
+                        if rejected:
+                            factor = min(1.0, factor)
+                        h_abs *= factor
+                        break
+                    h_abs *= max(0.2, 0.9 * err ** -0.2)
+                    rejected = True
+                t = t_new
+                y, y_new = y_new, y
+                y32, y_new32 = y_new32, y32
+                K[0] = K[6]
+            # torchdiffeq casts the solution back to y0's dtype (float32); ode.py:64
+            x32 = y32.view(shape)
+            if denoise:                                                       # ode.py:66-75
+                f, _ = sde.reverse_sde(x32, sde.T - eps, self.score_fn, probability_flow=True)
+                self.nfe += 1
+                x = ops.f32_to_f64(x32.contiguous())
+                ops.lincomb(x.view(-1), x.view(-1), [f.view(-1)], [eps])
+                return x
+            return x32

@@ -461,3 +461,27 @@ def test_full_size_network_gradients_against_live_oracle(name):
     print(f"{name}: loss {loss.item():.6f}; global grad rel-L2 {np.sqrt(num / den):.3e}; worst tensor {worst:.3e} ({worst_k})")
     assert np.sqrt(num / den) < 2e-5
     assert worst < 1e-4, (worst, worst_k)
+
+
+@pytest.mark.parametrize("tol", [1e-2, 1e-4])
+def test_bbode_sampler_against_scipy_oracle(tol):
+    """device-side RK45 vs the oracle (scipy solve_ivp RK45 on this box's CPU with the
+    oracle network).  Same step controller -> same accepted steps -> same NFE and a final state within
+    fp32-network noise."""
+    from psld_amd.registry import get_module
+    net, cfg, sd = _build("tiny")
+    cfg.evaluation.sampler.rtol = tol
+    cfg.evaluation.sampler.atol = tol
+    cfg.evaluation.sampler.solver = "RK45"
+    sde = get_module("sde", "psld")(cfg)
+    sampler = get_module("samplers", "bb_ode")(cfg, sde, net)
+    osde = O.PSLDOracle.from_config(cfg)
+    g = torch.Generator().manual_seed(3)
+    batch = torch.cat([torch.randn(2, 3, 16, 16, generator=g), torch.randn(2, 3, 16, 16, generator=g) * np.sqrt(osde.m)], 1)
+    x = sampler.sample(batch.to(DEV), None, None, denoise=True, eps=cfg.evaluation.eval_eps)
+    ref, nfe = O.bbode_sample(osde, lambda u, t: O.ncsnpp_forward(sd, cfg, u, t), batch, tol, tol, eps=cfg.evaluation.eval_eps)
+    err = rel_l2(x, ref)
+    print(f"BB-ODE tol={tol}: NFE {sampler.nfe} (oracle {nfe}), rel-L2 {err:.3e}")
+    assert x.dtype == torch.float64
+    assert sampler.nfe == nfe and sampler.mean_nfe == nfe
+    assert err < 1e-5

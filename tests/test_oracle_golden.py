@@ -283,3 +283,19 @@ def test_writer_loader_edges(golden):
     np.testing.assert_array_equal(O.samples_to_uint8(T(g["pred"])), g["u8"])
     assert torch.equal(O.images_to_tensor(g["img"]), T(g["tens"]))
     assert torch.equal(O.images_to_tensor(g["img"], norm=False), T(g["tens01"]))
+
+
+def test_bbode_oracle_runs_and_is_consistent():
+    """SURVEY 8(f) rank 2 (parity UNPINNED for the torchdiffeq bridge, see oracle header): the restated
+    sampler integrates the probability-flow ODE; tighter tolerances change the result by O(tolerance)."""
+    cfg = C.tiny()
+    meta = _net_meta()["tiny"]
+    sd = synth_state_dict([(k, tuple(s)) for k, s in meta["keys"]], meta["seed"])
+    sde = O.PSLDOracle.from_config(cfg)
+    g = torch.Generator().manual_seed(3)
+    batch = torch.cat([torch.randn(1, 3, 16, 16, generator=g), torch.randn(1, 3, 16, 16, generator=g) * np.sqrt(sde.m)], 1)
+    fn = lambda u, t: O.ncsnpp_forward(sd, cfg, u, t)
+    x1, n1 = O.bbode_sample(sde, fn, batch, 1e-2, 1e-2)
+    x2, n2 = O.bbode_sample(sde, fn, batch, 1e-3, 1e-3)
+    assert x1.dtype == torch.float64 and n2 >= n1 > 8
+    assert rel_l2(x1, x2) < 5e-2
