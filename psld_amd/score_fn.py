@@ -781,6 +781,9 @@ class NCSNpp(nn.Module):
         self.overlap_wgrad = _os.environ.get("PSLD_OVERLAP_WGRAD", "0") == "1"
         self._plist = None
         self._gviews = None
+        self.use_graphs = _os.environ.get("PSLD_GRAPHS", "0") == "1"
+        self._graphs = {}
+        self._conv_by_weight = {}
         self._side = None
 
     def _side_stream(self):
@@ -870,6 +873,7 @@ class NCSNpp(nn.Module):
         cached until the weights change."""
         w = conv.weight
         key = (id(w), dgrad)
+        self._conv_by_weight[id(w)] = conv
         ent = self._pack_cache.get(key)
         stamp = (self._epoch, w._version, w.data_ptr())
         if ent is not None and ent[0] == stamp:
@@ -934,8 +938,48 @@ class NCSNpp(nn.Module):
             if self._anchor is None or self._anchor.device != x.device:
                 self._anchor = torch.zeros(1, device=x.device, requires_grad=True)
             return _NCSNppFn.apply(x, t, self._anchor, self)
+        if self.use_graphs and not self.training:
+            return self._graph_forward(x, t)
         with torch.no_grad():
             return _Exec(self, record=False).run(x, t)
+
+    # ---- HIP-graph replay of the inference forward (launch-bound regime: small sampling batches) ----------
+    def enable_graphs(self, flag: bool = True):
+        """Capture the eval-mode forward into a HIP graph per input shape and replay it: one graph launch
+        instead of ~600 kernel launches issued from Python (the reference samples at 16 images/GPU,
+        where the forward is launch-bound).  Weights may keep changing (EMA): packed copies are refreshed
+        in place before a replay."""
+        self.use_graphs = bool(flag)
+        if not flag:
+            self._graphs = {}
+
+    def _graph_forward(self, x: Tensor, t: Tensor) -> Tensor:
+        key = (tuple(x.shape), x.device.index)
+        ent = self._graphs.get(key)
+        if ent is None:
+            sx, st = x.clone(), t.clone()
+            cur = torch.cuda.current_stream()
+            warm = torch.cuda.Stream(device=x.device)
+            warm.wait_stream(cur)
+            with torch.cuda.stream(warm), torch.no_grad():
+                for _ in range(2):   # packs weights, sizes workspaces, one-time kernel attributes
+                    _Exec(self, record=False).run(sx, st)
+            cur.wait_stream(warm)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph), torch.no_grad():
+                sy = _Exec(self, record=False).run(sx, st)
+            ent = self._graphs[key] = [graph, sx, st, sy, None]
+        graph, sx, st, sy, stamp = ent
+        now = (self._epoch, self._flat._version)
+        if stamp != now:
+            for (wid, dgrad), (_, _out) in list(self._pack_cache.items()):
+                if not dgrad:
+                    self._packed(self._conv_by_weight[wid])    # refreshes the same storage if stale
+            ent[4] = now
+        sx.copy_(x)
+        st.copy_(t)
+        graph.replay()
+        return sy.clone()
 
     def __deepcopy__(self, memo):
         import copy
@@ -943,7 +987,7 @@ class NCSNpp(nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         skip = {"_flat", "_flat_grad", "_pack_cache", "_anchor", "_reducer", "_offsets", "_module_offs", "_posfreq",
-                "_side", "_plist", "_gviews"}
+                "_side", "_plist", "_gviews", "_graphs", "_conv_by_weight"}
         for k, v in self.__dict__.items():
             if k in skip:
                 continue
@@ -951,6 +995,8 @@ class NCSNpp(nn.Module):
         new._flat = new._flat_grad = new._offsets = new._anchor = new._reducer = new._posfreq = new._side = None
         new._module_offs = None
         new._plist = new._gviews = None
+        new._graphs = {}
+        new._conv_by_weight = {}
         new._pack_cache = {}
         new._pack_key = None
         new._epoch = 0
