@@ -1,0 +1,222 @@
+"""Stand-alone drivers mirroring the reference's two entry points without Hydra / Lightning:
+
+    python -m psld_amd.cli train  --config c10_sota [key=value ...]        (main/train_sde.py:21-120)
+    python -m psld_amd.cli sample --config c10_sota [key=value ...]        (main/eval/sample.py:28-109)
+
+``key=value`` are Hydra-style dotted overrides on the ``dataset.diffusion`` node; the prefix
+``dataset.diffusion.`` is accepted and stripped, so the override lists of ``scripts_psld/**.sh`` can be
+pasted unchanged (``+dataset=...`` group selectors are ignored: ``--config`` picks the preset).
+Multi-GPU: launch with ``torchrun --nproc-per-node N`` — one process per GPU, RCCL gradient all-reduce
+for training (``psld_amd.ddp.BucketReducer``), collective-free sharding for sampling.
+
+Checkpoints use Lightning's layout (``{"state_dict": {"score_fn.<key>": ..., "ema_score_fn.<key>": ...},
+"global_step": ..., "epoch": ...}``, train_sde.py:67-73 / eval/sample.py:62-69), so ``.ckpt`` files written
+by the reference load here and vice versa.
+"""
+from __future__ import annotations
+
+import argparse
+import ast
+import copy
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+
+def parse_overrides(cfg, items):
+    for it in items:
+        if "=" not in it:
+            continue
+        k, v = it.split("=", 1)
+        k = k.lstrip("+")
+        if k == "dataset":          # Hydra group selector (+dataset=cifar10/cifar10_psld): --config picks the preset
+            continue
+        if k.startswith("dataset.diffusion."):
+            k = k[len("dataset.diffusion."):]
+        v = v.strip()
+        vs = v.strip("\\'\"")
+        try:
+            val = ast.literal_eval(vs)
+        except (ValueError, SyntaxError):
+            val = {"true": True, "false": False}.get(vs.lower(), vs)
+        cfg.override(k, val)
+    return cfg
+
+
+def build(cfg, device):
+    import psld_amd
+    from psld_amd.registry import get_module
+    psld_amd.import_modules_into_registry()
+    score_fn = get_module("score_fn", cfg.model.score_fn.name)(cfg).to(device)
+    ema = copy.deepcopy(score_fn)
+    for p in ema.parameters():
+        p.requires_grad = False
+    sde = get_module("sde", cfg.model.sde.name)(cfg)
+    return score_fn, ema, sde
+
+
+def save_checkpoint(path, wrapper, optim, step, epoch):
+    sd = {}
+    for k, v in wrapper.score_fn.state_dict().items():
+        sd["score_fn." + k] = v.detach().cpu()
+    for k, v in wrapper.ema_score_fn.state_dict().items():
+        sd["ema_score_fn." + k] = v.detach().cpu()
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    torch.save({"state_dict": sd, "global_step": step, "epoch": epoch,
+                "optimizer_states": [optim.state_dict()] if optim is not None else []}, path)
+
+
+def load_checkpoint(path, score_fn, ema, optim=None):
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    sd = ck["state_dict"] if "state_dict" in ck else ck
+    s1 = {k[len("score_fn."):]: v for k, v in sd.items() if k.startswith("score_fn.")}
+    s2 = {k[len("ema_score_fn."):]: v for k, v in sd.items() if k.startswith("ema_score_fn.")}
+    score_fn.load_state_dict(s1, strict=True)
+    ema.load_state_dict(s2 if s2 else s1, strict=True)
+    if optim is not None and ck.get("optimizer_states"):
+        try:
+            optim.load_state_dict(ck["optimizer_states"][0])
+        except Exception:  # noqa: BLE001  (a reference checkpoint carries torch.optim.Adam state)
+            pass
+    return ck.get("global_step", 0), ck.get("epoch", 0)
+
+
+def _dataset(cfg, args, device, rank):
+    """uint8 [N,H,W,3] array (``--data file.npy``) or synthetic CIFAR-shaped images; decoded on the device."""
+    size = cfg.data.image_size
+    if args.data and args.data != "synthetic":
+        arr = np.load(args.data, mmap_mode="r")
+        assert arr.dtype == np.uint8 and arr.shape[1:] == (size, size, 3), arr.shape
+        return torch.from_numpy(np.ascontiguousarray(arr)).to(device)
+    g = torch.Generator().manual_seed(1234 + rank)
+    return torch.randint(0, 256, (args.synthetic_size, size, size, 3), generator=g, dtype=torch.uint8).to(device)
+
+
+def train(args, overrides):
+    from psld_amd import config as C, ops
+    from psld_amd.ddp import BucketReducer, init_distributed
+    from psld_amd.optim import EMAWeightUpdate
+    from psld_amd.registry import get_module
+    import torch.distributed as dist
+    rank, local, world = init_distributed()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    cfg = parse_overrides(getattr(C, args.config)(), overrides)
+    torch.manual_seed(cfg.training.seed)                                 # train_sde.py:29
+    score_fn, ema, sde = build(cfg, dev)
+    score_fn.train()
+    crit = get_module("losses", cfg.training.loss.name)(cfg, sde)
+    wrapper = get_module("pl_modules", cfg.model.pl_module)(cfg, sde, score_fn, ema_score_fn=ema, criterion=crit)
+    ema_cb = EMAWeightUpdate(cfg.training.ema_decay) if cfg.training.use_ema else None
+    if world > 1:
+        score_fn.set_reducer(BucketReducer())
+    optim = wrapper.optimizers()
+    step, epoch0 = 0, 0
+    if cfg.training.restore_path:
+        step, epoch0 = load_checkpoint(cfg.training.restore_path, score_fn, ema, optim)
+        score_fn.to(dev), ema.to(dev)
+        optim._step = step
+    data = _dataset(cfg, args, dev, rank)
+    bs = cfg.training.batch_size
+    n = data.shape[0] // bs * bs                                          # drop_last (train_sde.py:100-110)
+    gen = torch.Generator(device=dev).manual_seed(cfg.training.seed + rank)
+    ckdir = os.path.join(cfg.training.results_dir or "psld_results", "checkpoints")
+    t0 = time.perf_counter()
+    for epoch in range(epoch0, cfg.training.epochs):
+        perm = torch.randperm(data.shape[0], device=dev, generator=gen)[:n]
+        for i in range(0, n, bs):
+            idx = perm[i:i + bs]
+            flip = (torch.rand(bs, device=dev, generator=gen) < 0.5).to(torch.uint8) if cfg.data.hflip else None
+            x0 = ops.uint8_to_images(data[idx].contiguous(), norm=cfg.data.norm, flip=flip)
+            loss = wrapper.training_step(x0, step)
+            if ema_cb is not None:
+                ema_cb.on_train_batch_end(None, wrapper)
+            step += 1
+            if rank == 0 and step % max(1, cfg.training.log_step * args.log_every) == 0:
+                dt = time.perf_counter() - t0
+                print(f"epoch {epoch} step {step} loss {loss.item():.4f} ({step * bs * world / dt:.1f} img/s)", flush=True)
+            if args.max_steps and step >= args.max_steps:
+                break
+        if rank == 0 and ((epoch + 1) % cfg.training.chkpt_interval == 0 or (args.max_steps and step >= args.max_steps)):
+            name = f"{cfg.model.sde.name}-{cfg.training.chkpt_prefix}-epoch={epoch:02d}-loss={loss.item():.4f}.ckpt"
+            save_checkpoint(os.path.join(ckdir, name), wrapper, optim, step, epoch + 1)
+            save_checkpoint(os.path.join(ckdir, "last.ckpt"), wrapper, optim, step, epoch + 1)
+        if args.max_steps and step >= args.max_steps:
+            break
+    if world > 1:
+        dist.barrier(device_ids=[local])
+        dist.destroy_process_group()
+
+
+def sample(args, overrides):
+    from psld_amd import config as C, ops
+    from psld_amd.ddp import init_distributed, shard_range
+    from psld_amd.registry import get_module
+    import torch.distributed as dist
+    rank, local, world = init_distributed()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    cfg = parse_overrides(getattr(C, args.config)(), overrides)
+    ev = cfg.evaluation
+    score_fn, ema, sde = build(cfg, dev)
+    if ev.chkpt_path:
+        load_checkpoint(ev.chkpt_path, score_fn, ema)
+        score_fn.to(dev), ema.to(dev)
+    score_fn.eval(), ema.eval()
+    sampler_cls = get_module("samplers", ev.sampler.name)
+    wrapper = get_module("pl_modules", cfg.model.pl_module)(cfg, sde, score_fn, ema_score_fn=ema,
+                                                            sampler_cls=sampler_cls)
+    wrapper.global_rank = rank
+    wrapper.on_predict_start()                                            # seed + rank (wrapper.py:93-99)
+    lo, hi = shard_range(ev.n_samples, rank, world)                       # eval/sample.py:108-109 shards the latents
+    base = os.path.join(ev.save_path or "psld_samples", str(ev.path_prefix)) if ev.path_prefix else (ev.save_path or "psld_samples")
+    out_dir = os.path.join(base, "images")
+    os.makedirs(out_dir, exist_ok=True)
+    size, ch = cfg.data.image_size, cfg.data.num_channels
+    t0 = time.perf_counter()
+    for bi, start in enumerate(range(lo, hi, ev.batch_size)):
+        b = min(ev.batch_size, hi - start)
+        batch = sde.prior_sampling((b, ch, size, size), device=dev)       # latent.py:10-19 (drawn per batch, on device)
+        x = wrapper.predict_step(batch, bi)
+        if x.dtype != torch.float64:
+            x = x.double()
+        u8 = ops.samples_to_uint8(x.contiguous(), is_augmented=cfg.model.sde.is_augmented, denorm=cfg.data.norm).cpu().numpy()
+        stem = os.path.join(out_dir, f"output_{ev.sample_prefix}_{rank}_{bi}")   # callbacks.py:120-122
+        if ev.save_mode == "image":
+            try:
+                from PIL import Image
+                for i, im in enumerate(u8):
+                    Image.fromarray(im).save(stem + "_%d.png" % i, "png")
+            except ImportError:
+                np.save(stem + ".npy", u8)
+        else:
+            np.save(stem + ".npy", u8)
+        if rank == 0:
+            done = start + b - lo
+            print(f"rank 0: {done}/{hi - lo} samples, {done / (time.perf_counter() - t0):.2f} img/s", flush=True)
+    if world > 1:
+        dist.barrier(device_ids=[local])
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="psld_amd.cli")
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    for name in ("train", "sample"):
+        p = sub.add_parser(name)
+        p.add_argument("--config", default="c10_sota", choices=["c10_sota", "celeba64_sota", "yaml_default", "tiny"])
+        p.add_argument("--data", default="synthetic", help="uint8 [N,H,W,3] .npy file or 'synthetic'")
+        p.add_argument("--synthetic-size", type=int, default=2048)
+        p.add_argument("--max-steps", type=int, default=0)
+        p.add_argument("--log-every", type=int, default=10)
+    args, overrides = ap.parse_known_args(argv)
+    if not torch.cuda.is_available():
+        raise SystemExit("psld_amd needs an MI355X: there is no CPU fallback")
+    (train if args.cmd == "train" else sample)(args, overrides)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
