@@ -459,8 +459,8 @@ __device__ __forceinline__ void store_kc_rows(float* lds, const f32x4 (&r)[NR]) 
 }
 
 // TBM = 128 (default) or 64 (small-M layers: the 8x8 convs give only 128 tiles of 128 rows for 256 CUs).
-template <int AMODE, int BMODE, int TBM>
-__global__ void __launch_bounds__(NTHREADS, 2) tile_kernel_fast(const TileArgs a, const FastGeom fg) {
+template <int AMODE, int BMODE, int TBM, int NBUF>
+__global__ void __launch_bounds__(NTHREADS, NBUF == 2 ? 2 : 3) tile_kernel_fast(const TileArgs a, const FastGeom fg) {
     constexpr bool A_KC = (AMODE == OP_KC || AMODE == OP_IM2COL);
     constexpr bool B_KC = (BMODE == OP_KC || BMODE == OP_IM2COL);
     static_assert(TBM == 128 || (TBM == 64 && A_KC), "TBM=64 needs a K-contiguous A operand");
@@ -470,7 +470,7 @@ __global__ void __launch_bounds__(NTHREADS, 2) tile_kernel_fast(const TileArgs a
     constexpr int B_SZ = B_KC ? BN * KC_LD : BK * MC_LD;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As0 = smem;
-    float* Bs0 = smem + 2 * A_SZ;
+    float* Bs0 = smem + NBUF * A_SZ;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -639,12 +639,21 @@ __global__ void __launch_bounds__(NTHREADS, 2) tile_kernel_fast(const TileArgs a
                     for (int n = 0; n < 2; ++n)
                         acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j & 1][i][s], bf[j & 1][n][s], acc[i][n], 0, 0, 0);
         }
-        if (more) {
-            store_a(As0 + (cur ^ 1) * A_SZ);
-            store_tile<BMODE>(Bs0 + (cur ^ 1) * B_SZ, rb);
+        if constexpr (NBUF == 2) {
+            if (more) {
+                store_a(As0 + (cur ^ 1) * A_SZ);
+                store_tile<BMODE>(Bs0 + (cur ^ 1) * B_SZ, rb);
+            }
+            __syncthreads();
+            cur ^= 1;
+        } else {
+            __syncthreads();
+            if (more) {
+                store_a(As0);
+                store_tile<BMODE>(Bs0, rb);
+                __syncthreads();
+            }
         }
-        __syncthreads();
-        cur ^= 1;
     }
 
     float* Cb = a.C + (long long)zb * a.c_stride_z + (long long)split * a.c_stride_split;
@@ -685,8 +694,8 @@ inline int ilog2_exact(int v) {
     return s;
 }
 
-template <int AMODE, int BMODE, int TBM = 128>
-int launch_fast(const TileArgs& a, FastGeom fg, int nz, hipStream_t stream, const char* name) {
+template <int AMODE, int BMODE, int TBM, int NBUF>
+int launch_fast_impl(const TileArgs& a, FastGeom fg, int nz, hipStream_t stream, const char* name) {
     static const float* zero_dev = nullptr;
     if (!zero_dev) {
         void* zptr = nullptr;
@@ -702,10 +711,10 @@ int launch_fast(const TileArgs& a, FastGeom fg, int nz, hipStream_t stream, cons
     constexpr bool B_KC = (BMODE == OP_KC || BMODE == OP_IM2COL);
     constexpr int A_SZ = A_KC ? TBM * KC_LD : BK * MC_LD;
     constexpr int B_SZ = B_KC ? BN * KC_LD : BK * MC_LD;
-    constexpr size_t LDS = (size_t)2 * (A_SZ + B_SZ) * sizeof(float);
+    constexpr size_t LDS = (size_t)NBUF * (A_SZ + B_SZ) * sizeof(float);
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_kernel_fast<AMODE, BMODE, TBM>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_kernel_fast<AMODE, BMODE, TBM, NBUF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         if (e != hipSuccess) {
             psld_set_error("%s: hipFuncSetAttribute failed: %s", name, hipGetErrorString(e));
@@ -716,9 +725,17 @@ int launch_fast(const TileArgs& a, FastGeom fg, int nz, hipStream_t stream, cons
     const long long tiles = (long long)cdiv(a.M, TBM) * cdiv(a.N, BN);
     PSLD_CHECK_ARG(tiles < (1LL << 31) && nz * a.nsplit <= 65535, "%s: grid too large", name);
     dim3 grid((unsigned)tiles, (unsigned)(nz * a.nsplit));
-    hipLaunchKernelGGL((tile_kernel_fast<AMODE, BMODE, TBM>), grid, dim3(NTHREADS), LDS, stream, a, fg);
+    hipLaunchKernelGGL((tile_kernel_fast<AMODE, BMODE, TBM, NBUF>), grid, dim3(NTHREADS), LDS, stream, a, fg);
     PSLD_CHECK_LAUNCH(name);
     return PSLD_OK;
+}
+
+template <int AMODE, int BMODE, int TBM = 128>
+int launch_fast(const TileArgs& a, FastGeom fg, int nz, hipStream_t stream, const char* name) {
+    // Measured on MI355X (tools/bench_tile.py): the conv / wgrad loaders prefer one LDS buffer at 3 workgroups
+    // per CU (+1.5 % / +3 %), the plain GEMM prefers two buffers at 2 per CU (+3 %).
+    constexpr int NBUF = (AMODE == OP_IM2COL || BMODE == OP_SHIFT) ? 1 : 2;
+    return launch_fast_impl<AMODE, BMODE, TBM, NBUF>(a, fg, nz, stream, name);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
