@@ -545,3 +545,29 @@ def test_cli_train_checkpoint_sample_roundtrip(tmp_path):
               "+evaluation.sampler.atol=1e-2", "+evaluation.sampler.solver=RK45"])
     assert len(os.listdir(os.path.join(out1 + "_sscs", "images"))) >= 1
     assert len(os.listdir(os.path.join(out1 + "_ode", "images"))) >= 1
+
+
+def test_latent_dataset_and_image_writer(tmp_path, golden):
+    from psld_amd.callbacks import SimpleImageWriter
+    from psld_amd.registry import get_module
+    import psld_amd
+    psld_amd.import_modules_into_registry()
+    cfg = C.tiny()
+    cfg.evaluation.n_samples = 6
+    sde = get_module("sde", "psld")(cfg)
+    ds = get_module("datasets", "latent")(sde, cfg, device=DEV)
+    assert len(ds) == 6 and ds[0].shape == (6, 16, 16) and ds.samples.is_cuda
+    ratio = (ds.samples[:, 3:].std() / ds.samples[:, :3].std()).item()
+    assert abs(ratio - np.sqrt(sde.m)) < 0.05                      # momentum half ~ N(0, m I) (psld.py:366-370)
+    ge = golden("edges.npz")
+    pred = T(ge["pred"]).to(DEV)
+
+    class PL:
+        global_rank = 3
+
+    wr = SimpleImageWriter(str(tmp_path), "batch", sample_prefix="gpu", save_mode="image")
+    wr.write_on_batch_end(None, PL(), pred, None, None, 7)
+    from PIL import Image
+    for i in range(pred.shape[0]):
+        im = np.asarray(Image.open(os.path.join(tmp_path, "images", f"output_gpu_3_7_{i}.png")))
+        np.testing.assert_array_equal(im, ge["u8"][i])             # identical to the reference's PNGs
