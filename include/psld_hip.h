@@ -237,6 +237,13 @@ int psld_lincomb_f64(double* out, const double* base, const double* const* v, co
 int psld_scaled_norm_sq_f64(const double* const* v, const double* coef, int nv, const double* p,
                             const double* q, double atol, double rtol, long long n, double* out,
                             void* workspace /* >= psld_reduce_workspace_bytes(n) */, hipStream_t stream);
+/* VP-SDE baseline (main/models/sde/vpsde.py:9-99): perturbation kernel and the reverse
+ * drift / Euler-Maruyama update (mode 0: f_bar = -f + g^2*score; mode 1: x <- x + f_bar*dt + g*sqrt(dt)*z). */
+int psld_vp_perturb_f32(const float* x0, const float* eps, const double* t, double beta0, double beta1,
+                        int batch, long long per_image, float* z_f32, double* u_f64, hipStream_t stream);
+int psld_vp_reverse_f64(double* x, const float* eps_pred, const double* z, double beta, double std, double dt,
+                        int probability_flow, int mode, long long n, double* f_bar, float* x_f32_out,
+                        hipStream_t stream);
 int psld_f64_to_f32(const double* x, float* y, long long n, hipStream_t stream);
 int psld_f32_to_f64(const float* x, double* y, long long n, hipStream_t stream);
 

@@ -195,6 +195,51 @@ class PSLDOracle:
 
 
 # --------------------------------------------------------------------------------------
+# VP-SDE baseline (main/models/sde/vpsde.py:9-99, main/losses.py:21-65) -- SURVEY.md 8(f) rank 4
+# --------------------------------------------------------------------------------------
+class VPSDEOracle:
+    def __init__(self, beta_min=0.1, beta_max=20.0):
+        self.beta_0, self.beta_1, self.T = beta_min, beta_max, 1.0
+
+    def beta_t(self, t):
+        return self.beta_0 + t * (self.beta_1 - self.beta_0)
+
+    def _lmc(self, t):                                                   # vpsde.py:74-76
+        return -0.25 * t ** 2 * (self.beta_1 - self.beta_0) - 0.5 * t * self.beta_0
+
+    def std(self, t):                                                    # vpsde.py:85-89
+        return torch.sqrt(1.0 - torch.exp(2.0 * self._lmc(t)))
+
+    def perturb_data(self, x_0, t, noise):                               # vpsde.py:29-37, 72-83
+        lmc = self._lmc(t)
+        mean = torch.exp(lmc[:, None, None, None]) * x_0
+        return mean + noise * bcast(torch.sqrt(1.0 - torch.exp(2.0 * lmc)), x_0)
+
+    def get_score(self, eps, t):                                         # vpsde.py:26-27
+        return -eps / bcast(self.std(t), eps)
+
+    def sde(self, x, t):                                                 # vpsde.py:39-45
+        beta = bcast(self.beta_t(t), x)
+        return -0.5 * beta * x, torch.sqrt(beta)
+
+    def reverse_sde(self, x, t, score_fn, probability_flow=False):       # vpsde.py:47-66
+        t = self.T - t
+        f, g = self.sde(x, t)
+        eps_pred = score_fn(x.type(torch.float32), t.type(torch.float32))
+        score = self.get_score(eps_pred, t)
+        if probability_flow:
+            score = 0.5 * score
+        return -f + g ** 2 * score, (torch.zeros_like(g) if probability_flow else g)
+
+
+def score_loss(sde: VPSDEOracle, x_0, t, score_fn, eps, reduce_mean=True):
+    """losses.py:41-65 with weighting='fid', l_type='l2'."""
+    x_t = sde.perturb_data(x_0, t, eps)
+    eps_pred = score_fn(x_t.type(torch.float32), t.type(torch.float32))
+    return F.mse_loss(eps_pred, eps, reduction="mean" if reduce_mean else "sum")
+
+
+# --------------------------------------------------------------------------------------
 # HSM / DSM loss  (main/losses.py:94-130)
 # --------------------------------------------------------------------------------------
 def psld_score_loss(sde: PSLDOracle, x_0: Tensor, t: Tensor, score_fn: Callable, eps: Tensor,

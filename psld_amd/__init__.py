@@ -6,4 +6,4 @@ from .registry import get_module, register_module, install_into  # noqa: F401
 
 def import_modules_into_registry():
     """Counterpart of main/util.py:116-121: importing the plug-ins registers them."""
-    from . import sde, score_fn, losses, samplers, wrapper, datasets  # noqa: F401
+    from . import sde, vpsde, score_fn, losses, samplers, wrapper, datasets  # noqa: F401

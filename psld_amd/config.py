@@ -144,3 +144,17 @@ def tiny(image_size: int = 16, nf: int = 32, ch_mult=(1, 2), num_res_blocks: int
     sf.attn_resolutions = list(attn_resolutions)
     sf.dropout = 0.0
     return c
+
+
+def tiny_vpsde() -> Config:
+    """Reduced VP-SDE baseline net (keys of main/configs/dataset/cifar10/cifar10_vpsde.yaml:10-40)."""
+    c = tiny()
+    sf = c.model.score_fn
+    sf.in_ch = sf.out_ch = 3
+    sf.fir = False
+    sf.progressive_input = "none"
+    sf.embedding_type = "positional"
+    c.model.sde = Config({"name": "vpsde", "beta_min": 0.1, "beta_max": 20.0, "n_timesteps": 1000,
+                          "is_augmented": False})
+    c.training.loss.name = "score_loss"
+    return c

@@ -291,7 +291,66 @@ __global__ void rk_final_kernel(const double* __restrict__ part, int nparts, dou
     if (threadIdx.x == 0) out[0] = acc;
 }
 
+// ---- VP-SDE baseline (main/models/sde/vpsde.py) ---------------------------------------------------
+// x_t = exp(lmc) * x0 + sqrt(1 - exp(2 lmc)) * eps, lmc = -0.25 t^2 (b1-b0) - 0.5 t b0   (vpsde.py:29-37, 72-83)
+__global__ void vp_perturb_kernel(const float* __restrict__ x0, const float* __restrict__ eps,
+                                  const double* __restrict__ t, double beta0, double beta1, int batch, long long per,
+                                  float* __restrict__ z, double* __restrict__ u) {
+    const long long n = (long long)batch * per;
+    GRID_STRIDE(i, n) {
+        const int b = (int)(i / per);
+        const double tt = t[b];
+        const double lmc = -0.25 * (tt * tt) * (beta1 - beta0) - 0.5 * tt * beta0;
+        const double mean = exp(lmc) * (double)x0[i];
+        const double sd = sqrt(1.0 - exp(2.0 * lmc));
+        const double v = mean + (double)eps[i] * sd;
+        if (z) z[i] = (float)v;
+        if (u) u[i] = v;
+    }
+}
+// reverse drift f_bar = 0.5 beta x + beta * score, score = -eps/std (f64), x0.5 for probability flow
+// (vpsde.py:26-27, 39-66); mode 0: write f_bar (and g_bar), mode 1: Euler-Maruyama update of x in place
+__global__ void vp_reverse_kernel(double* __restrict__ x, const float* __restrict__ eps, const double* __restrict__ z,
+                                  double beta, double sd, double dt, int pf, int mode, long long n,
+                                  double* __restrict__ fbar, float* __restrict__ xf) {
+    const double g = sqrt(beta);
+    const double sdt = sqrt(dt);
+    GRID_STRIDE(i, n) {
+        const double xv = x[i];
+        double score = -(double)eps[i] / sd;
+        if (pf) score = 0.5 * score;
+        const double fb = -(-0.5 * beta * xv) + (g * g) * score;
+        if (mode == 0) {
+            fbar[i] = fb;
+        } else {
+            double nx = xv + fb * dt;
+            if (z) nx = nx + g * sdt * z[i];
+            x[i] = nx;
+            if (xf) xf[i] = (float)nx;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int psld_vp_perturb_f32(const float* x0, const float* eps, const double* t, double beta0, double beta1,
+                                   int batch, long long per_image, float* z_f32, double* u_f64, hipStream_t stream) {
+    PSLD_CHECK_ARG(x0 && eps && t && batch > 0 && per_image > 0 && (z_f32 || u_f64), "psld_vp_perturb_f32: bad args");
+    hipLaunchKernelGGL(vp_perturb_kernel, dim3(grid_for((long long)batch * per_image)), dim3(256), 0, stream, x0, eps, t,
+                       beta0, beta1, batch, per_image, z_f32, u_f64);
+    PSLD_CHECK_LAUNCH("psld_vp_perturb_f32");
+    return PSLD_OK;
+}
+
+extern "C" int psld_vp_reverse_f64(double* x, const float* eps_pred, const double* z, double beta, double std, double dt,
+                                   int probability_flow, int mode, long long n, double* f_bar, float* x_f32_out,
+                                   hipStream_t stream) {
+    PSLD_CHECK_ARG(x && eps_pred && n > 0 && (mode == 1 || f_bar), "psld_vp_reverse_f64: bad args");
+    hipLaunchKernelGGL(vp_reverse_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, eps_pred, z, beta, std, dt,
+                       probability_flow, mode, n, f_bar, x_f32_out);
+    PSLD_CHECK_LAUNCH("psld_vp_reverse_f64");
+    return PSLD_OK;
+}
 
 extern "C" int psld_lincomb_f64(double* out, const double* base, const double* const* v, const double* coef, int nv,
                                 long long n, float* out_f32, hipStream_t stream) {

@@ -65,3 +65,28 @@ class PSLDScoreLoss(nn.Module):
             target = eps
         assert eps_pred.shape == target.shape
         return _SqErr.apply(eps_pred, target, self.reduce_strategy == "mean")
+
+
+@register_module(category="losses", name="score_loss")
+class ScoreLoss(nn.Module):
+    """Loss for non-augmented score models (VP-SDE), main/losses.py:21-65 — the 'fid' (eps-MSE) weighting."""
+
+    def __init__(self, config, sde):
+        super().__init__()
+        assert config.training.loss.weighting in ["nll", "fid"]
+        if config.training.loss.weighting != "fid" or config.training.loss.l_type != "l2":
+            raise NotImplementedError("ScoreLoss: only weighting='fid' with l_type='l2' is implemented")
+        self.sde = sde
+        self.l_type = config.training.loss.l_type
+        self.weighting = config.training.loss.weighting
+        self.reduce_strategy = "mean" if config.training.loss.reduce_mean else "sum"
+
+    def forward(self, x_0, t, score_fn, eps=None):
+        if eps is None:
+            eps = torch.randn_like(x_0)
+        assert eps.shape == x_0.shape
+        eps = eps.contiguous()
+        x_t = self.sde.perturb_f32(x_0, t, eps)                          # losses.py:48-49
+        t32 = ops.f64_to_f32(t.contiguous()) if t.dtype == torch.float64 else t.float()
+        eps_pred = score_fn(x_t, t32)
+        return _SqErr.apply(eps_pred, eps, self.reduce_strategy == "mean")

@@ -437,6 +437,26 @@ def scaled_norm_sq(vs: Sequence[Tensor], coefs: Sequence[float], p: Tensor, q: T
     return out
 
 
+def vp_perturb(x0: Tensor, eps: Tensor, t: Tensor, beta0: float, beta1: float, want_f32=True, want_f64=False):
+    b = x0.shape[0]
+    z = torch.empty_like(x0) if want_f32 else None
+    u = torch.empty(x0.shape, device=x0.device, dtype=torch.float64) if want_f64 else None
+    check(lib().psld_vp_perturb_f32(_chk(x0).data_ptr(), _chk(eps).data_ptr(), _chk(t, torch.float64).data_ptr(),
+                                    float(beta0), float(beta1), b, x0.numel() // b, _p(z), _p(u), _stream()),
+          "psld_vp_perturb_f32")
+    return z, u
+
+
+def vp_reverse(x: Tensor, eps_pred: Tensor, z: Optional[Tensor], beta: float, std: float, dt: float, pf: bool,
+               update: bool, x_f32: Optional[Tensor] = None):
+    """update=False -> returns f_bar; update=True -> Euler-Maruyama step of x in place."""
+    fbar = None if update else torch.empty_like(x)
+    check(lib().psld_vp_reverse_f64(_chk(x, torch.float64).data_ptr(), _chk(eps_pred).data_ptr(), _p(z), float(beta),
+                                    float(std), float(dt), 1 if pf else 0, 1 if update else 0, x.numel(), _p(fbar),
+                                    _p(x_f32), _stream()), "psld_vp_reverse_f64")
+    return fbar
+
+
 def f64_to_f32(x: Tensor) -> Tensor:
     y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
     check(lib().psld_f64_to_f32(_chk(x, torch.float64).data_ptr(), y.data_ptr(), x.numel(), _stream()), "f64_to_f32")

@@ -57,8 +57,7 @@ class EulerMaruyamaSampler(Sampler):
         t_rev = sde.T - t                                            # psld.py:348
         t32 = torch.full((x64.shape[0],), float(np.float32(t_rev)), device=x64.device, dtype=torch.float32)
         eps_pred = self.score_fn(x32, t32)                           # psld.py:354
-        k = sde.em_coeffs(t_rev, dt)
-        ops.em_step(x64, eps_pred.contiguous(), noise, k, x32)
+        sde.em_update(x64, eps_pred.contiguous(), noise, t_rev, dt, x32)   # PSLD or VP-SDE fused update
 
     def predictor_update_fn(self, x, t, dt):
         """Reference-shaped entry: returns (x, x_mean) for a float64/float32 state ``x``."""

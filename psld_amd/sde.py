@@ -237,6 +237,10 @@ class PSLD:
         k = self.em_coeffs(tt, 0.0, probability_flow)
         return ops.reverse_sde(u64, eps_pred.contiguous(), k)
 
+    def em_update(self, x64, eps_pred, noise, t_rev: float, dt: float, x32):
+        """One Euler-Maruyama predictor update in place on the float64 state (samplers/sde.py:16-26)."""
+        ops.em_step(x64, eps_pred, noise, self.em_coeffs(t_rev, dt), x32)
+
     def prior_sampling(self, shape, device=None):
         """psld.py:366-370 (drawn on the CPU by the reference; ``device`` draws it in place)."""
         p_x = torch.randn(*shape, device=device)

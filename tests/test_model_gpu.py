@@ -571,3 +571,42 @@ def test_latent_dataset_and_image_writer(tmp_path, golden):
     for i in range(pred.shape[0]):
         im = np.asarray(Image.open(os.path.join(tmp_path, "images", f"output_gpu_3_7_{i}.png")))
         np.testing.assert_array_equal(im, ge["u8"][i])             # identical to the reference's PNGs
+
+
+def test_vpsde_baseline_matches_reference(golden):
+    """VPSDE + ScoreLoss + the EM sampler on the VP-SDE, against the reference's vectors."""
+    import psld_amd
+    psld_amd.import_modules_into_registry()
+    from psld_amd.registry import get_module
+    from tests.test_oracle_golden import _vp_setup
+    g = golden("vpsde_tiny.npz")
+    cfg, sd = _vp_setup()
+    net = get_module("score_fn", "ncsnpp")(cfg)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).train()
+    sde = get_module("sde", "vpsde")(cfg)
+    x0, eps, t = T(g["x0"]).to(DEV), T(g["eps"]).to(DEV), T(g["t"]).to(DEV)
+    xt = sde.perturb_data(x0, t, noise=eps)
+    np.testing.assert_allclose(xt.cpu().numpy(), g["x_t"], rtol=1e-13, atol=1e-15)
+    loss = get_module("losses", "score_loss")(cfg, sde)(x0, t, net, eps=eps)
+    assert abs(loss.item() - float(g["loss"])) < 2e-5 * float(g["loss"])
+    loss.backward()
+    pd = dict(net.named_parameters())
+    norms = dict(zip(g["grad_norm_keys"].tolist(), g["grad_norms"].tolist()))
+    for k, p in pd.items():
+        if p.grad is not None:
+            assert abs(p.grad.double().norm().item() - norms[k]) <= 2e-4 * norms[k] + 1e-9, k
+    for k in g.files:
+        if k.startswith("g:"):
+            assert rel_l2(pd[k[2:]].grad, T(g[k])) < 1e-4, k
+    net.eval()
+    sampler = get_module("samplers", "em_sde")(cfg, sde, net)
+    noise = T(g["noise"]).to(DEV)
+    sampler.noise_fn = lambda i, x: noise[i]
+    x = sampler.sample(T(g["batch"]).to(DEV), T(g["ts"]).to(DEV), 4, denoise=True, eps=cfg.evaluation.eval_eps)
+    err = rel_l2(x, T(g["x_em"]))
+    print(f"VP-SDE EM: rel-L2 {err:.3e}")
+    assert x.dtype == torch.float64 and err < 1e-5
+    # generic reverse_sde entry (used by the BB-ODE sampler)
+    fb, gb = sde.reverse_sde(T(g["batch"]).to(DEV), 0.3, net, probability_flow=True)
+    assert fb.dtype == torch.float64 and float(gb.abs().max()) == 0.0

@@ -299,3 +299,30 @@ def test_bbode_oracle_runs_and_is_consistent():
     x2, n2 = O.bbode_sample(sde, fn, batch, 1e-3, 1e-3)
     assert x1.dtype == torch.float64 and n2 >= n1 > 8
     assert rel_l2(x1, x2) < 5e-2
+
+
+def _vp_setup():
+    with open(os.path.join(GOLDEN, "vpsde_meta.json")) as fh:
+        meta = json.load(fh)
+    return C.tiny_vpsde(), synth_state_dict([(k, tuple(s)) for k, s in meta["keys"]], meta["seed"])
+
+
+def test_vpsde_baseline(golden):
+    """VP-SDE perturbation, eps-MSE loss + gradients and EM sampling vs the reference."""
+    g = golden("vpsde_tiny.npz")
+    cfg, sd = _vp_setup()
+    sde = O.VPSDEOracle(cfg.model.sde.beta_min, cfg.model.sde.beta_max)
+    x0, eps, t = T(g["x0"]), T(g["eps"]), T(g["t"])
+    xt = sde.perturb_data(x0, t, eps)
+    assert xt.dtype == torch.float64 and torch.equal(xt, T(g["x_t"]))
+    p = {k: v.requires_grad_(True) for k, v in sd.items()}
+    loss = O.score_loss(sde, x0, t, lambda u, tt: O.ncsnpp_forward(p, cfg, u, tt), eps)
+    assert abs(loss.item() - float(g["loss"])) < 1e-6 * float(g["loss"])
+    loss.backward()
+    for k in g.files:
+        if k.startswith("g:"):
+            assert rel_l2(p[k[2:]].grad, T(g[k])) < 1e-5, k
+    with torch.no_grad():
+        x = O.em_sample(sde, lambda u, tt: O.ncsnpp_forward(sd, cfg, u, tt), T(g["batch"]), T(g["ts"]), 4, True,
+                        cfg.evaluation.eval_eps, noise=list(T(g["noise"])))
+    assert rel_l2(x, T(g["x_em"])) < 1e-6

@@ -376,6 +376,45 @@ def main():
     tens = torch.stack([torch.tensor(util.data_scaler(im, norm=True)).permute(2, 0, 1).float() for im in img])
     tens01 = torch.stack([torch.tensor(util.data_scaler(im, norm=False)).permute(2, 0, 1).float() for im in img])
     save("edges.npz", pred=pred, u8=u8, img=img, tens=tens, tens01=tens01)
+
+    # ------------------------------------------------------------------ L. VP-SDE baseline (8(f) rank 4)
+    print("VP-SDE (tiny)")
+    vcfg = C.tiny_vpsde()
+    VP = get("sde", "vpsde")
+    vsde = VP(vcfg)
+    net = NCSNpp(vcfg)
+    vks = load_synth(net, 4000)
+    net.train()
+    g = torch.Generator().manual_seed(91)
+    x0 = torch.rand(4, 3, 16, 16, generator=g) * 2 - 1
+    eps = torch.randn(4, 3, 16, 16, generator=g)
+    t = torch.rand(4, generator=g, dtype=torch.float64) * (1 - 1e-5) + 1e-5
+    out = {"x0": x0, "eps": eps, "t": t, "x_t": vsde.perturb_data(x0, t, noise=eps)}
+    vloss = get("losses", "score_loss")(vcfg, vsde)(x0, t, net, eps=eps)
+    vloss.backward()
+    out["loss"] = vloss.detach()
+    gn = {k: p.grad.norm().item() for k, p in net.named_parameters() if p.grad is not None}
+    out["grad_norm_keys"], out["grad_norms"] = np.array(list(gn.keys())), np.array(list(gn.values()))
+    names = [k for k, _ in net.named_parameters()]
+    for k in (names[0], names[2], names[5], names[-1]):
+        out["g:" + k] = dict(net.named_parameters())[k].grad
+    net.eval()
+    sampler = EM(vcfg, vsde, net)
+    batch = torch.randn(2, 3, 16, 16, generator=g)
+    n = 4
+    tsx = torch.linspace(0, vsde.T - vcfg.evaluation.eval_eps, n + 1, dtype=torch.float64)
+    noises = [torch.randn(2, 3, 16, 16, generator=g, dtype=torch.float64) for _ in range(n)]
+    it = iter(noises)
+    orig = torch.randn_like
+    torch.randn_like = lambda x_, **kw: next(it).to(x_.dtype)
+    try:
+        xf = sampler.sample(batch, tsx, n, denoise=True, eps=vcfg.evaluation.eval_eps)
+    finally:
+        torch.randn_like = orig
+    out.update(batch=batch, noise=torch.stack(noises), ts=tsx, x_em=xf)
+    save("vpsde_tiny.npz", **out)
+    with open(os.path.join(OUT, "vpsde_meta.json"), "w") as fh:
+        json.dump({"seed": 4000, "keys": [[k, list(s)] for k, s in vks]}, fh)
     print("done")
 
 
