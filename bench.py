@@ -145,6 +145,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--bucket-mb", type=int, default=64)
+    ap.add_argument("--config", default="c10_sota", choices=["c10_sota", "celeba64_sota"],
+                    help="c10_sota = BASELINE.json configs[0..2] (headline); celeba64_sota = configs[3] (extra data point)")
     ap.add_argument("--sample-batch", type=int, default=512, help="per-GPU batch of the EM sampling probe (0 = skip)")
     ap.add_argument("--sample-steps", type=int, default=4)
     args = ap.parse_args()
@@ -172,8 +174,9 @@ def main():
     psld_amd.import_modules_into_registry()
     ops.lib()
 
-    cfg = C.c10_sota()
+    cfg = getattr(C, args.config)()
     cfg.training.batch_size = args.batch
+    size = cfg.data.image_size
     torch.manual_seed(cfg.training.seed)                      # same seed on every rank (train_sde.py:29)
     net = get_module("score_fn", "ncsnpp")(cfg).to(dev).train()
     ema = copy.deepcopy(net)
@@ -187,7 +190,7 @@ def main():
     if world > 1 or force_pg:
         net.set_reducer(BucketReducer(bucket_bytes=args.bucket_mb << 20, force_collective=force_pg))
     g = torch.Generator(device=dev).manual_seed(rank)         # per-rank data
-    data = [torch.rand(args.batch, 3, 32, 32, device=dev, generator=g) * 2 - 1 for _ in range(4)]
+    data = [torch.rand(args.batch, 3, size, size, device=dev, generator=g) * 2 - 1 for _ in range(4)]
 
     def step(i):
         loss = wrapper.training_step(data[i % len(data)], i)
@@ -253,11 +256,16 @@ def main():
                                "share_of_step": ps["total_ms"] / (1e3 * dt)}
         else:
             out["roofline"] = None
-        step_flops = 229.4e9 * args.batch                       # train step = 3 x 76.46 GFLOP/img
+        fwd_gflop = {"c10_sota": 76.46, "celeba64_sota": 84.17}[args.config]   # measured fwd GFLOP/img
+        step_flops = 3 * fwd_gflop * 1e9 * args.batch           # train step = 3 x forward
         out["whole_step_tflops_per_gpu"] = step_flops * args.steps / dt / 1e12
-        if world == 1 and args.sample_batch > 0:
+        if args.config != "c10_sota":
+            out["metric"] = out["metric"].replace("CIFAR-10 PSLD (6ch 32x32)", f"{args.config} (6ch {size}x{size})")
+            out["config"]["workload"] = f"{args.config} NCSN++ full HSM train step"
+            out["config"]["image"] = f"6x{size}x{size}"
+        if world == 1 and args.sample_batch > 0 and args.config == "c10_sota":
             out["sampling"] = sampling_probe(cfg, ema, sde, dev, args.sample_batch, args.sample_steps)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == "c10_sota":
             try:
                 out["cpu_baseline"] = cpu_baseline(C.c10_sota())
             except Exception as e:  # noqa: BLE001
