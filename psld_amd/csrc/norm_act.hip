@@ -29,6 +29,7 @@ inline Map make_map(int batch, int hw, int c) {
     m.threads = m.cq * m.pl;
     // aim for >= ~2048 blocks in flight but <= 64 pixels per thread per chunk
     int chunks = cdiv(2048, batch);
+    if (chunks > 32) chunks = 32;             // the finalize kernels walk the chunks serially
     int max_chunks = cdiv(hw, m.pl);          // at least one pixel per thread
     if (chunks > max_chunks) chunks = max_chunks;
     int min_chunks = cdiv(hw, m.pl * 64);

@@ -364,7 +364,7 @@ extern "C" int psld_colsum_f32(const float* x, int ld, int batch, int hw, int c,
         int chunks = cdiv(1024, batch);
         const int max_chunks = cdiv(hw, pl * 4);
         if (chunks > max_chunks) chunks = max_chunks;
-        if (chunks > 64) chunks = 64;
+        if (chunks > 16) chunks = 16;
         if (chunks < 1) chunks = 1;
         const int chunk_px = cdiv(hw, chunks);
         chunks = cdiv(hw, chunk_px);
