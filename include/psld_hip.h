@@ -79,6 +79,18 @@ int psld_conv2d_nhwc_f32(const float* x1, int c1, const float* x2, int c2,
                          int oh, int ow, float* y, int ldy,
                          const psld_epilogue_t* epi, hipStream_t stream);
 
+/* Same convolution with an optional scratch buffer (>= psld_conv2d_workspace_bytes): layers whose output
+ * grid cannot fill the 256 CUs (small batches, 8x8 / 16x16 maps) split the K range over extra workgroups and
+ * apply the epilogue while summing the partial slabs.  workspace == NULL behaves like psld_conv2d_nhwc_f32. */
+long long psld_conv2d_workspace_bytes(int batch, int oh, int ow, int cout);
+int psld_conv2d_nhwc_ws_f32(const float* x1, int c1, const float* x2, int c2,
+                            int batch, int ih, int iw,
+                            const float* w_ohwi, int cout, int kh, int kw,
+                            int stride, int pad, int transposed_stride,
+                            int oh, int ow, float* y, int ldy,
+                            const psld_epilogue_t* epi, void* workspace, long long ws_bytes,
+                            hipStream_t stream);
+
 /* Weight gradient of the convolution above for one input source:
  * slabs[s][co][tap][col0 + ci] = sum over the s-th range of output pixels of dy[pix][co] * x[pix+tap][ci]. */
 int psld_conv2d_wgrad_nhwc_f32(const float* dy, int lddy, int cout,

@@ -68,6 +68,8 @@ SIGNATURES = {
     "psld_gemm_f32": (I, [I, I, I, I, I, P, I, LL, P, I, LL, P, I, LL, I, EP, P]),
     "psld_gemm_tn_splitk_f32": (I, [I, I, I, P, I, P, I, P, I, P]),
     "psld_conv2d_nhwc_f32": (I, [P, I, P, I, I, I, I, P, I, I, I, I, I, I, I, I, P, I, EP, P]),
+    "psld_conv2d_workspace_bytes": (LL, [I, I, I, I]),
+    "psld_conv2d_nhwc_ws_f32": (I, [P, I, P, I, I, I, I, P, I, I, I, I, I, I, I, I, P, I, EP, P, LL, P]),
     "psld_conv2d_wgrad_nhwc_f32": (I, [P, I, I, P, I, I, I, I, I, I, I, I, I, I, P, I, I, I, P]),
     "psld_reduce_slabs_f32": (I, [P, I, LL, P, I, I, I, I, F, P]),
     "psld_pack_oihw_to_ohwi_f32": (I, [P, P, I, I, I, P]),

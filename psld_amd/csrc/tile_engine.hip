@@ -738,6 +738,29 @@ int launch_fast(const TileArgs& a, FastGeom fg, int nz, hipStream_t stream, cons
     return launch_fast_impl<AMODE, BMODE, TBM, NBUF>(a, fg, nz, stream, name);
 }
 
+// out = epilogue(sum_s slabs[s]) for split-K convolutions (float4 along N)
+__global__ void conv_reduce_epilogue_kernel(const float* __restrict__ slabs, int nsplit, int M, int N, float* __restrict__ out,
+                                            int ldc, const Epilogue e) {
+    const int n4 = N >> 2;
+    const long long total = (long long)M * n4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % n4);
+        const int m = (int)(i / n4);
+        const long long off = (long long)m * N + q * 4;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(slabs + off);
+        for (int s = 1; s < nsplit; ++s) acc += *reinterpret_cast<const f32x4*>(slabs + (long long)s * M * N + off);
+        acc *= e.alpha;
+        if (e.bias) acc += *reinterpret_cast<const f32x4*>(e.bias + q * 4);
+        if (e.rowbias) acc += *reinterpret_cast<const f32x4*>(e.rowbias + (long long)(m / e.rows_per_img) * e.ld_rowbias + q * 4);
+        if (e.res) acc += *reinterpret_cast<const f32x4*>(e.res + (long long)m * e.ldres + q * 4);
+        acc *= e.out_scale;
+        float* cp = out + (long long)m * ldc + q * 4;
+        if (e.accumulate) acc += *reinterpret_cast<const f32x4*>(cp);
+        *reinterpret_cast<f32x4*>(cp) = acc;
+    }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 Epilogue make_epilogue(const psld_epilogue_t* e) {
@@ -812,12 +835,20 @@ extern "C" int psld_gemm_tn_splitk_f32(int M, int N, int K, const float* A, int 
     return launch<OP_MC, OP_MC>(a, 1, stream, "psld_gemm_tn_splitk_f32");
 }
 
-extern "C" int psld_conv2d_nhwc_f32(const float* x1, int c1, const float* x2, int c2,
-                                    int batch, int ih, int iw,
-                                    const float* w_ohwi, int cout, int kh, int kw,
-                                    int stride, int pad, int transposed_stride,
-                                    int oh, int ow, float* y, int ldy,
-                                    const psld_epilogue_t* epi, hipStream_t stream) {
+extern "C" long long psld_conv2d_workspace_bytes(int batch, int oh, int ow, int cout) {
+    return 8LL * batch * oh * ow * cout * (long long)sizeof(float);
+}
+
+// Same as psld_conv2d_nhwc_f32 plus an optional workspace: when the output grid cannot fill the chip
+// (small batches, 8x8 / 16x16 layers) the K range (channel chunks x taps) is split over extra workgroups
+// that write partial slabs, and one pass applies the epilogue to their sum.
+extern "C" int psld_conv2d_nhwc_ws_f32(const float* x1, int c1, const float* x2, int c2,
+                                       int batch, int ih, int iw,
+                                       const float* w_ohwi, int cout, int kh, int kw,
+                                       int stride, int pad, int transposed_stride,
+                                       int oh, int ow, float* y, int ldy,
+                                       const psld_epilogue_t* epi, void* workspace, long long ws_bytes,
+                                       hipStream_t stream) {
     PSLD_CHECK_ARG(x1 && w_ohwi && y, "psld_conv2d_nhwc_f32: null pointer");
     PSLD_CHECK_ARG(c1 > 0 && c2 >= 0 && (c2 == 0 || x2), "psld_conv2d_nhwc_f32: bad channel split");
     PSLD_CHECK_ARG(stride >= 1 && transposed_stride >= 1, "psld_conv2d_nhwc_f32: bad stride");
@@ -833,11 +864,52 @@ extern "C" int psld_conv2d_nhwc_f32(const float* x1, int c1, const float* x2, in
     a.e = make_epilogue(epi);
     if (a.A.vec && a.B.vec && c1 % BK == 0 && c2 % BK == 0 && transposed_stride == 1 && a.M > 0 && kh * kw <= 31) {
         FastGeom fg{kh * kw, 0, 0, ct / BK, nullptr};
-        if ((long long)cdiv(a.M, BM) * cdiv(a.N, BN) <= 256 && a.M > 64)
+        const long long tiles128 = (long long)cdiv(a.M, BM) * cdiv(a.N, BN);
+        const long long tiles64 = (long long)cdiv(a.M, 64) * cdiv(a.N, BN);
+        const int ksteps = a.K / BK;
+        // split-K when even the 64-row tiling leaves most of the 256 CUs x 3 slots empty
+        int ns = 1;
+        if (workspace && tiles64 <= 256 && a.M > 64 && cout % 4 == 0 && ldy % 4 == 0 && aligned16(y) &&
+            (!a.e.bias || aligned16(a.e.bias)) && (!a.e.rowbias || (aligned16(a.e.rowbias) && a.e.ld_rowbias % 4 == 0)) &&
+            (!a.e.res || (aligned16(a.e.res) && a.e.ldres % 4 == 0))) {
+            ns = (int)(768 / tiles64);
+            if (ns > 8) ns = 8;
+            if (ns > ksteps / 6) ns = ksteps / 6;
+            if ((long long)ns * a.M * a.N * (long long)sizeof(float) > ws_bytes) ns = 1;
+        }
+        if (ns >= 2) {
+            TileArgs p = a;
+            p.C = reinterpret_cast<float*>(workspace);
+            p.ldc = a.N;
+            p.c_stride_split = (long long)a.M * a.N;
+            p.nsplit = ns;
+            p.kper = cdiv(ksteps, ns) * BK;
+            p.e = make_epilogue(nullptr);
+            int st = launch_fast<OP_IM2COL, OP_KC, 64>(p, fg, 1, stream, "psld_conv2d_nhwc_f32[fast64,splitK]");
+            if (st != PSLD_OK) return st;
+            const long long total = (long long)a.M * (a.N / 4);
+            int blocks = (int)((total + 255) / 256);
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(conv_reduce_epilogue_kernel, dim3(blocks), dim3(256), 0, stream, p.C, ns, a.M, a.N, y, ldy,
+                               a.e);
+            PSLD_CHECK_LAUNCH("conv_reduce_epilogue_kernel");
+            return PSLD_OK;
+        }
+        if (tiles128 <= 256 && a.M > 64)
             return launch_fast<OP_IM2COL, OP_KC, 64>(a, fg, 1, stream, "psld_conv2d_nhwc_f32[fast64]");
         return launch_fast<OP_IM2COL, OP_KC>(a, fg, 1, stream, "psld_conv2d_nhwc_f32[fast]");
     }
     return launch<OP_IM2COL, OP_KC>(a, 1, stream, "psld_conv2d_nhwc_f32");
+}
+
+extern "C" int psld_conv2d_nhwc_f32(const float* x1, int c1, const float* x2, int c2,
+                                    int batch, int ih, int iw,
+                                    const float* w_ohwi, int cout, int kh, int kw,
+                                    int stride, int pad, int transposed_stride,
+                                    int oh, int ow, float* y, int ldy,
+                                    const psld_epilogue_t* epi, hipStream_t stream) {
+    return psld_conv2d_nhwc_ws_f32(x1, c1, x2, c2, batch, ih, iw, w_ohwi, cout, kh, kw, stride, pad, transposed_stride,
+                                   oh, ow, y, ldy, epi, nullptr, 0, stream);
 }
 
 // dW slabs: slabs[s][cout][kh*kw][cin_total] restricted to columns [col0, col0+cin) for input x.

@@ -108,9 +108,14 @@ def conv2d_nhwc(x1: Tensor, x2: Optional[Tensor], w_ohwi: Tensor, cout: int, kh:
                 tstride: int, oh: int, ow: int, y: Tensor, epi: Optional[Epilogue] = None, ldy: Optional[int] = None):
     b, ih, iw, c1 = x1.shape
     c2 = x2.shape[-1] if x2 is not None else 0
-    check(lib().psld_conv2d_nhwc_f32(x1.data_ptr(), c1, _p(x2), c2, b, ih, iw, w_ohwi.data_ptr(), cout, kh, kw,
-                                     stride, pad, tstride, oh, ow, y.data_ptr(), ldy if ldy is not None else cout,
-                                     C.byref(epi) if epi is not None else None, _stream()), "psld_conv2d_nhwc_f32")
+    ws, wsb = None, 0
+    if b * oh * ow <= 16384:     # only small grids ever split K (see psld_conv2d_nhwc_ws_f32)
+        wsb = lib().psld_conv2d_workspace_bytes(b, oh, ow, cout)
+        ws = workspace(wsb, x1.device).data_ptr()
+    check(lib().psld_conv2d_nhwc_ws_f32(x1.data_ptr(), c1, _p(x2), c2, b, ih, iw, w_ohwi.data_ptr(), cout, kh, kw,
+                                        stride, pad, tstride, oh, ow, y.data_ptr(), ldy if ldy is not None else cout,
+                                        C.byref(epi) if epi is not None else None, ws, wsb, _stream()),
+          "psld_conv2d_nhwc_f32")
 
 
 def conv2d_wgrad_nhwc(dy: Tensor, cout: int, x: Tensor, kh: int, kw: int, stride: int, pad: int, oh: int, ow: int,
