@@ -664,6 +664,25 @@ class _Exec:
         self.tape = None
 
 
+class _Pending:
+    """Counts forward passes whose backward has not run yet (released on backward or when autograd drops
+    the graph).  Parameter gradients are WRITTEN per backward, so two outstanding graphs of one network
+    would silently lose one contribution: backward refuses to run in that case."""
+
+    def __init__(self, net):
+        self.net = net
+        self.live = True
+        net._pending += 1
+
+    def release(self):
+        if self.live:
+            self.live = False
+            self.net._pending -= 1
+
+    def __del__(self):
+        self.release()
+
+
 class _NCSNppFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, t, anchor, net):
@@ -672,15 +691,24 @@ class _NCSNppFn(torch.autograd.Function):
         y = ex.run(x, t)
         ctx.ex = ex
         ctx.net = net
+        ctx.pending = _Pending(net)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         ex, net = ctx.ex, ctx.net
+        if ex is None:
+            raise RuntimeError("psld_amd.NCSNpp: backward through the same forward pass twice is not supported")
+        if net._pending > 1:
+            raise RuntimeError(
+                f"psld_amd.NCSNpp: {net._pending} forward passes of this network are awaiting backward. Parameter "
+                "gradients are written (not accumulated) per backward pass, so run one forward/backward at a time "
+                "(the reference's training loop does, wrapper.py:77-79).")
         ctx.ex = None
         net._begin_backward()
         ex.backward(gy)
         net._end_backward()
+        ctx.pending.release()
         return None, None, None, None
 
 
@@ -781,6 +809,7 @@ class NCSNpp(nn.Module):
         self.overlap_wgrad = _os.environ.get("PSLD_OVERLAP_WGRAD", "0") == "1"
         self._plist = None
         self._gviews = None
+        self._pending = 0
         self.use_graphs = _os.environ.get("PSLD_GRAPHS", "0") == "1"
         self._graphs = {}
         self._conv_by_weight = {}
@@ -812,11 +841,11 @@ class NCSNpp(nn.Module):
         params = self._params()
         flat = self._flat
         if flat is not None:
-            # fast validation: first, middle and last parameter still point into the flat buffer
+            # fast validation: every 16th parameter (and the last) still points into the flat buffer
             offs = self._offsets
             base = flat.data_ptr()
-            probe = (params[0], params[len(params) // 2], params[-1])
-            if all(q.data_ptr() == base + 4 * offs[id(q)] for q in probe):
+            if all(q.data_ptr() == base + 4 * offs[id(q)] for q in params[::16]) and \
+                    params[-1].data_ptr() == base + 4 * offs[id(params[-1])]:
                 return flat
         dev = params[0].device
         offs, total = self._layout()
@@ -997,6 +1026,7 @@ class NCSNpp(nn.Module):
         new._plist = new._gviews = None
         new._graphs = {}
         new._conv_by_weight = {}
+        new._pending = 0
         new._pack_cache = {}
         new._pack_key = None
         new._epoch = 0

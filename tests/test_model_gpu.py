@@ -610,3 +610,22 @@ def test_vpsde_baseline_matches_reference(golden):
     # generic reverse_sde entry (used by the BB-ODE sampler)
     fb, gb = sde.reverse_sde(T(g["batch"]).to(DEV), 0.3, net, probability_flow=True)
     assert fb.dtype == torch.float64 and float(gb.abs().max()) == 0.0
+
+
+def test_two_outstanding_forward_passes_are_refused():
+    """Gradients are written per backward; a second live autograd graph of the same network must not silently
+    overwrite the first one's contribution."""
+    net, cfg, _ = _build("tiny", train=True)
+    x = torch.randn(2, 6, 16, 16, device=DEV)
+    t = torch.rand(2, device=DEV) * 0.9 + 0.05
+    y1 = net(x, t)
+    y2 = net(x, t)
+    with pytest.raises(RuntimeError, match="awaiting backward"):
+        (y1.sum() + y2.sum()).backward()
+    del y1, y2
+    import gc
+    gc.collect()
+    assert net._pending == 0
+    y = net(x, t)           # a dropped graph releases its slot: the next single pass works
+    y.sum().backward()
+    assert net._pending == 0 and next(p for p in net.parameters() if p.requires_grad).grad is not None
