@@ -40,10 +40,10 @@ class FusedAdam(torch.optim.Optimizer):
         return self._norm
 
     def zero_grad(self, set_to_none: bool = True):
-        # gradients are (re)written, not accumulated, by the network's backward: nothing to clear
+        # No memset of 390 MB: the network's next backward overwrites the gradient buffer.
+        self.module.mark_grads_stale()
         if not set_to_none:
-            g = self.module.flat_grad()
-            g.zero_()
+            self.module.flat_grad().zero_()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -61,6 +61,7 @@ class FusedAdam(torch.optim.Optimizer):
                      self.grad_clip, group["lr"], group["betas"][0], group["betas"][1], group["eps"],
                      group["weight_decay"], self._step, self.ema_decay)
         self.module.weights_changed()
+        self.module.mark_grads_stale()      # consumed: a following backward starts a fresh gradient
         if self.ema_module is not None:
             self.ema_module.weights_changed()
 

@@ -296,6 +296,8 @@ def test_rccl_bucket_reducer_single_rank():
         x0, eps, t = T(g["x0"]).to(DEV), T(g["eps"]).to(DEV), T(g["t"]).to(DEV)
         crit(x0, t, net, eps=eps).backward()
         ref = net.flat_grad().clone()
+        for p in net.parameters():
+            p.grad = None
         red = BucketReducer(bucket_bytes=1 << 18, force_collective=True)
         net.set_reducer(red)
         crit(x0, t, net, eps=eps).backward()
@@ -390,6 +392,8 @@ def _dp_worker(rank, world, port, q):
         if rank == 0:   # single-process large-batch reference, before the reducer is attached
             crit(x0, t, net, eps=eps).backward()
             ref = net.flat_grad().clone()
+            for p in net.parameters():
+                p.grad = None
         red = BucketReducer(bucket_bytes=1 << 17)
         net.set_reducer(red)
         lo, hi = shard_range(4, rank, world)
@@ -612,20 +616,38 @@ def test_vpsde_baseline_matches_reference(golden):
     assert fb.dtype == torch.float64 and float(gb.abs().max()) == 0.0
 
 
-def test_two_outstanding_forward_passes_are_refused():
-    """Gradients are written per backward; a second live autograd graph of the same network must not silently
-    overwrite the first one's contribution."""
+def test_gradient_accumulation_semantics():
+    """torch semantics: a populated .grad is accumulated into.  Two micro-batches (and two simultaneously
+    outstanding graphs) must give the sum of the individual gradients; zero_grad() of either flavour resets."""
+    from psld_amd.optim import FusedAdam
     net, cfg, _ = _build("tiny", train=True)
-    x = torch.randn(2, 6, 16, 16, device=DEV)
-    t = torch.rand(2, device=DEV) * 0.9 + 0.05
-    y1 = net(x, t)
-    y2 = net(x, t)
-    with pytest.raises(RuntimeError, match="awaiting backward"):
-        (y1.sum() + y2.sum()).backward()
-    del y1, y2
-    import gc
-    gc.collect()
-    assert net._pending == 0
-    y = net(x, t)           # a dropped graph releases its slot: the next single pass works
-    y.sum().backward()
-    assert net._pending == 0 and next(p for p in net.parameters() if p.requires_grad).grad is not None
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(2, 6, 16, 16, generator=g).to(DEV) for _ in range(2)]
+    ts = [(torch.rand(2, generator=g) * 0.9 + 0.05).to(DEV) for _ in range(2)]
+    singles = []
+    for x, t in zip(xs, ts):
+        for p in net.parameters():
+            p.grad = None
+        net(x, t).square().sum().backward()
+        singles.append(net.flat_grad().clone())
+    want = singles[0] + singles[1]
+    # (a) sequential micro-batches without zeroing in between
+    for p in net.parameters():
+        p.grad = None
+    for x, t in zip(xs, ts):
+        net(x, t).square().sum().backward()
+    assert rel_l2(net.flat_grad(), want) < 1e-6
+    # (b) two graphs alive at once
+    for p in net.parameters():
+        p.grad = None
+    (net(xs[0], ts[0]).square().sum() + net(xs[1], ts[1]).square().sum()).backward()
+    assert rel_l2(net.flat_grad(), want) < 1e-6 and net._pending == 0
+    # (c) zero_grad(set_to_none=False) keeps .grad tensors: accumulate onto zeros == overwrite
+    torch.optim.SGD(net.parameters(), lr=0.0).zero_grad(set_to_none=False)
+    net(xs[0], ts[0]).square().sum().backward()
+    assert rel_l2(net.flat_grad(), singles[0]) < 1e-6
+    # (d) the fused optimiser's zero_grad marks the buffer stale: next backward overwrites, no extra pass
+    opt = FusedAdam(net, lr=0.0)
+    opt.zero_grad()
+    net(xs[1], ts[1]).square().sum().backward()
+    assert torch.equal(net.flat_grad(), singles[1])
