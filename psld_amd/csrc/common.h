@@ -56,13 +56,14 @@ __device__ __forceinline__ float dsilu_f(float z) {
     return s * (1.0f + z * (1.0f - s));
 }
 
-// Counter-based dropout decision (splitmix64 finaliser over seed and element index): the forward
-// and backward kernels re-derive the same mask without storing it.
+// Counter-based dropout decision: a 32-bit PCG-style permutation of (element index, seed) — the forward and
+// backward kernels re-derive the same mask without storing it.  32-bit integer ops only: the 64-bit
+// splitmix used at first cost 12 % of gn_apply's bandwidth.
 __device__ __forceinline__ bool psld_dropout_keep(unsigned long long seed, unsigned long long idx, float p) {
-    unsigned long long z = seed + (idx + 1ULL) * 0x9E3779B97F4A7C15ULL;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    z = z ^ (z >> 31);
-    const float u = (float)(z >> 40) * (1.0f / 16777216.0f);  // 24-bit uniform in [0,1)
+    unsigned int s = (unsigned int)idx ^ (unsigned int)(idx >> 32) * 0x85EBCA6Bu;
+    s = s * 747796405u + ((unsigned int)seed ^ (unsigned int)(seed >> 32)) * 2891336453u + 2891336453u;
+    unsigned int w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
+    w = (w >> 22u) ^ w;
+    const float u = (float)(w >> 8) * (1.0f / 16777216.0f);  // 24-bit uniform in [0,1)
     return u >= p;
 }

@@ -177,7 +177,58 @@ __global__ void colsum_kernel(const float* __restrict__ x, int ld, int hw, int c
     if (rl == 0 && col < c) out[(long long)b * c + col] = (float)((red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) * (double)alpha);
 }
 
-// one wave64 per row
+// one wave64 per row, row held in registers (L = 256 * V floats, V float4 per lane): one read, one write
+template <int V>
+__global__ void softmax_rows_reg_kernel(const float* __restrict__ x, float* __restrict__ y, long long rows, int L) {
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const f32x4* xp = reinterpret_cast<const f32x4*>(x + row * L);
+    f32x4 v[V];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        v[j] = xp[lane + 64 * j];
+        mx = fmaxf(mx, fmaxf(fmaxf(v[j][0], v[j][1]), fmaxf(v[j][2], v[j][3])));
+    }
+    mx = wave_max(mx);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < V; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[j][e] = expf(v[j][e] - mx);
+            s += v[j][e];
+        }
+    s = wave_sum(s);
+    const float inv = 1.0f / s;
+    f32x4* yp = reinterpret_cast<f32x4*>(y + row * L);
+#pragma unroll
+    for (int j = 0; j < V; ++j) yp[lane + 64 * j] = v[j] * inv;
+}
+template <int V>
+__global__ void softmax_rows_bwd_reg_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                            float* __restrict__ dx, long long rows, int L) {
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const f32x4* yp = reinterpret_cast<const f32x4*>(y + row * L);
+    const f32x4* gp = reinterpret_cast<const f32x4*>(dy + row * L);
+    f32x4 yv[V], gv[V];
+    float d = 0.f;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        yv[j] = yp[lane + 64 * j];
+        gv[j] = gp[lane + 64 * j];
+        d += yv[j][0] * gv[j][0] + yv[j][1] * gv[j][1] + yv[j][2] * gv[j][2] + yv[j][3] * gv[j][3];
+    }
+    d = wave_sum(d);
+    f32x4* op = reinterpret_cast<f32x4*>(dx + row * L);
+#pragma unroll
+    for (int j = 0; j < V; ++j) op[lane + 64 * j] = yv[j] * (gv[j] - d);
+}
+
+// generic fallback: one wave64 per row
 __global__ void softmax_rows_kernel(const float* __restrict__ x, float* __restrict__ y, long long rows, int L) {
     const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -384,6 +435,14 @@ extern "C" int psld_colsum_f32(const float* x, int ld, int batch, int hw, int c,
 extern "C" int psld_softmax_rows_f32(const float* x, float* y, long long rows, int L, hipStream_t stream) {
     PSLD_CHECK_ARG(x && y && rows >= 0 && L > 0, "psld_softmax_rows_f32: bad args");
     if (rows == 0) return PSLD_OK;
+    const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+    if (al && L == 256) {
+        hipLaunchKernelGGL(softmax_rows_reg_kernel<1>, dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, y, rows, L);
+    } else if (al && L == 512) {
+        hipLaunchKernelGGL(softmax_rows_reg_kernel<2>, dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, y, rows, L);
+    } else if (al && L == 1024) {
+        hipLaunchKernelGGL(softmax_rows_reg_kernel<4>, dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, y, rows, L);
+    } else
     hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, x, y, rows, L);
     PSLD_CHECK_LAUNCH("psld_softmax_rows_f32");
     return PSLD_OK;
@@ -392,6 +451,14 @@ extern "C" int psld_softmax_rows_bwd_f32(const float* y, const float* dy, float*
                                          hipStream_t stream) {
     PSLD_CHECK_ARG(y && dy && dx && rows >= 0 && L > 0, "psld_softmax_rows_bwd_f32: bad args");
     if (rows == 0) return PSLD_OK;
+    const bool al = ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
+    if (al && L == 256) {
+        hipLaunchKernelGGL(softmax_rows_bwd_reg_kernel<1>, dim3(cdiv(rows, 4)), dim3(256), 0, stream, y, dy, dx, rows, L);
+    } else if (al && L == 512) {
+        hipLaunchKernelGGL(softmax_rows_bwd_reg_kernel<2>, dim3(cdiv(rows, 4)), dim3(256), 0, stream, y, dy, dx, rows, L);
+    } else if (al && L == 1024) {
+        hipLaunchKernelGGL(softmax_rows_bwd_reg_kernel<4>, dim3(cdiv(rows, 4)), dim3(256), 0, stream, y, dy, dx, rows, L);
+    } else
     hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, y, dy, dx, rows, L);
     PSLD_CHECK_LAUNCH("psld_softmax_rows_bwd_f32");
     return PSLD_OK;

@@ -34,16 +34,21 @@ __global__ void upfirdn_nhwc_kernel(const float* __restrict__ x, float* __restri
         const int oy = (int)(t % out_h);
         const int n = (int)(t / out_h);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int ky = 0; ky < f.kh; ++ky) {
+        // only taps that land on a real (not zero-inserted) sample: ky = ky0, ky0 + up, ...
+        int ky0 = (f.pad_y0 - oy * f.down_y) % f.up_y;
+        if (ky0 < 0) ky0 += f.up_y;
+        int kx0 = (f.pad_x0 - ox * f.down_x) % f.up_x;
+        if (kx0 < 0) kx0 += f.up_x;
+        for (int ky = ky0; ky < f.kh; ky += f.up_y) {
             const int py = oy * f.down_y + ky - f.pad_y0;
-            if (py < 0 || py % f.up_y) continue;
+            if (py < 0) continue;
             const int iy = py / f.up_y;
-            if (iy >= in_h) continue;
-            for (int kx = 0; kx < f.kw; ++kx) {
+            if (iy >= in_h) break;
+            for (int kx = kx0; kx < f.kw; kx += f.up_x) {
                 const int px = ox * f.down_x + kx - f.pad_x0;
-                if (px < 0 || px % f.up_x) continue;
+                if (px < 0) continue;
                 const int ix = px / f.up_x;
-                if (ix >= in_w) continue;
+                if (ix >= in_w) break;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((long long)n * in_h + iy) * in_w + ix) * c + q * 4);
                 acc += v * f.w[ky * f.kw + kx];
             }

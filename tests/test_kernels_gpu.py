@@ -242,7 +242,7 @@ def test_pointwise_and_reductions(ops):
     cs = torch.empty(3, 70, device=DEV)
     ops.colsum(m.to(DEV), 70, 3, 50, 70, cs)
     assert rel_l2(cs, m.double().reshape(3, 50, 70).sum(1)) < 1e-6
-    for L in (64, 256, 100):
+    for L in (64, 256, 100, 512, 1024):
         s = gen(37, L, seed=66) * 4
         y = torch.empty(37, L, device=DEV)
         ops.softmax_rows(s.to(DEV), y, 37, L)
