@@ -203,6 +203,8 @@ class _Exec:
         # weight / bias gradients are off the dependency chain of backward: they run on a side HIP stream so
         # that their MFMA-bound kernels overlap the HBM-bound kernels of the chain (GN backward, reductions)
         self.side = net._side_stream() if (record and net.overlap_wgrad) else None
+        self.want_dx = False        # gradient w.r.t. the network input requested (x.requires_grad)
+        self.dx_nchw = None
 
     # -- helpers ------------------------------------------------------------------------------
     def push(self, fn, module=None):
@@ -530,6 +532,16 @@ class _Exec:
                 self.dgrad(dout, conv, 3, 2, 0, fh, fw, dxf, alpha=s)
                 pg, pacc = _gbuf(pyr)
                 ops.upfirdn2d_bwd_raw(dxf, k, 1, 1, pad, (pyr.v.shape[1], pyr.v.shape[2]), 1, out=pg, accumulate=pacc)
+            elif self.want_dx:
+                # first level reads the network input itself (NCHW): conv dgrad -> NCHW -> FIR backward
+                dxf = torch.empty_like(xf)
+                self.dgrad(dout, conv, 3, 2, 0, fh, fw, dxf, alpha=s)
+                dxf_nchw = ops.nhwc_to_nchw(dxf)
+                acc = self.dx_nchw is not None
+                if not acc:
+                    self.dx_nchw = torch.empty_like(pyr)
+                ops.upfirdn2d_bwd_raw(dxf_nchw, k, 1, 1, pad, (pyr.shape[2], pyr.shape[3]), 0, out=self.dx_nchw,
+                                      accumulate=acc)
 
         self.push(bwd, mod)
         return on
@@ -583,6 +595,14 @@ class _Exec:
                     self.bias_grad(g0, self.g(stem.bias))
 
                 self.on_side(side, g0, x_nhwc)
+                if self.want_dx:
+                    dxs = torch.empty_like(x_nhwc)
+                    self.dgrad(g0, stem, 3, 1, 1, hh, ww, dxs)
+                    dxs = ops.nhwc_to_nchw(dxs)
+                    if self.dx_nchw is None:
+                        self.dx_nchw = dxs
+                    else:
+                        ops.axpby(dxs, 1.0, None, 0.0, self.dx_nchw, accumulate=True)
 
             self.push(stem_bwd, stem)
         hs: List[_Node] = [n0]
@@ -688,6 +708,7 @@ class _NCSNppFn(torch.autograd.Function):
     def forward(ctx, x, t, anchor, net):
         ex = _Exec(net, record=True)
         ex.watermark = net._watermark_hook
+        ex.want_dx = bool(x.requires_grad)
         y = ex.run(x, t)
         ctx.ex = ex
         ctx.net = net
@@ -704,7 +725,7 @@ class _NCSNppFn(torch.autograd.Function):
         ex.backward(gy)
         net._end_backward()
         ctx.pending.release()
-        return None, None, None, None
+        return ex.dx_nchw, None, None, None
 
 
 @register_module(category="score_fn", name="ncsnpp")
@@ -935,8 +956,8 @@ class NCSNpp(nn.Module):
         self.flat_grad()
         # torch semantics: a populated .grad is accumulated into.  Kernels WRITE their results, so in that
         # case this pass goes to a scratch buffer that is added afterwards (one extra 0.4 GB pass).
-        probe = next(p for p in self._params() if p.requires_grad)
-        self._accumulating = (probe.grad is not None) and not self._grad_stale
+        probe = next((p for p in self._params() if p.requires_grad), None)
+        self._accumulating = probe is not None and (probe.grad is not None) and not self._grad_stale
         self._grad_stale = False
         target = self._flat_grad
         if self._accumulating:
@@ -984,9 +1005,7 @@ class NCSNpp(nn.Module):
         t = time_cond.contiguous()
         self.flatten_parameters()
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self._params())
-        if x.requires_grad:
-            raise NotImplementedError("gradient w.r.t. the network input is not on the hot path")
-        if need_grad:
+        if need_grad or (torch.is_grad_enabled() and x.requires_grad):
             self.flat_grad()
             if self._anchor is None or self._anchor.device != x.device:
                 self._anchor = torch.zeros(1, device=x.device, requires_grad=True)

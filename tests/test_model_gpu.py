@@ -651,3 +651,27 @@ def test_gradient_accumulation_semantics():
     opt.zero_grad()
     net(xs[1], ts[1]).square().sum().backward()
     assert torch.equal(net.flat_grad(), singles[1])
+
+
+def test_input_gradient_matches_oracle():
+    """d(out)/d(x): the stem conv data-gradient plus the first input-pyramid level (guidance-style use)."""
+    net, cfg, sd = _build("tiny", train=True)
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(2, 6, 16, 16, generator=g)
+    t = torch.rand(2, generator=g) * 0.9 + 0.05
+    gy = torch.randn(2, 6, 16, 16, generator=g)
+    xd = x.to(DEV).requires_grad_(True)
+    y = net(xd, t.to(DEV))
+    y.backward(gy.to(DEV))
+    xr = x.clone().requires_grad_(True)
+    yo = O.ncsnpp_forward(sd, cfg, xr, t)
+    yo.backward(gy)
+    assert xd.grad is not None and xd.grad.shape == x.shape
+    assert rel_l2(xd.grad, xr.grad) < 2e-5
+    # frozen network (EMA copy): input gradient only
+    for p in net.parameters():
+        p.requires_grad = False
+        p.grad = None
+    xd2 = x.to(DEV).requires_grad_(True)
+    net(xd2, t.to(DEV)).backward(gy.to(DEV))
+    assert rel_l2(xd2.grad, xr.grad) < 2e-5
