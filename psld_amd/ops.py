@@ -5,7 +5,6 @@ libpsld_hip.so.  All tensors must be contiguous CUDA(ROCm) tensors.
 from __future__ import annotations
 
 import ctypes as C
-import math
 from typing import Optional, Sequence, Tuple
 
 import numpy as np

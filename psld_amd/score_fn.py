@@ -233,23 +233,18 @@ class _Exec:
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
 
-    def wgrad(self, dy: Tensor, x: Tensor, conv: _Affine, k: int, stride: int, pad: int, alpha: float = 1.0,
-              cin_total: Optional[int] = None, col0: int = 0, slabs=None, nsplit=None, finish=True):
+    def wgrad(self, dy: Tensor, x: Tensor, conv: _Affine, k: int, stride: int, pad: int, alpha: float = 1.0):
+        """dW (OIHW, scaled by alpha) of ``conv`` from the output gradient and the conv's input: split-K partial
+        slabs in the stream's workspace, then one deterministic reduction straight into the flat gradient."""
         b, oh, ow, cout = dy.shape
         cin = x.shape[-1]
-        cin_total = cin_total or cin
         taps = k * k
-        n = cout * taps * cin_total
-        if nsplit is None:
-            tiles = ((cout + 127) // 128) * ((cin + 127) // 128) * taps
-            nsplit = _pick_nsplit(tiles, b * oh * ow)
-        if slabs is None:
-            slabs = ops.workspace(4 * n * nsplit, dy.device)
-        ops.conv2d_wgrad_nhwc(dy, cout, x, k, k, stride, pad, oh, ow, slabs, cin_total, col0, nsplit)
-        if finish:
-            ops.reduce_slabs(slabs, nsplit, n, self.g(conv.weight), layout=1, cout=cout, taps=taps, cin=cin_total,
-                             alpha=alpha)
-        return slabs, nsplit
+        n = cout * taps * cin
+        tiles = ((cout + 127) // 128) * ((cin + 127) // 128) * taps
+        nsplit = _pick_nsplit(tiles, b * oh * ow)
+        slabs = ops.workspace(4 * n * nsplit, dy.device)
+        ops.conv2d_wgrad_nhwc(dy, cout, x, k, k, stride, pad, oh, ow, slabs, cin, 0, nsplit)
+        ops.reduce_slabs(slabs, nsplit, n, self.g(conv.weight), layout=1, cout=cout, taps=taps, cin=cin, alpha=alpha)
 
     def bias_grad(self, dy: Tensor, out: Tensor, alpha: float = 1.0, per_image: Optional[Tensor] = None):
         b = dy.shape[0]

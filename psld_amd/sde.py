@@ -10,7 +10,7 @@ dtypes at the boundary (f64 ``u_t`` / ``f_bar``; f32 score), NaN coefficients ra
 from __future__ import annotations
 
 import math
-from typing import Callable, Optional, Tuple
+from typing import Callable
 
 import numpy as np
 import torch

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .optim import FusedAdam
-from .registry import get_module, register_module
+from .registry import register_module
 
 try:  # pragma: no cover - Lightning is not in the offline image
     import pytorch_lightning as pl
