@@ -459,15 +459,20 @@ __device__ __forceinline__ void store_kc_rows(float* lds, const f32x4 (&r)[NR]) 
 }
 
 // TBM = 128 (default) or 64 (small-M layers: the 8x8 convs give only 128 tiles of 128 rows for 256 CUs).
-template <int AMODE, int BMODE, int TBM, int NBUF>
-__global__ void __launch_bounds__(NTHREADS, NBUF == 2 ? 2 : 3) tile_kernel_fast(const TileArgs a, const FastGeom fg) {
+// TBN = 128 (default) or 256 (K-contiguous B only): each wave then owns 64 x 128 = 8 accumulators, the A tile is
+// fetched once for all 256 output channels, 0.19 instead of 0.25 fragment reads per MFMA.
+template <int AMODE, int BMODE, int TBM, int NBUF, int TBN>
+__global__ void __launch_bounds__(NTHREADS, (NBUF == 2 || TBN == 256) ? 2 : 3) tile_kernel_fast(const TileArgs a, const FastGeom fg) {
     constexpr bool A_KC = (AMODE == OP_KC || AMODE == OP_IM2COL);
     constexpr bool B_KC = (BMODE == OP_KC || BMODE == OP_IM2COL);
     static_assert(TBM == 128 || (TBM == 64 && A_KC), "TBM=64 needs a K-contiguous A operand");
     constexpr int MI = TBM / 64;          // 32-row MFMA tiles per wave along M
     constexpr int NRA = A_KC ? TBM / 32 : 4;  // A rows (KC) or k-rows (MC) staged per thread
+    static_assert(TBN == 128 || (TBN == 256 && B_KC), "TBN=256 needs a K-contiguous B operand");
+    constexpr int NI = TBN / 64;              // 32-column MFMA tiles per wave along N
+    constexpr int NRB = B_KC ? TBN / 32 : 4;  // B rows (KC) or k-rows (MC) staged per thread
     constexpr int A_SZ = A_KC ? TBM * KC_LD : BK * MC_LD;
-    constexpr int B_SZ = B_KC ? BN * KC_LD : BK * MC_LD;
+    constexpr int B_SZ = B_KC ? TBN * KC_LD : BK * MC_LD;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As0 = smem;
     float* Bs0 = smem + NBUF * A_SZ;
@@ -477,7 +482,7 @@ __global__ void __launch_bounds__(NTHREADS, NBUF == 2 ? 2 : 3) tile_kernel_fast(
     const int wr = wave >> 1, wc = wave & 1;
     const int r = lane & 31, h = lane >> 5;
 
-    const int tiles_n = (a.N + BN - 1) / BN;
+    const int tiles_n = (a.N + TBN - 1) / TBN;
     // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (private L2 each), so give
     // every XCD a contiguous run of tiles — the N-tiles of one M-tile and neighbouring M-tiles (halo
     // rows) then share one L2.  Bijective form (cdna guide T1) for any grid size.
@@ -500,7 +505,7 @@ __global__ void __launch_bounds__(NTHREADS, NBUF == 2 ? 2 : 3) tile_kernel_fast(
     }
     const int tile_m = bid / tiles_n;
     const int tile_n = bid - tile_m * tiles_n;
-    const int m0 = tile_m * TBM, n0 = tile_n * BN;
+    const int m0 = tile_m * TBM, n0 = tile_n * TBN;
 
     const int split = z % a.nsplit;
     const int zb = z / a.nsplit;
@@ -544,9 +549,9 @@ __global__ void __launch_bounds__(NTHREADS, NBUF == 2 ? 2 : 3) tile_kernel_fast(
 #pragma unroll
         for (int i = 0; i < NRA; ++i) ri[i].img = ri[i].oy = ri[i].ox = 0;
     }
-    RowInfo rib[4];
+    RowInfo rib[NRB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rib[i].img = rib[i].oy = rib[i].ox = 0;
+    for (int i = 0; i < NRB; ++i) rib[i].img = rib[i].oy = rib[i].ox = 0;
 
     // B operand of a conv: weights [N][tap][Ct] -> column of K-step ks is tap*Ct + chunk*32
     auto b_kstep_col = [&](int ks) -> int {
@@ -559,15 +564,19 @@ __global__ void __launch_bounds__(NTHREADS, NBUF == 2 ? 2 : 3) tile_kernel_fast(
         }
     };
 
-    f32x16 acc[MI][2];
+    f32x16 acc[MI][NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
-    f32x4 ra[NRA], rb[4];
+    f32x4 ra[NRA], rb[NRB];
+    auto store_b = [&](float* dst) {
+        if constexpr (B_KC) store_kc_rows<NRB>(dst, rb);
+        else store_tile<BMODE>(dst, rb);
+    };
     auto store_a = [&](float* dst) {
         if constexpr (A_KC) store_kc_rows<NRA>(dst, ra);
         else store_tile<AMODE>(dst, ra);
@@ -578,20 +587,20 @@ __global__ void __launch_bounds__(NTHREADS, NBUF == 2 ? 2 : 3) tile_kernel_fast(
             const int c4 = tid & 7, r0 = tid >> 3;
             const int col = b_kstep_col(ks) + c4 * 4;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NRB; ++i) {
                 const int gr = n0 + r0 + 32 * i;
                 const bool ok = gr < a.N;
                 rb[i] = ld4(ok ? Bbase + ((long long)gr * a.B.ld + col) : zp);
             }
         } else {
-            fast_load<BMODE, 4>(rb, a.B, a.g, fg, Bbase, n0, a.N, ks, kend, rib, zb, zp);
+            fast_load<BMODE, NRB>(rb, a.B, a.g, fg, Bbase, n0, a.N, ks, kend, rib, zb, zp);
         }
     };
 
     fast_load<AMODE, NRA>(ra, a.A, a.g, fg, Abase, m0, a.M, ks0, kend, ri, zb, zp);
     load_b(ks0);
     store_a(As0);
-    store_tile<BMODE>(Bs0, rb);
+    store_b(Bs0);
     __syncthreads();
 
     int cur = 0;
@@ -604,8 +613,8 @@ __global__ void __launch_bounds__(NTHREADS, NBUF == 2 ? 2 : 3) tile_kernel_fast(
         const float* As = As0 + cur * A_SZ;
         const float* Bs = Bs0 + cur * B_SZ;
         // fragment reads for 8 k-values (4 MFMA k-pairs) at a time, software-pipelined one group ahead
-        float af[2][MI][4], bf[2][2][4];
-        auto read_frags = [&](int j, float (&fa)[MI][4], float (&fb)[2][4]) {
+        float af[2][MI][4], bf[2][NI][4];
+        auto read_frags = [&](int j, float (&fa)[MI][4], float (&fb)[NI][4]) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 if constexpr (A_KC) {
@@ -617,9 +626,9 @@ __global__ void __launch_bounds__(NTHREADS, NBUF == 2 ? 2 : 3) tile_kernel_fast(
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 if constexpr (B_KC) {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(Bs + (wc * 64 + i * 32 + r) * KC_LD + 8 * j + 4 * h);
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(Bs + (wc * (TBN / 2) + i * 32 + r) * KC_LD + 8 * j + 4 * h);
                     fb[i][0] = t[0]; fb[i][1] = t[1]; fb[i][2] = t[2]; fb[i][3] = t[3];
                 } else {
 #pragma unroll
@@ -636,13 +645,13 @@ __global__ void __launch_bounds__(NTHREADS, NBUF == 2 ? 2 : 3) tile_kernel_fast(
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int n = 0; n < 2; ++n)
+                    for (int n = 0; n < NI; ++n)
                         acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j & 1][i][s], bf[j & 1][n][s], acc[i][n], 0, 0, 0);
         }
         if constexpr (NBUF == 2) {
             if (more) {
                 store_a(As0 + (cur ^ 1) * A_SZ);
-                store_tile<BMODE>(Bs0 + (cur ^ 1) * B_SZ, rb);
+                store_b(Bs0 + (cur ^ 1) * B_SZ);
             }
             __syncthreads();
             cur ^= 1;
@@ -650,7 +659,7 @@ __global__ void __launch_bounds__(NTHREADS, NBUF == 2 ? 2 : 3) tile_kernel_fast(
             __syncthreads();
             if (more) {
                 store_a(As0);
-                store_tile<BMODE>(Bs0, rb);
+                store_b(Bs0);
                 __syncthreads();
             }
         }
@@ -664,8 +673,8 @@ __global__ void __launch_bounds__(NTHREADS, NBUF == 2 ? 2 : 3) tile_kernel_fast(
         const int row_base = m0 + wr * (TBM / 2) + i * 32;          // wave-uniform, 32-aligned
         const int img_u = rb_uniform ? row_base / a.e.rows_per_img : 0;
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int gn = n0 + wc * 64 + n * 32 + r;
+        for (int n = 0; n < NI; ++n) {
+            const int gn = n0 + wc * (TBN / 2) + n * 32 + r;
             if (gn >= a.N) continue;
             float bias = a.e.bias ? a.e.bias[gn] : 0.f;
             // time-embedding bias: one value per (image, channel); a 32-row tile never straddles images
@@ -694,7 +703,7 @@ inline int ilog2_exact(int v) {
     return s;
 }
 
-template <int AMODE, int BMODE, int TBM, int NBUF>
+template <int AMODE, int BMODE, int TBM, int NBUF, int TBN>
 int launch_fast_impl(const TileArgs& a, FastGeom fg, int nz, hipStream_t stream, const char* name) {
     static const float* zero_dev = nullptr;
     if (!zero_dev) {
@@ -710,11 +719,11 @@ int launch_fast_impl(const TileArgs& a, FastGeom fg, int nz, hipStream_t stream,
     constexpr bool A_KC = (AMODE == OP_KC || AMODE == OP_IM2COL);
     constexpr bool B_KC = (BMODE == OP_KC || BMODE == OP_IM2COL);
     constexpr int A_SZ = A_KC ? TBM * KC_LD : BK * MC_LD;
-    constexpr int B_SZ = B_KC ? BN * KC_LD : BK * MC_LD;
+    constexpr int B_SZ = B_KC ? TBN * KC_LD : BK * MC_LD;
     constexpr size_t LDS = (size_t)NBUF * (A_SZ + B_SZ) * sizeof(float);
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_kernel_fast<AMODE, BMODE, TBM, NBUF>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_kernel_fast<AMODE, BMODE, TBM, NBUF, TBN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         if (e != hipSuccess) {
             psld_set_error("%s: hipFuncSetAttribute failed: %s", name, hipGetErrorString(e));
@@ -722,10 +731,10 @@ int launch_fast_impl(const TileArgs& a, FastGeom fg, int nz, hipStream_t stream,
         }
         configured = true;
     }
-    const long long tiles = (long long)cdiv(a.M, TBM) * cdiv(a.N, BN);
+    const long long tiles = (long long)cdiv(a.M, TBM) * cdiv(a.N, TBN);
     PSLD_CHECK_ARG(tiles < (1LL << 31) && nz * a.nsplit <= 65535, "%s: grid too large", name);
     dim3 grid((unsigned)tiles, (unsigned)(nz * a.nsplit));
-    hipLaunchKernelGGL((tile_kernel_fast<AMODE, BMODE, TBM, NBUF>), grid, dim3(NTHREADS), LDS, stream, a, fg);
+    hipLaunchKernelGGL((tile_kernel_fast<AMODE, BMODE, TBM, NBUF, TBN>), grid, dim3(NTHREADS), LDS, stream, a, fg);
     PSLD_CHECK_LAUNCH(name);
     return PSLD_OK;
 }
@@ -735,7 +744,14 @@ int launch_fast(const TileArgs& a, FastGeom fg, int nz, hipStream_t stream, cons
     // Measured on MI355X (tools/bench_tile.py): the conv / wgrad loaders prefer one LDS buffer at 3 workgroups
     // per CU (+1.5 % / +3 %), the plain GEMM prefers two buffers at 2 per CU (+3 %).
     constexpr int NBUF = (AMODE == OP_IM2COL || BMODE == OP_SHIFT) ? 1 : 2;
-    return launch_fast_impl<AMODE, BMODE, TBM, NBUF>(a, fg, nz, stream, name);
+    constexpr bool B_KC = (BMODE == OP_KC || BMODE == OP_IM2COL);
+    if constexpr (B_KC && TBM == 128) {
+        // 128x256 block tile (wave 64x128) when N is a multiple of 256 and the grid still fills the chip:
+        // measured +2..3 % on the 32x32 layers and the 4096^3 GEMM (134 TF), neutral-to-worse on smaller grids
+        if (a.N % 256 == 0 && (long long)cdiv(a.M, 128) * (a.N / 256) * nz >= 512)
+            return launch_fast_impl<AMODE, BMODE, TBM, 1, 256>(a, fg, nz, stream, name);
+    }
+    return launch_fast_impl<AMODE, BMODE, TBM, NBUF, 128>(a, fg, nz, stream, name);
 }
 
 // out = epilogue(sum_s slabs[s]) for split-K convolutions (float4 along N)
