@@ -33,6 +33,17 @@ extern "C" {
 int psld_version(void);
 const char* psld_last_error(void);
 
+/* Arithmetic of the MFMA tile kernels (GEMM / conv / wgrad).  Both take and return fp32 and accumulate in fp32.
+ *   PSLD_MATH_F32    v_mfma_f32_32x32x2_f32 on the operands as they are (one fmaf per k);
+ *   PSLD_MATH_BF16X6 every operand is split exactly into three bf16 limbs (hi + mid + lo == x, all 24 mantissa
+ *                    bits) and each product is the six leading limb products on v_mfma_f32_32x32x16_bf16; the three
+ *                    dropped terms are < 2^-23 of the product, i.e. below fp32 rounding of the product itself.
+ * Process-wide; the initial value comes from the environment variable PSLD_MATH ("f32" | "bf16x6"). */
+#define PSLD_MATH_F32 0
+#define PSLD_MATH_BF16X6 1
+int psld_set_math_mode(int mode);
+int psld_get_math_mode(void);
+
 /* ---- fused epilogue of every MFMA tile kernel ------------------------------------------
  * value = ((alpha * acc + bias[n] + rowbias[m / rows_per_img][n] + residual[m][n]) * out_scale)
  *         (+ C[m][n] if accumulate)
@@ -90,6 +101,22 @@ int psld_conv2d_nhwc_ws_f32(const float* x1, int c1, const float* x2, int c2,
                             int oh, int ow, float* y, int ldy,
                             const psld_epilogue_t* epi, void* workspace, long long ws_bytes,
                             hipStream_t stream);
+
+/* ---- 3x3 stride-1 pad-1 convolutions on bf16 limb MFMA (PSLD_MATH_BF16X6) --------------------------------
+ * Direct convolution: a (rows+2) x (W+2) halo tile of the input is split into limbs once per 32-channel chunk and
+ * read from LDS at the nine tap offsets; the weights come pre-split in MFMA fragment order
+ * (psld_pack_conv3x3_frag, once per optimizer step; psld_conv3x3_frag_bytes bytes).  Same contract as
+ * psld_conv2d_nhwc_ws_f32 for kh = kw = 3, stride = pad = 1 (input = concat(x1[c1], x2[c2]), fused epilogue,
+ * optional split-K workspace of psld_conv2d_workspace_bytes).  Shapes: c1, c2 multiples of 32, cout a multiple
+ * of 128, w in {8,16,32,64} with h*w dividing or divisible by 128 (psld_conv3x3_split_supported).
+ * dgrad = 1 packs the weights of the data-gradient (taps flipped, channel roles swapped: "cout" of the call that
+ * consumes them is the layer's cin).  Replaces nn.Conv2d 3x3 of every ResBlock (layerspp.py:29-39). */
+long long psld_conv3x3_frag_bytes(int cout, int cin);
+int psld_conv3x3_split_supported(int c1, int c2, int batch, int h, int w, int cout);
+int psld_pack_conv3x3_frag(const float* w_oihw, void* wfrag, int cout, int cin, int dgrad, hipStream_t stream);
+int psld_conv3x3_split_f32(const float* x1, int c1, const float* x2, int c2, int batch, int h, int w,
+                           const void* wfrag, int cout, float* y, int ldy, const psld_epilogue_t* epi,
+                           void* workspace, long long ws_bytes, hipStream_t stream);
 
 /* Weight gradient of the convolution above for one input source:
  * slabs[s][co][tap][col0 + ci] = sum over the s-th range of output pixels of dy[pix][co] * x[pix+tap][ci]. */

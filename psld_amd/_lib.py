@@ -65,12 +65,18 @@ EP = C.POINTER(Epilogue)
 SIGNATURES = {
     "psld_version": (I, []),
     "psld_last_error": (C.c_char_p, []),
+    "psld_set_math_mode": (I, [I]),
+    "psld_get_math_mode": (I, []),
     "psld_gemm_f32": (I, [I, I, I, I, I, P, I, LL, P, I, LL, P, I, LL, I, EP, P]),
     "psld_gemm_tn_splitk_f32": (I, [I, I, I, P, I, P, I, P, I, P]),
     "psld_conv2d_nhwc_f32": (I, [P, I, P, I, I, I, I, P, I, I, I, I, I, I, I, I, P, I, EP, P]),
     "psld_conv2d_workspace_bytes": (LL, [I, I, I, I]),
     "psld_conv2d_nhwc_ws_f32": (I, [P, I, P, I, I, I, I, P, I, I, I, I, I, I, I, I, P, I, EP, P, LL, P]),
     "psld_conv2d_wgrad_nhwc_f32": (I, [P, I, I, P, I, I, I, I, I, I, I, I, I, I, P, I, I, I, P]),
+    "psld_conv3x3_frag_bytes": (LL, [I, I]),
+    "psld_conv3x3_split_supported": (I, [I, I, I, I, I, I]),
+    "psld_pack_conv3x3_frag": (I, [P, P, I, I, I, P]),
+    "psld_conv3x3_split_f32": (I, [P, I, P, I, I, I, I, P, I, P, I, EP, P, LL, P]),
     "psld_reduce_slabs_f32": (I, [P, I, LL, P, I, I, I, I, F, P]),
     "psld_pack_oihw_to_ohwi_f32": (I, [P, P, I, I, I, P]),
     "psld_pack_oihw_to_dgrad_f32": (I, [P, P, I, I, I, P]),

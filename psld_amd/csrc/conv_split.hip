@@ -1,0 +1,380 @@
+// 3x3 stride-1 convolutions (forward, data-gradient, weight-gradient) on bf16 MFMA with fp32 operands carried
+// as three bf16 limbs ("bf16x6": PSLD_MATH_BF16X6 in include/psld_hip.h).
+//
+// Why: v_mfma_f32_32x32x2_f32 tops out at ~136 TFLOP/s on this chip; v_mfma_f32_32x32x16_bf16 moves 16x the
+// k-depth per instruction.  Every fp32 value x is decomposed EXACTLY into hi + mid + lo (bf16 each, 8 significant
+// bits apiece, 24 in total) and a product a*b is accumulated in fp32 from the six limb products of weight
+// >= 2^-16: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi.  The three dropped products are < 2^-23 |a*b| —
+// below the rounding of the fp32 product itself — so results agree with the fp32 MFMA path to fp32 rounding
+// (tests/test_kernels_gpu.py runs every parity case in both modes).
+//
+// Why a direct convolution rather than the im2col tile engine: the limb split costs VALU work and LDS stores,
+// so the A operand is converted ONCE per 32-channel chunk — a halo tile of (rows+2) x (W+2) pixels kept in LDS
+// and read at nine shifted offsets — and the weights are pre-split once per optimizer step into MFMA fragment
+// order, so a wave fetches its B fragments straight from L2 with one coalesced 16-byte load per lane: no LDS
+// staging, no conversion and no barrier per tap.  Per tap a wave issues 12 global loads, 12 ds_read_b128 and
+// 48 MFMAs.
+//
+// Replaces nn.Conv2d 3x3 (song_sde/layers.py:85-109 via layerspp.py:29-39) forward and backward for the layers
+// whose channel counts are multiples of 32 (in) / 128 (out) — every ResBlock conv of the C10 / CelebA-64 nets.
+#include <cstdlib>
+#include <cstring>
+
+#include "common.h"
+#include "psld_hip.h"
+#include "tile_shared.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+constexpr int ROWB = 80;        // bytes per pixel and limb in the LDS halo image: 32 bf16 + 8 pad (conflict-free b128)
+constexpr int STEP_U4 = 2 * 3 * 64;  // uint4 per (wave column, K step of 16): [n-block 2][limb 3][lane 64]
+
+int g_math_mode = -1;
+inline int math_mode() {
+    if (g_math_mode < 0) {
+        const char* e = getenv("PSLD_MATH");
+        g_math_mode = (e && !strcmp(e, "f32")) ? PSLD_MATH_F32 : PSLD_MATH_BF16X6;
+    }
+    return g_math_mode;
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// Exact three-limb decomposition of two fp32 values into packed bf16 pairs (x0 in the low half):
+// hi = rne_bf16(x), mid = rne_bf16(x - hi), lo = x - hi - mid (at most 8 significant bits left: exact).
+__device__ __forceinline__ void split3(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    const bf16x2 ph = {(__bf16)x0, (__bf16)x1};
+    hi = __builtin_bit_cast(unsigned, ph);
+    const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+    const bf16x2 pm = {(__bf16)r0, (__bf16)r1};
+    mid = __builtin_bit_cast(unsigned, pm);
+    const float s0 = r0 - __uint_as_float(mid << 16), s1 = r1 - __uint_as_float(mid & 0xffff0000u);
+    const bf16x2 pl = {(__bf16)s0, (__bf16)s1};
+    lo = __builtin_bit_cast(unsigned, pl);
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// ---- weights -> limb fragments ---------------------------------------------------------------------------
+// out[nt][wc][chunk][tap][ks][nb][limb][lane] (uint4 = 8 bf16): n = nt*128 + wc*64 + nb*32 + (lane & 31),
+// k = chunk*32 + ks*16 + (lane >> 5)*8 + j.   dgrad = 0: B[n][k] = w[co = n][ci = k][tap];
+// dgrad = 1: B[n][k] = w[co = k][ci = n][8 - tap] (the data-gradient of a stride-1 pad-1 3x3 conv is the same
+// conv with the taps flipped and the channel roles swapped).
+__global__ void pack_frag_kernel(const float* __restrict__ w, u32x4* __restrict__ out, int cout, int cin, int dgrad) {
+    const int n_out = dgrad ? cin : cout, k_in = dgrad ? cout : cin;
+    const int chunks = k_in / 32;
+    const long long total = (long long)n_out * chunks * 9 * 2 * 3 * 2;  // uint4 count / ... (see decode)
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        long long t = idx;
+        const int lane = (int)(t & 63); t >>= 6;
+        const int limb = (int)(t % 3); t /= 3;
+        const int nb = (int)(t & 1); t >>= 1;
+        const int ks = (int)(t & 1); t >>= 1;
+        const int tap = (int)(t % 9); t /= 9;
+        const int chunk = (int)(t % chunks); t /= chunks;
+        const int wc = (int)(t & 1); t >>= 1;
+        const int nt = (int)t;
+        const int n = nt * 128 + wc * 64 + nb * 32 + (lane & 31);
+        const int k0 = chunk * 32 + ks * 16 + (lane >> 5) * 8;
+        unsigned v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float x[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int k = k0 + 2 * j + e;
+                x[e] = dgrad ? w[((long long)k * cin + n) * 9 + (8 - tap)] : w[((long long)n * cin + k) * 9 + tap];
+            }
+            unsigned hi, mid, lo;
+            split3(x[0], x[1], hi, mid, lo);
+            v[j] = limb == 0 ? hi : (limb == 1 ? mid : lo);
+        }
+        out[idx] = u32x4{v[0], v[1], v[2], v[3]};
+    }
+}
+
+// ---- forward / data-gradient -------------------------------------------------------------------------------
+struct DConvArgs {
+    const float* x1;
+    const float* x2;
+    int C1, C2;
+    int B, H, W;            // stride 1, pad 1: output spatial == input spatial
+    const u32x4* wfrag;
+    int N, M;               // cout (multiple of 128), B*H*W
+    int chunks;             // (C1 + C2) / 32
+    int chunks_per_split;
+    float* C;
+    int ldc;
+    long long c_stride_split;
+    int nseg, rps;          // image segments per 128-pixel tile and output rows per segment
+    PsldEpilogue e;
+    const float* zero;
+};
+
+// NH = float4 halo items per thread per chunk: the LDS image has NH*32 pixel rows (>= nseg*(rps+2)*(W+2)).
+template <int NH>
+__global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int LIMB = NH * 32 * ROWB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int c4 = tid & 7;
+
+    const int tiles_n = a.N >> 7;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    const int m0 = tile_m * 128, n0 = tile_n * 128;
+    const int split = blockIdx.y;
+    const int c_beg = split * a.chunks_per_split;
+    const int c_end = min(a.chunks, c_beg + a.chunks_per_split);
+
+    const int W2 = a.W + 2, HW = a.H * a.W;
+    const int img0 = m0 / HW;
+    const int oy0 = (m0 - img0 * HW) / a.W;     // 0 when a tile holds whole images
+    const int seg_px = (a.rps + 2) * W2;
+    const float* zp = a.zero;
+
+    // source pixel of every halo item this thread stages (-1: zero padding / beyond the batch)
+    int hoff[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+        const int px = (tid + 256 * i) >> 3;
+        const int seg = px / seg_px;
+        const int rem = px - seg * seg_px;
+        const int hr = rem / W2, hx = rem - hr * W2;
+        const int img = img0 + seg, iy = oy0 + hr - 1, ix = hx - 1;
+        const bool ok = seg < a.nseg && img < a.B && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        hoff[i] = ok ? (img * a.H + iy) * a.W + ix : -1;
+    }
+    f32x4 hv[NH];
+    auto load_halo = [&](int c) {
+        const int c0 = c * 32;
+        const bool second = c0 >= a.C1;
+        const float* src = second ? a.x2 : a.x1;
+        const int cs = second ? a.C2 : a.C1;
+        const int cc = (second ? c0 - a.C1 : c0) + c4 * 4;
+#pragma unroll
+        for (int i = 0; i < NH; ++i) hv[i] = ld4(hoff[i] >= 0 ? src + ((long long)hoff[i] * cs + cc) : zp);
+    };
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            unsigned h0, m0_, l0, h1, m1, l1;
+            split3(hv[i][0], hv[i][1], h0, m0_, l0);
+            split3(hv[i][2], hv[i][3], h1, m1, l1);
+            unsigned char* q = smem + ((tid + 256 * i) >> 3) * ROWB + c4 * 8;
+            *reinterpret_cast<u32x2*>(q) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(q + LIMB) = u32x2{m0_, m1};
+            *reinterpret_cast<u32x2*>(q + 2 * LIMB) = u32x2{l0, l1};
+        }
+    };
+
+    // LDS byte offset of this lane's A fragment rows at tap (0, 0)
+    int abase[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int ml = wr * 64 + mb * 32 + r;
+        const int seg = ml / (a.rps * a.W);
+        const int rem = ml - seg * (a.rps * a.W);
+        const int ry = rem / a.W, ox = rem - ry * a.W;
+        abase[mb] = ((seg * (a.rps + 2) + ry) * W2 + ox) * ROWB + h * 16;
+    }
+
+    // B fragments of K step sigma = (chunk*9 + tap)*2 + ks for this wave's 64 columns
+    const u32x4* wp = a.wfrag + ((long long)(tile_n * 2 + wc) * a.chunks * 18) * STEP_U4 + lane;
+    const int sig_last = c_end * 18 - 1;
+    u32x4 bq[2][2][3];
+    auto load_b = [&](int sigma, u32x4 (&dst)[2][3]) {
+        const u32x4* p = wp + (long long)min(sigma, sig_last) * STEP_U4;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) dst[nb][l] = p[(nb * 3 + l) * 64];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+    load_halo(c_beg);
+    load_b(c_beg * 18, bq[0]);
+    store_halo();
+    __syncthreads();
+
+    for (int c = c_beg; c < c_end; ++c) {
+        const bool more = (c + 1) < c_end;
+        int tap_off = 0, kx = 0;
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap == 7 && more) load_halo(c + 1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                load_b((c * 9 + tap) * 2 + ks + 1, bq[ks ^ 1]);
+                u32x4 fa[2][3];
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int l = 0; l < 3; ++l)
+                        fa[mb][l] = *reinterpret_cast<const u32x4*>(smem + l * LIMB + abase[mb] + tap_off + ks * 32);
+                // limb products, smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma_bf16(fa[mb][PA[t]], bq[ks][nb][PB[t]], acc[mb][nb]);
+            }
+            if (++kx == 3) { kx = 0; tap_off += (W2 - 2) * ROWB; } else { tap_off += ROWB; }
+        }
+        __syncthreads();
+        if (more) {
+            store_halo();
+            __syncthreads();
+        }
+    }
+
+    float* Cb = a.C + (long long)split * a.c_stride_split;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+            epilogue_store_block(acc[mb][nb], m0 + wr * 64 + mb * 32, n0 + wc * 64 + nb * 32 + r, h, a.M, a.N, Cb, a.ldc,
+                                 a.e.res, a.e);
+}
+
+template <int NH>
+int launch_dconv(const DConvArgs& a, int nsplit, hipStream_t stream) {
+    constexpr size_t LDS = (size_t)3 * NH * 32 * ROWB;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv_kernel<NH>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        if (e != hipSuccess) {
+            psld_set_error("psld_conv3x3_split_f32: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return PSLD_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    dim3 grid((unsigned)(cdiv(a.M, 128) * (a.N / 128)), (unsigned)nsplit);
+    hipLaunchKernelGGL(dconv_kernel<NH>, grid, dim3(256), LDS, stream, a);
+    PSLD_CHECK_LAUNCH("psld_conv3x3_split_f32");
+    return PSLD_OK;
+}
+
+bool dconv_geometry(int h, int w, int* nseg, int* rps, int* halo_px) {
+    if (w != 8 && w != 16 && w != 32 && w != 64) return false;
+    const int hw = h * w;
+    if (hw >= 128) {
+        if (hw % 128) return false;
+        *nseg = 1;
+        *rps = 128 / w;
+    } else {
+        if (128 % hw) return false;
+        *nseg = 128 / hw;
+        *rps = h;
+    }
+    *halo_px = *nseg * (*rps + 2) * (w + 2);
+    return *halo_px <= 9 * 32;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+extern "C" int psld_set_math_mode(int mode) {
+    PSLD_CHECK_ARG(mode == PSLD_MATH_F32 || mode == PSLD_MATH_BF16X6, "psld_set_math_mode: unknown mode %d", mode);
+    g_math_mode = mode;
+    return PSLD_OK;
+}
+
+extern "C" int psld_get_math_mode(void) { return math_mode(); }
+
+extern "C" long long psld_conv3x3_frag_bytes(int cout, int cin) { return (long long)cout * cin * 9 * 6; }
+
+extern "C" int psld_conv3x3_split_supported(int c1, int c2, int batch, int h, int w, int cout) {
+    int nseg, rps, halo;
+    return c1 > 0 && c2 >= 0 && c1 % 32 == 0 && c2 % 32 == 0 && cout > 0 && cout % 128 == 0 && batch > 0 &&
+           dconv_geometry(h, w, &nseg, &rps, &halo);
+}
+
+extern "C" int psld_pack_conv3x3_frag(const float* w_oihw, void* wfrag, int cout, int cin, int dgrad,
+                                      hipStream_t stream) {
+    PSLD_CHECK_ARG(w_oihw && wfrag, "psld_pack_conv3x3_frag: null pointer");
+    const int n_out = dgrad ? cin : cout, k_in = dgrad ? cout : cin;
+    PSLD_CHECK_ARG(n_out > 0 && k_in > 0 && n_out % 128 == 0 && k_in % 32 == 0,
+                   "psld_pack_conv3x3_frag: needs out channels %%128 and in channels %%32 (got %d, %d)", n_out, k_in);
+    const long long total = (long long)n_out * (k_in / 32) * 9 * 2 * 3 * 2;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(pack_frag_kernel, dim3(blocks), dim3(256), 0, stream, w_oihw,
+                       reinterpret_cast<u32x4*>(wfrag), cout, cin, dgrad);
+    PSLD_CHECK_LAUNCH("psld_pack_conv3x3_frag");
+    return PSLD_OK;
+}
+
+extern "C" int psld_conv3x3_split_f32(const float* x1, int c1, const float* x2, int c2, int batch, int h, int w,
+                                      const void* wfrag, int cout, float* y, int ldy, const psld_epilogue_t* epi,
+                                      void* workspace, long long ws_bytes, hipStream_t stream) {
+    PSLD_CHECK_ARG(x1 && wfrag && y && (c2 == 0 || x2), "psld_conv3x3_split_f32: null pointer");
+    PSLD_CHECK_ARG(psld_conv3x3_split_supported(c1, c2, batch, h, w, cout),
+                   "psld_conv3x3_split_f32: unsupported shape c1=%d c2=%d %dx%d cout=%d", c1, c2, h, w, cout);
+    PSLD_CHECK_ARG(aligned16(x1) && (!x2 || aligned16(x2)) && aligned16(wfrag), "psld_conv3x3_split_f32: unaligned pointer");
+    DConvArgs a{};
+    a.x1 = x1; a.x2 = x2; a.C1 = c1; a.C2 = c2;
+    a.B = batch; a.H = h; a.W = w;
+    a.wfrag = reinterpret_cast<const u32x4*>(wfrag);
+    a.N = cout; a.M = batch * h * w;
+    a.chunks = (c1 + c2) / 32;
+    int halo_px = 0;
+    dconv_geometry(h, w, &a.nseg, &a.rps, &halo_px);
+    a.zero = psld_detail_zero_page("psld_conv3x3_split_f32");
+    if (!a.zero) return PSLD_ERR_LAUNCH;
+    const PsldEpilogue e = make_epilogue(epi);
+    const long long tiles = (long long)cdiv(a.M, 128) * (cout / 128);
+    // split the channel chunks over extra workgroups when the output grid cannot fill 256 CUs x 2 slots
+    int ns = 1;
+    if (workspace && tiles < 384 && ldy % 4 == 0 && aligned16(y) && (!e.bias || aligned16(e.bias)) &&
+        (!e.rowbias || (aligned16(e.rowbias) && e.ld_rowbias % 4 == 0)) && (!e.res || (aligned16(e.res) && e.ldres % 4 == 0))) {
+        ns = (int)(512 / tiles);
+        if (ns > 8) ns = 8;
+        if (ns > a.chunks / 2) ns = a.chunks / 2;
+        while (ns > 1 && (long long)ns * a.M * cout * (long long)sizeof(float) > ws_bytes) --ns;
+        if (ns < 1) ns = 1;
+    }
+    a.chunks_per_split = cdiv(a.chunks, ns);
+    ns = cdiv(a.chunks, a.chunks_per_split);
+    if (ns >= 2) {
+        a.C = reinterpret_cast<float*>(workspace);
+        a.ldc = cout;
+        a.c_stride_split = (long long)a.M * cout;
+        a.e = make_epilogue(nullptr);
+    } else {
+        a.C = y;
+        a.ldc = ldy;
+        a.c_stride_split = 0;
+        a.e = e;
+    }
+    const int nh = cdiv((long long)halo_px * 8, 256);
+    int st;
+    if (nh <= 6) st = launch_dconv<6>(a, ns, stream);
+    else if (nh <= 7) st = launch_dconv<7>(a, ns, stream);
+    else st = launch_dconv<9>(a, ns, stream);
+    if (st != PSLD_OK) return st;
+    if (ns >= 2) return psld_detail_conv_reduce_epilogue(a.C, ns, a.M, cout, y, ldy, e, stream);
+    return PSLD_OK;
+}

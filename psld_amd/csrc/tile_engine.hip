@@ -19,6 +19,7 @@
 // bank-conflict free (MI355X LDS: 64 banks, 16-lane groups for b128).
 #include "common.h"
 #include "psld_hip.h"
+#include "tile_shared.h"
 
 namespace {
 
@@ -41,18 +42,7 @@ struct ConvGeom {
     int IH, IW, C1, C2, OH, OW, KH, KW, stride, pad, tstride;
 };
 
-struct Epilogue {
-    float alpha;
-    const float* bias;      // [N] or null
-    const float* rowbias;   // [M/rows_per_img][ld_rowbias] or null (time-embedding bias)
-    int ld_rowbias;
-    int rows_per_img;
-    const float* res;       // residual [M][ldres] or null
-    int ldres;
-    long long res_stride_z;
-    float out_scale;
-    int accumulate;         // C += result
-};
+using Epilogue = PsldEpilogue;
 
 struct TileArgs {
     int M, N, K;
@@ -705,17 +695,8 @@ inline int ilog2_exact(int v) {
 
 template <int AMODE, int BMODE, int TBM, int NBUF, int TBN>
 int launch_fast_impl(const TileArgs& a, FastGeom fg, int nz, hipStream_t stream, const char* name) {
-    static const float* zero_dev = nullptr;
-    if (!zero_dev) {
-        void* zptr = nullptr;
-        hipError_t e = hipGetSymbolAddress(&zptr, HIP_SYMBOL(g_zero_page));
-        if (e != hipSuccess || !zptr) {
-            psld_set_error("%s: hipGetSymbolAddress failed: %s", name, hipGetErrorString(e));
-            return PSLD_ERR_LAUNCH;
-        }
-        zero_dev = static_cast<const float*>(zptr);
-    }
-    fg.zero = zero_dev;
+    fg.zero = psld_detail_zero_page(name);
+    if (!fg.zero) return PSLD_ERR_LAUNCH;
     constexpr bool A_KC = (AMODE == OP_KC || AMODE == OP_IM2COL);
     constexpr bool B_KC = (BMODE == OP_KC || BMODE == OP_IM2COL);
     constexpr int A_SZ = A_KC ? TBM * KC_LD : BK * MC_LD;
@@ -777,22 +758,32 @@ __global__ void conv_reduce_epilogue_kernel(const float* __restrict__ slabs, int
     }
 }
 
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-
-Epilogue make_epilogue(const psld_epilogue_t* e) {
-    Epilogue o;
-    o.alpha = 1.f; o.bias = nullptr; o.rowbias = nullptr; o.ld_rowbias = 0; o.rows_per_img = 1;
-    o.res = nullptr; o.ldres = 0; o.res_stride_z = 0; o.out_scale = 1.f; o.accumulate = 0;
-    if (e) {
-        o.alpha = e->alpha; o.bias = e->bias; o.rowbias = e->rowbias; o.ld_rowbias = e->ld_rowbias;
-        o.rows_per_img = e->rows_per_img > 0 ? e->rows_per_img : 1;
-        o.res = e->residual; o.ldres = e->ld_residual; o.res_stride_z = e->residual_stride_batch;
-        o.out_scale = e->out_scale; o.accumulate = e->accumulate;
-    }
-    return o;
-}
 
 }  // namespace
+
+const float* psld_detail_zero_page(const char* name) {
+    static const float* zero_dev = nullptr;
+    if (!zero_dev) {
+        void* zptr = nullptr;
+        hipError_t e = hipGetSymbolAddress(&zptr, HIP_SYMBOL(g_zero_page));
+        if (e != hipSuccess || !zptr) {
+            psld_set_error("%s: hipGetSymbolAddress failed: %s", name, hipGetErrorString(e));
+            return nullptr;
+        }
+        zero_dev = static_cast<const float*>(zptr);
+    }
+    return zero_dev;
+}
+
+int psld_detail_conv_reduce_epilogue(const float* slabs, int nsplit, int M, int N, float* y, int ldy,
+                                     const PsldEpilogue& e, hipStream_t stream) {
+    const long long total = (long long)M * (N / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv_reduce_epilogue_kernel, dim3(blocks), dim3(256), 0, stream, slabs, nsplit, M, N, y, ldy, e);
+    PSLD_CHECK_LAUNCH("conv_reduce_epilogue_kernel");
+    return PSLD_OK;
+}
 
 // ---------------------------------------------------------------------------------------
 // C ABI
@@ -903,13 +894,7 @@ extern "C" int psld_conv2d_nhwc_ws_f32(const float* x1, int c1, const float* x2,
             p.e = make_epilogue(nullptr);
             int st = launch_fast<OP_IM2COL, OP_KC, 64>(p, fg, 1, stream, "psld_conv2d_nhwc_f32[fast64,splitK]");
             if (st != PSLD_OK) return st;
-            const long long total = (long long)a.M * (a.N / 4);
-            int blocks = (int)((total + 255) / 256);
-            if (blocks > 4096) blocks = 4096;
-            hipLaunchKernelGGL(conv_reduce_epilogue_kernel, dim3(blocks), dim3(256), 0, stream, p.C, ns, a.M, a.N, y, ldy,
-                               a.e);
-            PSLD_CHECK_LAUNCH("conv_reduce_epilogue_kernel");
-            return PSLD_OK;
+            return psld_detail_conv_reduce_epilogue(p.C, ns, a.M, a.N, y, ldy, a.e, stream);
         }
         if (tiles128 <= 256 && a.M > 64)
             return launch_fast<OP_IM2COL, OP_KC, 64>(a, fg, 1, stream, "psld_conv2d_nhwc_f32[fast64]");

@@ -117,6 +117,42 @@ def conv2d_nhwc(x1: Tensor, x2: Optional[Tensor], w_ohwi: Tensor, cout: int, kh:
           "psld_conv2d_nhwc_f32")
 
 
+def set_math_mode(mode: str):
+    """'f32' (v_mfma_f32_32x32x2_f32) or 'bf16x6' (three-limb bf16 MFMA, fp32-equivalent); process-wide."""
+    check(lib().psld_set_math_mode({"f32": 0, "bf16x6": 1}[mode]), "psld_set_math_mode")
+
+
+def math_mode() -> str:
+    return ("f32", "bf16x6")[lib().psld_get_math_mode()]
+
+
+def conv3x3_split_supported(c1: int, c2: int, b: int, h: int, w: int, cout: int) -> bool:
+    return bool(lib().psld_conv3x3_split_supported(c1, c2, b, h, w, cout))
+
+
+def conv3x3_frag(w_oihw: Tensor, dgrad: bool, out: Optional[Tensor] = None) -> Tensor:
+    """Pre-split 3x3 weights into bf16 limb fragments (uint8 buffer of psld_conv3x3_frag_bytes)."""
+    co, ci = w_oihw.shape[0], w_oihw.shape[1]
+    if out is None:
+        out = torch.empty(lib().psld_conv3x3_frag_bytes(co, ci), dtype=torch.uint8, device=w_oihw.device)
+    check(lib().psld_pack_conv3x3_frag(w_oihw.data_ptr(), out.data_ptr(), co, ci, int(dgrad), _stream()),
+          "psld_pack_conv3x3_frag")
+    return out
+
+
+def conv3x3_split(x1: Tensor, x2: Optional[Tensor], wfrag: Tensor, cout: int, y: Tensor,
+                  epi: Optional[Epilogue] = None, ldy: Optional[int] = None):
+    b, h, w, c1 = x1.shape
+    c2 = x2.shape[-1] if x2 is not None else 0
+    ws, wsb = None, 0
+    if b * h * w <= 32768:
+        wsb = lib().psld_conv2d_workspace_bytes(b, h, w, cout)
+        ws = workspace(wsb, x1.device).data_ptr()
+    check(lib().psld_conv3x3_split_f32(x1.data_ptr(), c1, _p(x2), c2, b, h, w, wfrag.data_ptr(), cout, y.data_ptr(),
+                                       ldy if ldy is not None else cout, C.byref(epi) if epi is not None else None,
+                                       ws, wsb, _stream()), "psld_conv3x3_split_f32")
+
+
 def conv2d_wgrad_nhwc(dy: Tensor, cout: int, x: Tensor, kh: int, kw: int, stride: int, pad: int, oh: int, ow: int,
                       slabs: Tensor, cin_total: int, col0: int, nsplit: int):
     b, ih, iw, cin = x.shape

@@ -204,6 +204,7 @@ class _Exec:
         # that their MFMA-bound kernels overlap the HBM-bound kernels of the chain (GN backward, reductions)
         self.side = net._side_stream() if (record and net.overlap_wgrad) else None
         self.want_dx = False        # gradient w.r.t. the network input requested (x.requires_grad)
+        self.split = ops.math_mode() == "bf16x6"   # 3x3 convs on the bf16 limb kernels (csrc/conv_split.hip)
         self.dx_nchw = None
 
     # -- helpers ------------------------------------------------------------------------------
@@ -255,11 +256,24 @@ class _Exec:
         ops.colsum(tmp, c, 1, b, c, out, alpha)
         return tmp
 
+    def conv3(self, x: Tensor, conv: _Affine, out: Tensor, epi):
+        """3x3 stride-1 pad-1 convolution of an NHWC tensor."""
+        b, h, w, c = x.shape
+        cout = conv.weight.shape[0]
+        if self.split and ops.conv3x3_split_supported(c, 0, b, h, w, cout):
+            ops.conv3x3_split(x, None, self.net._frag(conv, False), cout, out, epi)
+        else:
+            ops.conv2d_nhwc(x, None, self.net._packed(conv), cout, 3, 3, 1, 1, 1, h, w, out, epi)
+
     def dgrad(self, dy: Tensor, conv: _Affine, k: int, stride: int, pad: int, ih: int, iw: int, out: Tensor,
               alpha: float = 1.0, accumulate: bool = False):
         cin = conv.weight.shape[1]
-        wd = self.net._packed(conv, dgrad=True)
         epi = ops.epilogue(alpha=alpha, accumulate=accumulate) if (alpha != 1.0 or accumulate) else None
+        if self.split and k == 3 and stride == 1 and pad == 1 and \
+                ops.conv3x3_split_supported(dy.shape[-1], 0, dy.shape[0], ih, iw, cin):
+            ops.conv3x3_split(dy, None, self.net._frag(conv, True), cin, out, epi)
+            return
+        wd = self.net._packed(conv, dgrad=True)
         ops.conv2d_nhwc(dy, None, wd, cin, k, k, 1, k - 1 - pad, stride, ih, iw, out, epi)
 
     def resample(self, x: Tensor, up: bool) -> Tensor:
@@ -332,8 +346,7 @@ class _Exec:
         if self.temb_act is not None:
             tp = ops.linear(self.temb_act.v, mod.Dense_0.weight, mod.Dense_0.bias)
         h1 = torch.empty((b, ho, wo, cout), device=x.v.device, dtype=torch.float32)
-        ops.conv2d_nhwc(a0r, None, net._packed(mod.Conv_0), cout, 3, 3, 1, 1, 1, ho, wo, h1,
-                        ops.epilogue(bias=mod.Conv_0.bias, rowbias=tp, rows_per_img=ho * wo))
+        self.conv3(a0r, mod.Conv_0, h1, ops.epilogue(bias=mod.Conv_0.bias, rowbias=tp, rows_per_img=ho * wo))
         st1 = ops.gn_stats(h1, gn1.weight, gn1.bias)
         drop_p, seed = 0.0, 0
         if self.drop_p > 0:
@@ -348,8 +361,7 @@ class _Exec:
             res = out
         else:
             res = xr
-        ops.conv2d_nhwc(a1, None, net._packed(mod.Conv_1), cout, 3, 3, 1, 1, 1, ho, wo, out,
-                        ops.epilogue(bias=mod.Conv_1.bias, residual=res, ld_residual=cout, out_scale=s))
+        self.conv3(a1, mod.Conv_1, out, ops.epilogue(bias=mod.Conv_1.bias, residual=res, ld_residual=cout, out_scale=s))
         on = _Node(out)
         if not self.record:
             return on
@@ -935,6 +947,19 @@ class NCSNpp(nn.Module):
         self._pack_cache[key] = (stamp, out)
         return out
 
+    def _frag(self, conv: _Affine, dgrad: bool) -> Tensor:
+        """bf16 limb fragments of a 3x3 weight (ops.conv3x3_frag), cached until the weights change."""
+        w = conv.weight
+        key = (id(w), dgrad, "frag")
+        self._conv_by_weight[id(w)] = conv
+        ent = self._pack_cache.get(key)
+        stamp = (self._epoch, w._version, w.data_ptr())
+        if ent is not None and ent[0] == stamp:
+            return ent[1]
+        out = ops.conv3x3_frag(w.detach(), dgrad, ent[1] if ent is not None and ent[1].device == w.device else None)
+        self._pack_cache[key] = (stamp, out)
+        return out
+
     def _pos_freq(self, device):
         if self._posfreq is None or self._posfreq.device != device:
             half = self.nf // 2
@@ -1039,9 +1064,10 @@ class NCSNpp(nn.Module):
         graph, sx, st, sy, stamp = ent
         now = (self._epoch, self._flat._version)
         if stamp != now:
-            for (wid, dgrad), (_, _out) in list(self._pack_cache.items()):
-                if not dgrad:
-                    self._packed(self._conv_by_weight[wid])    # refreshes the same storage if stale
+            for key in list(self._pack_cache):
+                if not key[1]:                                  # forward copies: refreshed in the same storage
+                    (self._frag(self._conv_by_weight[key[0]], False) if len(key) == 3
+                     else self._packed(self._conv_by_weight[key[0]]))
             ent[4] = now
         sx.copy_(x)
         st.copy_(t)

@@ -55,13 +55,20 @@ def main():
         fl = 2.0 * B * s * s * cout * 9 * cin
         t = timeit(lambda: ops.conv2d_nhwc(x, None, w, cout, 3, 3, 1, 1, 1, s, s, y, epi), args.iters)
         rows.append((f"conv fwd {cin}->{cout} @{s}", fl / t / 1e12, t * 1e6))
+        if ops.conv3x3_split_supported(cin, 0, B, s, s, cout):
+            w_oihw = w.view(cout, 3, 3, cin).permute(0, 3, 1, 2).contiguous()
+            wf = ops.conv3x3_frag(w_oihw, False)
+            y2 = torch.empty_like(y)
+            t = timeit(lambda: ops.conv3x3_split(x, None, wf, cout, y2, epi), args.iters)
+            err = ((y2 - y).norm() / y.norm()).item()
+            rows.append((f"conv fwd {cin}->{cout} @{s} bf16x6 (rel {err:.1e})", fl / t / 1e12, t * 1e6))
         dy = torch.randn(B, s, s, cout, device=DEV)
         nsplit = max(1, min((768 + 36 * (cin // 256) - 1) // (36 * (cin // 256)), B * s * s // 256))
         slabs = torch.empty(nsplit, cout, 9, cin, device=DEV)
         t = timeit(lambda: ops.conv2d_wgrad_nhwc(dy, cout, x, 3, 3, 1, 1, s, s, slabs, cin, 0, nsplit), args.iters)
         rows.append((f"conv wgrad {cin}->{cout} @{s} (split {nsplit})", fl / t / 1e12, t * 1e6))
     for name, tf, us in rows:
-        print(f"{name:44s} {tf:7.1f} TF  {us:9.1f} us")
+        print(f"{name:54s} {tf:7.1f} TF  {us:9.1f} us")
 
 
 if __name__ == "__main__":
