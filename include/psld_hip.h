@@ -118,6 +118,15 @@ int psld_conv3x3_split_f32(const float* x1, int c1, const float* x2, int c2, int
                            const void* wfrag, int cout, float* y, int ldy, const psld_epilogue_t* epi,
                            void* workspace, long long ws_bytes, hipStream_t stream);
 
+/* Weight gradient of the same convolution, same slab contract as psld_conv2d_wgrad_nhwc_f32 (kh = kw = 3,
+ * stride = pad = 1): slabs[s][cout][9][cin_total] restricted to columns [col0, col0 + cin), one slab per K range
+ * of ceil(batch*h*w/32 / nsplit) 32-pixel tiles (every slab must be non-empty); the caller reduces
+ * (psld_reduce_slabs_f32).  Shapes: cout, cin multiples of 64, w in {8,16,32,64}, h*w a multiple of 32. */
+int psld_conv3x3_wgrad_split_supported(int cout, int cin, int batch, int h, int w);
+int psld_conv3x3_wgrad_split_f32(const float* dy, int lddy, int cout, const float* x, int cin, int batch,
+                                 int h, int w, float* slabs, int cin_total, int col0, int nsplit,
+                                 hipStream_t stream);
+
 /* Weight gradient of the convolution above for one input source:
  * slabs[s][co][tap][col0 + ci] = sum over the s-th range of output pixels of dy[pix][co] * x[pix+tap][ci]. */
 int psld_conv2d_wgrad_nhwc_f32(const float* dy, int lddy, int cout,

@@ -223,6 +223,8 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
             if (tap == 7 && more) load_halo(c + 1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
+                // (pinning these loads ahead of the MFMA block with sched_barrier costs the third wave per SIMD and
+                // measures no faster: at 1.64 GHz under bf16 MFMA load the kernel sits at the chip's power limit)
                 load_b((c * 9 + tap) * 2 + ks + 1, bq[ks ^ 1]);
                 u32x4 fa[2][3];
 #pragma unroll
@@ -255,6 +257,169 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
         for (int nb = 0; nb < 2; ++nb)
             epilogue_store_block(acc[mb][nb], m0 + wr * 64 + mb * 32, n0 + wc * 64 + nb * 32 + r, h, a.M, a.N, Cb, a.ldc,
                                  a.e.res, a.e);
+}
+
+
+// ---- weight gradient ---------------------------------------------------------------------------------------
+// dW[co][tap][ci] = sum_p dy[p][co] * x[p + tap][ci].  One workgroup owns a 64 (co) x 64 (ci) tile for ALL nine taps
+// (each wave 32 x 32 x 9 = nine accumulators) over a range of 32-pixel K tiles: per K tile the dy rows and a
+// (rows+2) x (W+2) halo of x are split into limbs once and kept in LDS as [pixel][channel] images; both MFMA
+// operands need k (= pixel) along the register, so the fragments come from ds_read_b64_tr_b16 transposed reads
+// (rows of 192 B: the four pixel rows of a read land in disjoint bank quarters), the x fragment of tap (ky, kx)
+// simply (ky*(W+2) + kx) rows further.
+constexpr int WG_RS = 192;           // bytes per pixel row and limb: 64 channels bf16 + 64 pad
+constexpr int WG_AROWS = 32, WG_BROWS = 112;
+constexpr int WG_ALIMB = WG_AROWS * WG_RS, WG_BLIMB = WG_BROWS * WG_RS;
+constexpr int WG_NB = 7;             // x halo float4 items per thread (112 rows x 16 quads / 256)
+
+struct DWgradArgs {
+    const float* dy;
+    int lddy;
+    const float* x;
+    int cin;                // channels of x (row stride)
+    int B, H, W;
+    int cout_tiles, cin_tiles;
+    int ktiles, ktiles_per_split;
+    float* slabs;
+    int ld_tap;             // cin_total: stride between taps of one output channel
+    long long slab_stride;
+    int hw_w;               // halo width = min(W, 32) + 2
+    int hrows;              // halo rows = max(1, 32 / W) + 2
+    const float* zero;
+};
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ u32x2 lds_tr16(const unsigned char* p) {
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(__attribute__((address_space(3))) void*)(p));
+    return __builtin_bit_cast(u32x2, v);
+}
+
+__global__ void __launch_bounds__(256, 2) dwgrad_kernel(const DWgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* As = smem;                    // [3][32][192]
+    unsigned char* Bs = smem + 3 * WG_ALIMB;     // [3][112][192]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    // blocks of one K range read the same pixels: keep them on one XCD (shared L2)
+    const int tiles = a.cout_tiles * a.cin_tiles;
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = vid % tiles, split = vid / tiles;
+    const int co0 = (tile / a.cin_tiles) * 64, ci0 = (tile % a.cin_tiles) * 64;
+    const int kt_beg = split * a.ktiles_per_split;
+    const int kt_end = min(a.ktiles, kt_beg + a.ktiles_per_split);
+    const int HW = a.H * a.W;
+    const float* zp = a.zero;
+
+    // transposed-read lane roles: group of 16 lanes = 4 pixel rows x 16 channels
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, p4 = li & 3;
+    const int khalf = g >> 1, chalf = g & 1;
+    const int a_base = (8 * khalf + q) * WG_RS + (wr * 32 + 16 * chalf + 4 * p4) * 2;
+    int b_base[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = 16 * ks + 8 * khalf + 4 * j + q;
+            const int ry = a.W >= 32 ? 0 : k / a.W;
+            const int ox = a.W >= 32 ? k : k - ry * a.W;
+            b_base[ks][j] = (ry * a.hw_w + ox) * WG_RS + (wc * 32 + 16 * chalf + 4 * p4) * 2;
+        }
+
+    const int qa = tid & 15, ra = tid >> 4;     // dy staging: channel quad, pixel row (+16)
+    f32x4 va[2], vb[WG_NB];
+    auto load_tile = [&](int kt) {
+        const int p0 = kt * 32;
+        const int img = p0 / HW;
+        const int rem = p0 - img * HW;
+        const int oy0 = rem / a.W, ox0 = rem - oy0 * a.W;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) va[i] = ld4(a.dy + ((long long)(p0 + ra + 16 * i) * a.lddy + co0 + qa * 4));
+#pragma unroll
+        for (int i = 0; i < WG_NB; ++i) {
+            const int px = (tid + 256 * i) >> 4;
+            const int hr = px / a.hw_w, hx = px - hr * a.hw_w;
+            const int iy = oy0 + hr - 1, ix = ox0 + hx - 1;
+            const bool ok = hr < a.hrows && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            vb[i] = ld4(ok ? a.x + ((long long)((img * a.H + iy) * a.W + ix) * a.cin + ci0 + qa * 4) : zp);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            unsigned h0, m0, l0, h1, m1, l1;
+            split3(va[i][0], va[i][1], h0, m0, l0);
+            split3(va[i][2], va[i][3], h1, m1, l1);
+            unsigned char* d = As + (ra + 16 * i) * WG_RS + qa * 8;
+            *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(d + WG_ALIMB) = u32x2{m0, m1};
+            *reinterpret_cast<u32x2*>(d + 2 * WG_ALIMB) = u32x2{l0, l1};
+        }
+#pragma unroll
+        for (int i = 0; i < WG_NB; ++i) {
+            unsigned h0, m0, l0, h1, m1, l1;
+            split3(vb[i][0], vb[i][1], h0, m0, l0);
+            split3(vb[i][2], vb[i][3], h1, m1, l1);
+            unsigned char* d = Bs + ((tid + 256 * i) >> 4) * WG_RS + qa * 8;
+            *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(d + WG_BLIMB) = u32x2{m0, m1};
+            *reinterpret_cast<u32x2*>(d + 2 * WG_BLIMB) = u32x2{l0, l1};
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+
+    if (kt_beg < kt_end) load_tile(kt_beg);
+    for (int kt = kt_beg; kt < kt_end; ++kt) {
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < kt_end) load_tile(kt + 1);
+        u32x4 fa[2][3];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                const unsigned char* pa = As + l * WG_ALIMB + a_base + 16 * ks * WG_RS;
+                const u32x2 lo = lds_tr16(pa), hi = lds_tr16(pa + 4 * WG_RS);
+                fa[ks][l] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int toff = ((t / 3) * a.hw_w + (t % 3)) * WG_RS;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 fb[3];
+#pragma unroll
+                for (int l = 0; l < 3; ++l) {
+                    const u32x2 lo = lds_tr16(Bs + l * WG_BLIMB + b_base[ks][0] + toff);
+                    const u32x2 hi = lds_tr16(Bs + l * WG_BLIMB + b_base[ks][1] + toff);
+                    fb[l] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                }
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int u = 0; u < 6; ++u) acc[t] = mfma_bf16(fa[ks][PA[u]], fb[PB[u]], acc[t]);
+            }
+        }
+        __syncthreads();
+    }
+
+    float* S = a.slabs + (long long)split * a.slab_stride;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int co = co0 + wr * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+            S[((long long)co * 9 + t) * a.ld_tap + ci0 + wc * 32 + r] = acc[t][v];
+        }
 }
 
 template <int NH>
@@ -376,5 +541,47 @@ extern "C" int psld_conv3x3_split_f32(const float* x1, int c1, const float* x2, 
     else st = launch_dconv<9>(a, ns, stream);
     if (st != PSLD_OK) return st;
     if (ns >= 2) return psld_detail_conv_reduce_epilogue(a.C, ns, a.M, cout, y, ldy, e, stream);
+    return PSLD_OK;
+}
+
+extern "C" int psld_conv3x3_wgrad_split_supported(int cout, int cin, int batch, int h, int w) {
+    return cout > 0 && cin > 0 && cout % 64 == 0 && cin % 64 == 0 && batch > 0 &&
+           (w == 8 || w == 16 || w == 32 || w == 64) && (h * w) % 32 == 0;
+}
+
+extern "C" int psld_conv3x3_wgrad_split_f32(const float* dy, int lddy, int cout, const float* x, int cin, int batch,
+                                            int h, int w, float* slabs, int cin_total, int col0, int nsplit,
+                                            hipStream_t stream) {
+    PSLD_CHECK_ARG(dy && x && slabs && nsplit >= 1, "psld_conv3x3_wgrad_split_f32: bad args");
+    PSLD_CHECK_ARG(psld_conv3x3_wgrad_split_supported(cout, cin, batch, h, w),
+                   "psld_conv3x3_wgrad_split_f32: unsupported shape cout=%d cin=%d %dx%d", cout, cin, h, w);
+    PSLD_CHECK_ARG(aligned16(dy) && aligned16(x) && lddy % 4 == 0, "psld_conv3x3_wgrad_split_f32: unaligned operand");
+    DWgradArgs a{};
+    a.dy = dy; a.lddy = lddy; a.x = x; a.cin = cin;
+    a.B = batch; a.H = h; a.W = w;
+    a.cout_tiles = cout / 64; a.cin_tiles = cin / 64;
+    a.ktiles = batch * h * w / 32;
+    a.ktiles_per_split = cdiv(a.ktiles, nsplit);
+    PSLD_CHECK_ARG(cdiv(a.ktiles, a.ktiles_per_split) == nsplit, "psld_conv3x3_wgrad_split_f32: nsplit %d leaves empty slabs", nsplit);
+    a.slabs = slabs + col0;
+    a.ld_tap = cin_total;
+    a.slab_stride = (long long)cout * 9 * cin_total;
+    a.hw_w = (w < 32 ? w : 32) + 2;
+    a.hrows = (w >= 32 ? 1 : 32 / w) + 2;
+    a.zero = psld_detail_zero_page("psld_conv3x3_wgrad_split_f32");
+    if (!a.zero) return PSLD_ERR_LAUNCH;
+    constexpr size_t LDS = (size_t)3 * (WG_ALIMB + WG_BLIMB);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dwgrad_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        if (e != hipSuccess) {
+            psld_set_error("psld_conv3x3_wgrad_split_f32: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return PSLD_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL(dwgrad_kernel, dim3((unsigned)(a.cout_tiles * a.cin_tiles * nsplit)), dim3(256), LDS, stream, a);
+    PSLD_CHECK_LAUNCH("psld_conv3x3_wgrad_split_f32");
     return PSLD_OK;
 }

@@ -153,6 +153,16 @@ def conv3x3_split(x1: Tensor, x2: Optional[Tensor], wfrag: Tensor, cout: int, y:
                                        ws, wsb, _stream()), "psld_conv3x3_split_f32")
 
 
+def conv3x3_wgrad_split_supported(cout: int, cin: int, b: int, h: int, w: int) -> bool:
+    return bool(lib().psld_conv3x3_wgrad_split_supported(cout, cin, b, h, w))
+
+
+def conv3x3_wgrad_split(dy: Tensor, cout: int, x: Tensor, slabs: Tensor, cin_total: int, col0: int, nsplit: int):
+    b, h, w, cin = x.shape
+    check(lib().psld_conv3x3_wgrad_split_f32(dy.data_ptr(), cout, cout, x.data_ptr(), cin, b, h, w, slabs.data_ptr(),
+                                             cin_total, col0, nsplit, _stream()), "psld_conv3x3_wgrad_split_f32")
+
+
 def conv2d_wgrad_nhwc(dy: Tensor, cout: int, x: Tensor, kh: int, kw: int, stride: int, pad: int, oh: int, ow: int,
                       slabs: Tensor, cin_total: int, col0: int, nsplit: int):
     b, ih, iw, cin = x.shape

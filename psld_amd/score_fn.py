@@ -159,10 +159,10 @@ def _gbuf(node: _Node):
 _RESIDENT_BLOCKS = 512  # 256 CUs x 2 workgroups (64-72 KB LDS each) of the tile kernels
 
 
-def _pick_nsplit(tiles: int, k: int) -> int:
+def _pick_nsplit(tiles: int, k: int, min_k: int = 256) -> int:
     """Split-K factor of a weight-gradient GEMM: fill whole rounds of resident workgroups (a 1.5-round
-    grid wastes a quarter of the machine) while keeping >= 256 K per split."""
-    max_split = max(1, k // 256)
+    grid wastes a quarter of the machine) while keeping >= ``min_k`` K per split."""
+    max_split = max(1, k // min_k)
     best, best_eff = 1, 0.0
     for ns in range(1, min(max_split, 128) + 1):
         blocks = tiles * ns
@@ -241,6 +241,16 @@ class _Exec:
         cin = x.shape[-1]
         taps = k * k
         n = cout * taps * cin
+        if self.split and k == 3 and stride == 1 and pad == 1 and \
+                ops.conv3x3_wgrad_split_supported(cout, cin, b, oh, ow):
+            ktiles = b * oh * ow // 32
+            nsplit = _pick_nsplit((cout // 64) * (cin // 64), ktiles * 32, min_k=128)
+            per = -(-ktiles // nsplit)
+            nsplit = -(-ktiles // per)                 # every slab non-empty
+            slabs = ops.workspace(4 * n * nsplit, dy.device)
+            ops.conv3x3_wgrad_split(dy, cout, x, slabs, cin, 0, nsplit)
+            ops.reduce_slabs(slabs, nsplit, n, self.g(conv.weight), layout=1, cout=cout, taps=taps, cin=cin, alpha=alpha)
+            return
         tiles = ((cout + 127) // 128) * ((cin + 127) // 128) * taps
         nsplit = _pick_nsplit(tiles, b * oh * ow)
         slabs = ops.workspace(4 * n * nsplit, dy.device)

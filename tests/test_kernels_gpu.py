@@ -138,6 +138,132 @@ def test_conv_dgrad_and_wgrad(ops, cfg):
     assert rel_l2(dw, w.grad) < 3e-6
 
 
+# ---------------------------------------------------------------------------------------------------
+# 3x3 convolutions on bf16 limb MFMA (csrc/conv_split.hip): same fp32 tolerance as the fp32 MFMA kernels
+# ---------------------------------------------------------------------------------------------------
+def test_limb_fragments_exact(ops):
+    """The three bf16 limbs of every weight sum back to the fp32 value bit-exactly (hi + mid + lo == x), and sit
+    where the kernel's B-fragment loads expect them."""
+    co, ci = 128, 64
+    w = gen(co, ci, 3, 3, seed=90, scale=0.3)
+    w.view(-1)[:7] = torch.tensor([0.0, 1.0, -1.0, 1e-30, 1e-20, 65504.0, -3.3e38 / 4])
+    for dgrad in (False, True):
+        if dgrad:
+            w = gen(ci, co, 3, 3, seed=91, scale=0.3)    # n_out = cin must be a multiple of 128
+        frag = ops.conv3x3_frag(w.to(DEV), dgrad).cpu()
+        n_out, k_in = (w.shape[1], w.shape[0]) if dgrad else (w.shape[0], w.shape[1])
+        f = frag.view(torch.int16).view(n_out // 128, 2, k_in // 32, 9, 2, 2, 3, 64, 8)   # nt wc chunk tap ks nb limb lane j
+        limbs = (f.to(torch.int32) << 16).view(torch.float32).double().sum(dim=6)          # hi + mid + lo
+        # -> [nt, wc, chunk, tap, ks, nb, lane, j] ; n = nt*128 + wc*64 + nb*32 + lane%32 ; k = chunk*32 + ks*16 + lane//32*8 + j
+        limbs = limbs.view(n_out // 128, 2, k_in // 32, 9, 2, 2, 2, 32, 8)                 # lane -> (half, r)
+        rec = limbs.permute(0, 1, 5, 7, 2, 4, 6, 8, 3).reshape(n_out, k_in, 9)            # [n][k][tap]
+        wt = w.double().reshape(w.shape[0], w.shape[1], 9)
+        ref = wt.flip(2).permute(1, 0, 2) if dgrad else wt
+        assert torch.equal(rec, ref.contiguous())
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(b=2, c1=64, c2=0, co=128, h=8, w=8),        # two whole images per 128-pixel tile
+    dict(b=3, c1=32, c2=0, co=128, h=8, w=8),        # odd batch: the last tile holds one image only
+    dict(b=2, c1=64, c2=32, co=128, h=16, w=16),     # concat of two sources, half-image tiles
+    dict(b=1, c1=32, c2=0, co=256, h=32, w=32),      # 4-row tiles, two N tiles
+    dict(b=1, c1=32, c2=0, co=128, h=64, w=64),      # CelebA-64 resolution (2-row tiles)
+    dict(b=1, c1=256, c2=256, co=256, h=8, w=8),     # north-star K = 4608, split over the channel chunks
+    dict(b=2, c1=32, c2=0, co=128, h=4, w=8),        # h*w = 32: four images per tile
+])
+def test_conv3x3_split_forward(ops, cfg):
+    b, c1, c2, co, h, w_ = (cfg[n] for n in ("b", "c1", "c2", "co", "h", "w"))
+    assert ops.conv3x3_split_supported(c1, c2, b, h, w_, co)
+    x = gen(b, c1 + c2, h, w_, seed=40)
+    w = gen(co, c1 + c2, 3, 3, seed=41, scale=0.1)
+    bias, res = gen(co, seed=42), gen(b, co, h, w_, seed=43)
+    temb = gen(b, co, seed=44)
+    ref = (F.conv2d(x.double(), w.double(), bias.double(), padding=1) + temb.double()[:, :, None, None]
+           + res.double()) * 0.7
+    x1 = _nhwc(x[:, :c1]).to(DEV)
+    x2 = _nhwc(x[:, c1:]).to(DEV) if c2 else None
+    wf = ops.conv3x3_frag(w.to(DEV), False)
+    y = torch.full((b, h, w_, co), float("nan"), device=DEV)
+    epi = ops.epilogue(bias=bias.to(DEV), rowbias=temb.to(DEV), rows_per_img=h * w_, residual=_nhwc(res).to(DEV),
+                       ld_residual=co, out_scale=0.7)
+    ops.conv3x3_split(x1, x2, wf, co, y, epi)
+    assert rel_l2(y.permute(0, 3, 1, 2), ref) < 3e-6
+    # agrees with the fp32 MFMA kernel to fp32 rounding
+    wp = torch.empty(co, 9, c1 + c2, device=DEV)
+    ops.pack_ohwi(w.to(DEV), wp)
+    y32 = torch.empty_like(y)
+    ops.conv2d_nhwc(x1, x2, wp, co, 3, 3, 1, 1, 1, h, w_, y32, epi)
+    assert rel_l2(y, y32) < 3e-6
+
+
+def test_conv3x3_split_wide_dynamic_range(ops):
+    """Limb products keep fp32 accuracy when operands span many binades (gradients late in training are ~1e-8)."""
+    b, c, co, s = 2, 64, 128, 8
+    g = torch.Generator().manual_seed(50)
+    x = gen(b, c, s, s, seed=51) * torch.exp(torch.randn(b, c, s, s, generator=g) * 6.0) * 1e-6
+    w = gen(co, c, 3, 3, seed=52) * torch.exp(torch.randn(co, c, 3, 3, generator=g) * 4.0)
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    y = torch.empty(b, s, s, co, device=DEV)
+    ops.conv3x3_split(_nhwc(x).to(DEV), None, ops.conv3x3_frag(w.to(DEV), False), co, y)
+    ref32 = F.conv2d(x, w, padding=1)                   # plain fp32 on the CPU as the yardstick
+    assert rel_l2(y.permute(0, 3, 1, 2), ref) < 2.0 * max(rel_l2(ref32, ref), 2e-7)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(b=2, ci=128, co=64, h=8, w=8),
+    dict(b=3, ci=128, co=128, h=16, w=16),
+    dict(b=1, ci=256, co=64, h=32, w=32),
+    dict(b=1, ci=128, co=64, h=64, w=64),
+])
+def test_conv3x3_split_dgrad_and_wgrad(ops, cfg):
+    b, ci, co, h, w_ = (cfg[n] for n in ("b", "ci", "co", "h", "w"))
+    x = gen(b, ci, h, w_, seed=60).requires_grad_(True)
+    w = gen(co, ci, 3, 3, seed=61, scale=0.1).requires_grad_(True)
+    y = F.conv2d(x.double(), w.double(), padding=1)
+    gy = gen(*y.shape, seed=62)
+    y.backward(gy.double())
+    gyd = _nhwc(gy).to(DEV)
+    assert ops.conv3x3_split_supported(co, 0, b, h, w_, ci)
+    dx = torch.full((b, h, w_, ci), float("nan"), device=DEV)
+    ops.conv3x3_split(gyd, None, ops.conv3x3_frag(w.detach().to(DEV), True), ci, dx)
+    assert rel_l2(dx.permute(0, 3, 1, 2), x.grad) < 3e-6
+    # weight gradient: slabs over K ranges (one of them short), into a wider [co][9][cin_total] block at col0
+    assert ops.conv3x3_wgrad_split_supported(co, ci, b, h, w_)
+    ktiles = b * h * w_ // 32
+    nsplit = min(3, ktiles)
+    per = -(-ktiles // nsplit)
+    nsplit = -(-ktiles // per)
+    cin_total, col0 = ci + 64, 64
+    slabs = torch.zeros((nsplit, co, 9, cin_total), device=DEV)
+    ops.conv3x3_wgrad_split(gyd, co, _nhwc(x.detach()).to(DEV), slabs, cin_total, col0, nsplit)
+    dw = slabs.sum(0)[:, :, col0:].reshape(co, 3, 3, ci).permute(0, 3, 1, 2)
+    assert rel_l2(dw, w.grad) < 3e-6
+    assert torch.count_nonzero(slabs[:, :, :, :col0]) == 0
+
+
+def test_conv3x3_split_rejects_unsupported(ops):
+    assert not ops.conv3x3_split_supported(6, 0, 2, 32, 32, 128)      # stem: 6 input channels
+    assert not ops.conv3x3_split_supported(128, 0, 2, 32, 32, 6)      # head: 6 output channels
+    assert not ops.conv3x3_split_supported(64, 0, 2, 12, 12, 128)     # width not a power of two
+    assert not ops.conv3x3_wgrad_split_supported(96, 64, 2, 8, 8)
+    x = torch.zeros(2, 12, 12, 64, device=DEV)
+    with pytest.raises(RuntimeError, match="unsupported shape"):
+        ops.conv3x3_split(x, None, torch.zeros(128 * 64 * 54, dtype=torch.uint8, device=DEV), 128,
+                          torch.empty(2, 12, 12, 128, device=DEV))
+
+
+def test_math_mode_switch(ops):
+    mode = ops.math_mode()
+    try:
+        ops.set_math_mode("f32")
+        assert ops.math_mode() == "f32"
+        ops.set_math_mode("bf16x6")
+        assert ops.math_mode() == "bf16x6"
+    finally:
+        ops.set_math_mode(mode)
+
+
+
 def test_gemm_tn_splitk(ops):
     M, N, K = 64, 96, 1000
     A, B = gen(K, M, seed=30), gen(K, N, seed=31)

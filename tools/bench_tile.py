@@ -67,6 +67,17 @@ def main():
         slabs = torch.empty(nsplit, cout, 9, cin, device=DEV)
         t = timeit(lambda: ops.conv2d_wgrad_nhwc(dy, cout, x, 3, 3, 1, 1, s, s, slabs, cin, 0, nsplit), args.iters)
         rows.append((f"conv wgrad {cin}->{cout} @{s} (split {nsplit})", fl / t / 1e12, t * 1e6))
+        if ops.conv3x3_wgrad_split_supported(cout, cin, B, s, s):
+            tiles = (cout // 64) * (cin // 64)
+            kt = B * s * s // 32
+            ns2 = max(1, min(512 // tiles, kt // 4))
+            per = -(-kt // ns2)
+            ns2 = -(-kt // per)
+            slabs2 = torch.empty(ns2, cout, 9, cin, device=DEV)
+            t = timeit(lambda: ops.conv3x3_wgrad_split(dy, cout, x, slabs2, cin, 0, ns2), args.iters)
+            ref = slabs.sum(0)
+            err = ((slabs2.sum(0) - ref).norm() / ref.norm()).item()
+            rows.append((f"conv wgrad {cin}->{cout} @{s} bf16x6 (split {ns2}, rel {err:.1e})", fl / t / 1e12, t * 1e6))
     for name, tf, us in rows:
         print(f"{name:54s} {tf:7.1f} TF  {us:9.1f} us")
 
