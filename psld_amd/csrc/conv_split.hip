@@ -261,16 +261,16 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
 
 
 // ---- weight gradient ---------------------------------------------------------------------------------------
-// dW[co][tap][ci] = sum_p dy[p][co] * x[p + tap][ci].  One workgroup owns a 64 (co) x 64 (ci) tile for ALL nine taps
-// (each wave 32 x 32 x 9 = nine accumulators) over a range of 32-pixel K tiles: per K tile the dy rows and a
-// (rows+2) x (W+2) halo of x are split into limbs once and kept in LDS as [pixel][channel] images; both MFMA
-// operands need k (= pixel) along the register, so the fragments come from ds_read_b64_tr_b16 transposed reads
-// (rows of 192 B: the four pixel rows of a read land in disjoint bank quarters), the x fragment of tap (ky, kx)
-// simply (ky*(W+2) + kx) rows further.
+// dW[co][tap][ci] = sum_p dy[p][co] * x[p + tap][ci].  One workgroup owns a 64 (co) x 64 (ci) tile for the three
+// taps of ONE filter row ky (each wave 32 x 32 x 3 = three independent accumulator chains, 48 VGPRs, so three waves
+// fit per SIMD) over a range of 32-pixel K tiles: per K tile the dy rows and the input row(s) oy + ky - 1 of x,
+// W + 2 pixels wide, are split into limbs once and kept in LDS as [pixel][channel] images.  Both MFMA operands need
+// k (= pixel) along the register, so the fragments come from ds_read_b64_tr_b16 transposed reads (rows of 192 B: the
+// four pixel rows of a read land in disjoint bank quarters); the x fragment of tap kx sits kx rows further.
 constexpr int WG_RS = 192;           // bytes per pixel row and limb: 64 channels bf16 + 64 pad
-constexpr int WG_AROWS = 32, WG_BROWS = 112;
+constexpr int WG_AROWS = 32, WG_BROWS = 48;
 constexpr int WG_ALIMB = WG_AROWS * WG_RS, WG_BLIMB = WG_BROWS * WG_RS;
-constexpr int WG_NB = 7;             // x halo float4 items per thread (112 rows x 16 quads / 256)
+constexpr int WG_NB = 3;             // x float4 items per thread (48 rows x 16 quads / 256)
 
 struct DWgradArgs {
     const float* dy;
@@ -283,8 +283,8 @@ struct DWgradArgs {
     float* slabs;
     int ld_tap;             // cin_total: stride between taps of one output channel
     long long slab_stride;
-    int hw_w;               // halo width = min(W, 32) + 2
-    int hrows;              // halo rows = max(1, 32 / W) + 2
+    int hw_w;               // staged row width = min(W, 32) + 2
+    int hrows;              // staged rows per K tile = max(1, 32 / W)
     const float* zero;
 };
 
@@ -296,10 +296,10 @@ __device__ __forceinline__ u32x2 lds_tr16(const unsigned char* p) {
     return __builtin_bit_cast(u32x2, v);
 }
 
-__global__ void __launch_bounds__(256, 2) dwgrad_kernel(const DWgradArgs a) {
+__global__ void __launch_bounds__(256, 3) dwgrad_kernel(const DWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* As = smem;                    // [3][32][192]
-    unsigned char* Bs = smem + 3 * WG_ALIMB;     // [3][112][192]
+    unsigned char* Bs = smem + 3 * WG_ALIMB;     // [3][48][192]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -309,7 +309,9 @@ __global__ void __launch_bounds__(256, 2) dwgrad_kernel(const DWgradArgs a) {
     // blocks of one K range read the same pixels: keep them on one XCD (shared L2)
     const int tiles = a.cout_tiles * a.cin_tiles;
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile = vid % tiles, split = vid / tiles;
+    const int split = vid / (tiles * 3);
+    const int rest = vid - split * tiles * 3;
+    const int ky = rest / tiles, tile = rest - ky * tiles;
     const int co0 = (tile / a.cin_tiles) * 64, ci0 = (tile % a.cin_tiles) * 64;
     const int kt_beg = split * a.ktiles_per_split;
     const int kt_end = min(a.ktiles, kt_beg + a.ktiles_per_split);
@@ -331,7 +333,14 @@ __global__ void __launch_bounds__(256, 2) dwgrad_kernel(const DWgradArgs a) {
             b_base[ks][j] = (ry * a.hw_w + ox) * WG_RS + (wc * 32 + 16 * chalf + 4 * p4) * 2;
         }
 
-    const int qa = tid & 15, ra = tid >> 4;     // dy staging: channel quad, pixel row (+16)
+    const int qa = tid & 15, ra = tid >> 4;     // staging: channel quad, pixel row (+16 per item)
+    int hrow[WG_NB], hcol[WG_NB];               // staged x row / column of every item (K-tile invariant)
+#pragma unroll
+    for (int i = 0; i < WG_NB; ++i) {
+        const int px = ra + 16 * i;
+        hrow[i] = px / a.hw_w;
+        hcol[i] = px - hrow[i] * a.hw_w;
+    }
     f32x4 va[2], vb[WG_NB];
     auto load_tile = [&](int kt) {
         const int p0 = kt * 32;
@@ -342,83 +351,68 @@ __global__ void __launch_bounds__(256, 2) dwgrad_kernel(const DWgradArgs a) {
         for (int i = 0; i < 2; ++i) va[i] = ld4(a.dy + ((long long)(p0 + ra + 16 * i) * a.lddy + co0 + qa * 4));
 #pragma unroll
         for (int i = 0; i < WG_NB; ++i) {
-            const int px = (tid + 256 * i) >> 4;
-            const int hr = px / a.hw_w, hx = px - hr * a.hw_w;
-            const int iy = oy0 + hr - 1, ix = ox0 + hx - 1;
-            const bool ok = hr < a.hrows && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const int iy = oy0 + hrow[i] + ky - 1, ix = ox0 + hcol[i] - 1;
+            const bool ok = hrow[i] < a.hrows && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
             vb[i] = ld4(ok ? a.x + ((long long)((img * a.H + iy) * a.W + ix) * a.cin + ci0 + qa * 4) : zp);
         }
     };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            unsigned h0, m0, l0, h1, m1, l1;
-            split3(va[i][0], va[i][1], h0, m0, l0);
-            split3(va[i][2], va[i][3], h1, m1, l1);
-            unsigned char* d = As + (ra + 16 * i) * WG_RS + qa * 8;
-            *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
-            *reinterpret_cast<u32x2*>(d + WG_ALIMB) = u32x2{m0, m1};
-            *reinterpret_cast<u32x2*>(d + 2 * WG_ALIMB) = u32x2{l0, l1};
-        }
-#pragma unroll
-        for (int i = 0; i < WG_NB; ++i) {
-            unsigned h0, m0, l0, h1, m1, l1;
-            split3(vb[i][0], vb[i][1], h0, m0, l0);
-            split3(vb[i][2], vb[i][3], h1, m1, l1);
-            unsigned char* d = Bs + ((tid + 256 * i) >> 4) * WG_RS + qa * 8;
-            *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
-            *reinterpret_cast<u32x2*>(d + WG_BLIMB) = u32x2{m0, m1};
-            *reinterpret_cast<u32x2*>(d + 2 * WG_BLIMB) = u32x2{l0, l1};
-        }
+    auto store_rows = [&](unsigned char* img, int limb_stride, const f32x4& v, int row) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        split3(v[0], v[1], h0, m0, l0);
+        split3(v[2], v[3], h1, m1, l1);
+        unsigned char* d = img + row * WG_RS + qa * 8;
+        *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(d + limb_stride) = u32x2{m0, m1};
+        *reinterpret_cast<u32x2*>(d + 2 * limb_stride) = u32x2{l0, l1};
     };
 
-    f32x16 acc[9];
+    f32x16 acc[3];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
 
     if (kt_beg < kt_end) load_tile(kt_beg);
     for (int kt = kt_beg; kt < kt_end; ++kt) {
-        store_tile();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) store_rows(As, WG_ALIMB, va[i], ra + 16 * i);
+#pragma unroll
+        for (int i = 0; i < WG_NB; ++i) store_rows(Bs, WG_BLIMB, vb[i], ra + 16 * i);
         __syncthreads();
         if (kt + 1 < kt_end) load_tile(kt + 1);
-        u32x4 fa[2][3];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 fa[3], fb[3][3];
 #pragma unroll
             for (int l = 0; l < 3; ++l) {
                 const unsigned char* pa = As + l * WG_ALIMB + a_base + 16 * ks * WG_RS;
                 const u32x2 lo = lds_tr16(pa), hi = lds_tr16(pa + 4 * WG_RS);
-                fa[ks][l] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                fa[l] = u32x4{lo[0], lo[1], hi[0], hi[1]};
             }
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int toff = ((t / 3) * a.hw_w + (t % 3)) * WG_RS;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                u32x4 fb[3];
+            for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
                 for (int l = 0; l < 3; ++l) {
-                    const u32x2 lo = lds_tr16(Bs + l * WG_BLIMB + b_base[ks][0] + toff);
-                    const u32x2 hi = lds_tr16(Bs + l * WG_BLIMB + b_base[ks][1] + toff);
-                    fb[l] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                    const u32x2 lo = lds_tr16(Bs + l * WG_BLIMB + b_base[ks][0] + tx * WG_RS);
+                    const u32x2 hi = lds_tr16(Bs + l * WG_BLIMB + b_base[ks][1] + tx * WG_RS);
+                    fb[tx][l] = u32x4{lo[0], lo[1], hi[0], hi[1]};
                 }
-                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-                for (int u = 0; u < 6; ++u) acc[t] = mfma_bf16(fa[ks][PA[u]], fb[PB[u]], acc[t]);
-            }
+            for (int u = 0; u < 6; ++u)
+#pragma unroll
+                for (int tx = 0; tx < 3; ++tx) acc[tx] = mfma_bf16(fa[PA[u]], fb[tx][PB[u]], acc[tx]);
         }
         __syncthreads();
     }
 
     float* S = a.slabs + (long long)split * a.slab_stride;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int co = co0 + wr * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-            S[((long long)co * 9 + t) * a.ld_tap + ci0 + wc * 32 + r] = acc[t][v];
+            S[((long long)co * 9 + ky * 3 + tx) * a.ld_tap + ci0 + wc * 32 + r] = acc[tx][v];
         }
 }
 
@@ -567,7 +561,7 @@ extern "C" int psld_conv3x3_wgrad_split_f32(const float* dy, int lddy, int cout,
     a.ld_tap = cin_total;
     a.slab_stride = (long long)cout * 9 * cin_total;
     a.hw_w = (w < 32 ? w : 32) + 2;
-    a.hrows = (w >= 32 ? 1 : 32 / w) + 2;
+    a.hrows = w >= 32 ? 1 : 32 / w;
     a.zero = psld_detail_zero_page("psld_conv3x3_wgrad_split_f32");
     if (!a.zero) return PSLD_ERR_LAUNCH;
     constexpr size_t LDS = (size_t)3 * (WG_ALIMB + WG_BLIMB);
@@ -581,7 +575,7 @@ extern "C" int psld_conv3x3_wgrad_split_f32(const float* dy, int lddy, int cout,
         }
         configured = true;
     }
-    hipLaunchKernelGGL(dwgrad_kernel, dim3((unsigned)(a.cout_tiles * a.cin_tiles * nsplit)), dim3(256), LDS, stream, a);
+    hipLaunchKernelGGL(dwgrad_kernel, dim3((unsigned)(a.cout_tiles * a.cin_tiles * 3 * nsplit)), dim3(256), LDS, stream, a);
     PSLD_CHECK_LAUNCH("psld_conv3x3_wgrad_split_f32");
     return PSLD_OK;
 }

@@ -159,15 +159,15 @@ def _gbuf(node: _Node):
 _RESIDENT_BLOCKS = 512  # 256 CUs x 2 workgroups (64-72 KB LDS each) of the tile kernels
 
 
-def _pick_nsplit(tiles: int, k: int, min_k: int = 256) -> int:
+def _pick_nsplit(tiles: int, k: int, min_k: int = 256, resident: int = _RESIDENT_BLOCKS) -> int:
     """Split-K factor of a weight-gradient GEMM: fill whole rounds of resident workgroups (a 1.5-round
     grid wastes a quarter of the machine) while keeping >= ``min_k`` K per split."""
     max_split = max(1, k // min_k)
     best, best_eff = 1, 0.0
     for ns in range(1, min(max_split, 128) + 1):
         blocks = tiles * ns
-        rounds = -(-blocks // _RESIDENT_BLOCKS)
-        eff = blocks / (rounds * _RESIDENT_BLOCKS)
+        rounds = -(-blocks // resident)
+        eff = blocks / (rounds * resident)
         if eff > best_eff + 0.02:
             best, best_eff = ns, eff
     return best
@@ -244,7 +244,8 @@ class _Exec:
         if self.split and k == 3 and stride == 1 and pad == 1 and \
                 ops.conv3x3_wgrad_split_supported(cout, cin, b, oh, ow):
             ktiles = b * oh * ow // 32
-            nsplit = _pick_nsplit((cout // 64) * (cin // 64), ktiles * 32, min_k=128)
+            # 64x64 tiles x 3 filter rows, 3 workgroups (46 KB LDS) resident per CU
+            nsplit = _pick_nsplit((cout // 64) * (cin // 64) * 3, ktiles * 32, min_k=128, resident=768)
             per = -(-ktiles // nsplit)
             nsplit = -(-ktiles // per)                 # every slab non-empty
             slabs = ops.workspace(4 * n * nsplit, dy.device)

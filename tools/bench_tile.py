@@ -70,7 +70,7 @@ def main():
         if ops.conv3x3_wgrad_split_supported(cout, cin, B, s, s):
             tiles = (cout // 64) * (cin // 64)
             kt = B * s * s // 32
-            ns2 = max(1, min(512 // tiles, kt // 4))
+            ns2 = max(1, min(768 // (3 * tiles), kt // 4))
             per = -(-kt // ns2)
             ns2 = -(-kt // per)
             slabs2 = torch.empty(ns2, cout, 9, cin, device=DEV)
