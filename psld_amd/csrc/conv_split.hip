@@ -13,7 +13,7 @@
 // and read at nine shifted offsets — and the weights are pre-split once per optimizer step into MFMA fragment
 // order, so a wave fetches its B fragments straight from L2 with one coalesced 16-byte load per lane: no LDS
 // staging, no conversion and no barrier per tap.  Per tap a wave issues 12 global loads, 12 ds_read_b128 and
-// 48 MFMAs.
+// 96 v_mfma_f32_16x16x32_bf16.
 //
 // Replaces nn.Conv2d 3x3 (song_sde/layers.py:85-109 via layerspp.py:29-39) forward and backward for the layers
 // whose channel counts are multiples of 32 (in) / 128 (out) — every ResBlock conv of the C10 / CelebA-64 nets.
@@ -32,7 +32,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 constexpr int ROWB = 80;        // bytes per pixel and limb in the LDS halo image: 32 bf16 + 8 pad (conflict-free b128)
-constexpr int STEP_U4 = 2 * 3 * 64;  // uint4 per (wave column, K step of 16): [n-block 2][limb 3][lane 64]
+constexpr int TAP_U4 = 4 * 3 * 64;   // uint4 per (wave column, tap, 32-channel chunk): [n-block 4][limb 3][lane 64]
 
 int g_math_mode = -1;
 inline int math_mode() {
@@ -58,13 +58,16 @@ __device__ __forceinline__ void split3(float x0, float x1, unsigned& hi, unsigne
     lo = __builtin_bit_cast(unsigned, pl);
 }
 
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
 // ---- weights -> limb fragments ---------------------------------------------------------------------------
-// out[nt][wc][chunk][tap][ks][nb][limb][lane] (uint4 = 8 bf16): n = nt*128 + wc*64 + nb*32 + (lane & 31),
-// k = chunk*32 + ks*16 + (lane >> 5)*8 + j.   dgrad = 0: B[n][k] = w[co = n][ci = k][tap];
+// Operand order of v_mfma_f32_16x16x32_bf16: lane l holds B[k = 8*(l >> 4) + j][col = l & 15], j = 0..7.
+// out[nt][wc][chunk][tap][nb][limb][lane] (uint4 = 8 bf16): n = nt*128 + wc*64 + nb*16 + (lane & 15),
+// k = chunk*32 + (lane >> 4)*8 + j.   dgrad = 0: B[n][k] = w[co = n][ci = k][tap];
 // dgrad = 1: B[n][k] = w[co = k][ci = n][8 - tap] (the data-gradient of a stride-1 pad-1 3x3 conv is the same
 // conv with the taps flipped and the channel roles swapped).
 __global__ void pack_frag_kernel(const float* __restrict__ w, u32x4* __restrict__ out, int cout, int cin, int dgrad) {
@@ -76,14 +79,13 @@ __global__ void pack_frag_kernel(const float* __restrict__ w, u32x4* __restrict_
         long long t = idx;
         const int lane = (int)(t & 63); t >>= 6;
         const int limb = (int)(t % 3); t /= 3;
-        const int nb = (int)(t & 1); t >>= 1;
-        const int ks = (int)(t & 1); t >>= 1;
+        const int nb = (int)(t & 3); t >>= 2;
         const int tap = (int)(t % 9); t /= 9;
         const int chunk = (int)(t % chunks); t /= chunks;
         const int wc = (int)(t & 1); t >>= 1;
         const int nt = (int)t;
-        const int n = nt * 128 + wc * 64 + nb * 32 + (lane & 31);
-        const int k0 = chunk * 32 + ks * 16 + (lane >> 5) * 8;
+        const int n = nt * 128 + wc * 64 + nb * 16 + (lane & 15);
+        const int k0 = chunk * 32 + (lane >> 4) * 8;
         unsigned v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -128,7 +130,6 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int r = lane & 31, h = lane >> 5;
     const int c4 = tid & 7;
 
     const int tiles_n = a.N >> 7;
@@ -180,69 +181,79 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
         }
     };
 
-    // LDS byte offset of this lane's A fragment rows at tap (0, 0)
-    int abase[2];
+    // v_mfma_f32_16x16x32_bf16 (under this load it sustains a ~15 % higher clock than 32x32x16: measured 212 vs 184
+    // TFLOP/s on 256->256 @32x32): the 64x64 wave tile is 4x4 blocks, one 32-deep K step per tap and chunk.
+    // Lane l holds A[row = l & 15][k = 8*(l >> 4) + j]: LDS byte offset of its rows at tap (0, 0)
+    const int r16 = lane & 15, kq = lane >> 4;
+    int abase[4];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-        const int ml = wr * 64 + mb * 32 + r;
+    for (int mb = 0; mb < 4; ++mb) {
+        const int ml = wr * 64 + mb * 16 + r16;
         const int seg = ml / (a.rps * a.W);
         const int rem = ml - seg * (a.rps * a.W);
         const int ry = rem / a.W, ox = rem - ry * a.W;
-        abase[mb] = ((seg * (a.rps + 2) + ry) * W2 + ox) * ROWB + h * 16;
+        abase[mb] = ((seg * (a.rps + 2) + ry) * W2 + ox) * ROWB + kq * 16;
     }
 
-    // B fragments of K step sigma = (chunk*9 + tap)*2 + ks for this wave's 64 columns
-    const u32x4* wp = a.wfrag + ((long long)(tile_n * 2 + wc) * a.chunks * 18) * STEP_U4 + lane;
-    const int sig_last = c_end * 18 - 1;
-    u32x4 bq[2][2][3];
-    auto load_b = [&](int sigma, u32x4 (&dst)[2][3]) {
-        const u32x4* p = wp + (long long)min(sigma, sig_last) * STEP_U4;
+    // B fragments of K step sigma = chunk*9 + tap for this wave's 64 columns
+    const u32x4* wp = a.wfrag + ((long long)(tile_n * 2 + wc) * a.chunks * 9) * TAP_U4 + lane;
+    const int sig_last = c_end * 9 - 1;
+    u32x4 bq[2][4][3];
+    auto load_b = [&](int sigma, u32x4 (&dst)[4][3]) {
+        const u32x4* p = wp + (long long)min(sigma, sig_last) * TAP_U4;
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
             for (int l = 0; l < 3; ++l) dst[nb][l] = p[(nb * 3 + l) * 64];
     };
 
-    f32x16 acc[2][2];
+    f32x4v acc[4][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
     load_halo(c_beg);
-    load_b(c_beg * 18, bq[0]);
+    load_b(c_beg * 9, bq[0]);
     store_halo();
     __syncthreads();
 
     for (int c = c_beg; c < c_end; ++c) {
         const bool more = (c + 1) < c_end;
         int tap_off = 0, kx = 0;
-        for (int tap = 0; tap < 9; ++tap) {
-            if (tap == 7 && more) load_halo(c + 1);
+        for (int tap2 = 0; tap2 < 10; tap2 += 2) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                // (pinning these loads ahead of the MFMA block with sched_barrier costs the third wave per SIMD and
-                // measures no faster: at 1.64 GHz under bf16 MFMA load the kernel sits at the chip's power limit)
-                load_b((c * 9 + tap) * 2 + ks + 1, bq[ks ^ 1]);
-                u32x4 fa[2][3];
+            for (int pp = 0; pp < 2; ++pp) {       // taps alternate between the two B fragment buffers
+                const int tap = tap2 + pp;
+                if (tap < 9) {
+                    if (tap == 7 && more) load_halo(c + 1);
+                    load_b(c * 9 + tap + 1, bq[pp ^ 1]);
+                    u32x4 fa[4][3];
 #pragma unroll
-                for (int mb = 0; mb < 2; ++mb)
+                    for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-                    for (int l = 0; l < 3; ++l)
-                        fa[mb][l] = *reinterpret_cast<const u32x4*>(smem + l * LIMB + abase[mb] + tap_off + ks * 32);
-                // limb products, smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
-                constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+                        for (int l = 0; l < 3; ++l)
+                            fa[mb][l] = *reinterpret_cast<const u32x4*>(smem + l * LIMB + abase[mb] + tap_off);
+                    // limb products, smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
+                    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-                for (int t = 0; t < 6; ++t)
+                    for (int t = 0; t < 6; ++t)
 #pragma unroll
-                    for (int mb = 0; mb < 2; ++mb)
+                        for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-                        for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = mfma_bf16(fa[mb][PA[t]], bq[ks][nb][PB[t]], acc[mb][nb]);
+                            for (int nb = 0; nb < 4; ++nb)
+                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                    __builtin_bit_cast(bf16x8, fa[mb][PA[t]]), __builtin_bit_cast(bf16x8, bq[pp][nb][PB[t]]),
+                                    acc[mb][nb], 0, 0, 0);
+                    if (++kx == 3) { kx = 0; tap_off += (W2 - 2) * ROWB; } else { tap_off += ROWB; }
+                }
             }
-            if (++kx == 3) { kx = 0; tap_off += (W2 - 2) * ROWB; } else { tap_off += ROWB; }
         }
+        // tap 8 read bq[0] and prefetched the next chunk's tap 0 into bq[1]: move it to where tap 0 reads
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) bq[0][nb][l] = bq[1][nb][l];
         __syncthreads();
         if (more) {
             store_halo();
@@ -250,15 +261,34 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
         }
     }
 
+    // fused epilogue; C/D layout of the 16x16 MFMA: col = lane & 15, row = 4*(lane >> 4) + v
     float* Cb = a.C + (long long)split * a.c_stride_split;
+    const PsldEpilogue& e = a.e;
+    const bool rb_uniform = e.rowbias && (e.rows_per_img % 16 == 0);
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+    for (int mb = 0; mb < 4; ++mb) {
+        const int row_base = m0 + wr * 64 + mb * 16;
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-            epilogue_store_block(acc[mb][nb], m0 + wr * 64 + mb * 32, n0 + wc * 64 + nb * 32 + r, h, a.M, a.N, Cb, a.ldc,
-                                 a.e.res, a.e);
+        for (int nb = 0; nb < 4; ++nb) {
+            const int gn = n0 + wc * 64 + nb * 16 + r16;
+            float bias = e.bias ? e.bias[gn] : 0.f;
+            // time-embedding bias: one value per (image, channel); a 16-row block never straddles images
+            if (rb_uniform) bias += e.rowbias[(long long)(row_base / e.rows_per_img) * e.ld_rowbias + gn];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int gm = row_base + 4 * kq + v;
+                if (gm >= a.M) continue;
+                float x = acc[mb][nb][v] * e.alpha + bias;
+                if (e.rowbias && !rb_uniform) x += e.rowbias[(long long)(gm / e.rows_per_img) * e.ld_rowbias + gn];
+                if (e.res) x += e.res[(long long)gm * e.ldres + gn];
+                x *= e.out_scale;
+                float* cp = Cb + (long long)gm * a.ldc + gn;
+                if (e.accumulate) x += *cp;
+                *cp = x;
+            }
+        }
+    }
 }
-
 
 // ---- weight gradient ---------------------------------------------------------------------------------------
 // dW[co][tap][ci] = sum_p dy[p][co] * x[p + tap][ci].  One workgroup owns a 64 (co) x 64 (ci) tile for the three

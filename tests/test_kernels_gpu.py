@@ -152,11 +152,11 @@ def test_limb_fragments_exact(ops):
             w = gen(ci, co, 3, 3, seed=91, scale=0.3)    # n_out = cin must be a multiple of 128
         frag = ops.conv3x3_frag(w.to(DEV), dgrad).cpu()
         n_out, k_in = (w.shape[1], w.shape[0]) if dgrad else (w.shape[0], w.shape[1])
-        f = frag.view(torch.int16).view(n_out // 128, 2, k_in // 32, 9, 2, 2, 3, 64, 8)   # nt wc chunk tap ks nb limb lane j
-        limbs = (f.to(torch.int32) << 16).view(torch.float32).double().sum(dim=6)          # hi + mid + lo
-        # -> [nt, wc, chunk, tap, ks, nb, lane, j] ; n = nt*128 + wc*64 + nb*32 + lane%32 ; k = chunk*32 + ks*16 + lane//32*8 + j
-        limbs = limbs.view(n_out // 128, 2, k_in // 32, 9, 2, 2, 2, 32, 8)                 # lane -> (half, r)
-        rec = limbs.permute(0, 1, 5, 7, 2, 4, 6, 8, 3).reshape(n_out, k_in, 9)            # [n][k][tap]
+        f = frag.view(torch.int16).view(n_out // 128, 2, k_in // 32, 9, 4, 3, 64, 8)      # nt wc chunk tap nb limb lane j
+        limbs = (f.to(torch.int32) << 16).view(torch.float32).double().sum(dim=5)          # hi + mid + lo
+        # lane -> (k group of 8, column): n = nt*128 + wc*64 + nb*16 + lane%16 ; k = chunk*32 + lane//16*8 + j
+        limbs = limbs.view(n_out // 128, 2, k_in // 32, 9, 4, 4, 16, 8)                    # nt wc chunk tap nb kq col j
+        rec = limbs.permute(0, 1, 4, 6, 2, 5, 7, 3).reshape(n_out, k_in, 9)               # [n][k][tap]
         wt = w.double().reshape(w.shape[0], w.shape[1], 9)
         ref = wt.flip(2).permute(1, 0, 2) if dgrad else wt
         assert torch.equal(rec, ref.contiguous())
