@@ -292,12 +292,14 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
 
 // ---- weight gradient ---------------------------------------------------------------------------------------
 // dW[co][tap][ci] = sum_p dy[p][co] * x[p + tap][ci].  One workgroup owns a 64 (co) x 64 (ci) tile for the three
-// taps of ONE filter row ky (each wave 32 x 32 x 3 = three independent accumulator chains, 48 VGPRs, so three waves
-// fit per SIMD) over a range of 32-pixel K tiles: per K tile the dy rows and the input row(s) oy + ky - 1 of x,
-// W + 2 pixels wide, are split into limbs once and kept in LDS as [pixel][channel] images.  Both MFMA operands need
-// k (= pixel) along the register, so the fragments come from ds_read_b64_tr_b16 transposed reads (rows of 192 B: the
-// four pixel rows of a read land in disjoint bank quarters); the x fragment of tap kx sits kx rows further.
-constexpr int WG_RS = 192;           // bytes per pixel row and limb: 64 channels bf16 + 64 pad
+// taps of ONE filter row ky (each wave 32 x 32 x 3 taps = twelve 16x16 accumulators, 48 VGPRs, so four waves fit
+// per SIMD) over a range of 32-pixel K tiles: per K tile the dy rows and the input row(s) oy + ky - 1 of x, W + 2
+// pixels wide, are split into limbs once and kept in LDS as [pixel][channel] images.  Both MFMA operands need
+// k (= pixel) along the register, so the fragments come from ds_read_b64_tr_b16 transposed reads; the x fragment of
+// tap kx sits kx rows further.  One v_mfma_f32_16x16x32_bf16 consumes the whole K tile; its k slot (group g = lane
+// >> 4, j, q) is pixel 4g + 16j + q, so the two 16-lane groups of a half-wave read eight CONSECUTIVE pixel rows,
+// which the 160-byte row stride spreads over all 64 banks (conflict-free).
+constexpr int WG_RS = 160;           // bytes per pixel row and limb: 64 channels bf16 + 32 pad
 constexpr int WG_AROWS = 32, WG_BROWS = 48;
 constexpr int WG_ALIMB = WG_AROWS * WG_RS, WG_BLIMB = WG_BROWS * WG_RS;
 constexpr int WG_NB = 3;             // x float4 items per thread (48 rows x 16 quads / 256)
@@ -328,13 +330,12 @@ __device__ __forceinline__ u32x2 lds_tr16(const unsigned char* p) {
 
 __global__ void __launch_bounds__(256, 3) dwgrad_kernel(const DWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* As = smem;                    // [3][32][192]
-    unsigned char* Bs = smem + 3 * WG_ALIMB;     // [3][48][192]
+    unsigned char* As = smem;                    // [3][32][160]
+    unsigned char* Bs = smem + 3 * WG_ALIMB;     // [3][48][160]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int r = lane & 31, h = lane >> 5;
 
     // blocks of one K range read the same pixels: keep them on one XCD (shared L2)
     const int tiles = a.cout_tiles * a.cin_tiles;
@@ -348,20 +349,18 @@ __global__ void __launch_bounds__(256, 3) dwgrad_kernel(const DWgradArgs a) {
     const int HW = a.H * a.W;
     const float* zp = a.zero;
 
-    // transposed-read lane roles: group of 16 lanes = 4 pixel rows x 16 channels
-    const int g = lane >> 4, li = lane & 15, q = li >> 2, p4 = li & 3;
-    const int khalf = g >> 1, chalf = g & 1;
-    const int a_base = (8 * khalf + q) * WG_RS + (wr * 32 + 16 * chalf + 4 * p4) * 2;
-    int b_base[2][2];
+    // transposed-read lane roles: a group of 16 lanes reads 4 pixel rows x 16 channels; lane 4q + p supplies the
+    // address of row q, channels 4p..4p+3 and receives channel (lane & 15) of the four rows
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3;
+    int a_base[2], b_base[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int k = 16 * ks + 8 * khalf + 4 * j + q;
-            const int ry = a.W >= 32 ? 0 : k / a.W;
-            const int ox = a.W >= 32 ? k : k - ry * a.W;
-            b_base[ks][j] = (ry * a.hw_w + ox) * WG_RS + (wc * 32 + 16 * chalf + 4 * p4) * 2;
-        }
+    for (int j = 0; j < 2; ++j) {
+        const int k = 4 * g + 16 * j + q;              // pixel of this lane's row in read j
+        a_base[j] = k * WG_RS + (wr * 32 + 4 * p4) * 2;
+        const int ry = a.W >= 32 ? 0 : k / a.W;
+        const int ox = a.W >= 32 ? k : k - ry * a.W;
+        b_base[j] = (ry * a.hw_w + ox) * WG_RS + (wc * 32 + 4 * p4) * 2;
+    }
 
     const int qa = tid & 15, ra = tid >> 4;     // staging: channel quad, pixel row (+16 per item)
     int hrow[WG_NB], hcol[WG_NB];               // staged x row / column of every item (K-tile invariant)
@@ -395,12 +394,18 @@ __global__ void __launch_bounds__(256, 3) dwgrad_kernel(const DWgradArgs a) {
         *reinterpret_cast<u32x2*>(d + limb_stride) = u32x2{m0, m1};
         *reinterpret_cast<u32x2*>(d + 2 * limb_stride) = u32x2{l0, l1};
     };
+    auto frag = [&](const unsigned char* img, const int (&base)[2], int off) -> u32x4 {
+        const u32x2 lo = lds_tr16(img + base[0] + off), hi = lds_tr16(img + base[1] + off);
+        return u32x4{lo[0], lo[1], hi[0], hi[1]};
+    };
 
-    f32x16 acc[3];
+    f32x4v acc[3][2][2];
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
     if (kt_beg < kt_end) load_tile(kt_beg);
     for (int kt = kt_beg; kt < kt_end; ++kt) {
@@ -410,40 +415,45 @@ __global__ void __launch_bounds__(256, 3) dwgrad_kernel(const DWgradArgs a) {
         for (int i = 0; i < WG_NB; ++i) store_rows(Bs, WG_BLIMB, vb[i], ra + 16 * i);
         __syncthreads();
         if (kt + 1 < kt_end) load_tile(kt + 1);
+        u32x4 fa[2][3];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            u32x4 fa[3], fb[3][3];
+        for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int l = 0; l < 3; ++l) {
-                const unsigned char* pa = As + l * WG_ALIMB + a_base + 16 * ks * WG_RS;
-                const u32x2 lo = lds_tr16(pa), hi = lds_tr16(pa + 4 * WG_RS);
-                fa[l] = u32x4{lo[0], lo[1], hi[0], hi[1]};
-            }
+            for (int l = 0; l < 3; ++l) fa[cb][l] = frag(As, a_base, l * WG_ALIMB + cb * 32);
 #pragma unroll
-            for (int tx = 0; tx < 3; ++tx)
+        for (int tx = 0; tx < 3; ++tx) {
+            u32x4 fb[2][3];
 #pragma unroll
-                for (int l = 0; l < 3; ++l) {
-                    const u32x2 lo = lds_tr16(Bs + l * WG_BLIMB + b_base[ks][0] + tx * WG_RS);
-                    const u32x2 hi = lds_tr16(Bs + l * WG_BLIMB + b_base[ks][1] + tx * WG_RS);
-                    fb[tx][l] = u32x4{lo[0], lo[1], hi[0], hi[1]};
-                }
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int l = 0; l < 3; ++l) fb[nb][l] = frag(Bs, b_base, l * WG_BLIMB + nb * 32 + tx * WG_RS);
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
             for (int u = 0; u < 6; ++u)
 #pragma unroll
-                for (int tx = 0; tx < 3; ++tx) acc[tx] = mfma_bf16(fa[PA[u]], fb[tx][PB[u]], acc[tx]);
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+                        acc[tx][cb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, fa[cb][PA[u]]), __builtin_bit_cast(bf16x8, fb[nb][PB[u]]),
+                            acc[tx][cb][nb], 0, 0, 0);
         }
         __syncthreads();
     }
 
+    // C/D layout of the 16x16 MFMA: col (ci) = lane & 15, row (co) = 4*(lane >> 4) + v
     float* S = a.slabs + (long long)split * a.slab_stride;
 #pragma unroll
     for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int co = co0 + wr * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-            S[((long long)co * 9 + ky * 3 + tx) * a.ld_tap + ci0 + wc * 32 + r] = acc[tx][v];
-        }
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int co = co0 + wr * 32 + cb * 16 + 4 * g + v;
+                    S[((long long)co * 9 + ky * 3 + tx) * a.ld_tap + ci0 + wc * 32 + nb * 16 + i16] = acc[tx][cb][nb][v];
+                }
 }
 
 template <int NH>
