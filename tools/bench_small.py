@@ -1,0 +1,41 @@
+import os, sys, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from psld_amd import ops
+ops.lib()
+DEV="cuda"
+def timeit(fn, iters=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e)/iters*1e-3
+B=128
+M,c=B*256,256
+hn=torch.randn(M,c,device=DEV); W=torch.randn(c,c,device=DEV)*0.05; y=torch.empty(M,c,device=DEV); bias=torch.zeros(c,device=DEV)
+t=timeit(lambda: ops.gemm_raw(0,0,M,c,c,hn,c,0,W,c,0,y,c,0,epi=ops.epilogue(bias=bias)))
+print(f"NIN fwd NN {M}x{c}x{c}: {t*1e6:.1f} us {2*M*c*c/t/1e12:.1f} TF")
+t=timeit(lambda: ops.gemm_raw(0,1,M,c,c,hn,c,0,W,c,0,y,c,0))
+print(f"NIN dgrad NT {M}x{c}x{c}: {t*1e6:.1f} us {2*M*c*c/t/1e12:.1f} TF")
+hw=256
+q=torch.randn(B,hw,c,device=DEV); k=torch.randn(B,hw,c,device=DEV); p=torch.empty(B,hw,hw,device=DEV); v=torch.randn(B,hw,c,device=DEV); ho=torch.empty(B,hw,c,device=DEV)
+t=timeit(lambda: ops.gemm_raw(0,1,hw,hw,c,q,c,hw*c,k,c,hw*c,p,hw,hw*hw,B,ops.epilogue(alpha=0.0625)))
+print(f"QK^T batched NT: {t*1e6:.1f} us {2*B*hw*hw*c/t/1e12:.1f} TF")
+t=timeit(lambda: ops.gemm_raw(0,0,hw,c,hw,p,hw,hw*hw,v,c,hw*c,ho,c,hw*c,B))
+print(f"PV batched NN: {t*1e6:.1f} us {2*B*hw*hw*c/t/1e12:.1f} TF")
+t=timeit(lambda: ops.gemm_raw(1,0,hw,c,hw,p,hw,hw*hw,v,c,hw*c,ho,c,hw*c,B))
+print(f"P^T dHo batched TN: {t*1e6:.1f} us {2*B*hw*hw*c/t/1e12:.1f} TF")
+M2=B*1024
+x=torch.randn(M2,512,device=DEV); W2=torch.randn(256,512,device=DEV)*0.05; y2=torch.empty(M2,256,device=DEV)
+t=timeit(lambda: ops.gemm_raw(0,1,M2,256,512,x,512,0,W2,512,0,y2,256,0))
+print(f"1x1 512->256 @32 NT: {t*1e6:.1f} us {2*M2*256*512/t/1e12:.1f} TF")
+dx=torch.empty(M2,512,device=DEV)
+t=timeit(lambda: ops.gemm_raw(0,0,M2,512,256,y2,256,0,W2,512,0,dx,512,0))
+print(f"1x1 dgrad NN {M2}x512x256: {t*1e6:.1f} us {2*M2*256*512/t/1e12:.1f} TF")
+sl=torch.empty(16,c,c,device=DEV)
+t=timeit(lambda: ops.gemm_tn_splitk(c,c,M,hn,c,y,c,sl,16))
+print(f"NIN wgrad TN splitk16: {t*1e6:.1f} us {2*M*c*c/t/1e12:.1f} TF")
+x4=torch.randn(M,c,device=DEV)
+t=timeit(lambda: ops.silu(x4))
+print(f"silu {M}x{c}: {t*1e6:.1f} us {2*M*c*4/t/1e12:.2f} TB/s")
