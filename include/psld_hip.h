@@ -118,6 +118,20 @@ int psld_conv3x3_split_f32(const float* x1, int c1, const float* x2, int c2, int
                            const void* wfrag, int cout, float* y, int ldy, const psld_epilogue_t* epi,
                            void* workspace, long long ws_bytes, hipStream_t stream);
 
+/* Pointwise sibling of the kernel above: C = epilogue(A * B^T), A = concat(a1[m][k1], a2[m][k2]) row-major fp32,
+ * B given as limb fragments of an [n][k] matrix (psld_pack_gemm_frag: element (n, k) is read at
+ * b[n*stride_n + k*stride_k], so a [k][n] matrix such as NIN.W packs with stride_n = 1, stride_k = n;
+ * psld_gemm_frag_bytes bytes).  Shapes: k1, k2 multiples of 32, k1 + k2 a multiple of 64, n a multiple of 128.
+ * Replaces the 1x1 shortcut convolution (layerspp.py:268-270) and the NIN projections of the attention block
+ * (layers.py:531-540, layerspp.py:78-88) and their data gradients. */
+long long psld_gemm_frag_bytes(int n, int k);
+int psld_gemm_split_supported(int k1, int k2, int m, int n);
+int psld_pack_gemm_frag(const float* b, void* bfrag, int n, int k, long long stride_n, long long stride_k,
+                        hipStream_t stream);
+int psld_gemm_split_f32(const float* a1, int k1, const float* a2, int k2, int m, const void* bfrag, int n,
+                        float* y, int ldy, const psld_epilogue_t* epi, void* workspace, long long ws_bytes,
+                        hipStream_t stream);
+
 /* Weight gradient of the same convolution, same slab contract as psld_conv2d_wgrad_nhwc_f32 (kh = kw = 3,
  * stride = pad = 1): slabs[s][cout][9][cin_total] restricted to columns [col0, col0 + cin), one slab per K range
  * of ceil(batch*h*w/32 / nsplit) 32-pixel tiles (every slab must be non-empty); the caller reduces

@@ -77,6 +77,10 @@ SIGNATURES = {
     "psld_conv3x3_split_supported": (I, [I, I, I, I, I, I]),
     "psld_pack_conv3x3_frag": (I, [P, P, I, I, I, P]),
     "psld_conv3x3_split_f32": (I, [P, I, P, I, I, I, I, P, I, P, I, EP, P, LL, P]),
+    "psld_gemm_frag_bytes": (LL, [I, I]),
+    "psld_gemm_split_supported": (I, [I, I, I, I]),
+    "psld_pack_gemm_frag": (I, [P, P, I, I, LL, LL, P]),
+    "psld_gemm_split_f32": (I, [P, I, P, I, I, P, I, P, I, EP, P, LL, P]),
     "psld_conv3x3_wgrad_split_supported": (I, [I, I, I, I, I]),
     "psld_conv3x3_wgrad_split_f32": (I, [P, I, I, P, I, I, I, I, P, I, I, I, P]),
     "psld_reduce_slabs_f32": (I, [P, I, LL, P, I, I, I, I, F, P]),

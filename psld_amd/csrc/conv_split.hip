@@ -19,6 +19,7 @@
 // whose channel counts are multiples of 32 (in) / 128 (out) — every ResBlock conv of the C10 / CelebA-64 nets.
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "common.h"
 #include "psld_hip.h"
@@ -70,37 +71,44 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, cons
 // k = chunk*32 + (lane >> 4)*8 + j.   dgrad = 0: B[n][k] = w[co = n][ci = k][tap];
 // dgrad = 1: B[n][k] = w[co = k][ci = n][8 - tap] (the data-gradient of a stride-1 pad-1 3x3 conv is the same
 // conv with the taps flipped and the channel roles swapped).
-__global__ void pack_frag_kernel(const float* __restrict__ w, u32x4* __restrict__ out, int cout, int cin, int dgrad) {
-    const int n_out = dgrad ? cin : cout, k_in = dgrad ? cout : cin;
+// General form: B[n][k] for tap t is w[n*sn + k*sk + (flip ? taps-1-t : t)*st]; taps = 1 gives the fragments of a
+// plain NT GEMM (the pointwise kernel: 1x1 convolutions, NIN projections).
+__global__ void pack_frag_kernel(const float* __restrict__ w, u32x4* __restrict__ out, int n_out, int k_in, int taps,
+                                 long long sn, long long sk, long long st, int flip) {
     const int chunks = k_in / 32;
-    const long long total = (long long)n_out * chunks * 9 * 2 * 3 * 2;  // uint4 count / ... (see decode)
+    const long long total = (long long)n_out * chunks * taps * 2 * 3 * 2;  // uint4 count (see decode)
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
         long long t = idx;
         const int lane = (int)(t & 63); t >>= 6;
         const int limb = (int)(t % 3); t /= 3;
         const int nb = (int)(t & 3); t >>= 2;
-        const int tap = (int)(t % 9); t /= 9;
+        const int tap = (int)(t % taps); t /= taps;
         const int chunk = (int)(t % chunks); t /= chunks;
         const int wc = (int)(t & 1); t >>= 1;
         const int nt = (int)t;
         const int n = nt * 128 + wc * 64 + nb * 16 + (lane & 15);
         const int k0 = chunk * 32 + (lane >> 4) * 8;
+        const float* src = w + n * sn + (flip ? taps - 1 - tap : tap) * st;
         unsigned v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float x[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int k = k0 + 2 * j + e;
-                x[e] = dgrad ? w[((long long)k * cin + n) * 9 + (8 - tap)] : w[((long long)n * cin + k) * 9 + tap];
-            }
             unsigned hi, mid, lo;
-            split3(x[0], x[1], hi, mid, lo);
+            split3(src[(k0 + 2 * j) * sk], src[(k0 + 2 * j + 1) * sk], hi, mid, lo);
             v[j] = limb == 0 ? hi : (limb == 1 ? mid : lo);
         }
         out[idx] = u32x4{v[0], v[1], v[2], v[3]};
     }
+}
+
+int launch_pack(const float* w, void* out, int n_out, int k_in, int taps, long long sn, long long sk, long long st,
+                int flip, hipStream_t stream, const char* name) {
+    const long long total = (long long)n_out * (k_in / 32) * taps * 2 * 3 * 2;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(pack_frag_kernel, dim3(blocks), dim3(256), 0, stream, w, reinterpret_cast<u32x4*>(out), n_out,
+                       k_in, taps, sn, sk, st, flip);
+    PSLD_CHECK_LAUNCH(name);
+    return PSLD_OK;
 }
 
 // ---- forward / data-gradient -------------------------------------------------------------------------------
@@ -121,11 +129,16 @@ struct DConvArgs {
     const float* zero;
 };
 
-// NH = float4 halo items per thread per chunk: the LDS image has NH*32 pixel rows (>= nseg*(rps+2)*(W+2)).
-template <int NH>
+// NH = float4 staging items per thread and stage: the LDS image has NH*32 pixel rows per limb.
+// TAPS = K steps (of 32 channels) served by one staged image: the 9 filter taps of a 3x3 convolution (PW = false:
+// the image is the halo tile of ONE 32-channel chunk, >= nseg*(rps+2)*(W+2) rows), or, for the pointwise kernel
+// (PW = true: plain NT GEMM / 1x1 convolution, the image is the tile's 128 rows), TAPS consecutive 32-channel chunks
+// stored one after the other (NH = 4*TAPS).
+template <int NH, int TAPS, bool PW>
 __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LIMB = NH * 32 * ROWB;
+    static_assert(!PW || NH == 4 * TAPS, "pointwise staging: 128 rows x 8 quads per 32-channel chunk");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -137,36 +150,47 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
     const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
     const int m0 = tile_m * 128, n0 = tile_n * 128;
     const int split = blockIdx.y;
-    const int c_beg = split * a.chunks_per_split;
+    const int c_beg = split * a.chunks_per_split;               // stages: chunks (conv) or groups of TAPS chunks (PW)
     const int c_end = min(a.chunks, c_beg + a.chunks_per_split);
 
-    const int W2 = a.W + 2, HW = a.H * a.W;
-    const int img0 = m0 / HW;
-    const int oy0 = (m0 - img0 * HW) / a.W;     // 0 when a tile holds whole images
-    const int seg_px = (a.rps + 2) * W2;
+    const int W2 = a.W + 2;
     const float* zp = a.zero;
 
-    // source pixel of every halo item this thread stages (-1: zero padding / beyond the batch)
+    // source pixel of every item this thread stages (-1: zero padding / beyond the batch)
     int hoff[NH];
+    if constexpr (PW) {
 #pragma unroll
-    for (int i = 0; i < NH; ++i) {
-        const int px = (tid + 256 * i) >> 3;
-        const int seg = px / seg_px;
-        const int rem = px - seg * seg_px;
-        const int hr = rem / W2, hx = rem - hr * W2;
-        const int img = img0 + seg, iy = oy0 + hr - 1, ix = hx - 1;
-        const bool ok = seg < a.nseg && img < a.B && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-        hoff[i] = ok ? (img * a.H + iy) * a.W + ix : -1;
+        for (int i = 0; i < NH; ++i) {
+            const int gm = m0 + (((tid + 256 * i) >> 3) & 127);
+            hoff[i] = gm < a.M ? gm : -1;
+        }
+    } else {
+        const int HW = a.H * a.W;
+        const int img0 = m0 / HW;
+        const int oy0 = (m0 - img0 * HW) / a.W;     // 0 when a tile holds whole images
+        const int seg_px = (a.rps + 2) * W2;
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int px = (tid + 256 * i) >> 3;
+            const int seg = px / seg_px;
+            const int rem = px - seg * seg_px;
+            const int hr = rem / W2, hx = rem - hr * W2;
+            const int img = img0 + seg, iy = oy0 + hr - 1, ix = hx - 1;
+            const bool ok = seg < a.nseg && img < a.B && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            hoff[i] = ok ? (img * a.H + iy) * a.W + ix : -1;
+        }
     }
     f32x4 hv[NH];
     auto load_halo = [&](int c) {
-        const int c0 = c * 32;
-        const bool second = c0 >= a.C1;
-        const float* src = second ? a.x2 : a.x1;
-        const int cs = second ? a.C2 : a.C1;
-        const int cc = (second ? c0 - a.C1 : c0) + c4 * 4;
 #pragma unroll
-        for (int i = 0; i < NH; ++i) hv[i] = ld4(hoff[i] >= 0 ? src + ((long long)hoff[i] * cs + cc) : zp);
+        for (int i = 0; i < NH; ++i) {
+            const int c0 = (PW ? c * TAPS + (i >> 2) : c) * 32;   // item i of a pointwise stage belongs to chunk i / 4
+            const bool second = c0 >= a.C1;
+            const float* src = second ? a.x2 : a.x1;
+            const int cs = second ? a.C2 : a.C1;
+            const int cc = (second ? c0 - a.C1 : c0) + c4 * 4;
+            hv[i] = ld4(hoff[i] >= 0 ? src + ((long long)hoff[i] * cs + cc) : zp);
+        }
     };
     auto store_halo = [&]() {
 #pragma unroll
@@ -189,18 +213,22 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
         const int ml = wr * 64 + mb * 16 + r16;
-        const int seg = ml / (a.rps * a.W);
-        const int rem = ml - seg * (a.rps * a.W);
-        const int ry = rem / a.W, ox = rem - ry * a.W;
-        abase[mb] = ((seg * (a.rps + 2) + ry) * W2 + ox) * ROWB + kq * 16;
+        if constexpr (PW) {
+            abase[mb] = ml * ROWB + kq * 16;
+        } else {
+            const int seg = ml / (a.rps * a.W);
+            const int rem = ml - seg * (a.rps * a.W);
+            const int ry = rem / a.W, ox = rem - ry * a.W;
+            abase[mb] = ((seg * (a.rps + 2) + ry) * W2 + ox) * ROWB + kq * 16;
+        }
     }
 
-    // B fragments of K step sigma = chunk*9 + tap for this wave's 64 columns
-    const u32x4* wp = a.wfrag + ((long long)(tile_n * 2 + wc) * a.chunks * 9) * TAP_U4 + lane;
-    const int sig_last = c_end * 9 - 1;
+    // B fragments of K step sigma = stage*TAPS + tap for this wave's 64 columns
+    const u32x4* wp = a.wfrag + ((long long)(tile_n * 2 + wc) * a.chunks * TAPS) * TAP_U4 + lane;
+    const int sig_beg = c_beg * TAPS, sig_end = c_end * TAPS;
     u32x4 bq[2][4][3];
     auto load_b = [&](int sigma, u32x4 (&dst)[4][3]) {
-        const u32x4* p = wp + (long long)min(sigma, sig_last) * TAP_U4;
+        const u32x4* p = wp + (long long)min(sigma, sig_end - 1) * TAP_U4;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
@@ -214,51 +242,52 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
     load_halo(c_beg);
-    load_b(c_beg * 9, bq[0]);
+    load_b(sig_beg, bq[0]);
     store_halo();
     __syncthreads();
 
-    for (int c = c_beg; c < c_end; ++c) {
+    int c = c_beg, tap = 0, tap_off = 0, kx = 0;
+    constexpr int PREFETCH_TAP = TAPS >= 2 ? TAPS - 2 : 0;     // where the next stage's global loads are issued
+    // one K step; pp (compile time) = which B fragment buffer it reads, the other one receives the next step's
+    auto step = [&](int sigma, auto PP) {
+        constexpr int pp = decltype(PP)::value;
         const bool more = (c + 1) < c_end;
-        int tap_off = 0, kx = 0;
-        for (int tap2 = 0; tap2 < 10; tap2 += 2) {
+        if (tap == PREFETCH_TAP && more) load_halo(c + 1);
+        load_b(sigma + 1, bq[pp ^ 1]);
+        u32x4 fa[4][3];
 #pragma unroll
-            for (int pp = 0; pp < 2; ++pp) {       // taps alternate between the two B fragment buffers
-                const int tap = tap2 + pp;
-                if (tap < 9) {
-                    if (tap == 7 && more) load_halo(c + 1);
-                    load_b(c * 9 + tap + 1, bq[pp ^ 1]);
-                    u32x4 fa[4][3];
+        for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-                    for (int mb = 0; mb < 4; ++mb)
+            for (int l = 0; l < 3; ++l)
+                fa[mb][l] = *reinterpret_cast<const u32x4*>(smem + l * LIMB + abase[mb] + tap_off);
+        // limb products, smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-                        for (int l = 0; l < 3; ++l)
-                            fa[mb][l] = *reinterpret_cast<const u32x4*>(smem + l * LIMB + abase[mb] + tap_off);
-                    // limb products, smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
-                    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+        for (int t = 0; t < 6; ++t)
 #pragma unroll
-                    for (int t = 0; t < 6; ++t)
+            for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-                        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                            for (int nb = 0; nb < 4; ++nb)
-                                acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                    __builtin_bit_cast(bf16x8, fa[mb][PA[t]]), __builtin_bit_cast(bf16x8, bq[pp][nb][PB[t]]),
-                                    acc[mb][nb], 0, 0, 0);
-                    if (++kx == 3) { kx = 0; tap_off += (W2 - 2) * ROWB; } else { tap_off += ROWB; }
-                }
-            }
-        }
-        // tap 8 read bq[0] and prefetched the next chunk's tap 0 into bq[1]: move it to where tap 0 reads
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-            for (int l = 0; l < 3; ++l) bq[0][nb][l] = bq[1][nb][l];
-        __syncthreads();
-        if (more) {
-            store_halo();
+                for (int nb = 0; nb < 4; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, fa[mb][PA[t]]), __builtin_bit_cast(bf16x8, bq[pp][nb][PB[t]]),
+                        acc[mb][nb], 0, 0, 0);
+        if (++tap == TAPS) {            // stage done: swap in the next image
+            tap = 0; tap_off = 0; kx = 0;
             __syncthreads();
+            if (more) {
+                store_halo();
+                __syncthreads();
+            }
+            ++c;
+        } else if constexpr (PW) {
+            tap_off += 128 * ROWB;
+        } else {
+            if (++kx == 3) { kx = 0; tap_off += (W2 - 2) * ROWB; } else { tap_off += ROWB; }
         }
+    };
+    for (int sigma = sig_beg; sigma < sig_end; sigma += 2) {
+        step(sigma, std::integral_constant<int, 0>{});
+        if (sigma + 1 < sig_end) step(sigma + 1, std::integral_constant<int, 1>{});
     }
 
     // fused epilogue; C/D layout of the 16x16 MFMA: col = lane & 15, row = 4*(lane >> 4) + v
@@ -456,23 +485,52 @@ __global__ void __launch_bounds__(256, 3) dwgrad_kernel(const DWgradArgs a) {
                 }
 }
 
-template <int NH>
-int launch_dconv(const DConvArgs& a, int nsplit, hipStream_t stream) {
+template <int NH, int TAPS, bool PW>
+int launch_dconv(const DConvArgs& a, int nsplit, hipStream_t stream, const char* name) {
     constexpr size_t LDS = (size_t)3 * NH * 32 * ROWB;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv_kernel<NH>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv_kernel<NH, TAPS, PW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         if (e != hipSuccess) {
-            psld_set_error("psld_conv3x3_split_f32: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            psld_set_error("%s: hipFuncSetAttribute failed: %s", name, hipGetErrorString(e));
             return PSLD_ERR_LAUNCH;
         }
         configured = true;
     }
     dim3 grid((unsigned)(cdiv(a.M, 128) * (a.N / 128)), (unsigned)nsplit);
-    hipLaunchKernelGGL(dconv_kernel<NH>, grid, dim3(256), LDS, stream, a);
-    PSLD_CHECK_LAUNCH("psld_conv3x3_split_f32");
+    hipLaunchKernelGGL((dconv_kernel<NH, TAPS, PW>), grid, dim3(256), LDS, stream, a);
+    PSLD_CHECK_LAUNCH(name);
     return PSLD_OK;
+}
+
+// split the K stages over extra workgroups when the output grid cannot fill 256 CUs x 2 slots; returns the number
+// of slabs (1 = write the output directly) and fills the slab fields of `a`
+int plan_split(DConvArgs& a, const PsldEpilogue& e, float* y, int ldy, void* workspace, long long ws_bytes) {
+    const long long tiles = (long long)cdiv(a.M, 128) * (a.N / 128);
+    int ns = 1;
+    if (workspace && tiles < 384 && ldy % 4 == 0 && aligned16(y) && (!e.bias || aligned16(e.bias)) &&
+        (!e.rowbias || (aligned16(e.rowbias) && e.ld_rowbias % 4 == 0)) && (!e.res || (aligned16(e.res) && e.ldres % 4 == 0))) {
+        ns = (int)(512 / tiles);
+        if (ns > 8) ns = 8;
+        if (ns > a.chunks / 2) ns = a.chunks / 2;
+        while (ns > 1 && (long long)ns * a.M * a.N * (long long)sizeof(float) > ws_bytes) --ns;
+        if (ns < 1) ns = 1;
+    }
+    a.chunks_per_split = cdiv(a.chunks, ns);
+    ns = cdiv(a.chunks, a.chunks_per_split);
+    if (ns >= 2) {
+        a.C = reinterpret_cast<float*>(workspace);
+        a.ldc = a.N;
+        a.c_stride_split = (long long)a.M * a.N;
+        a.e = make_epilogue(nullptr);
+    } else {
+        a.C = y;
+        a.ldc = ldy;
+        a.c_stride_split = 0;
+        a.e = e;
+    }
+    return ns;
 }
 
 bool dconv_geometry(int h, int w, int* nseg, int* rps, int* halo_px) {
@@ -518,12 +576,8 @@ extern "C" int psld_pack_conv3x3_frag(const float* w_oihw, void* wfrag, int cout
     const int n_out = dgrad ? cin : cout, k_in = dgrad ? cout : cin;
     PSLD_CHECK_ARG(n_out > 0 && k_in > 0 && n_out % 128 == 0 && k_in % 32 == 0,
                    "psld_pack_conv3x3_frag: needs out channels %%128 and in channels %%32 (got %d, %d)", n_out, k_in);
-    const long long total = (long long)n_out * (k_in / 32) * 9 * 2 * 3 * 2;
-    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(pack_frag_kernel, dim3(blocks), dim3(256), 0, stream, w_oihw,
-                       reinterpret_cast<u32x4*>(wfrag), cout, cin, dgrad);
-    PSLD_CHECK_LAUNCH("psld_pack_conv3x3_frag");
-    return PSLD_OK;
+    if (dgrad) return launch_pack(w_oihw, wfrag, n_out, k_in, 9, 9, (long long)cin * 9, 1, 1, stream, "psld_pack_conv3x3_frag");
+    return launch_pack(w_oihw, wfrag, n_out, k_in, 9, (long long)cin * 9, 9, 1, 0, stream, "psld_pack_conv3x3_frag");
 }
 
 extern "C" int psld_conv3x3_split_f32(const float* x1, int c1, const float* x2, int c2, int batch, int h, int w,
@@ -544,35 +598,13 @@ extern "C" int psld_conv3x3_split_f32(const float* x1, int c1, const float* x2, 
     a.zero = psld_detail_zero_page("psld_conv3x3_split_f32");
     if (!a.zero) return PSLD_ERR_LAUNCH;
     const PsldEpilogue e = make_epilogue(epi);
-    const long long tiles = (long long)cdiv(a.M, 128) * (cout / 128);
-    // split the channel chunks over extra workgroups when the output grid cannot fill 256 CUs x 2 slots
-    int ns = 1;
-    if (workspace && tiles < 384 && ldy % 4 == 0 && aligned16(y) && (!e.bias || aligned16(e.bias)) &&
-        (!e.rowbias || (aligned16(e.rowbias) && e.ld_rowbias % 4 == 0)) && (!e.res || (aligned16(e.res) && e.ldres % 4 == 0))) {
-        ns = (int)(512 / tiles);
-        if (ns > 8) ns = 8;
-        if (ns > a.chunks / 2) ns = a.chunks / 2;
-        while (ns > 1 && (long long)ns * a.M * cout * (long long)sizeof(float) > ws_bytes) --ns;
-        if (ns < 1) ns = 1;
-    }
-    a.chunks_per_split = cdiv(a.chunks, ns);
-    ns = cdiv(a.chunks, a.chunks_per_split);
-    if (ns >= 2) {
-        a.C = reinterpret_cast<float*>(workspace);
-        a.ldc = cout;
-        a.c_stride_split = (long long)a.M * cout;
-        a.e = make_epilogue(nullptr);
-    } else {
-        a.C = y;
-        a.ldc = ldy;
-        a.c_stride_split = 0;
-        a.e = e;
-    }
+    const int ns = plan_split(a, e, y, ldy, workspace, ws_bytes);
     const int nh = cdiv((long long)halo_px * 8, 256);
+    const char* name = "psld_conv3x3_split_f32";
     int st;
-    if (nh <= 6) st = launch_dconv<6>(a, ns, stream);
-    else if (nh <= 7) st = launch_dconv<7>(a, ns, stream);
-    else st = launch_dconv<9>(a, ns, stream);
+    if (nh <= 6) st = launch_dconv<6, 9, false>(a, ns, stream, name);
+    else if (nh <= 7) st = launch_dconv<7, 9, false>(a, ns, stream, name);
+    else st = launch_dconv<9, 9, false>(a, ns, stream, name);
     if (st != PSLD_OK) return st;
     if (ns >= 2) return psld_detail_conv_reduce_epilogue(a.C, ns, a.M, cout, y, ldy, e, stream);
     return PSLD_OK;
@@ -617,5 +649,42 @@ extern "C" int psld_conv3x3_wgrad_split_f32(const float* dy, int lddy, int cout,
     }
     hipLaunchKernelGGL(dwgrad_kernel, dim3((unsigned)(a.cout_tiles * a.cin_tiles * 3 * nsplit)), dim3(256), LDS, stream, a);
     PSLD_CHECK_LAUNCH("psld_conv3x3_wgrad_split_f32");
+    return PSLD_OK;
+}
+
+// ---- pointwise (NT GEMM with pre-split B) -------------------------------------------------------------------
+extern "C" long long psld_gemm_frag_bytes(int n, int k) { return (long long)n * k * 6; }
+
+extern "C" int psld_gemm_split_supported(int k1, int k2, int m, int n) {
+    return k1 > 0 && k2 >= 0 && k1 % 32 == 0 && k2 % 32 == 0 && (k1 + k2) % 64 == 0 && n > 0 && n % 128 == 0 && m > 0;
+}
+
+extern "C" int psld_pack_gemm_frag(const float* b, void* bfrag, int n, int k, long long stride_n, long long stride_k,
+                                   hipStream_t stream) {
+    PSLD_CHECK_ARG(b && bfrag, "psld_pack_gemm_frag: null pointer");
+    PSLD_CHECK_ARG(n > 0 && k > 0 && n % 128 == 0 && k % 64 == 0, "psld_pack_gemm_frag: needs n %%128 and k %%64 (got %d, %d)", n, k);
+    return launch_pack(b, bfrag, n, k, 1, stride_n, stride_k, 0, 0, stream, "psld_pack_gemm_frag");
+}
+
+extern "C" int psld_gemm_split_f32(const float* a1, int k1, const float* a2, int k2, int m, const void* bfrag, int n,
+                                   float* y, int ldy, const psld_epilogue_t* epi, void* workspace, long long ws_bytes,
+                                   hipStream_t stream) {
+    PSLD_CHECK_ARG(a1 && bfrag && y && (k2 == 0 || a2), "psld_gemm_split_f32: null pointer");
+    PSLD_CHECK_ARG(psld_gemm_split_supported(k1, k2, m, n), "psld_gemm_split_f32: unsupported shape k1=%d k2=%d m=%d n=%d", k1, k2, m, n);
+    PSLD_CHECK_ARG(aligned16(a1) && (!a2 || aligned16(a2)) && aligned16(bfrag), "psld_gemm_split_f32: unaligned pointer");
+    DConvArgs a{};
+    a.x1 = a1; a.x2 = a2; a.C1 = k1; a.C2 = k2;
+    a.B = 1; a.H = 1; a.W = 1;
+    a.wfrag = reinterpret_cast<const u32x4*>(bfrag);
+    a.N = n; a.M = m;
+    a.chunks = (k1 + k2) / 64;          // stages of two 32-channel chunks
+    a.nseg = 1; a.rps = 1;
+    a.zero = psld_detail_zero_page("psld_gemm_split_f32");
+    if (!a.zero) return PSLD_ERR_LAUNCH;
+    const PsldEpilogue e = make_epilogue(epi);
+    const int ns = plan_split(a, e, y, ldy, workspace, ws_bytes);
+    const int st = launch_dconv<8, 2, true>(a, ns, stream, "psld_gemm_split_f32");
+    if (st != PSLD_OK) return st;
+    if (ns >= 2) return psld_detail_conv_reduce_epilogue(a.C, ns, m, n, y, ldy, e, stream);
     return PSLD_OK;
 }

@@ -153,6 +153,33 @@ def conv3x3_split(x1: Tensor, x2: Optional[Tensor], wfrag: Tensor, cout: int, y:
                                        ws, wsb, _stream()), "psld_conv3x3_split_f32")
 
 
+def gemm_split_supported(k1: int, k2: int, m: int, n: int) -> bool:
+    return bool(lib().psld_gemm_split_supported(k1, k2, m, n))
+
+
+def gemm_frag(b: Tensor, n: int, k: int, stride_n: int, stride_k: int, out: Optional[Tensor] = None) -> Tensor:
+    """Limb fragments of the [n][k] matrix whose element (i, j) sits at b.flatten()[i*stride_n + j*stride_k]."""
+    if out is None:
+        out = torch.empty(lib().psld_gemm_frag_bytes(n, k), dtype=torch.uint8, device=b.device)
+    check(lib().psld_pack_gemm_frag(b.data_ptr(), out.data_ptr(), n, k, stride_n, stride_k, _stream()),
+          "psld_pack_gemm_frag")
+    return out
+
+
+def gemm_split(a1: Tensor, a2: Optional[Tensor], m: int, bfrag: Tensor, n: int, y: Tensor,
+               epi: Optional[Epilogue] = None, ldy: Optional[int] = None):
+    """y[m][n] = epilogue(concat(a1, a2) @ B^T) on the bf16 limb kernels; a1 / a2 are [m][k1] / [m][k2] contiguous."""
+    k1 = a1.shape[-1]
+    k2 = a2.shape[-1] if a2 is not None else 0
+    ws, wsb = None, 0
+    if m <= 32768:
+        wsb = 8 * m * n * 4
+        ws = workspace(wsb, a1.device).data_ptr()
+    check(lib().psld_gemm_split_f32(a1.data_ptr(), k1, _p(a2), k2, m, bfrag.data_ptr(), n, y.data_ptr(),
+                                    ldy if ldy is not None else n, C.byref(epi) if epi is not None else None,
+                                    ws, wsb, _stream()), "psld_gemm_split_f32")
+
+
 def conv3x3_wgrad_split_supported(cout: int, cin: int, b: int, h: int, w: int) -> bool:
     return bool(lib().psld_conv3x3_wgrad_split_supported(cout, cin, b, h, w))
 

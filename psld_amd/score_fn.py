@@ -258,12 +258,14 @@ class _Exec:
         ops.conv2d_wgrad_nhwc(dy, cout, x, k, k, stride, pad, oh, ow, slabs, cin, 0, nsplit)
         ops.reduce_slabs(slabs, nsplit, n, self.g(conv.weight), layout=1, cout=cout, taps=taps, cin=cin, alpha=alpha)
 
-    def bias_grad(self, dy: Tensor, out: Tensor, alpha: float = 1.0, per_image: Optional[Tensor] = None):
+    def bias_grad(self, dy: Tensor, out: Tensor, alpha: float = 1.0, per_image: Optional[Tensor] = None,
+                  ld: Optional[int] = None):
+        """``ld``: row stride of ``dy`` when it is a column slice of a wider buffer."""
         b = dy.shape[0]
         c = dy.shape[-1]
         hw = dy.numel() // (b * c)
         tmp = per_image if per_image is not None else torch.empty((b, c), device=dy.device, dtype=torch.float32)
-        ops.colsum(dy, c, b, hw, c, tmp)
+        ops.colsum(dy, ld if ld is not None else c, b, hw, c, tmp)
         ops.colsum(tmp, c, 1, b, c, out, alpha)
         return tmp
 
@@ -367,8 +369,12 @@ class _Exec:
         a1 = ops.gn_apply(h1, st1, True, drop_p=drop_p, seed=seed)
         out = torch.empty((b, ho, wo, cout), device=x.v.device, dtype=torch.float32)
         if mod.has_shortcut:
-            ops.conv2d_nhwc(xr, None, mod.Conv_2.weight, cout, 1, 1, 1, 0, 1, ho, wo, out,
-                            ops.epilogue(bias=mod.Conv_2.bias))
+            c2 = mod.Conv_2
+            if self.split and ops.gemm_split_supported(cin, 0, b * ho * wo, cout):
+                fr = net._gfrag(c2.weight, "fwd", lambda prev: ops.gemm_frag(c2.weight.detach(), cout, cin, cin, 1, prev))
+                ops.gemm_split(xr, None, b * ho * wo, fr, cout, out, ops.epilogue(bias=c2.bias))
+            else:
+                ops.conv2d_nhwc(xr, None, c2.weight, cout, 1, 1, 1, 0, 1, ho, wo, out, ops.epilogue(bias=c2.bias))
             res = out
         else:
             res = xr
@@ -419,15 +425,21 @@ class _Exec:
             if mod.has_shortcut:
                 c2 = mod.Conv_2
                 m = b * ho * wo
+                def shortcut_dgrad(dst, epi):
+                    if self.split and ops.gemm_split_supported(cout, 0, m, cin):
+                        fr = net._gfrag(c2.weight, "dgrad",
+                                        lambda prev: ops.gemm_frag(c2.weight.detach(), cin, cout, 1, cin, prev))
+                        ops.gemm_split(dout, None, m, fr, cin, dst, epi)
+                    else:
+                        ops.gemm_raw(0, 0, m, cin, cout, dout, cout, 0, c2.weight, cin, 0, dst, cin, 0, epi=epi)
+
                 if up or down:
                     dxr = torch.empty((b, ho, wo, cin), device=dout.device, dtype=torch.float32)
-                    ops.gemm_raw(0, 0, m, cin, cout, dout, cout, 0, c2.weight, cin, 0, dxr, cin, 0,
-                                 epi=ops.epilogue(alpha=s))
+                    shortcut_dgrad(dxr, ops.epilogue(alpha=s))
                     self.resample_bwd(dxr, up, (h, w), xg, acc)
                     del dxr
                 else:
-                    ops.gemm_raw(0, 0, m, cin, cout, dout, cout, 0, c2.weight, cin, 0, xg, cin, 0,
-                                 epi=ops.epilogue(alpha=s, accumulate=acc))
+                    shortcut_dgrad(xg, ops.epilogue(alpha=s, accumulate=acc))
             else:
                 ops.axpby(dout, s, None, 0.0, xg, accumulate=acc)
             if up or down:
@@ -451,58 +463,90 @@ class _Exec:
         gn = mod.GroupNorm_0
         st = ops.gn_stats(x.v, gn.weight, gn.bias)
         hn = ops.gn_apply(x.v, st, False)
-        qkv = []
-        for nin in (mod.NIN_0, mod.NIN_1, mod.NIN_2):
-            y = torch.empty((b, hw, c), device=dev, dtype=torch.float32)
-            ops.gemm_raw(0, 0, m, c, c, hn, c, 0, nin.W, c, 0, y, c, 0, epi=ops.epilogue(bias=nin.b))
-            qkv.append(y)
-        q, k, v = qkv
+        n0, n1, n2, n3 = mod.NIN_0, mod.NIN_1, mod.NIN_2, mod.NIN_3
         scale = float(int(c) ** (-0.5))
+        # limb kernels: q|k|v come from ONE GEMM against the concatenated projections (N = 3c) into one buffer
+        fused = self.split and ops.gemm_split_supported(c, 0, m, c)
+        net = self.net
+        if fused:
+            def build_qkv(prev):
+                wcat = torch.cat([n0.W.detach(), n1.W.detach(), n2.W.detach()], dim=1).contiguous()      # [in][3 out]
+                pf, pd, pb = prev if prev is not None else (None, None, None)
+                bcat = torch.cat([n0.b.detach(), n1.b.detach(), n2.b.detach()])
+                return (ops.gemm_frag(wcat, 3 * c, c, 1, 3 * c, pf),        # forward:  B[n][k] = wcat[k][n]
+                        ops.gemm_frag(wcat, c, 3 * c, 3 * c, 1, pd),        # data gradient: B[n][k] = wcat[n][k]
+                        bcat if pb is None else pb.copy_(bcat))
+            f_qkv, f_qkv_d, b_qkv = net._gfrag(n0.W, "qkv", build_qkv)
+            qkv = torch.empty((b, hw, 3 * c), device=dev, dtype=torch.float32)
+            ops.gemm_split(hn, None, m, f_qkv, 3 * c, qkv, ops.epilogue(bias=b_qkv))
+            q, k, v = qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
+            ld = 3 * c
+        else:
+            qkv = []
+            for nin in (n0, n1, n2):
+                y = torch.empty((b, hw, c), device=dev, dtype=torch.float32)
+                ops.gemm_raw(0, 0, m, c, c, hn, c, 0, nin.W, c, 0, y, c, 0, epi=ops.epilogue(bias=nin.b))
+                qkv.append(y)
+            q, k, v = qkv
+            ld = c
         p = torch.empty((b, hw, hw), device=dev, dtype=torch.float32)
-        ops.gemm_raw(0, 1, hw, hw, c, q, c, hw * c, k, c, hw * c, p, hw, hw * hw, b, ops.epilogue(alpha=scale))
+        ops.gemm_raw(0, 1, hw, hw, c, q, ld, hw * ld, k, ld, hw * ld, p, hw, hw * hw, b, ops.epilogue(alpha=scale))
         ops.softmax_rows(p, p, b * hw, hw)
         ho = torch.empty((b, hw, c), device=dev, dtype=torch.float32)
-        ops.gemm_raw(0, 0, hw, c, hw, p, hw, hw * hw, v, c, hw * c, ho, c, hw * c, b)
+        ops.gemm_raw(0, 0, hw, c, hw, p, hw, hw * hw, v, ld, hw * ld, ho, c, hw * c, b)
         out = torch.empty_like(x.v)
-        n3 = mod.NIN_3
-        ops.gemm_raw(0, 0, m, c, c, ho, c, 0, n3.W, c, 0, out, c, 0,
-                     epi=ops.epilogue(bias=n3.b, residual=x.v, ld_residual=c, out_scale=s))
+        epi_out = ops.epilogue(bias=n3.b, residual=x.v, ld_residual=c, out_scale=s)
+        if fused:
+            f_o = net._gfrag(n3.W, "fwd", lambda prev: ops.gemm_frag(n3.W.detach(), c, c, 1, c, prev))
+            ops.gemm_split(ho, None, m, f_o, c, out, epi_out)
+        else:
+            ops.gemm_raw(0, 0, m, c, c, ho, c, 0, n3.W, c, 0, out, c, 0, epi=epi_out)
         on = _Node(out)
         if not self.record:
             return on
 
-        def nin_wgrad(a_in: Tensor, dy: Tensor, nin: NIN, alpha: float):
-            # dW[in,out] = a_in^T dy  (K = B*HW -> split-K slabs)
+        def nin_wgrad(a_in: Tensor, dy: Tensor, nin: NIN, alpha: float, ldd: int):
+            # dW[in,out] = a_in^T dy  (K = B*HW -> split-K slabs); dy may be a column slice (row stride ldd)
             nsplit = _pick_nsplit(((c + 127) // 128) ** 2, m)
             slabs = ops.workspace(4 * c * c * nsplit, dev)
-            ops.gemm_tn_splitk(c, c, m, a_in, c, dy, c, slabs, nsplit)
+            ops.gemm_tn_splitk(c, c, m, a_in, c, dy, ldd, slabs, nsplit)
             ops.reduce_slabs(slabs, nsplit, c * c, self.g(nin.W), alpha=alpha)
-            self.bias_grad(dy.view(b, hw, 1, c), self.g(nin.b), alpha=alpha)
+            self.bias_grad(dy.view(b, hw, 1, c) if ldd == c else dy, self.g(nin.b), alpha=alpha, ld=ldd)
 
         def bwd():
             dout = on.g
             on.g = None
-            self.on_side(lambda: nin_wgrad(ho, dout, n3, s), ho, dout)
+            self.on_side(lambda: nin_wgrad(ho, dout, n3, s, c), ho, dout)
             dho = torch.empty_like(ho)
-            ops.gemm_raw(0, 1, m, c, c, dout, c, 0, n3.W, c, 0, dho, c, 0, epi=ops.epilogue(alpha=s))
+            if fused:
+                f_od = net._gfrag(n3.W, "dgrad", lambda prev: ops.gemm_frag(n3.W.detach(), c, c, c, 1, prev))
+                ops.gemm_split(dout, None, m, f_od, c, dho, ops.epilogue(alpha=s))
+            else:
+                ops.gemm_raw(0, 1, m, c, c, dout, c, 0, n3.W, c, 0, dho, c, 0, epi=ops.epilogue(alpha=s))
             # dP = dho v^T ; dv = P^T dho
             dp = torch.empty_like(p)
-            ops.gemm_raw(0, 1, hw, hw, c, dho, c, hw * c, v, c, hw * c, dp, hw, hw * hw, b)
-            dv = torch.empty_like(v)
-            ops.gemm_raw(1, 0, hw, c, hw, p, hw, hw * hw, dho, c, hw * c, dv, c, hw * c, b)
+            ops.gemm_raw(0, 1, hw, hw, c, dho, c, hw * c, v, ld, hw * ld, dp, hw, hw * hw, b)
+            if fused:
+                dqkv = torch.empty_like(qkv)
+                dq, dk, dv = dqkv[..., :c], dqkv[..., c:2 * c], dqkv[..., 2 * c:]
+            else:
+                dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            ops.gemm_raw(1, 0, hw, c, hw, p, hw, hw * hw, dho, c, hw * c, dv, ld, hw * ld, b)
             ds = dp
             ops.softmax_rows_bwd(p, dp, ds, b * hw, hw)
-            dq = torch.empty_like(q)
-            ops.gemm_raw(0, 0, hw, c, hw, ds, hw, hw * hw, k, c, hw * c, dq, c, hw * c, b, ops.epilogue(alpha=scale))
-            dk = dho  # reuse
-            ops.gemm_raw(1, 0, hw, c, hw, ds, hw, hw * hw, q, c, hw * c, dk, c, hw * c, b, ops.epilogue(alpha=scale))
+            ops.gemm_raw(0, 0, hw, c, hw, ds, hw, hw * hw, k, ld, hw * ld, dq, ld, hw * ld, b, ops.epilogue(alpha=scale))
+            ops.gemm_raw(1, 0, hw, c, hw, ds, hw, hw * hw, q, ld, hw * ld, dk, ld, hw * ld, b, ops.epilogue(alpha=scale))
             dhn = torch.empty_like(hn)
-            first = True
-            for nin, d in ((mod.NIN_0, dq), (mod.NIN_1, dk), (mod.NIN_2, dv)):
-                self.on_side(lambda nin=nin, d=d: nin_wgrad(hn, d, nin, 1.0), hn, d)
-                ops.gemm_raw(0, 1, m, c, c, d, c, 0, nin.W, c, 0, dhn, c, 0,
-                             epi=None if first else ops.epilogue(accumulate=True))
-                first = False
+            for nin, d in ((n0, dq), (n1, dk), (n2, dv)):
+                self.on_side(lambda nin=nin, d=d: nin_wgrad(hn, d, nin, 1.0, ld), hn, d)
+            if fused:
+                ops.gemm_split(dqkv, None, m, f_qkv_d, c, dhn)
+            else:
+                first = True
+                for nin, d in ((n0, dq), (n1, dk), (n2, dv)):
+                    ops.gemm_raw(0, 1, m, c, c, d, c, 0, nin.W, c, 0, dhn, c, 0,
+                                 epi=None if first else ops.epilogue(accumulate=True))
+                    first = False
             xg, acc = _gbuf(x)
             ops.axpby(dout, s, None, 0.0, xg, accumulate=acc)
             ops.gn_bwd(dhn, x.v, st, gn.weight, gn.bias, False, xg, self.g(gn.weight), self.g(gn.bias),
@@ -971,6 +1015,20 @@ class NCSNpp(nn.Module):
         self._pack_cache[key] = (stamp, out)
         return out
 
+    def _gfrag(self, owner: nn.Parameter, tag: str, build):
+        """Limb fragments derived from ``owner`` (and possibly sibling parameters), cached until the weights change.
+        ``build(prev)`` returns the tensor (or tuple of tensors) to keep and refreshes ``prev`` IN PLACE when given
+        (captured graphs hold these addresses)."""
+        key = (id(owner), tag, "gfrag")
+        ent = self._pack_cache.get(key)
+        stamp = (self._epoch, owner._version, owner.data_ptr())
+        if ent is not None and ent[0] == stamp:
+            return ent[1]
+        prev = ent[1] if ent is not None and (ent[1][0] if isinstance(ent[1], tuple) else ent[1]).device == owner.device else None
+        out = build(prev)
+        self._pack_cache[key] = (stamp, out, owner, build)
+        return out
+
     def _pos_freq(self, device):
         if self._posfreq is None or self._posfreq.device != device:
             half = self.nf // 2
@@ -1075,10 +1133,12 @@ class NCSNpp(nn.Module):
         graph, sx, st, sy, stamp = ent
         now = (self._epoch, self._flat._version)
         if stamp != now:
-            for key in list(self._pack_cache):
-                if not key[1]:                                  # forward copies: refreshed in the same storage
-                    (self._frag(self._conv_by_weight[key[0]], False) if len(key) == 3
-                     else self._packed(self._conv_by_weight[key[0]]))
+            for ck, cv in list(self._pack_cache.items()):       # refresh, in the same storage, what the graph reads
+                if ck[-1] == "gfrag":
+                    self._gfrag(cv[2], ck[1], cv[3])
+                elif not ck[1]:
+                    (self._frag(self._conv_by_weight[ck[0]], False) if len(ck) == 3
+                     else self._packed(self._conv_by_weight[ck[0]]))
             ent[4] = now
         sx.copy_(x)
         st.copy_(t)

@@ -241,6 +241,32 @@ def test_conv3x3_split_dgrad_and_wgrad(ops, cfg):
     assert torch.count_nonzero(slabs[:, :, :, :col0]) == 0
 
 
+@pytest.mark.parametrize("m,n,k1,k2", [(256, 128, 64, 0), (1000, 256, 256, 0), (640, 128, 96, 32), (4096, 768, 256, 0),
+                                       (130, 128, 512, 0)])
+def test_gemm_split(ops, m, n, k1, k2):
+    """Pointwise limb kernel: y = (concat(a1, a2) @ B^T + bias + residual) * scale, B from an [n][k] or a [k][n] matrix."""
+    a = gen(m, k1 + k2, seed=70)
+    bmat = gen(n, k1 + k2, seed=71, scale=0.1)
+    bias, res = gen(n, seed=72), gen(m, n, seed=73)
+    ref = (a.double() @ bmat.double().t() + bias.double() + res.double()) * 0.5
+    a1 = a[:, :k1].contiguous().to(DEV)
+    a2 = a[:, k1:].contiguous().to(DEV) if k2 else None
+    assert ops.gemm_split_supported(k1, k2, m, n)
+    epi = ops.epilogue(bias=bias.to(DEV), residual=res.to(DEV), ld_residual=n, out_scale=0.5)
+    for transposed in (False, True):
+        src = (bmat.t().contiguous() if transposed else bmat).to(DEV)          # [k][n] (NIN.W layout) or [n][k]
+        sn, sk = (1, n) if transposed else (k1 + k2, 1)
+        frag = ops.gemm_frag(src, n, k1 + k2, sn, sk)
+        y = torch.full((m, n), float("nan"), device=DEV)
+        ops.gemm_split(a1, a2, m, frag, n, y, epi)
+        assert rel_l2(y, ref) < 3e-6
+    # strided output (one third of a fused q|k|v buffer)
+    wide = torch.zeros(m, 3 * n, device=DEV)
+    ops.gemm_split(a1, a2, m, frag, n, wide[:, n:], None, ldy=3 * n)
+    assert rel_l2(wide[:, n:2 * n], a.double() @ bmat.double().t()) < 3e-6
+    assert torch.count_nonzero(wide[:, :n]) == 0 and torch.count_nonzero(wide[:, 2 * n:]) == 0
+
+
 def test_conv3x3_split_rejects_unsupported(ops):
     assert not ops.conv3x3_split_supported(6, 0, 2, 32, 32, 128)      # stem: 6 input channels
     assert not ops.conv3x3_split_supported(128, 0, 2, 32, 32, 6)      # head: 6 output channels
