@@ -114,6 +114,12 @@ int psld_conv2d_nhwc_ws_f32(const float* x1, int c1, const float* x2, int c2,
 long long psld_conv3x3_frag_bytes(int cout, int cin);
 int psld_conv3x3_split_supported(int c1, int c2, int batch, int h, int w, int cout);
 int psld_pack_conv3x3_frag(const float* w_oihw, void* wfrag, int cout, int cin, int dgrad, hipStream_t stream);
+/* All weight tensors of a network in ONE launch (the per-tensor packs above are launch-bound: 228 x 7 us per step).
+ * table_dev: device array of `entries` x 8 int64: {src pointer, dst pointer, n_out, k_in, taps | flip << 32,
+ * stride_n, stride_k, first work item}; an entry has n_out*k_in/8 work items (one per lane slot, all taps and limbs)
+ * and produces exactly what psld_pack_conv3x3_frag (taps 9) / psld_pack_gemm_frag (taps 1) would;
+ * total_items = sum over entries. */
+int psld_pack_frag_batch(const long long* table_dev, int entries, long long total_items, hipStream_t stream);
 int psld_conv3x3_split_f32(const float* x1, int c1, const float* x2, int c2, int batch, int h, int w,
                            const void* wfrag, int cout, float* y, int ldy, const psld_epilogue_t* epi,
                            void* workspace, long long ws_bytes, hipStream_t stream);
@@ -214,6 +220,12 @@ long long psld_colsum_workspace_bytes(int batch, int hw, int c);
 int psld_colsum_f32(const float* x, int ld, int batch, int hw, int c, float* out, float alpha,
                     void* workspace /* >= psld_colsum_workspace_bytes, NULL = slow scalar path */,
                     hipStream_t stream);
+/* Bias gradient in three launches (two chained psld_colsum_f32 calls take four): out[c] = alpha * sum over (batch, hw) of x[b][p][0..c) (row stride ld), and, when
+ * per_image is not NULL, per_image[b][c] = the unscaled per-image sums (the time-embedding gradient needs them,
+ * layerspp.py:262-263).  Same workspace as psld_colsum_f32; c % 4 == 0, c <= 1024, 16-byte aligned x. */
+int psld_bias_grad_f32(const float* x, int ld, int batch, int hw, int c, float* per_image, float* out, float alpha,
+                       void* workspace, hipStream_t stream);
+
 /* dst[r][0:cols] (+)= src[r][0:cols] with row strides: channel concat (ncsnpp.py:374) and its split. */
 int psld_copy2d_f32(const float* src, int ld_src, float* dst, int ld_dst, long long rows, int cols,
                     int accumulate, hipStream_t stream);

@@ -76,6 +76,7 @@ SIGNATURES = {
     "psld_conv3x3_frag_bytes": (LL, [I, I]),
     "psld_conv3x3_split_supported": (I, [I, I, I, I, I, I]),
     "psld_pack_conv3x3_frag": (I, [P, P, I, I, I, P]),
+    "psld_pack_frag_batch": (I, [P, I, LL, P]),
     "psld_conv3x3_split_f32": (I, [P, I, P, I, I, I, I, P, I, P, I, EP, P, LL, P]),
     "psld_gemm_frag_bytes": (LL, [I, I]),
     "psld_gemm_split_supported": (I, [I, I, I, I]),
@@ -99,6 +100,7 @@ SIGNATURES = {
     "psld_silu_bwd_f32": (I, [P, P, P, LL, P]),
     "psld_colsum_workspace_bytes": (LL, [I, I, I]),
     "psld_colsum_f32": (I, [P, I, I, I, I, P, F, P, P]),
+    "psld_bias_grad_f32": (I, [P, I, I, I, I, P, P, F, P, P]),
     "psld_copy2d_f32": (I, [P, I, P, I, LL, I, I, P]),
     "psld_softmax_rows_f32": (I, [P, P, LL, I, P]),
     "psld_softmax_rows_bwd_f32": (I, [P, P, P, LL, I, P]),

@@ -73,37 +73,61 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, cons
 // conv with the taps flipped and the channel roles swapped).
 // General form: B[n][k] for tap t is w[n*sn + k*sk + (flip ? taps-1-t : t)*st]; taps = 1 gives the fragments of a
 // plain NT GEMM (the pointwise kernel: 1x1 convolutions, NIN projections).
+// One work item = one lane slot (nt, wc, chunk, nb, lane) for ALL taps and limbs: its 8 k-values x taps source
+// elements are neighbours in memory (OIHW keeps the 9 taps of a (co, ci) pair together), and split3 yields the three
+// limbs at once.
+__device__ __forceinline__ void pack_frag_item(const float* __restrict__ w, u32x4* __restrict__ out, long long item,
+                                               int k_in, int taps, long long sn, long long sk, long long st, int flip) {
+    const int chunks = k_in / 32;
+    long long t = item;
+    const int lane = (int)(t & 63); t >>= 6;
+    const int nb = (int)(t & 3); t >>= 2;
+    const int chunk = (int)(t % chunks); t /= chunks;
+    const int wc = (int)(t & 1); t >>= 1;
+    const int nt = (int)t;
+    const int n = nt * 128 + wc * 64 + nb * 16 + (lane & 15);
+    const int k0 = chunk * 32 + (lane >> 4) * 8;
+    const float* src = w + n * sn + k0 * sk;
+    // uint4 index of (tap, limb) for this slot: ((((nt*2 + wc)*chunks + chunk)*taps + tap)*4 + nb)*3 + limb)*64 + lane
+    const long long base = ((long long)(nt * 2 + wc) * chunks + chunk) * taps;
+    for (int tap = 0; tap < taps; ++tap) {
+        const float* p = src + (flip ? taps - 1 - tap : tap) * st;
+        unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split3(p[(2 * j) * sk], p[(2 * j + 1) * sk], hi[j], mid[j], lo[j]);
+        u32x4* o = out + (((base + tap) * 4 + nb) * 3) * 64 + lane;
+        o[0] = u32x4{hi[0], hi[1], hi[2], hi[3]};
+        o[64] = u32x4{mid[0], mid[1], mid[2], mid[3]};
+        o[128] = u32x4{lo[0], lo[1], lo[2], lo[3]};
+    }
+}
+
 __global__ void pack_frag_kernel(const float* __restrict__ w, u32x4* __restrict__ out, int n_out, int k_in, int taps,
                                  long long sn, long long sk, long long st, int flip) {
-    const int chunks = k_in / 32;
-    const long long total = (long long)n_out * chunks * taps * 2 * 3 * 2;  // uint4 count (see decode)
+    const long long items = (long long)n_out * (k_in / 32) * 4;     // n_out/128 * 2 * chunks * 4 * 64
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < items; i += (long long)gridDim.x * blockDim.x)
+        pack_frag_item(w, out, i, k_in, taps, sn, sk, st, flip);
+}
+
+// Many weight tensors in one launch.  tab[8*i ..]: src pointer, dst pointer, n_out, k_in, taps | flip << 32, sn, sk,
+// first work item of tensor i in the launch-wide numbering (st = 1; a tensor has n_out * k_in / 8 items).
+__global__ void pack_frag_batch_kernel(const long long* __restrict__ tab, int ntab, long long total) {
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
-        long long t = idx;
-        const int lane = (int)(t & 63); t >>= 6;
-        const int limb = (int)(t % 3); t /= 3;
-        const int nb = (int)(t & 3); t >>= 2;
-        const int tap = (int)(t % taps); t /= taps;
-        const int chunk = (int)(t % chunks); t /= chunks;
-        const int wc = (int)(t & 1); t >>= 1;
-        const int nt = (int)t;
-        const int n = nt * 128 + wc * 64 + nb * 16 + (lane & 15);
-        const int k0 = chunk * 32 + (lane >> 4) * 8;
-        const float* src = w + n * sn + (flip ? taps - 1 - tap : tap) * st;
-        unsigned v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            unsigned hi, mid, lo;
-            split3(src[(k0 + 2 * j) * sk], src[(k0 + 2 * j + 1) * sk], hi, mid, lo);
-            v[j] = limb == 0 ? hi : (limb == 1 ? mid : lo);
+        int lo = 0, hi = ntab - 1;
+        while (lo < hi) {                       // last entry whose first item is <= idx
+            const int mid = (lo + hi + 1) >> 1;
+            if (tab[8 * mid + 7] <= idx) lo = mid; else hi = mid - 1;
         }
-        out[idx] = u32x4{v[0], v[1], v[2], v[3]};
+        const long long* d = tab + 8 * lo;
+        pack_frag_item(reinterpret_cast<const float*>(d[0]), reinterpret_cast<u32x4*>(d[1]), idx - d[7], (int)d[3],
+                       (int)(d[4] & 0xffffffffLL), d[5], d[6], 1, (int)(d[4] >> 32));
     }
 }
 
 int launch_pack(const float* w, void* out, int n_out, int k_in, int taps, long long sn, long long sk, long long st,
                 int flip, hipStream_t stream, const char* name) {
-    const long long total = (long long)n_out * (k_in / 32) * taps * 2 * 3 * 2;
+    const long long total = (long long)n_out * (k_in / 32) * 4;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(pack_frag_kernel, dim3(blocks), dim3(256), 0, stream, w, reinterpret_cast<u32x4*>(out), n_out,
                        k_in, taps, sn, sk, st, flip);
@@ -578,6 +602,15 @@ extern "C" int psld_pack_conv3x3_frag(const float* w_oihw, void* wfrag, int cout
                    "psld_pack_conv3x3_frag: needs out channels %%128 and in channels %%32 (got %d, %d)", n_out, k_in);
     if (dgrad) return launch_pack(w_oihw, wfrag, n_out, k_in, 9, 9, (long long)cin * 9, 1, 1, stream, "psld_pack_conv3x3_frag");
     return launch_pack(w_oihw, wfrag, n_out, k_in, 9, (long long)cin * 9, 9, 1, 0, stream, "psld_pack_conv3x3_frag");
+}
+
+extern "C" int psld_pack_frag_batch(const long long* table_dev, int entries, long long total_items, hipStream_t stream) {
+    PSLD_CHECK_ARG(table_dev && entries > 0 && total_items > 0, "psld_pack_frag_batch: bad args");
+    const long long want = (total_items + 255) / 256;
+    hipLaunchKernelGGL(pack_frag_batch_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, stream,
+                       table_dev, entries, total_items);
+    PSLD_CHECK_LAUNCH("psld_pack_frag_batch");
+    return PSLD_OK;
 }
 
 extern "C" int psld_conv3x3_split_f32(const float* x1, int c1, const float* x2, int c2, int batch, int h, int w,

@@ -150,6 +150,21 @@ __global__ void colsum_final_kernel(const double* __restrict__ part, int chunks,
     for (int k = 0; k < chunks; ++k) t += part[((long long)b * chunks + k) * c + col];
     out[(long long)b * c + col] = (float)(t * (double)alpha);
 }
+// per-image sums [batch][c] -> batch total: grid c/64, block 256 = 64 columns x 4 image lanes; every lane adds its
+// images in index order, the four lanes are combined in lane order (fixed order, no atomics: bitwise repeatable)
+__global__ void colsum_total_kernel(const float* __restrict__ per_image, int batch, int c, float* __restrict__ out,
+                                    float alpha) {
+    __shared__ double red[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int bl = threadIdx.x >> 6;
+    double tot = 0.0;
+    if (col < c)
+        for (int b = bl; b < batch; b += 4) tot += (double)per_image[(long long)b * c + col];
+    red[bl][threadIdx.x & 63] = tot;
+    __syncthreads();
+    if (bl == 0 && col < c)
+        out[col] = (float)((red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) * (double)alpha);
+}
 // scalar fallback: grid (c/64, batch); block 256 = 64 columns x 4 row lanes
 __global__ void colsum_kernel(const float* __restrict__ x, int ld, int hw, int c, float* __restrict__ out,
                               float alpha) {
@@ -430,6 +445,37 @@ extern "C" int psld_colsum_f32(const float* x, int ld, int batch, int hw, int c,
     }
     hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(c, 64), batch), dim3(256), 0, stream, x, ld, hw, c, out, alpha);
     PSLD_CHECK_LAUNCH("psld_colsum_f32");
+    return PSLD_OK;
+}
+// out[c] = alpha * sum over (batch, hw) of x; per_image[b][c] (optional, unscaled) = sum over hw.  Three launches
+// (chunk partials, per-image sums, batch total) instead of the four of two chained psld_colsum_f32 calls.
+extern "C" int psld_bias_grad_f32(const float* x, int ld, int batch, int hw, int c, float* per_image, float* out,
+                                  float alpha, void* workspace, hipStream_t stream) {
+    PSLD_CHECK_ARG(x && out && workspace && batch > 0 && hw > 0 && c > 0, "psld_bias_grad_f32: bad args");
+    PSLD_CHECK_ARG(c % 4 == 0 && ld % 4 == 0 && c / 4 <= 256 && (reinterpret_cast<uintptr_t>(x) & 15) == 0,
+                   "psld_bias_grad_f32: needs c %%4 == 0 (<= 1024), ld %%4 == 0 and a 16-byte aligned input");
+    const int cq = c / 4;
+    int pl = 256 / cq;
+    if (pl < 1) pl = 1;
+    if (pl > hw) pl = hw;
+    int chunks = cdiv(1024, batch);
+    const int max_chunks = cdiv(hw, pl * 4);
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks > 16) chunks = 16;
+    if (chunks < 1) chunks = 1;
+    const int chunk_px = cdiv(hw, chunks);
+    chunks = cdiv(hw, chunk_px);
+    double* part = reinterpret_cast<double*>(workspace);
+    // without a caller buffer the per-image sums live behind the partials (psld_colsum_workspace_bytes covers
+    // 64 chunk rows per image, at most 16 are used)
+    float* pim = per_image ? per_image : reinterpret_cast<float*>(part + (long long)batch * 16 * c);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(chunks, batch), dim3(cq * pl), (size_t)pl * cq * 4 * sizeof(double),
+                       stream, x, ld, hw, c, cq, pl, chunk_px, chunks, part);
+    PSLD_CHECK_LAUNCH("colsum_partial_kernel");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(c, 128), batch), dim3(128), 0, stream, part, chunks, c, pim, 1.0f);
+    PSLD_CHECK_LAUNCH("colsum_final_kernel");
+    hipLaunchKernelGGL(colsum_total_kernel, dim3(cdiv(c, 64)), dim3(256), 0, stream, pim, batch, c, out, alpha);
+    PSLD_CHECK_LAUNCH("colsum_total_kernel");
     return PSLD_OK;
 }
 extern "C" int psld_softmax_rows_f32(const float* x, float* y, long long rows, int L, hipStream_t stream) {

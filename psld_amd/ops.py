@@ -140,6 +140,19 @@ def conv3x3_frag(w_oihw: Tensor, dgrad: bool, out: Optional[Tensor] = None) -> T
     return out
 
 
+def conv3x3_frag_entry(w_oihw: Tensor, dgrad: bool, out: Tensor):
+    """Table entry (without the running index) of ``pack_frag_batch`` equivalent to conv3x3_frag(w, dgrad, out)."""
+    co, ci = w_oihw.shape[0], w_oihw.shape[1]
+    if dgrad:
+        return [w_oihw.data_ptr(), out.data_ptr(), ci, co, 9 | (1 << 32), 9, ci * 9]
+    return [w_oihw.data_ptr(), out.data_ptr(), co, ci, 9, ci * 9, 9]
+
+
+def pack_frag_batch(table: Tensor, entries: int, total_items: int):
+    """table rows: conv3x3_frag_entry(...) + [first work item]; a tensor has cout*cin/8 work items."""
+    check(lib().psld_pack_frag_batch(table.data_ptr(), entries, total_items, _stream()), "psld_pack_frag_batch")
+
+
 def conv3x3_split(x1: Tensor, x2: Optional[Tensor], wfrag: Tensor, cout: int, y: Tensor,
                   epi: Optional[Epilogue] = None, ldy: Optional[int] = None):
     b, h, w, c1 = x1.shape
@@ -369,6 +382,15 @@ def colsum(x: Tensor, ld: int, batch: int, hw: int, c: int, out: Tensor, alpha: 
     ws = workspace(lib().psld_colsum_workspace_bytes(batch, hw, c), x.device)
     check(lib().psld_colsum_f32(x.data_ptr(), ld, batch, hw, c, out.data_ptr(), alpha, ws.data_ptr(), _stream()),
           "psld_colsum_f32")
+    return out
+
+
+def bias_grad(x: Tensor, ld: int, batch: int, hw: int, c: int, out: Tensor, alpha: float = 1.0,
+              per_image: Optional[Tensor] = None):
+    """out[c] = alpha * column sums over (batch, hw); per_image[b][c] (optional) = unscaled per-image sums."""
+    ws = workspace(lib().psld_colsum_workspace_bytes(batch, hw, c), x.device)
+    check(lib().psld_bias_grad_f32(x.data_ptr(), ld, batch, hw, c, _p(per_image), out.data_ptr(), alpha, ws.data_ptr(),
+                                   _stream()), "psld_bias_grad_f32")
     return out
 
 

@@ -258,14 +258,20 @@ class _Exec:
         ops.conv2d_wgrad_nhwc(dy, cout, x, k, k, stride, pad, oh, ow, slabs, cin, 0, nsplit)
         ops.reduce_slabs(slabs, nsplit, n, self.g(conv.weight), layout=1, cout=cout, taps=taps, cin=cin, alpha=alpha)
 
-    def bias_grad(self, dy: Tensor, out: Tensor, alpha: float = 1.0, per_image: Optional[Tensor] = None,
-                  ld: Optional[int] = None):
-        """``ld``: row stride of ``dy`` when it is a column slice of a wider buffer."""
+    def bias_grad(self, dy: Tensor, out: Tensor, alpha: float = 1.0, per_image=None, ld: Optional[int] = None):
+        """``per_image``: True (or a [b, c] tensor) to also get the per-image sums back; ``ld``: row stride of
+        ``dy`` when it is a column slice of a wider buffer."""
         b = dy.shape[0]
         c = dy.shape[-1]
         hw = dy.numel() // (b * c)
-        tmp = per_image if per_image is not None else torch.empty((b, c), device=dy.device, dtype=torch.float32)
-        ops.colsum(dy, ld if ld is not None else c, b, hw, c, tmp)
+        ldx = ld if ld is not None else c
+        if c % 4 == 0 and c <= 1024 and ldx % 4 == 0 and dy.data_ptr() % 16 == 0:
+            if per_image is True:
+                per_image = torch.empty((b, c), device=dy.device, dtype=torch.float32)
+            ops.bias_grad(dy, ldx, b, hw, c, out, alpha, per_image)
+            return per_image
+        tmp = per_image if isinstance(per_image, Tensor) else torch.empty((b, c), device=dy.device, dtype=torch.float32)
+        ops.colsum(dy, ldx, b, hw, c, tmp)
         ops.colsum(tmp, c, 1, b, c, out, alpha)
         return tmp
 
@@ -407,7 +413,7 @@ class _Exec:
             # Conv_0 + time-embedding bias
             def side0():
                 self.wgrad(dh1, a0r, mod.Conv_0, 3, 1, 1)
-                dtp = self.bias_grad(dh1, self.g(mod.Conv_0.bias))
+                dtp = self.bias_grad(dh1, self.g(mod.Conv_0.bias), per_image=True if temb_act is not None else None)
                 if temb_act is not None:
                     d0 = mod.Dense_0
                     kd = d0.weight.shape[1]
@@ -875,6 +881,7 @@ class NCSNpp(nn.Module):
         self._flat_grad: Optional[Tensor] = None
         self._offsets = None
         self._pack_cache = {}
+        self._frag_table = None     # (signature, device table, entries, total work items) of the batched fragment refresh
         self._pack_key = None
         self._epoch = 0
         self._anchor = None
@@ -1003,7 +1010,8 @@ class NCSNpp(nn.Module):
         return out
 
     def _frag(self, conv: _Affine, dgrad: bool) -> Tensor:
-        """bf16 limb fragments of a 3x3 weight (ops.conv3x3_frag), cached until the weights change."""
+        """bf16 limb fragments of a 3x3 weight (ops.conv3x3_frag), cached until the weights change; once two or
+        more exist, a weight update refreshes ALL of them with one batched launch."""
         w = conv.weight
         key = (id(w), dgrad, "frag")
         self._conv_by_weight[id(w)] = conv
@@ -1011,9 +1019,37 @@ class NCSNpp(nn.Module):
         stamp = (self._epoch, w._version, w.data_ptr())
         if ent is not None and ent[0] == stamp:
             return ent[1]
+        if ent is not None and ent[1].device == w.device and self._refresh_frags():
+            ent = self._pack_cache[key]
+            if ent[0] == stamp:
+                return ent[1]
         out = ops.conv3x3_frag(w.detach(), dgrad, ent[1] if ent is not None and ent[1].device == w.device else None)
         self._pack_cache[key] = (stamp, out)
+        self._frag_table = None
         return out
+
+    def _refresh_frags(self) -> bool:
+        """Re-split every registered 3x3 weight into its existing fragment buffer with ONE launch
+        (psld_pack_frag_batch).  False when there is nothing to batch."""
+        keys = [k for k in self._pack_cache if len(k) == 3 and k[2] == "frag"]
+        if len(keys) < 2:
+            return False
+        ws = [self._conv_by_weight[k[0]].weight for k in keys]
+        outs = [self._pack_cache[k][1] for k in keys]
+        if any(o.device != w.device for o, w in zip(outs, ws)):
+            return False
+        sig = tuple((k, w.data_ptr(), o.data_ptr()) for k, w, o in zip(keys, ws, outs))
+        if self._frag_table is None or self._frag_table[0] != sig:
+            rows, total = [], 0
+            for k, w, o in zip(keys, ws, outs):
+                rows.append(ops.conv3x3_frag_entry(w.detach(), k[1], o) + [total])
+                total += w.shape[0] * w.shape[1] // 8            # work items: one per lane slot
+            self._frag_table = (sig, torch.tensor(rows, dtype=torch.int64, device=ws[0].device), len(rows), total)
+        _, table, n, total = self._frag_table
+        ops.pack_frag_batch(table, n, total)
+        for k, w, o in zip(keys, ws, outs):
+            self._pack_cache[k] = ((self._epoch, w._version, w.data_ptr()), o)
+        return True
 
     def _gfrag(self, owner: nn.Parameter, tag: str, build):
         """Limb fragments derived from ``owner`` (and possibly sibling parameters), cached until the weights change.
@@ -1150,7 +1186,7 @@ class NCSNpp(nn.Module):
         cls = self.__class__
         new = cls.__new__(cls)
         memo[id(self)] = new
-        skip = {"_flat", "_flat_grad", "_pack_cache", "_anchor", "_reducer", "_offsets", "_module_offs", "_posfreq",
+        skip = {"_flat", "_flat_grad", "_pack_cache", "_frag_table", "_anchor", "_reducer", "_offsets", "_module_offs", "_posfreq",
                 "_side", "_plist", "_gviews", "_graphs", "_conv_by_weight", "_scratch_grad", "_sviews"}
         for k, v in self.__dict__.items():
             if k in skip:
@@ -1165,6 +1201,7 @@ class NCSNpp(nn.Module):
         new._scratch_grad = new._sviews = None
         new._accumulating = new._grad_stale = False
         new._pack_cache = {}
+        new._frag_table = None
         new._pack_key = None
         new._epoch = 0
         # detach copied params from the source's flat buffer (they are re-flattened on first use)

@@ -267,6 +267,34 @@ def test_gemm_split(ops, m, n, k1, k2):
     assert torch.count_nonzero(wide[:, :n]) == 0 and torch.count_nonzero(wide[:, 2 * n:]) == 0
 
 
+def test_pack_frag_batch_matches_single(ops):
+    ws = [gen(128, 64, 3, 3, seed=80).to(DEV), gen(256, 32, 3, 3, seed=81).to(DEV), gen(64, 128, 3, 3, seed=82).to(DEV)]
+    dg = [False, False, True]
+    single = [ops.conv3x3_frag(w, d) for w, d in zip(ws, dg)]
+    outs = [torch.zeros_like(t) for t in single]
+    rows, total = [], 0
+    for w, d, o in zip(ws, dg, outs):
+        rows.append(ops.conv3x3_frag_entry(w, d, o) + [total])
+        total += w.shape[0] * w.shape[1] // 8
+    ops.pack_frag_batch(torch.tensor(rows, dtype=torch.int64, device=DEV), len(rows), total)
+    for a, b in zip(single, outs):
+        assert torch.equal(a, b)
+
+
+def test_bias_grad(ops):
+    b, hw, c, ld = 5, 64, 128, 384
+    x = gen(b, hw, ld, seed=83).to(DEV)
+    sl = x[..., 128:256]                                    # column slice of a wider buffer
+    per = torch.full((b, c), float("nan"), device=DEV)
+    out = torch.full((c,), float("nan"), device=DEV)
+    ops.bias_grad(sl, ld, b, hw, c, out, 0.5, per)
+    ref = sl.double().sum(dim=1)
+    assert rel_l2(per, ref) < 1e-6 and rel_l2(out, 0.5 * ref.sum(dim=0)) < 1e-6
+    out2 = torch.empty_like(out)
+    ops.bias_grad(sl, ld, b, hw, c, out2, 0.5, None)
+    assert torch.equal(out, out2)
+
+
 def test_conv3x3_split_rejects_unsupported(ops):
     assert not ops.conv3x3_split_supported(6, 0, 2, 32, 32, 128)      # stem: 6 input channels
     assert not ops.conv3x3_split_supported(128, 0, 2, 32, 32, 6)      # head: 6 output channels
