@@ -32,7 +32,11 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
-constexpr int ROWB = 80;        // bytes per pixel and limb in the LDS halo image: 32 bf16 + 8 pad (conflict-free b128)
+constexpr int ROWB = 64;        // bytes per pixel and limb in the LDS image: 32 bf16, no padding.  The 16-byte slot s
+                                // (8 channels) of pixel row p sits at slot s ^ lds_swz(p): with it the ds_read_b128 of
+                                // the 16x16x32 A operand (16 consecutive rows x 4 slots per wave) is bank-conflict
+                                // free for every row offset, i.e. for all nine taps (a linear padded image is 2-way)
+__device__ __forceinline__ int lds_swz(int p) { return (p >> 1) & 2; }
 constexpr int TAP_U4 = 4 * 3 * 64;   // uint4 per (wave column, tap, 32-channel chunk): [n-block 4][limb 3][lane 64]
 
 int g_math_mode = -1;
@@ -222,7 +226,8 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
             unsigned h0, m0_, l0, h1, m1, l1;
             split3(hv[i][0], hv[i][1], h0, m0_, l0);
             split3(hv[i][2], hv[i][3], h1, m1, l1);
-            unsigned char* q = smem + ((tid + 256 * i) >> 3) * ROWB + c4 * 8;
+            const int prow = (tid + 256 * i) >> 3;
+            unsigned char* q = smem + prow * ROWB + (((c4 >> 1) ^ lds_swz(prow)) << 4) + (c4 & 1) * 8;
             *reinterpret_cast<u32x2*>(q) = u32x2{h0, h1};
             *reinterpret_cast<u32x2*>(q + LIMB) = u32x2{m0_, m1};
             *reinterpret_cast<u32x2*>(q + 2 * LIMB) = u32x2{l0, l1};
@@ -231,19 +236,19 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
 
     // v_mfma_f32_16x16x32_bf16 (under this load it sustains a ~15 % higher clock than 32x32x16: measured 212 vs 184
     // TFLOP/s on 256->256 @32x32): the 64x64 wave tile is 4x4 blocks, one 32-deep K step per tap and chunk.
-    // Lane l holds A[row = l & 15][k = 8*(l >> 4) + j]: LDS byte offset of its rows at tap (0, 0)
+    // Lane l holds A[row = l & 15][k = 8*(l >> 4) + j]: LDS pixel row of its rows at tap (0, 0)
     const int r16 = lane & 15, kq = lane >> 4;
     int abase[4];
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
         const int ml = wr * 64 + mb * 16 + r16;
         if constexpr (PW) {
-            abase[mb] = ml * ROWB + kq * 16;
+            abase[mb] = ml;
         } else {
             const int seg = ml / (a.rps * a.W);
             const int rem = ml - seg * (a.rps * a.W);
             const int ry = rem / a.W, ox = rem - ry * a.W;
-            abase[mb] = ((seg * (a.rps + 2) + ry) * W2 + ox) * ROWB + kq * 16;
+            abase[mb] = (seg * (a.rps + 2) + ry) * W2 + ox;
         }
     }
 
@@ -270,7 +275,7 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
     store_halo();
     __syncthreads();
 
-    int c = c_beg, tap = 0, tap_off = 0, kx = 0;
+    int c = c_beg, tap = 0, tap_off = 0, kx = 0;     // tap_off: pixel-row offset of the current tap in the image
     constexpr int PREFETCH_TAP = TAPS >= 2 ? TAPS - 2 : 0;     // where the next stage's global loads are issued
     // one K step; pp (compile time) = which B fragment buffer it reads, the other one receives the next step's
     auto step = [&](int sigma, auto PP) {
@@ -280,10 +285,12 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
         load_b(sigma + 1, bq[pp ^ 1]);
         u32x4 fa[4][3];
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
+        for (int mb = 0; mb < 4; ++mb) {
+            const int prow = abase[mb] + tap_off;
+            const unsigned char* q = smem + prow * ROWB + ((kq ^ lds_swz(prow)) << 4);
 #pragma unroll
-            for (int l = 0; l < 3; ++l)
-                fa[mb][l] = *reinterpret_cast<const u32x4*>(smem + l * LIMB + abase[mb] + tap_off);
+            for (int l = 0; l < 3; ++l) fa[mb][l] = *reinterpret_cast<const u32x4*>(q + l * LIMB);
+        }
         // limb products, smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
@@ -304,9 +311,9 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
             }
             ++c;
         } else if constexpr (PW) {
-            tap_off += 128 * ROWB;
+            tap_off += 128;
         } else {
-            if (++kx == 3) { kx = 0; tap_off += (W2 - 2) * ROWB; } else { tap_off += ROWB; }
+            if (++kx == 3) { kx = 0; tap_off += W2 - 2; } else { tap_off += 1; }
         }
     };
     for (int sigma = sig_beg; sigma < sig_end; sigma += 2) {
