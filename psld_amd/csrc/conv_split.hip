@@ -407,7 +407,6 @@ __global__ void __launch_bounds__(256, 3) dwgrad_kernel(const DWgradArgs a) {
     const int kt_beg = split * a.ktiles_per_split;
     const int kt_end = min(a.ktiles, kt_beg + a.ktiles_per_split);
     const int HW = a.H * a.W;
-    const float* zp = a.zero;
 
     // transposed-read lane roles: a group of 16 lanes reads 4 pixel rows x 16 channels; lane 4q + p supplies the
     // address of row q, channels 4p..4p+3 and receives channel (lane & 15) of the four rows
@@ -423,26 +422,45 @@ __global__ void __launch_bounds__(256, 3) dwgrad_kernel(const DWgradArgs a) {
     }
 
     const int qa = tid & 15, ra = tid >> 4;     // staging: channel quad, pixel row (+16 per item)
-    int hrow[WG_NB], hcol[WG_NB];               // staged x row / column of every item (K-tile invariant)
+    // Staged x items: everything that does not change from K tile to K tile is folded into a byte offset and a few
+    // validity bits per item; per tile only a scalar base pointer and a scalar row mask move.  Loads go through a
+    // raw buffer resource, whose range check returns zeros for the offset 0xFFFFFFFF given to padding items
+    // (no zero-page select, ~4 VALU per item instead of ~15).  Measured: neutral - and so was a double-buffered LDS
+    // variant with one barrier per K tile at two workgroups per CU (181-188 vs 200-209 TFLOP/s): the kernel runs
+    // best as three single-buffered workgroups per CU overlapping each other's staging phases.
+    unsigned xoff[WG_NB];   // byte offset from pixel (img, oy0 + ky - 1, ox0 - 1), channel ci0
+    int xrow[WG_NB];        // staged row of the item (>= 8: never valid)
+    int xcol[WG_NB];        // bit 0: column valid when the K tile starts at ox0 = 0, bit 1: at ox0 = 32 (W = 64)
 #pragma unroll
     for (int i = 0; i < WG_NB; ++i) {
         const int px = ra + 16 * i;
-        hrow[i] = px / a.hw_w;
-        hcol[i] = px - hrow[i] * a.hw_w;
+        const int hr = px / a.hw_w, hc = px - hr * a.hw_w;
+        xoff[i] = (unsigned)(((hr * a.W + hc) * a.cin + qa * 4) * 4);
+        xrow[i] = hr < a.hrows ? hr : 31;
+        xcol[i] = ((hc >= 1 && hc <= a.W) ? 1 : 0) | ((hc + 31 < a.W) ? 2 : 0);
     }
+    const unsigned aoff = (unsigned)((ra * a.lddy + qa * 4) * 4);
     f32x4 va[2], vb[WG_NB];
     auto load_tile = [&](int kt) {
         const int p0 = kt * 32;
         const int img = p0 / HW;
         const int rem = p0 - img * HW;
         const int oy0 = rem / a.W, ox0 = rem - oy0 * a.W;
+        const int iy0 = oy0 + ky - 1;
+        unsigned rowmask = 0;                       // bit r: staged row r lies inside the image
+        for (int rr = 0; rr < a.hrows; ++rr) rowmask |= (iy0 + rr >= 0 && iy0 + rr < a.H) ? 1u << rr : 0u;
+        const int colsel = ox0 >> 5;
+        const float* xb = a.x + ((long long)((img * a.H + iy0) * a.W + ox0 - 1) * a.cin + ci0);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.dy + ((long long)p0 * a.lddy + co0)), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) va[i] = ld4(a.dy + ((long long)(p0 + ra + 16 * i) * a.lddy + co0 + qa * 4));
+        for (int i = 0; i < 2; ++i)
+            va[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, aoff + i * 16 * a.lddy * 4, 0, 0));
 #pragma unroll
         for (int i = 0; i < WG_NB; ++i) {
-            const int iy = oy0 + hrow[i] + ky - 1, ix = ox0 + hcol[i] - 1;
-            const bool ok = hrow[i] < a.hrows && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            vb[i] = ld4(ok ? a.x + ((long long)((img * a.H + iy) * a.W + ix) * a.cin + ci0 + qa * 4) : zp);
+            const bool ok = ((rowmask >> xrow[i]) & (unsigned)(xcol[i] >> colsel) & 1u) != 0;
+            vb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xoff[i] : 0xffffffffu, 0, 0));
         }
     };
     auto store_rows = [&](unsigned char* img, int limb_stride, const f32x4& v, int row) {

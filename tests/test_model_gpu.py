@@ -63,6 +63,29 @@ def test_network_forward_matches_reference(golden, name):
     assert err < 2e-5
 
 
+def test_network_forward_in_f32_mfma_mode(golden):
+    """PSLD_MATH=f32 (fp32 MFMA for every contraction) stays a supported, parity-green path, and agrees with the
+    default bf16x6 limb arithmetic to fp32 rounding on the north-star network."""
+    from psld_amd import ops
+    net, cfg, _ = _build("c10_sota")
+    g = golden("net_c10_sota.npz")
+    x, t = T(g["x"]).to(DEV), T(g["t"]).to(DEV)
+    mode = ops.math_mode()
+    try:
+        ops.set_math_mode("f32")
+        with torch.no_grad():
+            y32 = net(x, t)
+        ops.set_math_mode("bf16x6")
+        with torch.no_grad():
+            y6 = net(x, t)
+    finally:
+        ops.set_math_mode(mode)
+    e32, e6, d = rel_l2(y32, T(g["y"])), rel_l2(y6, T(g["y"])), rel_l2(y6, y32)
+    print(f"c10_sota forward: f32 MFMA {e32:.3e}, bf16x6 {e6:.3e} vs reference; bf16x6 vs f32 {d:.3e}")
+    assert e32 < 2e-5 and e6 < 2e-5 and d < 5e-6
+    assert not torch.equal(y32, y6)          # the two modes really are different kernels
+
+
 def test_native_library_is_what_ran():
     """The HIP shared object must be mapped into this process (no silent eager fallback)."""
     from psld_amd import _lib
