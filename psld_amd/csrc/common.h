@@ -49,10 +49,15 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-__device__ __forceinline__ float silu_f(float z) { return z / (1.0f + expf(-z)); }
+// sigmoid through v_exp_f32 / v_rcp_f32 (1 ulp each; e^-z = 2^(-z log2 e)): the IEEE expf + division sequence
+// it replaces made the GroupNorm+SiLU kernels VALU-bound instead of HBM-bound.  z -> -inf gives 1/(1+inf) = 0.
+__device__ __forceinline__ float sigmoid_f(float z) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+}
+__device__ __forceinline__ float silu_f(float z) { return z * sigmoid_f(z); }
 // d/dz [z*sigmoid(z)] = s*(1 + z*(1-s))
 __device__ __forceinline__ float dsilu_f(float z) {
-    float s = 1.0f / (1.0f + expf(-z));
+    const float s = sigmoid_f(z);
     return s * (1.0f + z * (1.0f - s));
 }
 

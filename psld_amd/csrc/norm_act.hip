@@ -20,16 +20,18 @@ struct Map {
     int cq, pl, threads, chunks, chunk_px;
 };
 
-inline Map make_map(int batch, int hw, int c) {
+// elementwise: true for the apply kernels (no cross-chunk reduction behind them: more, shorter blocks stream better —
+// measured 43 vs 48 us on 128x32x32x256), false for the statistics kernels whose finalize pass walks the chunks
+inline Map make_map(int batch, int hw, int c, bool elementwise = false) {
     Map m;
     m.cq = c / 4;
     m.pl = MAXT / m.cq;
     if (m.pl < 1) m.pl = 1;
     if (m.pl > hw) m.pl = hw;
     m.threads = m.cq * m.pl;
-    // aim for >= ~2048 blocks in flight but <= 64 pixels per thread per chunk
-    int chunks = cdiv(2048, batch);
-    if (chunks > 32) chunks = 32;             // the finalize kernels walk the chunks serially
+    // aim for ~1024 (statistics) / ~8192 (elementwise) blocks but <= 64 pixels per thread per chunk
+    int chunks = cdiv(elementwise ? 8192 : 1024, batch);
+    if (!elementwise && chunks > 32) chunks = 32;   // the finalize kernels walk the chunks serially
     int max_chunks = cdiv(hw, m.pl);          // at least one pixel per thread
     if (chunks > max_chunks) chunks = max_chunks;
     int min_chunks = cdiv(hw, m.pl * 64);
@@ -52,6 +54,7 @@ __global__ void gn_partial_kernel(const float* __restrict__ x, int hw, int c, in
     const int p0 = chunk * chunk_px, p1 = min(hw, p0 + chunk_px);
     const float* base = x + ((long long)n * hw) * c + q * 4;
     float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+#pragma unroll 4
     for (int p = p0 + l; p < p1; p += pl) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)p * c);
 #pragma unroll
@@ -120,6 +123,7 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, const float* __rest
     const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + (long long)n * c + q * 4);
     const long long off = ((long long)n * hw) * c + q * 4;
     const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+#pragma unroll 4
     for (int p = p0 + l; p < p1; p += pl) {
         const long long idx = off + (long long)p * c;
         const f32x4 v = *reinterpret_cast<const f32x4*>(x + idx);
@@ -161,6 +165,7 @@ __global__ void gn_bwd_partial_kernel(const float* __restrict__ dy, const float*
     const long long off = ((long long)n * hw) * c + q * 4;
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+#pragma unroll 4
     for (int p = p0 + l; p < p1; p += pl) {
         const long long idx = off + (long long)p * c;
         const f32x4 xv = *reinterpret_cast<const f32x4*>(x + idx);
@@ -273,6 +278,7 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
     }
     const long long off = ((long long)n * hw) * c + q * 4;
     const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+#pragma unroll 4
     for (int p = p0 + l; p < p1; p += pl) {
         const long long idx = off + (long long)p * c;
         const f32x4 xv = *reinterpret_cast<const f32x4*>(x + idx);
@@ -330,7 +336,7 @@ extern "C" int psld_gn_apply_nhwc_f32(const float* x, const float* scale, const 
                                       hipStream_t stream) {
     PSLD_CHECK_ARG(x && scale && shift && y, "psld_gn_apply: null pointer");
     PSLD_CHECK_ARG(c % 4 == 0 && c / 4 <= MAXT, "psld_gn_apply: unsupported C=%d", c);
-    const Map m = make_map(batch, hw, c);
+    const Map m = make_map(batch, hw, c, true);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(m.chunks, batch), dim3(m.threads), 0, stream, x, scale, shift, y, hw, c,
                        m.cq, m.pl, m.chunk_px, act, drop_p, seed);
     PSLD_CHECK_LAUNCH("gn_apply_kernel");
@@ -361,8 +367,9 @@ extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float
     PSLD_CHECK_LAUNCH("gn_bwd_finalize_kernel");
     hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(cdiv(c, 64), 2), dim3(256), 0, stream, sums, batch, c, dgamma, dbeta);
     PSLD_CHECK_LAUNCH("gn_bwd_param_kernel");
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(m.chunks, batch), dim3(m.threads), 0, stream, dy, x, mean, rstd,
-                       gamma, beta, coef, hw, c, groups, m.cq, m.pl, m.chunk_px, act, drop_p, seed, accumulate_dx, dx);
+    const Map ma = make_map(batch, hw, c, true);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ma.chunks, batch), dim3(ma.threads), 0, stream, dy, x, mean, rstd,
+                       gamma, beta, coef, hw, c, groups, ma.cq, ma.pl, ma.chunk_px, act, drop_p, seed, accumulate_dx, dx);
     PSLD_CHECK_LAUNCH("gn_bwd_apply_kernel");
     return PSLD_OK;
 }

@@ -131,6 +131,7 @@ __global__ void colsum_partial_kernel(const float* __restrict__ x, int ld, int h
     const int p0 = chunk * chunk_px, p1 = min(hw, p0 + chunk_px);
     const float* base = x + ((long long)b * hw) * ld + q * 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
     for (int p = p0 + l; p < p1; p += pl) acc += *reinterpret_cast<const f32x4*>(base + (long long)p * ld);
 #pragma unroll
     for (int e = 0; e < 4; ++e) red[(long long)l * cq * 4 + q * 4 + e] = (double)acc[e];
