@@ -318,6 +318,11 @@ int psld_vp_perturb_f32(const float* x0, const float* eps, const double* t, doub
 int psld_vp_reverse_f64(double* x, const float* eps_pred, const double* z, double beta, double std, double dt,
                         int probability_flow, int mode, long long n, double* f_bar, float* x_f32_out,
                         hipStream_t stream);
+/* Inpainting combine (ES3EulerMaruyamaInpainter.inpaint_update_fn, samplers/sde.py:161-181): for the state
+ * x = [x | m] and the re-perturbed known image u = [x_k | m_k], both [B,2C,HW] f64, x <- x*(1-mask) + u*mask with
+ * mask [B,C,HW] f32 in {0,1} applied to both halves; optionally refreshes the f32 copy the network reads. */
+int psld_mask_combine_f64(double* x, const double* u, const float* mask, int batch, int c, int hw,
+                          float* x_f32_out, hipStream_t stream);
 int psld_f64_to_f32(const double* x, float* y, long long n, hipStream_t stream);
 int psld_f32_to_f64(const float* x, double* y, long long n, hipStream_t stream);
 

@@ -304,6 +304,55 @@ def em_sample(sde: PSLDOracle, score_fn: Callable, batch: Tensor, ts: Tensor, n_
 
 
 # --------------------------------------------------------------------------------------
+# Inpainting sampler ES3EulerMaruyamaInpainter (main/samplers/sde.py:117-224) -- SURVEY.md 8(f) rank 4
+# --------------------------------------------------------------------------------------
+def inpaint_sample(sde: PSLDOracle, score_fn: Callable, x_0: Tensor, mask: Tensor, ts: Tensor, n_steps: int,
+                   denoise: bool = True, eps: float = 1e-3, training_mode: str = "hsm",
+                   draw: Optional[Callable] = None) -> Tensor:
+    """samplers/sde.py:188-224.  ``draw(shape, dtype)`` replaces, in call order, every random draw of the
+    reference: the two ``torch.randn`` of ``prior_sampling`` (psld.py:368-369), and per update the predictor's
+    ``randn_like(x)`` (sde.py:156) followed by ``_perturb``'s ``randn_like(x_0)`` and ``randn_like(z_0)``
+    (sde.py:129,139; the momentum draw happens even in HSM mode, where it is then discarded)."""
+    if draw is None:
+        draw = lambda shape, dtype: torch.randn(*shape, dtype=dtype)
+
+    def perturb(t):                                                   # sde.py:127-142
+        m_0 = np.sqrt(sde.mm_0) * draw(tuple(x_0.shape), x_0.dtype)
+        mm_0 = 0.0
+        if training_mode == "hsm":
+            m_0 = torch.zeros_like(x_0)
+            mm_0 = sde.mm_0
+        e = draw((x_0.shape[0], 2 * x_0.shape[1], *x_0.shape[2:]), x_0.dtype)
+        z_t, mu_t, _ = sde.perturb_data(x_0, m_0, 0, mm_0, t, eps=e)
+        return z_t, mu_t
+
+    def combine(a, k):                                                # sde.py:170-174 / 176-180
+        a_x, a_m = torch.chunk(a, 2, dim=1)
+        k_x, k_m = torch.chunk(k, 2, dim=1)
+        return torch.cat([a_x * (1 - mask) + k_x * mask, a_m * (1 - mask) + k_m * mask], dim=1)
+
+    def update(x, t, dt):                                             # sde.py:161-181
+        tt = t * torch.ones(x.shape[0], dtype=torch.float64)
+        f, g = sde.reverse_sde(x, tt, score_fn, probability_flow=False)
+        x_mean = x + f * dt                                           # sde.py:155
+        x = x_mean + g * torch.sqrt(dt) * draw(tuple(x.shape), x.dtype)
+        u_k, mu_k = perturb((sde.T - t) * torch.ones(x.shape[0], dtype=torch.float64))
+        return combine(x, u_k), combine(x_mean, mu_k)
+
+    px = draw(tuple(x_0.shape), torch.float32)                        # psld.py:366-370
+    pm = draw(tuple(x_0.shape), torch.float32) * np.sqrt(sde.m)
+    x = torch.cat([px, pm], dim=1)
+    u_k, _ = perturb(sde.T * torch.ones(x.shape[0], dtype=torch.float64))   # sde.py:195-198
+    x = combine(x, u_k)
+    with torch.no_grad():
+        for i in range(n_steps):
+            x, _ = update(x, ts[i], bcast(ts[i + 1] - ts[i], x))
+        if denoise:
+            _, x = update(x, torch.tensor(sde.T - eps), bcast(torch.tensor(eps), x))   # sde.py:213-221
+    return x
+
+
+# --------------------------------------------------------------------------------------
 # Symmetric-splitting (SSCS) sampler  (main/samplers/sde.py:227-370) -- SURVEY.md 8(f) rank 1
 # --------------------------------------------------------------------------------------
 def sscs_mean(sde: PSLDOracle, u: Tensor, t: Tensor, dt) -> Tensor:

@@ -2,6 +2,8 @@
 
     python -m psld_amd.cli train  --config c10_sota [key=value ...]        (main/train_sde.py:21-120)
     python -m psld_amd.cli sample --config c10_sota [key=value ...]        (main/eval/sample.py:28-109)
+    python -m psld_amd.cli inpaint --config c10_sota --data x.npy --mask m.npy [key=value ...]
+                                                                           (main/eval/inpaint.py:29-135)
 
 ``key=value`` are Hydra-style dotted overrides on the ``dataset.diffusion`` node; the prefix
 ``dataset.diffusion.`` is accepted and stripped, so the override lists of ``scripts_psld/**.sh`` can be
@@ -202,20 +204,90 @@ def sample(args, overrides):
         dist.destroy_process_group()
 
 
+def _save_u8(stem, u8, save_mode):
+    if save_mode == "image":
+        try:
+            from PIL import Image
+            for i, im in enumerate(u8):
+                Image.fromarray(im).save(stem + "_%d.png" % i, "png")
+            return
+        except ImportError:
+            pass
+    np.save(stem + ".npy", u8)
+
+
+def inpaint(args, overrides):
+    """main/eval/inpaint.py: images of ``--data`` with the pixels where ``--mask`` is 0 re-synthesised by the
+    ``ip_em_sde`` sampler.  Masks: uint8/bool [N,H,W,3] (1 = keep; the reference derives them from MNIST digits,
+    datasets/inpaint.py:34-41) or, with ``--mask synthetic``, a centred square hole.  Writes images/, corrupt/ and
+    batch/ like InpaintingImageWriter(save_batch=True) (callbacks.py:155-215)."""
+    from psld_amd import config as C, ops
+    from psld_amd.ddp import init_distributed, shard_range
+    from psld_amd.registry import get_module
+    import torch.distributed as dist
+    rank, local, world = init_distributed()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    cfg = parse_overrides(getattr(C, args.config)(), overrides)
+    ev = cfg.evaluation
+    score_fn, ema, sde = build(cfg, dev)
+    if ev.chkpt_path:
+        load_checkpoint(ev.chkpt_path, score_fn, ema)
+        score_fn.to(dev), ema.to(dev)
+    score_fn.eval(), ema.eval()
+    wrapper = get_module("pl_modules", cfg.model.pl_module)(cfg, sde, score_fn, ema_score_fn=ema,
+                                                            sampler_cls=get_module("samplers", "ip_em_sde"))
+    wrapper.global_rank = rank
+    wrapper.on_predict_start()
+    data = _dataset(cfg, args, dev, 0)
+    size = cfg.data.image_size
+    n = min(ev.n_samples, data.shape[0])                                  # datasets/inpaint.py:43-44
+    if args.mask and args.mask != "synthetic":
+        marr = np.load(args.mask, mmap_mode="r")
+        assert marr.shape[1:] == (size, size, 3), marr.shape
+        masks = torch.from_numpy(np.ascontiguousarray(marr[:n])).to(dev).ne(0)
+    else:
+        masks = torch.ones((n, size, size, 3), dtype=torch.bool, device=dev)
+        masks[:, size // 4: 3 * size // 4, size // 4: 3 * size // 4] = False
+    lo, hi = shard_range(n, rank, world)
+    base = os.path.join(ev.save_path or "psld_inpaint", str(ev.path_prefix)) if ev.path_prefix else (ev.save_path or "psld_inpaint")
+    dirs = {k: os.path.join(base, k) for k in ("images", "corrupt", "batch")}
+    for d in dirs.values():
+        os.makedirs(d, exist_ok=True)
+    for bi, start in enumerate(range(lo, hi, ev.batch_size)):
+        stop = min(start + ev.batch_size, hi)
+        x0 = ops.uint8_to_images(data[start:stop].contiguous(), norm=cfg.data.norm)
+        mask = masks[start:stop].permute(0, 3, 1, 2).contiguous().to(torch.long)
+        x = wrapper.predict_step((x0, mask), bi)
+        name = f"output_{ev.sample_prefix}_{rank}_{bi}"
+        u8 = ops.samples_to_uint8(x.contiguous(), is_augmented=cfg.model.sde.is_augmented, denorm=cfg.data.norm)
+        _save_u8(os.path.join(dirs["images"], name), u8.cpu().numpy(), ev.save_mode)
+        img01 = (x0 * 0.5 + 0.5) if cfg.data.norm else x0                   # callbacks.py:198
+        to_u8 = lambda t: (t.clamp(0, 1) * 255).round().to(torch.uint8).permute(0, 2, 3, 1).cpu().numpy()
+        _save_u8(os.path.join(dirs["corrupt"], name), to_u8(img01 * mask), ev.save_mode)
+        _save_u8(os.path.join(dirs["batch"], name), to_u8(img01), ev.save_mode)
+        if rank == 0:
+            print(f"rank 0: inpainted {stop - lo}/{hi - lo}", flush=True)
+    if world > 1:
+        dist.barrier(device_ids=[local])
+        dist.destroy_process_group()
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="psld_amd.cli")
     sub = ap.add_subparsers(dest="cmd", required=True)
-    for name in ("train", "sample"):
+    for name in ("train", "sample", "inpaint"):
         p = sub.add_parser(name)
         p.add_argument("--config", default="c10_sota", choices=["c10_sota", "celeba64_sota", "yaml_default", "tiny"])
         p.add_argument("--data", default="synthetic", help="uint8 [N,H,W,3] .npy file or 'synthetic'")
         p.add_argument("--synthetic-size", type=int, default=2048)
         p.add_argument("--max-steps", type=int, default=0)
         p.add_argument("--log-every", type=int, default=10)
+        p.add_argument("--mask", default="synthetic", help="inpaint: uint8 [N,H,W,3] .npy (1 = keep) or 'synthetic'")
     args, overrides = ap.parse_known_args(argv)
     if not torch.cuda.is_available():
         raise SystemExit("psld_amd needs an MI355X: there is no CPU fallback")
-    (train if args.cmd == "train" else sample)(args, overrides)
+    {"train": train, "sample": sample, "inpaint": inpaint}[args.cmd](args, overrides)
 
 
 if __name__ == "__main__":

@@ -377,7 +377,6 @@ struct DWgradArgs {
     long long slab_stride;
     int hw_w;               // staged row width = min(W, 32) + 2
     int hrows;              // staged rows per K tile = max(1, 32 / W)
-    const float* zero;
 };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -692,8 +691,6 @@ extern "C" int psld_conv3x3_wgrad_split_f32(const float* dy, int lddy, int cout,
     a.slab_stride = (long long)cout * 9 * cin_total;
     a.hw_w = (w < 32 ? w : 32) + 2;
     a.hrows = w >= 32 ? 1 : 32 / w;
-    a.zero = psld_detail_zero_page("psld_conv3x3_wgrad_split_f32");
-    if (!a.zero) return PSLD_ERR_LAUNCH;
     constexpr size_t LDS = (size_t)3 * (WG_ALIMB + WG_BLIMB);
     static bool configured = false;
     if (!configured) {

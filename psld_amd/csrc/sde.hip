@@ -352,6 +352,30 @@ extern "C" int psld_vp_reverse_f64(double* x, const float* eps_pred, const doubl
     return PSLD_OK;
 }
 
+// x <- x*(1 - mask) + u*mask on both halves [x | m] of the state (samplers/sde.py:170-174): mask is {0, 1}, so this
+// selects; the reference's arithmetic form is kept (built with -ffp-contract=off) to stay bit-identical with it.
+__global__ void mask_combine_kernel(double* __restrict__ x, const double* __restrict__ u, const float* __restrict__ mask,
+                                    long long per_img, long long total, float* __restrict__ x_f32) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long img = i / (2 * per_img), r = i - img * 2 * per_img;
+        const double m = (double)mask[img * per_img + (r < per_img ? r : r - per_img)];
+        const double v = x[i] * (1.0 - m) + u[i] * m;
+        x[i] = v;
+        if (x_f32) x_f32[i] = (float)v;
+    }
+}
+
+extern "C" int psld_mask_combine_f64(double* x, const double* u, const float* mask, int batch, int c, int hw,
+                                     float* x_f32_out, hipStream_t stream) {
+    PSLD_CHECK_ARG(x && u && mask && batch > 0 && c > 0 && hw > 0, "psld_mask_combine_f64: bad args");
+    const long long per_img = (long long)c * hw, total = 2 * per_img * batch;
+    hipLaunchKernelGGL(mask_combine_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, u, mask, per_img, total,
+                       x_f32_out);
+    PSLD_CHECK_LAUNCH("psld_mask_combine_f64");
+    return PSLD_OK;
+}
+
 extern "C" int psld_lincomb_f64(double* out, const double* base, const double* const* v, const double* coef, int nv,
                                 long long n, float* out_f32, hipStream_t stream) {
     PSLD_CHECK_ARG(out && v && coef && nv >= 0 && nv <= 8 && n > 0, "psld_lincomb_f64: bad args");

@@ -5,7 +5,9 @@
 // through ATen: nn.Conv2d 3x3/1x1 (song_sde/layers.py:85-109), NIN (layers.py:531-540),
 // nn.Linear (layerspp.py:225-228, ncsnpp.py:99-105), the attention einsums
 // (layerspp.py:82-87) and the strided pyramid conv (up_or_down_sampling.py:177) — and their
-// autograd backward passes.
+// autograd backward passes.  In the default arithmetic mode (PSLD_MATH_BF16X6) the 3x3 stride-1
+// convolutions and the 1x1 / NIN projections of 128-multiple widths go to conv_split.hip instead;
+// this engine keeps everything else (and everything when PSLD_MATH=f32).
 //
 // Design (CDNA4):  one workgroup = 256 threads = 4 wave64, block tile 128x128, K step 32.
 // Each wave owns a 64x64 sub-tile = 2x2 v_mfma_f32_32x32x2_f32 accumulators (64 VGPRs);

@@ -556,6 +556,15 @@ def vp_reverse(x: Tensor, eps_pred: Tensor, z: Optional[Tensor], beta: float, st
     return fbar
 
 
+def mask_combine(x: Tensor, u: Tensor, mask: Tensor, x_f32: Optional[Tensor] = None):
+    """x <- x*(1-mask) + u*mask in place on the f64 state [B,2C,H,W]; mask [B,C,H,W] f32 of {0,1}."""
+    b, c2, h, w = x.shape
+    check(lib().psld_mask_combine_f64(_chk(x, torch.float64).data_ptr(), _chk(u, torch.float64).data_ptr(),
+                                      _chk(mask).data_ptr(), b, c2 // 2, h * w, _p(x_f32), _stream()),
+          "psld_mask_combine_f64")
+    return x
+
+
 def f64_to_f32(x: Tensor) -> Tensor:
     y = torch.empty(x.shape, device=x.device, dtype=torch.float32)
     check(lib().psld_f64_to_f32(_chk(x, torch.float64).data_ptr(), y.data_ptr(), x.numel(), _stream()), "f64_to_f32")

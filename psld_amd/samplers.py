@@ -101,6 +101,69 @@ class EulerMaruyamaSampler(Sampler):
         return x64
 
 
+@register_module(category="samplers", name="ip_em_sde")
+class ES3EulerMaruyamaInpainter(EulerMaruyamaSampler):
+    """Inpainting with the EM sampler (samplers/sde.py:117-224): after every predictor update the
+    known image is perturbed to the current reverse time and written over the masked-in pixels of both state halves.
+    ``sample((x_0, mask), ts, n)``: ``x_0`` f32 [B,C,H,W], ``mask`` [B,C,H,W] of {0,1} (1 = known pixel).  Per step:
+    one network call, the fused EM kernel, the fused perturbation kernel and one combine kernel.  Random draws are
+    made in the reference's order (prior x, prior m; then per update: predictor noise, momentum draw - discarded in
+    HSM mode like the reference does -, perturbation noise), so a seeded run consumes the stream the same way."""
+
+    def __init__(self, config, sde, score_fn, corrector_fn=None):
+        super().__init__(config, sde, score_fn, corrector_fn=corrector_fn)
+        self.draw_fn = None   # test hook: callable(shape, dtype, device) -> tensor replacing torch.randn
+
+    def _draw(self, shape, dtype, device):
+        if self.draw_fn is not None:
+            return self.draw_fn(tuple(shape), dtype, device)
+        return torch.randn(*shape, dtype=dtype, device=device)
+
+    def _perturb(self, x_0, t_rev: float):
+        """sde.py:127-142: (u_t, mu_t) f64 of the known image at forward time ``t_rev``."""
+        sde = self.sde
+        m_0 = float(np.sqrt(sde.mm_0)) * self._draw(x_0.shape, x_0.dtype, x_0.device)
+        mm_0 = 0.0
+        if self.config.training.mode == "hsm":
+            m_0, mm_0 = None, sde.mm_0                                # zeros: the kernel takes NULL
+        eps = self._draw((x_0.shape[0], 2 * x_0.shape[1], *x_0.shape[2:]), x_0.dtype, x_0.device)
+        t = torch.full((x_0.shape[0],), t_rev, device=x_0.device, dtype=torch.float64)
+        u, mu, _ = sde.perturb_data(x_0, m_0, 0, mm_0, t, eps=eps)
+        return u, mu
+
+    def sample(self, batch, ts, n_discrete_steps, denoise=True, eps=1e-3):
+        x_0, mask = batch
+        if not x_0.is_cuda:
+            raise RuntimeError("psld_amd sampler needs device tensors (no CPU fallback)")
+        self.nfe = n_discrete_steps
+        sde, dev = self.sde, x_0.device
+        x_0 = x_0.to(torch.float32).contiguous()
+        maskf = mask.to(device=dev, dtype=torch.float32).contiguous()
+        tl = ts.detach().to(torch.float64).cpu().tolist()
+        px = self._draw(x_0.shape, torch.float32, dev)               # psld.py:366-370
+        pm = self._draw(x_0.shape, torch.float32, dev) * float(np.sqrt(sde.m))
+        x32 = torch.cat([px, pm], dim=1).contiguous()
+        x64 = ops.f32_to_f64(x32)
+        u_k, _ = self._perturb(x_0, float(sde.T))                    # sde.py:195-203
+        ops.mask_combine(x64, u_k, maskf, x32)
+        with torch.no_grad():
+            for i in range(n_discrete_steps):
+                dt = tl[i + 1] - tl[i]
+                z = self._draw(x64.shape, torch.float64, dev)
+                self._step(x64, x32, tl[i], dt, z.contiguous())
+                u_k, _ = self._perturb(x_0, sde.T - tl[i])          # sde.py:166-169
+                ops.mask_combine(x64, u_k, maskf, x32)
+            if denoise:
+                # sde.py:213-221: torch.tensor(T - eps) / torch.tensor(eps) are float32 0-d tensors; the predictor's
+                # noise is drawn and discarded, the result is the combined x_mean
+                t_d = float(np.float32(sde.T - eps))
+                self._draw(x64.shape, torch.float64, dev)
+                self._step(x64, x32, t_d, float(np.float32(eps)), None)
+                _, mu_k = self._perturb(x_0, float(np.float32(sde.T) - np.float32(t_d)))
+                ops.mask_combine(x64, mu_k, maskf, None)
+        return x64
+
+
 @register_module(category="samplers", name="sscs_sde")
 class SSCSSampler(Sampler):
     """Symmetric-splitting CLD sampler (samplers/sde.py:227-370): per step two analytic Ornstein-

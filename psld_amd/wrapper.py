@@ -114,7 +114,8 @@ class SDEWrapper(_Base):
         return ts
 
     def predict_step(self, batch, batch_idx, dataloader_idx=None):
-        ts = self.sampling_times(batch.device)                           # wrapper.py:101-114
+        first = batch[0] if isinstance(batch, (tuple, list)) else batch   # (x_0, mask) for the inpainter
+        ts = self.sampling_times(first.device)                           # wrapper.py:101-114
         return self.sampler.sample(batch, ts, self.n_discrete_steps, denoise=self.denoise, eps=self.eval_eps)
 
     def configure_optimizers(self):

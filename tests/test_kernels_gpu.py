@@ -306,6 +306,17 @@ def test_conv3x3_split_rejects_unsupported(ops):
                           torch.empty(2, 12, 12, 128, device=DEV))
 
 
+def test_mask_combine(ops):
+    b, c, h = 3, 3, 8
+    x, u = gen(b, 2 * c, h, h, seed=85).double(), gen(b, 2 * c, h, h, seed=86).double()
+    mask = (gen(b, c, h, h, seed=87) > 0).float()
+    m2 = torch.cat([mask, mask], dim=1).double()
+    ref = x * (1 - m2) + u * m2
+    xd, x32 = x.to(DEV).clone(), torch.empty(b, 2 * c, h, h, device=DEV)
+    ops.mask_combine(xd, u.to(DEV), mask.to(DEV), x32)
+    assert torch.equal(xd.cpu(), ref) and torch.equal(x32.cpu(), ref.float())
+
+
 def test_math_mode_switch(ops):
     mode = ops.math_mode()
     try:

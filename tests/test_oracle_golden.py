@@ -277,6 +277,32 @@ def test_sscs_sampler(golden, tag):
     assert rel_l2(x, T(g[f"x_{tag}"])) < 1e-12
 
 
+@pytest.mark.parametrize("tag", ["hsm_3", "hsm_6", "dsm_3", "dsm_6"])
+def test_inpainting_sampler(golden, tag):
+    """ES3EulerMaruyamaInpainter (EM step, re-perturbed known pixels, mask combine) with every
+    random draw of the reference replayed in call order."""
+    g = golden("inpaint_tiny.npz")
+    cfg = _net_cfg("tiny")
+    meta = _net_meta()["tiny"]
+    sd = synth_state_dict([(k, tuple(s)) for k, s in meta["keys"]], meta["seed"])
+    sde = O.PSLDOracle.from_config(cfg)
+    mode, n_disc = tag.split("_")
+    draws = iter([T(g[f"draw_{tag}_{i}"]) for i in range(int(g[f"ndraws_{tag}"]))])
+
+    def draw(shape, dtype):
+        d = next(draws)
+        assert tuple(d.shape) == tuple(shape)
+        return d.to(dtype)
+
+    x = O.inpaint_sample(sde, lambda u, t: O.ncsnpp_forward(sd, cfg, u, t), T(g[f"x0_{tag}"]), T(g[f"mask_{tag}"]),
+                         T(g[f"ts_{tag}"]), int(n_disc) - 1, True, cfg.evaluation.eval_eps, training_mode=mode, draw=draw)
+    assert x.dtype == torch.float64 and next(draws, None) is None
+    assert rel_l2(x, T(g[f"x_{tag}"])) < 1e-6
+    known = T(g[f"mask_{tag}"]).bool()
+    # where the mask is 1 the x half of the result is the perturbation MEAN of the known image at t = eps
+    assert rel_l2(x[:, :3][known], (T(g[f"x0_{tag}"]).double() * 1.0)[known]) < 0.05
+
+
 def test_writer_loader_edges(golden):
     """vectors produced by the reference's save_as_images (PNG read back) and data_scaler."""
     g = golden("edges.npz")

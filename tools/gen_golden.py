@@ -50,8 +50,55 @@ def load_synth(module, seed):
     return ks
 
 
+def inpaint_section(get, C):
+    """M. ES3EulerMaruyamaInpainter (8(f) rank 4): EM step + perturb the known image to the current time + mask
+    combine, samplers/sde.py:117-224.  Every random draw (torch.randn of prior_sampling, torch.randn_like of the
+    predictor and of _perturb) is replaced by a recorded tensor, in call order."""
+    print("inpainting sampler (tiny)")
+    PSLD, NCSNpp, IP = get("sde", "psld"), get("score_fn", "ncsnpp"), get("samplers", "ip_em_sde")
+    out = {}
+    for mode in ("hsm", "dsm"):
+        cfg = C.tiny()
+        cfg.training.mode = mode
+        sde = PSLD(cfg)
+        net = NCSNpp(cfg)
+        load_synth(net, 1000)
+        net.eval()
+        sampler = IP(cfg, sde, net)
+        for n_disc in (3, 6):
+            g = torch.Generator().manual_seed(120 + n_disc)
+            x0 = torch.rand(2, 3, 16, 16, generator=g) * 2 - 1
+            mask = (torch.rand(2, 3, 16, 16, generator=g) > 0.4).type(torch.long)
+            n = n_disc - 1
+            tsx = torch.linspace(0, sde.T - cfg.evaluation.eval_eps, n + 1, dtype=torch.float64)
+            draws = []
+            o_like, o_randn = torch.randn_like, torch.randn
+
+            def draw(shape, dtype):
+                d = o_randn(*shape, generator=g, dtype=torch.float64)
+                draws.append(d)
+                return d.to(dtype)
+
+            torch.randn_like = lambda x_, **kw: draw(tuple(x_.shape), x_.dtype)
+            torch.randn = lambda *shape, **kw: draw(tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else shape, torch.float32)
+            try:
+                xf = sampler.sample((x0, mask), tsx, n, denoise=True, eps=cfg.evaluation.eval_eps)
+            finally:
+                torch.randn_like, torch.randn = o_like, o_randn
+            tag = f"{mode}_{n_disc}"
+            out[f"x0_{tag}"], out[f"mask_{tag}"], out[f"ts_{tag}"], out[f"x_{tag}"] = x0, mask, tsx, xf
+            out[f"ndraws_{tag}"] = np.array(len(draws))
+            for i, d in enumerate(draws):
+                out[f"draw_{tag}_{i}"] = d
+            assert xf.dtype == torch.float64 and len(draws) == 4 + 3 * (n + 1)
+    save("inpaint_tiny.npz", **out)
+
+
 def main():
     util = import_reference()
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "inpaint":
+        inpaint_section(util.get_module, C)
+        return
     get = util.get_module
     PSLD = get("sde", "psld")
     NCSNpp = get("score_fn", "ncsnpp")
@@ -415,6 +462,7 @@ def main():
     save("vpsde_tiny.npz", **out)
     with open(os.path.join(OUT, "vpsde_meta.json"), "w") as fh:
         json.dump({"seed": 4000, "keys": [[k, list(s)] for k, s in vks]}, fh)
+    inpaint_section(get, C)
     print("done")
 
 
