@@ -618,7 +618,7 @@ def pyramid_downsample(x, sd, p, fir=True, fir_k=(1, 3, 3, 1)):
 # NCSN++ forward  (song_sde/ncsnpp.py:287-438), functional over a state_dict
 # --------------------------------------------------------------------------------------
 def ncsnpp_forward(sd: Dict[str, Tensor], config, x: Tensor, time_cond: Tensor,
-                   dropout_masks: Optional[List[Tensor]] = None) -> Tensor:
+                   dropout_masks: Optional[List[Tensor]] = None, _classifier: bool = False) -> Tensor:
     """ncsnpp.py:287-438 for resblock_type='biggan', progressive='none',
     progressive_input in {'none','residual'}, embedding_type in {'fourier','positional'}.
 
@@ -626,7 +626,7 @@ def ncsnpp_forward(sd: Dict[str, Tensor], config, x: Tensor, time_cond: Tensor,
     (``all_modules.<i>.<Sub>.<param>``).  ``dropout_masks`` — one pre-scaled mask per
     ResBlock in call order — replaces nn.Dropout (None = eval).
     """
-    sf = config.model.score_fn
+    sf = config.model.clf_fn if _classifier else config.model.score_fn
     nf, ch_mult, nres = sf.nf, list(sf.ch_mult), sf.num_res_blocks
     attn_res = list(sf.attn_resolutions)
     nlev = len(ch_mult)
@@ -690,6 +690,10 @@ def ncsnpp_forward(sd: Dict[str, Tensor], config, x: Tensor, time_cond: Tensor,
     h = res(h, temb)
     h = attn_block(h, sd, nxt(), skip_rescale)
     h = res(h, temb)
+    if _classifier:                                                   # ncsnpp_clf.py:277-283
+        h = F.linear(torch.flatten(h, start_dim=1), sd[nxt() + ".weight"])
+        assert h.shape[-1] == sf.n_cls and f"all_modules.{mi[0]}.weight" not in sd
+        return h
 
     # up path: ncsnpp.py:372-420
     for lvl in reversed(range(nlev)):
@@ -707,6 +711,65 @@ def ncsnpp_forward(sd: Dict[str, Tensor], config, x: Tensor, time_cond: Tensor,
     h = F.conv2d(h, sd[p + ".weight"], sd[p + ".bias"], padding=1)
     assert f"all_modules.{mi[0]}.weight" not in sd and f"all_modules.{mi[0]}.W" not in sd
     return h
+
+
+def ncsnpp_clf_forward(sd: Dict[str, Tensor], config_clf, x: Tensor, time_cond: Tensor,
+                       dropout_masks: Optional[List[Tensor]] = None) -> Tensor:
+    """NCSNppClassifier.forward (ncsnpp_clf.py:203-283): the NCSN++ down path and middle block (identical module
+    order to ncsnpp.py up to :367) followed by flatten + a bias-free Linear to ``n_cls`` logits.  ``config_clf`` is
+    the ``clf`` config node (reads ``model.clf_fn``)."""
+    return ncsnpp_forward(sd, config_clf, x, time_cond, dropout_masks, _classifier=True)
+
+
+def tce_loss(sde: "PSLDOracle", x_0: Tensor, y: Tensor, t: Tensor, clf_fn: Callable, mode: str = "hsm",
+             reduce_mean: bool = True, m0_draw: Optional[Tensor] = None, eps: Optional[Tensor] = None):
+    """PSLDTimeCELoss.forward (losses.py:150-178): cross entropy of the noise-conditioned classifier on the perturbed
+    state, plus top-1 accuracy in percent.  ``m0_draw`` / ``eps`` replace the two ``randn_like`` draws (:152, :164)."""
+    if m0_draw is None:
+        m0_draw = torch.randn_like(x_0)
+    m_0 = np.sqrt(sde.mm_0) * m0_draw
+    mm_0 = 0.0
+    if mode == "hsm":
+        m_0 = torch.zeros_like(x_0)
+        mm_0 = sde.mm_0
+    if eps is None:
+        eps = torch.randn_like(torch.cat([x_0, m_0], dim=1))
+    u_t, _, _ = sde.perturb_data(x_0, m_0, 0, mm_0, t, eps=eps)
+    y_pred = clf_fn(u_t.type(torch.float32), t)
+    loss = F.cross_entropy(y_pred, y, reduction="mean" if reduce_mean else "sum")
+    acc = (y_pred.argmax(dim=1) == y).float().mean() * 100.0            # util.compute_top_k(k=1)
+    return loss, acc
+
+
+def cc_em_sample(sde: "PSLDOracle", score_fn: Callable, clf_fn: Callable, batch: Tensor, ts: Tensor, n_steps: int,
+                 label, clf_temp: float, denoise: bool = True, eps: float = 1e-3,
+                 noise: Optional[Sequence[Tensor]] = None) -> Tensor:
+    """ClassCondEulerMaruyamaSampler (samplers/sde.py:62-114): EM step whose drift gets g^2 * clf_temp *
+    grad_x log p(y | x_t) added (:84-94).  The classifier sees the SAMPLER time t (not T - t) as float32 (:87-88).
+    ``noise[i]`` replaces the i-th ``randn_like`` (one per update, the denoising update included)."""
+    x = batch
+    it = iter(noise) if noise is not None else None
+
+    def update(x, t, dt):
+        tt = t * torch.ones(x.shape[0], dtype=torch.float64)
+        with torch.no_grad():
+            f, g = sde.reverse_sde(x, tt, score_fn, probability_flow=False)
+        with torch.enable_grad():
+            x_in = x.clone().requires_grad_()
+            logits = clf_fn(x_in.type(torch.float32), t * torch.ones(x.shape[0], dtype=torch.float32))
+            sel = F.log_softmax(logits, dim=-1)[range(len(logits)), label]
+            grad = torch.autograd.grad(sel.sum(), x_in)[0] * clf_temp
+        with torch.no_grad():
+            f = f + (g ** 2) * grad
+            x_mean = x + f * dt
+            z = next(it) if it is not None else torch.randn_like(x)
+            return x_mean + g * torch.sqrt(dt) * z, x_mean
+
+    for i in range(n_steps):
+        x, _ = update(x, ts[i], bcast(ts[i + 1] - ts[i], x))
+    if denoise:
+        _, x = update(x, torch.tensor(sde.T - eps), bcast(torch.tensor(eps), x))
+    return x
 
 
 def count_resblocks(config) -> int:

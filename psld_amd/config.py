@@ -158,3 +158,65 @@ def tiny_vpsde() -> Config:
                           "is_augmented": False})
     c.training.loss.name = "score_loss"
     return c
+
+
+# ---- classifier guidance: the ``clf`` node of cifar10_psld.yaml:101-170 -------------------------
+def _clf_yaml_defaults() -> dict:
+    return {
+        "data": {"root": "", "name": "cifar10", "image_size": 32, "hflip": True, "num_channels": 3, "norm": True,
+                 "return_target": True},
+        "model": {
+            "pl_module": "tclf_wrapper",
+            "clf_fn": {
+                "name": "ncsnpp_clf", "in_ch": 6, "nonlinearity": "swish", "nf": 128, "ch_mult": [1, 2, 2, 2],
+                "num_res_blocks": 2, "attn_resolutions": [16], "dropout": 0.1, "resamp_with_conv": True,
+                "noise_cond": True, "fir": False, "fir_kernel": [1, 3, 3, 1], "skip_rescale": True,
+                "resblock_type": "biggan", "progressive": "none", "progressive_input": "none",
+                "progressive_combine": "sum", "embedding_type": "positional", "init_scale": 0.0,
+                "fourier_scale": 16, "n_cls": 10,
+            },
+        },
+        "training": {
+            "seed": 0, "continuous": True,
+            "loss": {"name": "tce_loss", "l_type": "l2", "reduce_mean": True},
+            "optimizer": {"name": "Adam", "lr": 2e-4, "beta_1": 0.9, "beta_2": 0.999, "weight_decay": 0,
+                          "eps": 1e-8, "warmup": 5000},
+            "fp16": False, "batch_size": 32, "epochs": 500, "log_step": 1, "accelerator": "gpu", "devices": [0],
+            "chkpt_interval": 1, "restore_path": "", "results_dir": "", "workers": 1, "chkpt_prefix": "",
+        },
+        "evaluation": {"seed": 0, "chkpt_path": "", "accelerator": "gpu", "devices": [0], "workers": 1,
+                       "batch_size": 64, "clf_temp": 1.0, "label_to_sample": 0},
+    }
+
+
+def clf_default() -> Config:
+    """The shipped ``clf`` YAML node (n_cls is ``???`` there; 10 = CIFAR-10)."""
+    return Config(_clf_yaml_defaults())
+
+
+def clf_c10() -> Config:
+    """Classifier of scripts_psld/ablations/cond/cifar10/{train,sample}_tclf_psld.sh."""
+    c = clf_default()
+    cf = c.model.clf_fn
+    cf.ch_mult = [1, 2, 3, 4]
+    cf.num_res_blocks = 4
+    cf.attn_resolutions = [16, 8]
+    cf.n_cls = 10
+    return c
+
+
+def tiny_clf(image_size: int = 16, nf: int = 32, ch_mult=(1, 2), num_res_blocks: int = 1,
+             attn_resolutions=(8,), n_cls: int = 10) -> Config:
+    """Reduced classifier with every block kind of the shipped one (parity tests)."""
+    c = clf_default()
+    c.data.image_size = image_size
+    cf = c.model.clf_fn
+    cf.nf, cf.ch_mult, cf.num_res_blocks = nf, list(ch_mult), num_res_blocks
+    cf.attn_resolutions, cf.n_cls, cf.dropout = list(attn_resolutions), n_cls, 0.0
+    return c
+
+
+def with_clf(diffusion: Config, clf: Config) -> Config:
+    """Root node of the classifier-guidance apps (``config.dataset`` in main/train_clf.py:27 and
+    main/eval/class_cond_sample.py:33): ``.diffusion`` and ``.clf`` side by side."""
+    return Config({"diffusion": diffusion, "clf": clf})

@@ -303,6 +303,61 @@ def test_inpainting_sampler(golden, tag):
     assert rel_l2(x[:, :3][known], (T(g[f"x0_{tag}"]).double() * 1.0)[known]) < 0.05
 
 
+def _clf_sd():
+    with open(os.path.join(GOLDEN, "clf_meta.json")) as fh:
+        meta = json.load(fh)
+    return synth_state_dict([(k, tuple(sh)) for k, sh in meta["keys"]], meta["seed"]), meta
+
+
+def test_classifier_logits_and_input_gradient(golden):
+    """NCSNppClassifier (ncsnpp_clf.py) - logits and d log p(y|x) / dx, the guidance signal."""
+    g = golden("clf_tiny.npz")
+    sd, _ = _clf_sd()
+    cfg = C.tiny_clf()
+    x = T(g["x"]).requires_grad_()
+    logits = O.ncsnpp_clf_forward(sd, cfg, x, T(g["t"]))
+    assert rel_l2(logits, T(g["logits"])) < 1e-5
+    sel = torch.log_softmax(logits, dim=-1)[range(4), T(g["y"])]
+    assert rel_l2(torch.autograd.grad(sel.sum(), x)[0], T(g["dsel_dx"])) < 1e-5
+
+
+def test_classifier_tce_loss_and_grads(golden):
+    g = golden("clf_tiny.npz")
+    sd, _ = _clf_sd()
+    sd = {k: v.requires_grad_() for k, v in sd.items()}
+    cfg, sde = C.tiny_clf(), O.PSLDOracle.from_config(C.tiny())
+    loss, acc = O.tce_loss(sde, T(g["x0"]), T(g["y"]), T(g["t_loss"]), lambda u, t: O.ncsnpp_clf_forward(sd, cfg, u, t),
+                           m0_draw=T(g["m0_draw"]), eps=T(g["eps"]))
+    assert abs(loss.item() - float(g["loss"])) < 1e-6 * abs(float(g["loss"])) and float(acc) == float(g["acc"])
+    loss.backward()
+    norms = dict(zip(g["grad_norm_keys"].tolist(), g["grad_norms"].tolist()))
+    for k, v in sd.items():
+        if v.grad is not None:
+            assert abs(v.grad.norm().item() - norms[k]) <= 2e-5 * norms[k] + 1e-9, k
+    for k in g.files:
+        if k.startswith("g:"):
+            assert rel_l2(sd[k[2:]].grad, T(g[k])) < 1e-5, k
+
+
+@pytest.mark.parametrize("tag", ["cc3", "cc5"])
+def test_class_conditional_em_sampler(golden, tag):
+    """ClassCondEulerMaruyamaSampler (samplers/sde.py:62-114): scalar label and per-sample label tensor."""
+    g = golden("clf_tiny.npz")
+    csd, meta = _clf_sd()
+    ccfg, dcfg = C.tiny_clf(), C.tiny()
+    nm = _net_meta()["tiny"]
+    sd = synth_state_dict([(k, tuple(s)) for k, s in nm["keys"]], nm["seed"])
+    sde = O.PSLDOracle.from_config(dcfg)
+    lab = T(g[f"label_{tag}"])
+    lab = int(lab) if lab.dim() == 0 else lab
+    n = int(tag[2:]) - 1
+    x = O.cc_em_sample(sde, lambda u, t: O.ncsnpp_forward(sd, dcfg, u, t), lambda u, t: O.ncsnpp_clf_forward(csd, ccfg, u, t),
+                       T(g[f"batch_{tag}"]), T(g[f"ts_{tag}"]), n, lab, meta["clf_temp"], True, dcfg.evaluation.eval_eps,
+                       noise=list(T(g[f"noise_{tag}"])))
+    assert x.dtype == torch.float64
+    assert rel_l2(x, T(g[f"x_{tag}"])) < 1e-6
+
+
 def test_writer_loader_edges(golden):
     """vectors produced by the reference's save_as_images (PNG read back) and data_scaler."""
     g = golden("edges.npz")

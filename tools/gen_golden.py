@@ -94,10 +94,81 @@ def inpaint_section(get, C):
     save("inpaint_tiny.npz", **out)
 
 
+def clf_section(get, C):
+    """N. classifier guidance (8(f) rank 4): NCSNppClassifier logits and input gradient, PSLDTimeCELoss with
+    gradients, ClassCondEulerMaruyamaSampler with replayed noise."""
+    print("classifier guidance (tiny)")
+    PSLD, NCSNpp = get("sde", "psld"), get("score_fn", "ncsnpp")
+    Clf, TCE, CC = get("clf_fn", "ncsnpp_clf"), get("losses", "tce_loss"), get("samplers", "cc_em_sde")
+    dcfg, ccfg = C.tiny(), C.tiny_clf()
+    root = C.with_clf(dcfg, ccfg)
+    root.clf.evaluation.clf_temp = 2.5
+    sde = PSLD(dcfg)
+    clf = Clf(ccfg)
+    cks = load_synth(clf, 5000)
+    g = torch.Generator().manual_seed(130)
+    out = {}
+    # forward + gradient of the selected log-probability w.r.t. the input (what the sampler uses)
+    clf.eval()
+    x = torch.randn(4, 6, 16, 16, generator=g)
+    t = torch.rand(4, generator=g) * 0.9 + 0.05
+    y = torch.tensor([3, 0, 9, 3])
+    xin = x.clone().requires_grad_()
+    logits = clf(xin, t)
+    sel = torch.log_softmax(logits, dim=-1)[range(4), y]
+    out.update(x=x, t=t, y=y, logits=logits.detach(), dsel_dx=torch.autograd.grad(sel.sum(), xin)[0])
+    # training loss (HSM) with parameter gradients
+    clf.train()
+    x0 = torch.rand(4, 3, 16, 16, generator=g) * 2 - 1
+    tt = torch.rand(4, generator=g, dtype=torch.float64) * (1 - 1e-5) + 1e-5
+    m0d, epsd = torch.randn(4, 3, 16, 16, generator=g), torch.randn(4, 6, 16, 16, generator=g)
+    it = iter([m0d, epsd])
+    orig = torch.randn_like
+    torch.randn_like = lambda x_, **kw: next(it).to(x_.dtype)
+    try:
+        loss, acc = TCE(root, sde)(x0, y, tt, clf)
+    finally:
+        torch.randn_like = orig
+    loss.backward()
+    out.update(x0=x0, t_loss=tt, m0_draw=m0d, eps=epsd, loss=loss.detach(), acc=torch.as_tensor(acc))
+    gn = {k: p.grad.norm().item() for k, p in clf.named_parameters() if p.grad is not None}
+    out["grad_norm_keys"], out["grad_norms"] = np.array(list(gn.keys())), np.array(list(gn.values()))
+    names = [k for k, _ in clf.named_parameters()]
+    for k in (names[0], names[3], names[-1]):
+        out["g:" + k] = dict(clf.named_parameters())[k].grad
+    # class-conditional EM sampling
+    clf.eval()
+    net = NCSNpp(dcfg)
+    load_synth(net, 1000)
+    net.eval()
+    for lab, n_disc in ((7, 3), (torch.tensor([1, 4]), 5)):
+        root.clf.evaluation.label_to_sample = lab
+        sampler = CC(root, sde, net, clf)
+        batch = torch.cat([torch.randn(2, 3, 16, 16, generator=g),
+                           torch.randn(2, 3, 16, 16, generator=g) * np.sqrt(sde.m)], dim=1)
+        n = n_disc - 1
+        tsx = torch.linspace(0, sde.T - dcfg.evaluation.eval_eps, n + 1, dtype=torch.float64)
+        noises = [torch.randn(2, 6, 16, 16, generator=g, dtype=torch.float64) for _ in range(n + 1)]
+        it = iter(noises)
+        torch.randn_like = lambda x_, **kw: next(it).to(x_.dtype)
+        try:
+            xf = sampler.sample(batch, tsx, n, denoise=True, eps=dcfg.evaluation.eval_eps)
+        finally:
+            torch.randn_like = orig
+        tag = f"cc{n_disc}"
+        out[f"batch_{tag}"], out[f"noise_{tag}"], out[f"ts_{tag}"], out[f"x_{tag}"] = batch, torch.stack(noises), tsx, xf
+        out[f"label_{tag}"] = torch.as_tensor(lab)
+        assert xf.dtype == torch.float64 and next(it, None) is None
+    save("clf_tiny.npz", **out)
+    with open(os.path.join(OUT, "clf_meta.json"), "w") as fh:
+        json.dump({"seed": 5000, "keys": [[k, list(s)] for k, s in cks], "clf_temp": 2.5}, fh)
+
+
 def main():
     util = import_reference()
-    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "inpaint":
-        inpaint_section(util.get_module, C)
+    if "--only" in sys.argv:
+        which = sys.argv[sys.argv.index("--only") + 1]
+        {"inpaint": inpaint_section, "clf": clf_section}[which](util.get_module, C)
         return
     get = util.get_module
     PSLD = get("sde", "psld")
@@ -463,6 +534,7 @@ def main():
     with open(os.path.join(OUT, "vpsde_meta.json"), "w") as fh:
         json.dump({"seed": 4000, "keys": [[k, list(s)] for k, s in vks]}, fh)
     inpaint_section(get, C)
+    clf_section(get, C)
     print("done")
 
 
