@@ -318,6 +318,16 @@ int psld_vp_perturb_f32(const float* x0, const float* eps, const double* t, doub
 int psld_vp_reverse_f64(double* x, const float* eps_pred, const double* z, double beta, double std, double dt,
                         int probability_flow, int mode, long long n, double* f_bar, float* x_f32_out,
                         hipStream_t stream);
+/* Classifier guidance (ClassCondEulerMaruyamaSampler.predictor_update_fn, samplers/sde.py:90-97): x += coef * grad
+ * with coef_x on the position half and coef_m on the momentum half of the [B,2C,HW] f64 state (coef = g^2 * dt,
+ * the classifier temperature already folded into grad); optionally refreshes the f32 copy. */
+int psld_guide_f64(double* x, const float* grad, double coef_x, double coef_m, int batch, int c, int hw,
+                   float* x_f32_out, hipStream_t stream);
+/* Softmax cross entropy of [rows][n] logits vs int64 labels (nn.CrossEntropyLoss in PSLDTimeCELoss,
+ * losses.py:147-173): *loss = loss_scale * sum_r (logsumexp(z_r) - z_r[y_r]); dlogits (optional) =
+ * grad_scale * (softmax(z_r) - onehot(y_r)); *correct (optional) = number of rows whose argmax is the label. */
+int psld_softmax_xent_f32(const float* logits, const long long* labels, int rows, int n, float loss_scale,
+                          float grad_scale, float* loss, float* dlogits, float* correct, hipStream_t stream);
 /* Inpainting combine (ES3EulerMaruyamaInpainter.inpaint_update_fn, samplers/sde.py:161-181): for the state
  * x = [x | m] and the re-perturbed known image u = [x_k | m_k], both [B,2C,HW] f64, x <- x*(1-mask) + u*mask with
  * mask [B,C,HW] f32 in {0,1} applied to both halves; optionally refreshes the f32 copy the network reads. */

@@ -120,6 +120,8 @@ SIGNATURES = {
     "psld_vp_perturb_f32": (I, [P, P, P, D, D, I, LL, P, P, P]),
     "psld_vp_reverse_f64": (I, [P, P, P, D, D, D, I, I, LL, P, P, P]),
     "psld_mask_combine_f64": (I, [P, P, P, I, I, I, P, P]),
+    "psld_guide_f64": (I, [P, P, D, D, I, I, I, P, P]),
+    "psld_softmax_xent_f32": (I, [P, P, I, I, F, F, P, P, P, P]),
     "psld_f64_to_f32": (I, [P, P, LL, P]),
     "psld_f32_to_f64": (I, [P, P, LL, P]),
     "psld_grad_norm_f32": (I, [P, LL, P, P, P]),

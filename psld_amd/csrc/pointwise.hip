@@ -479,6 +479,52 @@ extern "C" int psld_bias_grad_f32(const float* x, int ld, int batch, int hw, int
     PSLD_CHECK_LAUNCH("colsum_total_kernel");
     return PSLD_OK;
 }
+// Cross entropy of [rows][n] logits against int64 labels (nn.CrossEntropyLoss, losses.py:147-173) with its gradient:
+// one block; every thread walks rows tid, tid+256, ...; the per-thread sums are combined in thread order.
+__global__ void softmax_xent_kernel(const float* __restrict__ logits, const long long* __restrict__ labels, int rows,
+                                    int n, float loss_scale, float grad_scale, float* __restrict__ loss,
+                                    float* __restrict__ dlogits, float* __restrict__ correct) {
+    __shared__ double sl[256];
+    __shared__ int sc[256];
+    double lsum = 0.0;
+    int csum = 0;
+    for (int r = threadIdx.x; r < rows; r += blockDim.x) {
+        const float* z = logits + (long long)r * n;
+        float mx = z[0];
+        int arg = 0;
+        for (int j = 1; j < n; ++j)
+            if (z[j] > mx) { mx = z[j]; arg = j; }
+        float se = 0.f;
+        for (int j = 0; j < n; ++j) se += expf(z[j] - mx);
+        const int y = (int)labels[r];
+        lsum += (double)(logf(se) + mx - z[y]);
+        csum += arg == y;
+        if (dlogits) {
+            const float inv = 1.0f / se;
+            for (int j = 0; j < n; ++j)
+                dlogits[(long long)r * n + j] = grad_scale * (expf(z[j] - mx) * inv - (j == y ? 1.f : 0.f));
+        }
+    }
+    sl[threadIdx.x] = lsum;
+    sc[threadIdx.x] = csum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        int c = 0;
+        for (int i = 0; i < (int)blockDim.x; ++i) { t += sl[i]; c += sc[i]; }
+        if (loss) *loss = (float)(t * (double)loss_scale);
+        if (correct) *correct = (float)c;
+    }
+}
+
+extern "C" int psld_softmax_xent_f32(const float* logits, const long long* labels, int rows, int n, float loss_scale,
+                                     float grad_scale, float* loss, float* dlogits, float* correct, hipStream_t stream) {
+    PSLD_CHECK_ARG(logits && labels && rows > 0 && n > 0, "psld_softmax_xent_f32: bad args");
+    hipLaunchKernelGGL(softmax_xent_kernel, dim3(1), dim3(256), 0, stream, logits, labels, rows, n, loss_scale, grad_scale,
+                       loss, dlogits, correct);
+    PSLD_CHECK_LAUNCH("psld_softmax_xent_f32");
+    return PSLD_OK;
+}
 extern "C" int psld_softmax_rows_f32(const float* x, float* y, long long rows, int L, hipStream_t stream) {
     PSLD_CHECK_ARG(x && y && rows >= 0 && L > 0, "psld_softmax_rows_f32: bad args");
     if (rows == 0) return PSLD_OK;

@@ -366,6 +366,29 @@ __global__ void mask_combine_kernel(double* __restrict__ x, const double* __rest
     }
 }
 
+// Classifier guidance (samplers/sde.py:90-94): adding g^2 * grad to the drift moves the state by g^2 * grad * dt;
+// g^2 differs between the position and momentum halves (psld.py:201-203), so one coefficient per half.
+__global__ void guide_kernel(double* __restrict__ x, const float* __restrict__ grad, double cx, double cm,
+                             long long per_img, long long total, float* __restrict__ x_f32) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i % (2 * per_img);
+        const double v = x[i] + (r < per_img ? cx : cm) * (double)grad[i];
+        x[i] = v;
+        if (x_f32) x_f32[i] = (float)v;
+    }
+}
+
+extern "C" int psld_guide_f64(double* x, const float* grad, double coef_x, double coef_m, int batch, int c, int hw,
+                              float* x_f32_out, hipStream_t stream) {
+    PSLD_CHECK_ARG(x && grad && batch > 0 && c > 0 && hw > 0, "psld_guide_f64: bad args");
+    const long long per_img = (long long)c * hw, total = 2 * per_img * batch;
+    hipLaunchKernelGGL(guide_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, grad, coef_x, coef_m, per_img, total,
+                       x_f32_out);
+    PSLD_CHECK_LAUNCH("psld_guide_f64");
+    return PSLD_OK;
+}
+
 extern "C" int psld_mask_combine_f64(double* x, const double* u, const float* mask, int batch, int c, int hw,
                                      float* x_f32_out, hipStream_t stream) {
     PSLD_CHECK_ARG(x && u && mask && batch > 0 && c > 0 && hw > 0, "psld_mask_combine_f64: bad args");

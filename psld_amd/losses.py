@@ -90,3 +90,53 @@ class ScoreLoss(nn.Module):
         t32 = ops.f64_to_f32(t.contiguous()) if t.dtype == torch.float64 else t.float()
         eps_pred = score_fn(x_t, t32)
         return _SqErr.apply(eps_pred, eps, self.reduce_strategy == "mean")
+
+
+class _SoftmaxXent(torch.autograd.Function):
+    """loss = mean|sum cross entropy; the kernel also emits d loss / d logits and the top-1 hit count."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, reduce_mean):
+        scale = 1.0 / logits.shape[0] if reduce_mean else 1.0
+        loss, grad, correct = ops.softmax_xent(logits.contiguous(), labels.contiguous(), scale, scale)
+        ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(correct)
+        return loss, correct
+
+    @staticmethod
+    def backward(ctx, g, _g_correct):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None
+
+
+@register_module(category="losses", name="tce_loss")
+class PSLDTimeCELoss(nn.Module):
+    """Loss of the noise-conditioned classifier used for guidance (main/losses.py:132-178).
+    ``forward(x_0, y, t, clf_fn) -> (loss, top-1 accuracy in percent)``; ``config`` is the root node holding
+    ``.diffusion`` and ``.clf``.  Both ``randn_like`` draws of the reference are made, in its order (the momentum
+    draw is discarded in HSM mode, exactly like there)."""
+
+    def __init__(self, config, sde):
+        super().__init__()
+        assert config.diffusion.training.mode in ["hsm", "dsm"]
+        assert isinstance(sde, get_module("sde", "psld"))
+        self.sde = sde
+        self.l_type = config.clf.training.loss.l_type
+        self.mode = config.diffusion.training.mode
+        self.reduce_strategy = "mean" if config.diffusion.training.loss.reduce_mean else "sum"
+
+    def forward(self, x_0, y, t, clf_fn, m0_draw=None, eps=None):
+        sde = self.sde
+        if m0_draw is None:
+            m0_draw = torch.randn_like(x_0)                              # losses.py:152 (drawn in both modes)
+        if self.mode == "hsm":
+            m_0, mm_0 = None, sde.mm_0
+        else:
+            m_0, mm_0 = np.sqrt(sde.mm_0) * m0_draw, 0.0
+        if eps is None:
+            eps = torch.randn(x_0.shape[0], 2 * x_0.shape[1], *x_0.shape[2:], device=x_0.device)   # :164
+        u_t = sde.perturb_f32(x_0, m_0, 0, mm_0, t, eps.contiguous())   # losses.py:167 + the .type(float32) of :170
+        t32 = ops.f64_to_f32(t.contiguous()) if t.dtype == torch.float64 else t.float()   # layers.py: timesteps.float()
+        y_pred = clf_fn(u_t, t32)
+        loss, correct = _SoftmaxXent.apply(y_pred, y, self.reduce_strategy == "mean")
+        return loss, correct * (100.0 / y_pred.shape[0])                # util.compute_top_k(k=1)

@@ -556,6 +556,26 @@ def vp_reverse(x: Tensor, eps_pred: Tensor, z: Optional[Tensor], beta: float, st
     return fbar
 
 
+def guide(x: Tensor, grad: Tensor, coef_x: float, coef_m: float, x_f32: Optional[Tensor] = None):
+    """x[:, :C] += coef_x * grad[:, :C]; x[:, C:] += coef_m * grad[:, C:] in place on the f64 state (grad f32)."""
+    b, c2, h, w = x.shape
+    check(lib().psld_guide_f64(_chk(x, torch.float64).data_ptr(), _chk(grad).data_ptr(), float(coef_x), float(coef_m),
+                               b, c2 // 2, h * w, _p(x_f32), _stream()), "psld_guide_f64")
+    return x
+
+
+def softmax_xent(logits: Tensor, labels: Tensor, loss_scale: float, grad_scale: float, want_grad: bool = True):
+    """(loss 0-d f32, dlogits or None, correct 0-d f32): cross entropy of [rows][n] logits vs int64 labels."""
+    rows, n = logits.shape
+    loss = torch.empty((), device=logits.device, dtype=torch.float32)
+    correct = torch.empty((), device=logits.device, dtype=torch.float32)
+    grad = torch.empty_like(logits) if want_grad else None
+    check(lib().psld_softmax_xent_f32(_chk(logits).data_ptr(), _chk(labels, torch.int64).data_ptr(), rows, n,
+                                      float(loss_scale), float(grad_scale), loss.data_ptr(), _p(grad),
+                                      correct.data_ptr(), _stream()), "psld_softmax_xent_f32")
+    return loss, grad, correct
+
+
 def mask_combine(x: Tensor, u: Tensor, mask: Tensor, x_f32: Optional[Tensor] = None):
     """x <- x*(1-mask) + u*mask in place on the f64 state [B,2C,H,W]; mask [B,C,H,W] f32 of {0,1}."""
     b, c2, h, w = x.shape

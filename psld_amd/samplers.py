@@ -101,6 +101,71 @@ class EulerMaruyamaSampler(Sampler):
         return x64
 
 
+@register_module(category="samplers", name="cc_em_sde")
+class ClassCondEulerMaruyamaSampler(EulerMaruyamaSampler):
+    """Class-conditional EM sampling with classifier guidance (samplers/sde.py:62-114):
+    ``f <- f + g^2 * clf_temp * grad_x log p(y | x_t)`` before the Euler step.  ``config`` is the root node with
+    ``.diffusion`` and ``.clf``; ``clf_fn`` is an ``NCSNppClassifier``.  Per step: score-network forward, classifier
+    forward + backward to its input (same executor and kernels as the score network), the fused EM kernel and one
+    guidance kernel.  Like the reference, the classifier is evaluated at the SAMPLER time t (as float32), not T - t."""
+
+    def __init__(self, config, sde, score_fn, clf_fn, corrector_fn=None):
+        super().__init__(config, sde, score_fn, corrector_fn=corrector_fn)
+        self.clf_fn = clf_fn
+        self.y = self.config.clf.evaluation.label_to_sample
+        self.clf_temp = self.config.clf.evaluation.clf_temp
+
+    def _labels(self, b, device):
+        y = self.y
+        if torch.is_tensor(y) and y.dim() > 0:
+            return y.to(device=device, dtype=torch.int64).contiguous()
+        return torch.full((b,), int(y), device=device, dtype=torch.int64)
+
+    def _guidance(self, x32, t: float):
+        """d/dx sum_r log softmax(clf(x, t))_r[y_r] (sde.py:84-92), float32, without the temperature."""
+        x_in = x32.detach().clone().requires_grad_()
+        t32 = torch.full((x32.shape[0],), float(np.float32(t)), device=x32.device, dtype=torch.float32)
+        with torch.enable_grad():
+            logits = self.clf_fn(x_in, t32)
+            # d log_softmax(z)[y] / dz = onehot(y) - softmax(z)
+            _, dlogits, _ = ops.softmax_xent(logits.detach().contiguous(), self._labels(x32.shape[0], x32.device), 1.0, -1.0)
+            (grad,) = torch.autograd.grad(logits, x_in, grad_outputs=dlogits)
+        return grad.contiguous()
+
+    def _step(self, x64, x32, t: float, dt: float, noise):
+        grad = self._guidance(x32, t)                                  # at the state BEFORE the update
+        with torch.no_grad():
+            super()._step(x64, x32, t, dt, noise)
+        sde = self.sde
+        beta = float(sde.beta_t(sde.T - t))
+        gx2 = float(np.sqrt(beta * sde.gamma)) ** 2                    # psld.py:339-340, squared at sde.py:94
+        gm2 = float(np.sqrt(beta * sde.m * sde.nu)) ** 2
+        ops.guide(x64, grad, gx2 * self.clf_temp * dt, gm2 * self.clf_temp * dt, x32)
+
+    def sample(self, batch, ts, n_discrete_steps, denoise=True, eps=1e-3):
+        if not batch.is_cuda:
+            raise RuntimeError("psld_amd sampler needs device tensors (no CPU fallback)")
+        self.nfe = n_discrete_steps
+        tl = ts.detach().to(torch.float64).cpu().tolist()
+        x32 = batch.to(torch.float32).contiguous().clone()
+        x64 = ops.f32_to_f64(x32) if batch.dtype != torch.float64 else batch.contiguous().clone()
+        for i in range(n_discrete_steps):
+            z = self.noise_fn(i, x64) if self.noise_fn is not None else torch.randn_like(x64)
+            self._step(x64, x32, tl[i], tl[i + 1] - tl[i], z.contiguous())
+            if self.corrector_fn is not None:
+                x64, _ = self.corrector_update_fn(x64, ts[i], tl[i + 1] - tl[i])
+                x64 = x64.contiguous()
+                x32 = ops.f64_to_f32(x64)
+        if denoise:
+            # sde.py:107-113: the predictor draws its noise here too; the result is x_mean
+            if self.noise_fn is not None:
+                self.noise_fn(n_discrete_steps, x64)
+            else:
+                torch.randn_like(x64)
+            self._step(x64, x32, float(np.float32(self.sde.T - eps)), float(np.float32(eps)), None)
+        return x64
+
+
 @register_module(category="samplers", name="ip_em_sde")
 class ES3EulerMaruyamaInpainter(EulerMaruyamaSampler):
     """Inpainting with the EM sampler (samplers/sde.py:117-224): after every predictor update the

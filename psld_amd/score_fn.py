@@ -697,6 +697,9 @@ class _Exec:
         hnode = self.resblock(hnode, mods[mi]); mi += 1
         hnode = self.attn(hnode, mods[mi]); mi += 1
         hnode = self.resblock(hnode, mods[mi]); mi += 1
+        if net.is_classifier:
+            assert mi + 1 == len(mods)
+            return self.clf_head(hnode, mods[mi])
         for lvl in reversed(range(net.num_resolutions)):
             for _ in range(net.num_res_blocks + 1):
                 hnode = self.resblock(self.concat(hnode, hs.pop()), mods[mi])
@@ -737,13 +740,35 @@ class _Exec:
             self.push(head_bwd, gnf)
         return ops.nhwc_to_nchw(y)
 
+    # -- NCSNppClassifier head (ncsnpp_clf.py:277-283): flatten in NCHW order + Linear(bias=False) ------------------
+    def clf_head(self, hnode: _Node, lin: nn.Linear) -> Tensor:
+        b, h, w, c = hnode.v.shape
+        flat = ops.nhwc_to_nchw(hnode.v).view(b, c * h * w)
+        n_cls, k = lin.weight.shape
+        logits = ops.linear(flat, lin.weight)
+        if self.record:
+            hg = self.head_grad = _Node(logits)
+
+            def head_bwd():
+                dy = hg.g                                                   # [B, n_cls]
+                self.on_side(lambda: ops.gemm_raw(1, 0, n_cls, k, b, dy, n_cls, 0, flat, k, 0, self.g(lin.weight), k, 0),
+                             dy, flat)
+                dflat = torch.empty_like(flat)
+                ops.gemm_raw(0, 0, b, k, n_cls, dy, n_cls, 0, lin.weight, k, 0, dflat, k, 0)
+                xg, acc = _gbuf(hnode)
+                ops.axpby(ops.nchw_to_nhwc(dflat.view(b, c, h, w)), 1.0, None, 0.0, xg, accumulate=acc)
+
+            self.push(head_bwd, lin)
+        return logits
+
     def backward(self, grad_out_nchw: Tensor):
         with ops.stream_scope():
             self._backward(grad_out_nchw)
 
     def _backward(self, grad_out_nchw: Tensor):
         net = self.net
-        self.head_grad.g = ops.nchw_to_nhwc(grad_out_nchw.contiguous())
+        g_out = grad_out_nchw.contiguous()
+        self.head_grad.g = g_out if net.is_classifier else ops.nchw_to_nhwc(g_out)
         for fn, module in reversed(self.tape):
             fn()
             if module is not None and self.watermark is not None:
@@ -800,10 +825,15 @@ class _NCSNppFn(torch.autograd.Function):
 class NCSNpp(nn.Module):
     """NCSN++ (ncsnpp.py:35-285 for the module list; forward in ``_Exec.run``)."""
 
+    is_classifier = False
+
+    def _net_config(self, config):
+        return config.model.score_fn
+
     def __init__(self, config):
         super().__init__()
         self.config = config.model
-        sf = self.sf = config.model.score_fn
+        sf = self.sf = self._net_config(config)
         if sf.nonlinearity.lower() != "swish":
             raise NotImplementedError("only nonlinearity='swish' is on the north-star path")
         if sf.resblock_type.lower() != "biggan" or sf.progressive.lower() != "none":
@@ -862,18 +892,23 @@ class NCSNpp(nn.Module):
         modules.append(rb(in_ch=in_ch))
         modules.append(AttnBlockpp(in_ch, init_scale))
         modules.append(rb(in_ch=in_ch))
-        for lvl in reversed(range(nlev)):
-            for _ in range(nres + 1):
-                out_ch = nf * ch_mult[lvl]
-                modules.append(rb(in_ch=in_ch + hs_c.pop(), out_ch=out_ch))
-                in_ch = out_ch
-            if self.all_resolutions[lvl] in self.attn_resolutions:
-                modules.append(AttnBlockpp(in_ch, init_scale))
-            if lvl != 0:
-                modules.append(rb(in_ch=in_ch, up=True))
-        assert not hs_c
-        modules.append(_groupnorm(in_ch))
-        modules.append(_conv(in_ch, sf.out_ch, 3, init_scale))
+        if self.is_classifier:
+            # ncsnpp_clf.py:196-199: flatten (NCHW order) + bias-free Linear to the class logits
+            self.n_cls = sf.n_cls
+            modules.append(nn.Linear(in_ch * self.all_resolutions[-1] ** 2, self.n_cls, bias=False))
+        else:
+            for lvl in reversed(range(nlev)):
+                for _ in range(nres + 1):
+                    out_ch = nf * ch_mult[lvl]
+                    modules.append(rb(in_ch=in_ch + hs_c.pop(), out_ch=out_ch))
+                    in_ch = out_ch
+                if self.all_resolutions[lvl] in self.attn_resolutions:
+                    modules.append(AttnBlockpp(in_ch, init_scale))
+                if lvl != 0:
+                    modules.append(rb(in_ch=in_ch, up=True))
+            assert not hs_c
+            modules.append(_groupnorm(in_ch))
+            modules.append(_conv(in_ch, sf.out_ch, 3, init_scale))
         self.all_modules = nn.ModuleList(modules)
 
         # executor state (never part of state_dict)
@@ -1208,3 +1243,17 @@ class NCSNpp(nn.Module):
         for p in new.parameters():
             p.data = p.data.clone()
         return new
+
+
+@register_module(category="clf_fn", name="ncsnpp_clf")
+class NCSNppClassifier(NCSNpp):
+    """Noise-conditioned classifier for guidance (ncsnpp_clf.py:36-283): the NCSN++ time
+    embedding, stem, down path and middle block - the same modules, kernels and executor as ``NCSNpp`` - followed
+    by flatten + Linear(bias=False) to ``n_cls`` logits.  Built from the ``clf`` config node (reads
+    ``model.clf_fn``); ``clf(x f32[B,in_ch,H,W], t f32[B]) -> f32[B,n_cls]`` with autograd to the parameters
+    (training, ``tce_loss``) and to ``x`` (the guidance gradient of ``cc_em_sde``)."""
+
+    is_classifier = True
+
+    def _net_config(self, config):
+        return config.model.clf_fn

@@ -133,3 +133,74 @@ class SDEWrapper(_Base):
         scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda)
         return {"optimizer": optimizer,
                 "lr_scheduler": {"scheduler": scheduler, "interval": "step", "strict": False}}
+
+
+@register_module(category="pl_modules", name="tclf_wrapper")
+class TClfWrapper(_Base):
+    """The reference's classifier-guidance Lightning module (main/models/clf_wrapper.py:11-135):
+    ``training_step((x_0, y))`` trains the noise-conditioned classifier with ``tce_loss``; ``predict_step`` draws
+    class-conditional samples with ``cc_em_sde``.  ``config`` is the root node with ``.diffusion`` and ``.clf``.
+    The reference leaves the optimisation to Lightning's automatic mode (zero_grad, backward, Adam step, LambdaLR
+    step per batch, no gradient clipping); the same sequence is issued here explicitly."""
+
+    def __init__(self, config, sde, clf_fn, score_fn=None, criterion=None, sampler_cls=None, corrector_fn=None):
+        super().__init__()
+        self.config = config
+        self.sde = sde
+        self.clf_fn = clf_fn
+        self.criterion = criterion
+        self.train_eps = self.config.diffusion.training.train_eps
+        self.score_fn = score_fn
+        self.sampler = None
+        if sampler_cls is not None:
+            self.sampler = sampler_cls(self.config, self.sde, self.score_fn, self.clf_fn, corrector_fn=corrector_fn)
+        ev = self.config.diffusion.evaluation
+        self.eval_eps = ev.eval_eps
+        self.denoise = ev.denoise
+        self.n_discrete_steps = ev.n_discrete_steps - 1 if self.denoise else ev.n_discrete_steps
+        self.val_eps = ev.eval_eps
+        self.stride_type = ev.stride_type
+        self.automatic_optimization = False
+
+    def forward(self):
+        pass
+
+    def training_step(self, batch, batch_idx):
+        optim = self.optimizers()
+        lr_sched = self.lr_schedulers()
+        x_0, y = batch
+        t_ = torch.rand(x_0.shape[0], device=x_0.device, dtype=torch.float64)   # clf_wrapper.py:63-64
+        t = t_ * (self.sde.T - self.train_eps) + self.train_eps
+        loss, acc = self.criterion(x_0, y, t, self.clf_fn)
+        optim.zero_grad()
+        self.manual_backward(loss)
+        optim.step()
+        lr_sched.step()
+        self.log("loss", loss, prog_bar=True)
+        self.log("Top1-Acc", acc, prog_bar=True)
+        return loss
+
+    def on_predict_start(self):
+        torch.manual_seed(self.config.clf.evaluation.seed + self.global_rank)   # clf_wrapper.py:73-79
+
+    def sampling_times(self, device):
+        t_final = self.sde.T - self.eval_eps
+        ts = torch.linspace(0, t_final, self.n_discrete_steps + 1, device=device, dtype=torch.float64)
+        if self.stride_type == "quadratic":
+            ts = t_final * torch.flip(1 - (ts / t_final) ** 2.0, dims=[0])
+        return ts
+
+    def predict_step(self, batch, batch_idx, dataloader_idx=None):
+        return self.sampler.sample(batch, self.sampling_times(batch.device), self.n_discrete_steps,
+                                   denoise=self.denoise, eps=self.eval_eps)
+
+    def configure_optimizers(self):
+        oc = self.config.clf.training.optimizer
+        if oc.name != "Adam":
+            raise NotImplementedError(f"Optimizer {oc.name} not supported yet!")
+        optimizer = FusedAdam(self.clf_fn, lr=oc.lr, betas=(oc.beta_1, oc.beta_2), eps=oc.eps,
+                              weight_decay=oc.weight_decay, grad_clip=0.0)
+        lr_lambda = (lambda step: 1.0) if oc.warmup == 0 else (lambda step: min(step / oc.warmup, 1.0))
+        scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda)
+        return {"optimizer": optimizer,
+                "lr_scheduler": {"scheduler": scheduler, "interval": "step", "strict": False}}

@@ -306,6 +306,23 @@ def test_conv3x3_split_rejects_unsupported(ops):
                           torch.empty(2, 12, 12, 128, device=DEV))
 
 
+def test_softmax_xent_and_guide(ops):
+    rows, n = 37, 10
+    z = gen(rows, n, seed=88) * 3
+    y = torch.randint(0, n, (rows,), generator=torch.Generator().manual_seed(89))
+    loss, grad, correct = ops.softmax_xent(z.to(DEV), y.to(DEV), 1.0 / rows, 1.0 / rows)
+    zr = z.double().requires_grad_()
+    ref = F.cross_entropy(zr, y)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-6 and rel_l2(grad, zr.grad) < 1e-6
+    assert float(correct) == float((z.argmax(1) == y).sum())
+    x, gd = gen(2, 6, 4, 4, seed=90).double(), gen(2, 6, 4, 4, seed=91)
+    xd, x32 = x.to(DEV).clone(), torch.empty(2, 6, 4, 4, device=DEV)
+    ops.guide(xd, gd.to(DEV), 0.25, -1.5, x32)
+    ref = x + torch.cat([0.25 * gd[:, :3].double(), -1.5 * gd[:, 3:].double()], dim=1)
+    assert torch.equal(xd.cpu(), ref) and torch.equal(x32.cpu(), ref.float())
+
+
 def test_mask_combine(ops):
     b, c, h = 3, 3, 8
     x, u = gen(b, 2 * c, h, h, seed=85).double(), gen(b, 2 * c, h, h, seed=86).double()

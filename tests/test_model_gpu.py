@@ -276,6 +276,94 @@ def test_inpainting_sampler_matches_reference(golden, tag):
     assert torch.isfinite(y).all() and rel_l2(y[:, :3][known], x0.double()[known]) < 0.05
 
 
+def _build_clf(train=False):
+    import json, os
+    import psld_amd
+    from psld_amd.registry import get_module
+    from tests.synth import synth_state_dict
+    psld_amd.import_modules_into_registry()
+    with open(os.path.join(os.path.dirname(__file__), "golden", "clf_meta.json")) as fh:
+        meta = json.load(fh)
+    cfg = C.tiny_clf()
+    clf = get_module("clf_fn", "ncsnpp_clf")(cfg)
+    sd = synth_state_dict([(k, tuple(sh)) for k, sh in meta["keys"]], meta["seed"])
+    assert list(clf.state_dict().keys()) == list(sd.keys())
+    clf.load_state_dict(sd, strict=True)
+    clf = clf.to(DEV)
+    clf.train(train)
+    return clf, cfg, meta
+
+
+def test_classifier_logits_and_input_gradient(golden):
+    """NCSNppClassifier on the shared executor - logits and the guidance gradient vs the reference."""
+    g = golden("clf_tiny.npz")
+    clf, _, _ = _build_clf()
+    x = T(g["x"]).to(DEV).requires_grad_()
+    logits = clf(x, T(g["t"]).to(DEV))
+    assert logits.shape == (4, 10)
+    e1 = rel_l2(logits, T(g["logits"]))
+    from psld_amd import ops
+    _, dlog, _ = ops.softmax_xent(logits.detach().contiguous(), T(g["y"]).to(DEV), 1.0, -1.0)
+    (gx,) = torch.autograd.grad(logits, x, grad_outputs=dlog)
+    e2 = rel_l2(gx, T(g["dsel_dx"]))
+    print(f"classifier: logits {e1:.3e}, d log p(y|x)/dx {e2:.3e}")
+    assert e1 < 2e-5 and e2 < 1e-4
+
+
+def test_classifier_tce_loss_and_gradients(golden):
+    from psld_amd.registry import get_module
+    g = golden("clf_tiny.npz")
+    clf, ccfg, _ = _build_clf(train=True)
+    root = C.with_clf(C.tiny(), ccfg)
+    sde = get_module("sde", "psld")(root.diffusion)
+    crit = get_module("losses", "tce_loss")(root, sde)
+    loss, acc = crit(T(g["x0"]).to(DEV), T(g["y"]).to(DEV), T(g["t_loss"]).to(DEV), clf,
+                     m0_draw=T(g["m0_draw"]).to(DEV), eps=T(g["eps"]).to(DEV))
+    assert abs(loss.item() - float(g["loss"])) < 2e-5 * abs(float(g["loss"])) and float(acc) == float(g["acc"])
+    loss.backward()
+    norms = dict(zip(g["grad_norm_keys"].tolist(), g["grad_norms"].tolist()))
+    tot = float(np.sqrt(sum(v * v for v in norms.values())))
+    pd = dict(clf.named_parameters())
+    for k, v in norms.items():
+        assert abs(pd[k].grad.norm().item() - v) <= 1e-4 * v + 1e-5 * tot, k
+    for k in g.files:
+        if k.startswith("g:"):
+            assert rel_l2(pd[k[2:]].grad, T(g[k])) < 1e-4, k
+    # one optimiser step through the reference-shaped Lightning module (no warm-up: LambdaLR gives lr = 0 at step 0)
+    root.clf.training.optimizer.warmup = 0
+    wr = get_module("pl_modules", "tclf_wrapper")(root, sde, clf, criterion=crit)
+    before = next(iter(clf.parameters())).detach().clone()
+    out = wr.training_step((T(g["x0"]).to(DEV), T(g["y"]).to(DEV)), 0)
+    assert torch.isfinite(out) and not torch.equal(before, next(iter(clf.parameters())).detach())
+
+
+@pytest.mark.parametrize("tag", ["cc3", "cc5"])
+def test_class_conditional_sampler_matches_reference(golden, tag):
+    from psld_amd.registry import get_module
+    g = golden("clf_tiny.npz")
+    clf, ccfg, meta = _build_clf()
+    net, dcfg, _ = _build("tiny")
+    root = C.with_clf(dcfg, ccfg)
+    root.clf.evaluation.clf_temp = meta["clf_temp"]
+    lab = T(g[f"label_{tag}"])
+    root.clf.evaluation.label_to_sample = int(lab) if lab.dim() == 0 else lab
+    sde = get_module("sde", "psld")(dcfg)
+    sampler = get_module("samplers", "cc_em_sde")(root, sde, net, clf)
+    noise = T(g[f"noise_{tag}"]).to(DEV)
+    sampler.noise_fn = lambda i, x: noise[i]
+    n = int(tag[2:]) - 1
+    x = sampler.sample(T(g[f"batch_{tag}"]).to(DEV), T(g[f"ts_{tag}"]).to(DEV), n, denoise=True, eps=dcfg.evaluation.eval_eps)
+    err = rel_l2(x, T(g[f"x_{tag}"]))
+    print(f"class-conditional EM {tag}: rel-L2 = {err:.3e}")
+    assert x.dtype == torch.float64 and err < 1e-4
+    # guidance really acts: temperature 0 gives a different trajectory
+    root.clf.evaluation.clf_temp = 0.0
+    s0 = get_module("samplers", "cc_em_sde")(root, sde, net, clf)
+    s0.noise_fn = lambda i, x: noise[i]
+    x0 = s0.sample(T(g[f"batch_{tag}"]).to(DEV), T(g[f"ts_{tag}"]).to(DEV), n, denoise=True, eps=dcfg.evaluation.eval_eps)
+    assert rel_l2(x0, x) > 1e-4
+
+
 def test_sde_interface_matches_oracle(golden):
     from psld_amd.registry import get_module
     cfg = C.c10_sota()
