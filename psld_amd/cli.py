@@ -4,6 +4,12 @@
     python -m psld_amd.cli sample --config c10_sota [key=value ...]        (main/eval/sample.py:28-109)
     python -m psld_amd.cli inpaint --config c10_sota --data x.npy --mask m.npy [key=value ...]
                                                                            (main/eval/inpaint.py:29-135)
+    python -m psld_amd.cli train_clf --config c10_sota --clf-config clf_c10 --data x.npy --labels y.npy [...]
+                                                                           (main/train_clf.py:24-110)
+    python -m psld_amd.cli cc_sample --config c10_sota --clf-config clf_c10 [dataset.clf.evaluation.label_to_sample=9 ...]
+                                                                           (main/eval/class_cond_sample.py:29-138)
+
+For the two classifier-guidance commands ``dataset.clf.<key>=value`` / ``clf.<key>=value`` go to the ``clf`` node.
 
 ``key=value`` are Hydra-style dotted overrides on the ``dataset.diffusion`` node; the prefix
 ``dataset.diffusion.`` is accepted and stripped, so the override lists of ``scripts_psld/**.sh`` can be
@@ -204,6 +210,131 @@ def sample(args, overrides):
         dist.destroy_process_group()
 
 
+def _split_overrides(items):
+    """(diffusion overrides, clf overrides): ``dataset.clf.x=..`` / ``clf.x=..`` belong to the clf node."""
+    dif, clf = [], []
+    for it in items:
+        k = it.split("=", 1)[0].lstrip("+")
+        if k.startswith("dataset.clf.") or k.startswith("clf."):
+            clf.append(it.lstrip("+").replace("dataset.clf.", "", 1).replace("clf.", "", 1) if "=" in it else it)
+        else:
+            dif.append(it)
+    return dif, clf
+
+
+def _root_config(args, overrides):
+    from psld_amd import config as C
+    dif, clf = _split_overrides(overrides)
+    dcfg = parse_overrides(getattr(C, args.config)(), dif)
+    ccfg = parse_overrides(getattr(C, args.clf_config)(), clf)
+    ccfg.data.image_size = dcfg.data.image_size
+    return C.with_clf(dcfg, ccfg)
+
+
+def train_clf(args, overrides):
+    """main/train_clf.py: train the noise-conditioned classifier (``ncsnpp_clf`` + ``tce_loss``) on (image, label)
+    pairs; checkpoints in Lightning layout under ``clf.training.results_dir/checkpoints`` (keys ``clf_fn.<param>``)."""
+    from psld_amd import ops
+    from psld_amd.ddp import BucketReducer, init_distributed
+    from psld_amd.registry import get_module
+    import psld_amd
+    import torch.distributed as dist
+    rank, local, world = init_distributed()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    root = _root_config(args, overrides)
+    cc = root.clf
+    torch.manual_seed(cc.training.seed)
+    psld_amd.import_modules_into_registry()
+    clf = get_module("clf_fn", cc.model.clf_fn.name)(cc).to(dev).train()
+    sde = get_module("sde", root.diffusion.model.sde.name)(root.diffusion)
+    crit = get_module("losses", cc.training.loss.name)(root, sde)
+    wrapper = get_module("pl_modules", cc.model.pl_module)(root, sde, clf, score_fn=None, criterion=crit)
+    if world > 1:
+        clf.set_reducer(BucketReducer())
+    data = _dataset(root.diffusion, args, dev, rank)
+    if args.labels and args.labels != "synthetic":
+        labels = torch.from_numpy(np.load(args.labels).astype(np.int64)).to(dev)
+    else:
+        labels = torch.randint(0, cc.model.clf_fn.n_cls, (data.shape[0],),
+                               generator=torch.Generator().manual_seed(4321 + rank)).to(dev)
+    assert labels.shape[0] == data.shape[0]
+    bs = min(cc.training.batch_size, data.shape[0])
+    n = data.shape[0] // bs * bs
+    gen = torch.Generator(device=dev).manual_seed(cc.training.seed + rank)
+    ckdir = os.path.join(cc.training.results_dir or "psld_clf_results", "checkpoints")
+    step = 0
+    for epoch in range(cc.training.epochs):
+        perm = torch.randperm(data.shape[0], device=dev, generator=gen)[:n]
+        for i in range(0, n, bs):
+            idx = perm[i:i + bs]
+            flip = (torch.rand(bs, device=dev, generator=gen) < 0.5).to(torch.uint8) if cc.data.hflip else None
+            x0 = ops.uint8_to_images(data[idx].contiguous(), norm=cc.data.norm, flip=flip)
+            loss = wrapper.training_step((x0, labels[idx].contiguous()), step)
+            step += 1
+            if rank == 0 and step % max(1, cc.training.log_step * args.log_every) == 0:
+                print(f"epoch {epoch} step {step} loss {loss.item():.4f} top1 {float(wrapper.logged['Top1-Acc']):.1f}%", flush=True)
+            if args.max_steps and step >= args.max_steps:
+                break
+        done = args.max_steps and step >= args.max_steps
+        if rank == 0 and ((epoch + 1) % cc.training.chkpt_interval == 0 or done):
+            sd = {"clf_fn." + k: v.detach().cpu() for k, v in clf.state_dict().items()}
+            os.makedirs(ckdir, exist_ok=True)
+            name = f"{cc.model.clf_fn.name}-{root.diffusion.model.sde.name}-{cc.training.chkpt_prefix}-epoch={epoch:02d}-loss={loss.item():.4f}.ckpt"
+            for fn in (name, "last.ckpt"):
+                torch.save({"state_dict": sd, "global_step": step, "epoch": epoch + 1}, os.path.join(ckdir, fn))
+        if done:
+            break
+    if world > 1:
+        dist.barrier(device_ids=[local])
+        dist.destroy_process_group()
+
+
+def cc_sample(args, overrides):
+    """main/eval/class_cond_sample.py: class-conditional samples with classifier guidance (``cc_em_sde``)."""
+    from psld_amd import ops
+    from psld_amd.ddp import init_distributed, shard_range
+    from psld_amd.registry import get_module
+    import torch.distributed as dist
+    rank, local, world = init_distributed()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    root = _root_config(args, overrides)
+    cfg, cc = root.diffusion, root.clf
+    ev = cfg.evaluation
+    score_fn, ema, sde = build(cfg, dev)
+    if ev.chkpt_path:
+        load_checkpoint(ev.chkpt_path, score_fn, ema)
+        score_fn.to(dev), ema.to(dev)
+    net = ema if ev.sample_from == "target" else score_fn
+    net.eval()
+    clf = get_module("clf_fn", cc.model.clf_fn.name)(cc)
+    if cc.evaluation.chkpt_path:
+        ck = torch.load(cc.evaluation.chkpt_path, map_location="cpu", weights_only=False)
+        sd = ck["state_dict"] if "state_dict" in ck else ck
+        clf.load_state_dict({k[len("clf_fn."):]: v for k, v in sd.items() if k.startswith("clf_fn.")}, strict=True)
+    clf = clf.to(dev).eval()
+    sampler_cls = get_module("samplers", "cc_em_sde" if ev.sampler.name == "em_sde" else ev.sampler.name)
+    wrapper = get_module("pl_modules", cc.model.pl_module)(root, sde, clf, score_fn=net, sampler_cls=sampler_cls)
+    wrapper.global_rank = rank
+    wrapper.on_predict_start()
+    lo, hi = shard_range(ev.n_samples, rank, world)
+    base = os.path.join(ev.save_path or "psld_cc_samples", str(ev.path_prefix)) if ev.path_prefix else (ev.save_path or "psld_cc_samples")
+    out_dir = os.path.join(base, "images")
+    os.makedirs(out_dir, exist_ok=True)
+    size, ch = cfg.data.image_size, cfg.data.num_channels
+    for bi, start in enumerate(range(lo, hi, ev.batch_size)):
+        b = min(ev.batch_size, hi - start)
+        x = wrapper.predict_step(sde.prior_sampling((b, ch, size, size), device=dev), bi)
+        u8 = ops.samples_to_uint8(x.contiguous(), is_augmented=cfg.model.sde.is_augmented, denorm=cfg.data.norm)
+        _save_u8(os.path.join(out_dir, f"output_{ev.sample_prefix}_{rank}_{bi}"), u8.cpu().numpy(), ev.save_mode)
+        if rank == 0:
+            print(f"rank 0: {start + b - lo}/{hi - lo} samples of class {cc.evaluation.label_to_sample}", flush=True)
+    if world > 1:
+        dist.barrier(device_ids=[local])
+        dist.destroy_process_group()
+
+
 def _save_u8(stem, u8, save_mode):
     if save_mode == "image":
         try:
@@ -276,7 +407,7 @@ def inpaint(args, overrides):
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="psld_amd.cli")
     sub = ap.add_subparsers(dest="cmd", required=True)
-    for name in ("train", "sample", "inpaint"):
+    for name in ("train", "sample", "inpaint", "train_clf", "cc_sample"):
         p = sub.add_parser(name)
         p.add_argument("--config", default="c10_sota", choices=["c10_sota", "celeba64_sota", "yaml_default", "tiny"])
         p.add_argument("--data", default="synthetic", help="uint8 [N,H,W,3] .npy file or 'synthetic'")
@@ -284,10 +415,13 @@ def main(argv=None):
         p.add_argument("--max-steps", type=int, default=0)
         p.add_argument("--log-every", type=int, default=10)
         p.add_argument("--mask", default="synthetic", help="inpaint: uint8 [N,H,W,3] .npy (1 = keep) or 'synthetic'")
+        p.add_argument("--clf-config", default="clf_c10", choices=["clf_c10", "clf_default", "tiny_clf"])
+        p.add_argument("--labels", default="synthetic", help="train_clf: int [N] .npy or 'synthetic'")
     args, overrides = ap.parse_known_args(argv)
     if not torch.cuda.is_available():
         raise SystemExit("psld_amd needs an MI355X: there is no CPU fallback")
-    {"train": train, "sample": sample, "inpaint": inpaint}[args.cmd](args, overrides)
+    {"train": train, "sample": sample, "inpaint": inpaint, "train_clf": train_clf,
+     "cc_sample": cc_sample}[args.cmd](args, overrides)
 
 
 if __name__ == "__main__":
