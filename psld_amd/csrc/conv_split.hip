@@ -426,7 +426,8 @@ __global__ void __launch_bounds__(256, 3) dwgrad_kernel(const DWgradArgs a) {
     // raw buffer resource, whose range check returns zeros for the offset 0xFFFFFFFF given to padding items
     // (no zero-page select, ~4 VALU per item instead of ~15).  Measured: neutral - and so was a double-buffered LDS
     // variant with one barrier per K tile at two workgroups per CU (181-188 vs 200-209 TFLOP/s): the kernel runs
-    // best as three single-buffered workgroups per CU overlapping each other's staging phases.
+    // best as three single-buffered workgroups per CU overlapping each other's staging phases.  s_setprio(1) around
+    // the MFMA phase: neutral.  Upper bound of removing the limb split altogether (operands pre-split in HBM): +9 %.
     unsigned xoff[WG_NB];   // byte offset from pixel (img, oy0 + ky - 1, ox0 - 1), channel ci0
     int xrow[WG_NB];        // staged row of the item (>= 8: never valid)
     int xcol[WG_NB];        // bit 0: column valid when the K tile starts at ox0 = 0, bit 1: at ox0 = 32 (W = 64)
