@@ -77,6 +77,31 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nsplit,
     }
 }
 
+// float4 form (n, cin multiples of 4, 16-byte aligned slabs): four consecutive ci per thread, all slabs' loads
+// independent; the OIHW scatter writes four floats `taps` apart
+__global__ void reduce_slabs4_kernel(const float* __restrict__ slabs, int nsplit, long long n, float* __restrict__ out,
+                                     int layout, int taps, int cin, float alpha) {
+    const long long n4 = n >> 2;
+    GRID_STRIDE(q, n4) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(slabs) + q;
+        f32x4 acc = p[0];
+        for (int s = 1; s < nsplit; ++s) acc += p[(long long)s * n4];
+        acc *= alpha;
+        const long long i = q << 2;
+        if (layout == 1) {  // [co][tap][ci] -> [co][ci][tap]
+            const int ci = (int)(i % cin);
+            long long t = i / cin;
+            const int tap = (int)(t % taps);
+            const long long co = t / taps;
+            float* o = out + (co * cin + ci) * taps + tap;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[(long long)e * taps] = acc[e];
+        } else {
+            reinterpret_cast<f32x4*>(out)[q] = acc;
+        }
+    }
+}
+
 // ---- pointwise ----------------------------------------------------------------------------------
 __global__ void axpby_kernel(const float* __restrict__ a, float sa, const float* __restrict__ b, float sb,
                              float* __restrict__ y, long long n4, long long n, int accumulate) {
@@ -151,20 +176,24 @@ __global__ void colsum_final_kernel(const double* __restrict__ part, int chunks,
     for (int k = 0; k < chunks; ++k) t += part[((long long)b * chunks + k) * c + col];
     out[(long long)b * c + col] = (float)(t * (double)alpha);
 }
-// per-image sums [batch][c] -> batch total: grid c/64, block 256 = 64 columns x 4 image lanes; every lane adds its
-// images in index order, the four lanes are combined in lane order (fixed order, no atomics: bitwise repeatable)
+// per-image sums [batch][c] -> batch total: grid c/64, block 1024 = 64 columns x 16 image lanes; every lane adds its
+// images in index order, the lanes are combined in lane order (fixed order, no atomics: bitwise repeatable)
 __global__ void colsum_total_kernel(const float* __restrict__ per_image, int batch, int c, float* __restrict__ out,
                                     float alpha) {
-    __shared__ double red[4][64];
+    __shared__ double red[16][64];
     const int col = blockIdx.x * 64 + (threadIdx.x & 63);
     const int bl = threadIdx.x >> 6;
     double tot = 0.0;
     if (col < c)
-        for (int b = bl; b < batch; b += 4) tot += (double)per_image[(long long)b * c + col];
+        for (int b = bl; b < batch; b += 16) tot += (double)per_image[(long long)b * c + col];
     red[bl][threadIdx.x & 63] = tot;
     __syncthreads();
-    if (bl == 0 && col < c)
-        out[col] = (float)((red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) * (double)alpha);
+    if (bl == 0 && col < c) {
+        double t = 0.0;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) t += red[l][threadIdx.x];
+        out[col] = (float)(t * (double)alpha);
+    }
 }
 // scalar fallback: grid (c/64, batch); block 256 = 64 columns x 4 row lanes
 __global__ void colsum_kernel(const float* __restrict__ x, int ld, int hw, int c, float* __restrict__ out,
@@ -374,8 +403,14 @@ extern "C" int psld_reduce_slabs_f32(const float* slabs, int nsplit, long long n
                                      int taps, int cin, float alpha, hipStream_t stream) {
     PSLD_CHECK_ARG(slabs && out && nsplit >= 1, "psld_reduce_slabs_f32: bad args");
     PSLD_CHECK_ARG(layout == 0 || n == (long long)cout * taps * cin, "psld_reduce_slabs_f32: shape mismatch");
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(n)), dim3(256), 0, stream, slabs, nsplit, n, out, layout,
-                       taps, cin, alpha);
+    const bool vec = n % 4 == 0 && (layout == 0 || cin % 4 == 0) && (reinterpret_cast<uintptr_t>(slabs) & 15) == 0 &&
+                     (layout == 1 || (reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    if (vec)
+        hipLaunchKernelGGL(reduce_slabs4_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, slabs, nsplit, n, out, layout,
+                           taps, cin, alpha);
+    else
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(n)), dim3(256), 0, stream, slabs, nsplit, n, out, layout,
+                           taps, cin, alpha);
     PSLD_CHECK_LAUNCH("psld_reduce_slabs_f32");
     return PSLD_OK;
 }
@@ -475,7 +510,7 @@ extern "C" int psld_bias_grad_f32(const float* x, int ld, int batch, int hw, int
     PSLD_CHECK_LAUNCH("colsum_partial_kernel");
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(c, 128), batch), dim3(128), 0, stream, part, chunks, c, pim, 1.0f);
     PSLD_CHECK_LAUNCH("colsum_final_kernel");
-    hipLaunchKernelGGL(colsum_total_kernel, dim3(cdiv(c, 64)), dim3(256), 0, stream, pim, batch, c, out, alpha);
+    hipLaunchKernelGGL(colsum_total_kernel, dim3(cdiv(c, 64)), dim3(1024), 0, stream, pim, batch, c, out, alpha);
     PSLD_CHECK_LAUNCH("colsum_total_kernel");
     return PSLD_OK;
 }
