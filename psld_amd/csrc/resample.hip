@@ -59,6 +59,45 @@ __global__ void upfirdn_nhwc_kernel(const float* __restrict__ x, float* __restri
     }
 }
 
+// Fast NHWC forms of the two resamplers the network uses with the 4x4 FIR (up_or_down_sampling.py:195-257): x2 up
+// (2x2 contributing taps per output) and x2 down (all 16 taps); compile-time tap structure, one block row per output
+// row so that no thread divides by a run-time extent.  grid = (ceil(out_w*cq / 256), batch*out_h).
+template <int UP, int DOWN>
+__global__ void upfirdn4_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, const Fir f, int c, int in_h,
+                                     int in_w, int out_h, int out_w, int accumulate) {
+    const int cq = c >> 2;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= out_w * cq) return;
+    const int ox = t / cq, q = t - ox * cq;
+    const int n = blockIdx.y / out_h, oy = blockIdx.y - n * out_h;
+    const float* xin = x + (long long)n * in_h * in_w * c + q * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    constexpr int STEP = UP;                       // taps that land on real samples are UP apart
+    int ky0 = 0, kx0 = 0;
+    if (UP == 2) {
+        ky0 = (f.pad_y0 - oy) & 1;
+        kx0 = (f.pad_x0 - ox) & 1;
+    }
+#pragma unroll
+    for (int a = 0; a < 4 / STEP; ++a) {
+        const int ky = ky0 + a * STEP;
+        const int py = oy * DOWN + ky - f.pad_y0;
+        const int iy = UP == 2 ? py >> 1 : py;
+        if (py < 0 || iy >= in_h) continue;
+#pragma unroll
+        for (int b = 0; b < 4 / STEP; ++b) {
+            const int kx = kx0 + b * STEP;
+            const int px = ox * DOWN + kx - f.pad_x0;
+            const int ix = UP == 2 ? px >> 1 : px;
+            if (px < 0 || ix >= in_w) continue;
+            acc += *reinterpret_cast<const f32x4*>(xin + ((long long)iy * in_w + ix) * c) * f.w[ky * 4 + kx];
+        }
+    }
+    float* op = y + (((long long)n * out_h + oy) * out_w + ox) * c + q * 4;
+    if (accumulate) acc += *reinterpret_cast<const f32x4*>(op);
+    *reinterpret_cast<f32x4*>(op) = acc;
+}
+
 __global__ void upfirdn_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, const Fir f, int planes,
                                     int in_h, int in_w, int out_h, int out_w, int accumulate) {
     const long long total = (long long)planes * out_h * out_w;
@@ -119,6 +158,18 @@ extern "C" int psld_upfirdn2d_f32(const float* x, float* y, int batch, int c, in
         for (int kx = 0; kx < kw; ++kx) f.w[ky * kw + kx] = kernel_host[(kh - 1 - ky) * kw + (kw - 1 - kx)];
     if (layout == 1) {
         PSLD_CHECK_ARG(c % 4 == 0, "psld_upfirdn2d_f32: NHWC needs C%%4==0 (C=%d)", c);
+        const bool k4 = kh == 4 && kw == 4 && up_x == up_y && down_x == down_y && (long long)batch * out_h < 65536;
+        if (k4 && ((up_x == 2 && down_x == 1) || (up_x == 1 && down_x == 2))) {
+            const dim3 grid((unsigned)cdiv((long long)out_w * (c / 4), 256), (unsigned)(batch * out_h));
+            if (up_x == 2)
+                hipLaunchKernelGGL((upfirdn4_nhwc_kernel<2, 1>), grid, dim3(256), 0, stream, x, y, f, c, in_h, in_w, out_h,
+                                   out_w, accumulate);
+            else
+                hipLaunchKernelGGL((upfirdn4_nhwc_kernel<1, 2>), grid, dim3(256), 0, stream, x, y, f, c, in_h, in_w, out_h,
+                                   out_w, accumulate);
+            PSLD_CHECK_LAUNCH("psld_upfirdn2d_f32");
+            return PSLD_OK;
+        }
         const long long total = (long long)batch * out_h * out_w * (c / 4);
         const int blocks = (int)min((long long)cdiv(total, 256), 256LL * 32);
         hipLaunchKernelGGL(upfirdn_nhwc_kernel, dim3(blocks), dim3(256), 0, stream, x, y, f, batch, c, in_h, in_w,
