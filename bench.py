@@ -276,6 +276,7 @@ def main():
                              "replaces is 157.3 TFLOP/s.  Under this load the chip holds ~1.65-1.8 GHz (PMC, "
                              "profiles/r01), i.e. the kernel runs at the power limit.",
                 "mfma_issued_tflops": LIMB_PRODUCTS * ps["tflops"],
+                "frac_of_f32_mfma_peak": ps["tflops"] / PEAK_F32_MFMA_TFLOPS,
                 "traffic": pmc.get("traffic_bytes") if pmc else None,
                 "traffic_note": pmc.get("note") if pmc else None,
                 "launches": ps["launches"], "avg_launch_us": ps["avg_us"],
