@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
             const int gn = n0 + wc * 64 + nb * 16 + r16;
             float bias = e.bias ? e.bias[gn] : 0.f;
             // time-embedding bias: one value per (image, channel); a 16-row block never straddles images
-            if (rb_uniform) bias += e.rowbias[(long long)(row_base / e.rows_per_img) * e.ld_rowbias + gn];
+            if (rb_uniform && row_base < a.M) bias += e.rowbias[(long long)(row_base / e.rows_per_img) * e.ld_rowbias + gn];
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int gm = row_base + 4 * kq + v;

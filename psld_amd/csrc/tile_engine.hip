@@ -670,7 +670,8 @@ __global__ void __launch_bounds__(NTHREADS, (NBUF == 2 || TBN == 256) ? 2 : 3) t
             if (gn >= a.N) continue;
             float bias = a.e.bias ? a.e.bias[gn] : 0.f;
             // time-embedding bias: one value per (image, channel); a 32-row tile never straddles images
-            if (rb_uniform) bias += a.e.rowbias[(long long)img_u * a.e.ld_rowbias + gn];
+            // (a block of rows entirely beyond M must not touch the row of a non-existent image)
+            if (rb_uniform && row_base < a.M) bias += a.e.rowbias[(long long)img_u * a.e.ld_rowbias + gn];
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int gm = row_base + (v & 3) + 8 * (v >> 2) + 4 * h;

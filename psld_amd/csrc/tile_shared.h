@@ -53,7 +53,7 @@ __device__ __forceinline__ void epilogue_store_block(const f32x16& acc, int row_
     const bool rb_uniform = e.rowbias && (e.rows_per_img % 32 == 0);
     float bias = e.bias ? e.bias[gn] : 0.f;
     // time-embedding bias: one value per (image, channel); a 32-row block never straddles images
-    if (rb_uniform) bias += e.rowbias[(long long)(row_base / e.rows_per_img) * e.ld_rowbias + gn];
+    if (rb_uniform && row_base < M) bias += e.rowbias[(long long)(row_base / e.rows_per_img) * e.ld_rowbias + gn];
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
         const int gm = row_base + (v & 3) + 8 * (v >> 2) + 4 * h;

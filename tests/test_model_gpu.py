@@ -86,6 +86,42 @@ def test_network_forward_in_f32_mfma_mode(golden):
     assert not torch.equal(y32, y6)          # the two modes really are different kernels
 
 
+def test_modes_agree_across_networks_and_odd_batches():
+    """Several networks and batch sizes in ONE process, both arithmetic modes on the same inputs: partial M tiles
+    (B=1: 64 rows at 8x8), workspace growth, fragment caches.  (This sequence once exposed an out-of-bounds read of the
+    time-embedding bias by row blocks beyond M.)"""
+    import psld_amd
+    from psld_amd import ops
+    from psld_amd.registry import get_module
+    psld_amd.import_modules_into_registry()
+    mode0 = ops.math_mode()
+    try:
+        for cfgname, batches in (("c10_sota", (1, 3)), ("celeba64_sota", (1,)), ("yaml_default", (5,))):
+            cfg = getattr(C, cfgname)()
+            cfg.model.score_fn.dropout = 0.0
+            torch.manual_seed(1)
+            net = get_module("score_fn", "ncsnpp")(cfg).to(DEV).train()
+            size = cfg.data.image_size
+            for b in batches:
+                x = torch.randn(b, 6, size, size, device=DEV)
+                t = torch.rand(b, device=DEV) * 0.9 + 0.05
+                res = {}
+                for mode in ("f32", "bf16x6"):
+                    ops.set_math_mode(mode)
+                    for p in net.parameters():
+                        p.grad = None
+                    net.mark_grads_stale()
+                    y = net(x, t)
+                    (y * torch.linspace(-1, 1, y.numel(), device=DEV).view_as(y)).sum().backward()
+                    g = torch.cat([p.grad.flatten() for p in net.parameters() if p.grad is not None])
+                    res[mode] = (y.detach().clone(), g.clone())
+                assert rel_l2(res["bf16x6"][0], res["f32"][0]) < 5e-6, (cfgname, b)
+                assert rel_l2(res["bf16x6"][1], res["f32"][1]) < 5e-6, (cfgname, b)
+            del net
+    finally:
+        ops.set_math_mode(mode0)
+
+
 def test_native_library_is_what_ran():
     """The HIP shared object must be mapped into this process (no silent eager fallback)."""
     from psld_amd import _lib
