@@ -122,6 +122,35 @@ def test_modes_agree_across_networks_and_odd_batches():
         ops.set_math_mode(mode0)
 
 
+def test_graph_replay_tracks_weight_updates_on_the_limb_kernels():
+    """HIP-graph replay of the north-star forward stays bit-identical to the eager forward after optimiser steps:
+    the captured launches read the limb-fragment buffers, which must be refreshed in place (3x3 fragments in one
+    batched launch, the fused q|k|v / 1x1 fragments through their builders)."""
+    import copy
+    from psld_amd.registry import get_module
+    net, cfg, _ = _build("c10_sota")
+    cfg.training.optimizer.warmup = 0
+    sde = get_module("sde", "psld")(cfg)
+    crit = get_module("losses", "psld_score_loss")(cfg, sde)
+    wr = get_module("pl_modules", "sde_wrapper")(cfg, sde, net, ema_score_fn=copy.deepcopy(net), criterion=crit)
+    x = torch.randn(2, 6, 32, 32, device=DEV)
+    t = torch.rand(2, device=DEV) * 0.9 + 0.05
+    with torch.no_grad():
+        e0 = net(x, t)
+        net.enable_graphs(True)
+        assert torch.equal(net(x, t), e0)
+    net.enable_graphs(False)
+    net.train()
+    wr.training_step(torch.rand(4, 3, 32, 32, device=DEV) * 2 - 1, 0)
+    net.eval()
+    with torch.no_grad():
+        e1 = net(x, t)
+        net.enable_graphs(True)
+        g1 = net(x, t)
+    net.enable_graphs(False)
+    assert not torch.equal(e0, e1) and torch.equal(e1, g1)
+
+
 def test_native_library_is_what_ran():
     """The HIP shared object must be mapped into this process (no silent eager fallback)."""
     from psld_amd import _lib
