@@ -229,6 +229,17 @@ int psld_bias_grad_f32(const float* x, int ld, int batch, int hw, int c, float* 
 /* dst[r][0:cols] (+)= src[r][0:cols] with row strides: channel concat (ncsnpp.py:374) and its split. */
 int psld_copy2d_f32(const float* src, int ld_src, float* dst, int ld_dst, long long rows, int cols,
                     int accumulate, hipStream_t stream);
+/* 3x3 im2col of a few-channel NHWC tensor (9*c <= ld_out): cols[m][ch*9 + tap] (zero-filled to ld_out columns), so
+ * that the 6-channel stem / first-pyramid convolutions (ncsnpp.py:317, layerspp.py:149-163) and the data / weight
+ * gradients of the 6-channel head (ncsnpp.py:430) run as K = 64 GEMMs on the tile engine.  flip = 1 (stride 1 only)
+ * stores tap 8 - t in the column of tap t (what a data gradient reads).  The column order ch*9 + tap is OIHW's. */
+int psld_im2col3x3_small_f32(const float* x, int batch, int ih, int iw, int c, int oh, int ow, int stride, int pad,
+                             int flip, float* out, int ld_out, hipStream_t stream);
+/* dst[r][j] = alpha * src[r][j], j < cols, arbitrary cols / leading dimensions (pads and un-pads the small K = 54
+ * weight matrices of the calls above). */
+int psld_scale_copy2d_f32(const float* src, int ld_src, float* dst, int ld_dst, long long rows, int cols, float alpha,
+                          hipStream_t stream);
+
 /* rows of length L: y = softmax(x) ; dx = y * (dy - sum(y*dy)) (layerspp.py:84). */
 int psld_softmax_rows_f32(const float* x, float* y, long long rows, int L, hipStream_t stream);
 int psld_softmax_rows_bwd_f32(const float* y, const float* dy, float* dx, long long rows, int L, hipStream_t stream);

@@ -102,6 +102,8 @@ SIGNATURES = {
     "psld_colsum_f32": (I, [P, I, I, I, I, P, F, P, P]),
     "psld_bias_grad_f32": (I, [P, I, I, I, I, P, P, F, P, P]),
     "psld_copy2d_f32": (I, [P, I, P, I, LL, I, I, P]),
+    "psld_im2col3x3_small_f32": (I, [P, I, I, I, I, I, I, I, I, I, P, I, P]),
+    "psld_scale_copy2d_f32": (I, [P, I, P, I, LL, I, F, P]),
     "psld_softmax_rows_f32": (I, [P, P, LL, I, P]),
     "psld_softmax_rows_bwd_f32": (I, [P, P, P, LL, I, P]),
     "psld_time_embed_f32": (I, [P, P, P, I, I, I, P]),

@@ -102,6 +102,43 @@ __global__ void reduce_slabs4_kernel(const float* __restrict__ slabs, int nsplit
     }
 }
 
+// im2col of a few-channel NHWC tensor (the 6-channel network input / output gradient) for a 3x3 convolution:
+// cols[m][ch*9 + t] = x[n][oy*stride + ky - pad][ox*stride + kx - pad][ch] (0 outside), t = ky*3 + kx, zero-filled up
+// to ld_out columns; flip = 1 (stride 1) mirrors the taps: the column of tap t holds tap 8 - t.  With 9*c <= 64 the
+// stem / head / first pyramid convolutions become plain GEMMs with K = 64 on the fast tile engine instead of the
+// scalar-gather fallback (K = 54 does not fit its 32-channel chunking).
+__global__ void im2col3x3_small_kernel(const float* __restrict__ x, int ih, int iw, int c, int oh, int ow, int stride,
+                                       int pad, int flip, float* __restrict__ out, int ld_out, long long total) {
+    GRID_STRIDE(i, total) {          // one thread per (row m, column j)
+        const int j = (int)(i % ld_out);
+        const long long m = i / ld_out;
+        float v = 0.f;
+        if (j < 9 * c) {
+            const int ch = j / 9;
+            int t = j - ch * 9;
+            if (flip) t = 8 - t;
+            const int ky = t / 3, kx = t - ky * 3;
+            const int ox = (int)(m % ow);
+            const long long r = m / ow;
+            const int oy = (int)(r % oh);
+            const long long n = r / oh;
+            const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
+            if (iy >= 0 && iy < ih && ix >= 0 && ix < iw) v = x[((n * ih + iy) * iw + ix) * c + ch];
+        }
+        out[i] = v;
+    }
+}
+
+// dst[r*ld_dst + j] = alpha * src[r*ld_src + j] for j < cols: any column count (padding / un-padding small matrices)
+__global__ void scale_copy2d_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int ld_dst,
+                                    long long rows, int cols, float alpha) {
+    GRID_STRIDE(i, rows * cols) {
+        const long long r = i / cols;
+        const int j = (int)(i - r * cols);
+        dst[r * ld_dst + j] = alpha * src[r * ld_src + j];
+    }
+}
+
 // ---- pointwise ----------------------------------------------------------------------------------
 __global__ void axpby_kernel(const float* __restrict__ a, float sa, const float* __restrict__ b, float sb,
                              float* __restrict__ y, long long n4, long long n, int accumulate) {
@@ -412,6 +449,28 @@ extern "C" int psld_reduce_slabs_f32(const float* slabs, int nsplit, long long n
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(n)), dim3(256), 0, stream, slabs, nsplit, n, out, layout,
                            taps, cin, alpha);
     PSLD_CHECK_LAUNCH("psld_reduce_slabs_f32");
+    return PSLD_OK;
+}
+
+extern "C" int psld_im2col3x3_small_f32(const float* x, int batch, int ih, int iw, int c, int oh, int ow, int stride,
+                                        int pad, int flip, float* out, int ld_out, hipStream_t stream) {
+    PSLD_CHECK_ARG(x && out && batch > 0 && c > 0 && 9 * c <= ld_out && oh > 0 && ow > 0 && stride >= 1,
+                   "psld_im2col3x3_small_f32: bad args (c=%d ld_out=%d)", c, ld_out);
+    PSLD_CHECK_ARG(!flip || stride == 1, "psld_im2col3x3_small_f32: flip needs stride 1");
+    const long long total = (long long)batch * oh * ow * ld_out;
+    hipLaunchKernelGGL(im2col3x3_small_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, ih, iw, c, oh, ow, stride,
+                       pad, flip, out, ld_out, total);
+    PSLD_CHECK_LAUNCH("psld_im2col3x3_small_f32");
+    return PSLD_OK;
+}
+
+extern "C" int psld_scale_copy2d_f32(const float* src, int ld_src, float* dst, int ld_dst, long long rows, int cols,
+                                     float alpha, hipStream_t stream) {
+    PSLD_CHECK_ARG(src && dst && rows >= 0 && cols > 0 && ld_src >= cols && ld_dst >= cols, "psld_scale_copy2d_f32: bad args");
+    if (rows == 0) return PSLD_OK;
+    hipLaunchKernelGGL(scale_copy2d_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, stream, src, ld_src, dst, ld_dst,
+                       rows, cols, alpha);
+    PSLD_CHECK_LAUNCH("psld_scale_copy2d_f32");
     return PSLD_OK;
 }
 

@@ -394,6 +394,21 @@ def bias_grad(x: Tensor, ld: int, batch: int, hw: int, c: int, out: Tensor, alph
     return out
 
 
+def im2col3x3_small(x: Tensor, oh: int, ow: int, stride: int, pad: int, flip: bool = False, ld_out: int = 64) -> Tensor:
+    """[B*oh*ow, ld_out] im2col (column = channel*9 + tap, zero-padded) of a few-channel NHWC tensor."""
+    b, ih, iw, c = x.shape
+    out = torch.empty((b * oh * ow, ld_out), device=x.device, dtype=torch.float32)
+    check(lib().psld_im2col3x3_small_f32(_chk(x).data_ptr(), b, ih, iw, c, oh, ow, stride, pad, int(flip), out.data_ptr(),
+                                         ld_out, _stream()), "psld_im2col3x3_small_f32")
+    return out
+
+
+def scale_copy2d(src: Tensor, ld_src: int, dst: Tensor, ld_dst: int, rows: int, cols: int, alpha: float = 1.0,
+                 src_off: int = 0, dst_off: int = 0):
+    check(lib().psld_scale_copy2d_f32(src.data_ptr() + 4 * src_off, ld_src, dst.data_ptr() + 4 * dst_off, ld_dst, rows,
+                                      cols, alpha, _stream()), "psld_scale_copy2d_f32")
+
+
 def copy2d(src: Tensor, ld_src: int, dst: Tensor, ld_dst: int, rows: int, cols: int, accumulate: bool = False,
            src_off: int = 0, dst_off: int = 0):
     check(lib().psld_copy2d_f32(src.data_ptr() + 4 * src_off, ld_src, dst.data_ptr() + 4 * dst_off, ld_dst, rows, cols,

@@ -284,6 +284,62 @@ class _Exec:
         else:
             ops.conv2d_nhwc(x, None, self.net._packed(conv), cout, 3, 3, 1, 1, 1, h, w, out, epi)
 
+    # -- few-channel 3x3 convolutions (6-channel stem / first pyramid level in, 6-channel head out) as K = 64 GEMMs ----
+    # K = 9*6 = 54 does not fit the tile engine's 32-channel chunking, so these convolutions used its scalar-gather
+    # fallback (1.3 % of a step for 0.1 % of the FLOPs); an explicit im2col of the few-channel tensor (33 MB at
+    # B = 128) turns them into fast-path GEMMs.
+    def small_in_weights(self, conv: _Affine) -> Tensor:
+        """[cout][64]: the OIHW rows (ci*9 + tap, 54 values) zero-padded."""
+        co, ci = conv.weight.shape[0], conv.weight.shape[1]
+
+        def build(prev):
+            out = prev if prev is not None else torch.zeros((co, 64), device=conv.weight.device, dtype=torch.float32)
+            ops.scale_copy2d(conv.weight.detach(), ci * 9, out, 64, co, ci * 9)
+            return out
+        return self.net._gfrag(conv.weight, "small_in", build)
+
+    def small_in_conv(self, x: Tensor, conv: _Affine, stride: int, pad: int, oh: int, ow: int, out: Tensor, epi):
+        """Forward of a 3x3 convolution whose input has <= 7 channels; returns the im2col matrix for the wgrad."""
+        cols = ops.im2col3x3_small(x, oh, ow, stride, pad)
+        m, cout = cols.shape[0], conv.weight.shape[0]
+        ops.gemm_raw(0, 1, m, cout, 64, cols, 64, 0, self.small_in_weights(conv), 64, 0, out, cout, 0, 1, epi)
+        return cols
+
+    def small_in_wgrad(self, dy: Tensor, cols: Tensor, conv: _Affine, alpha: float = 1.0):
+        cout, k = conv.weight.shape[0], conv.weight.shape[1] * 9
+        m = cols.shape[0]
+        nsplit = _pick_nsplit(((cout + 127) // 128), m)
+        slabs = ops.workspace(4 * cout * 64 * (nsplit + 1), dy.device)
+        ops.gemm_tn_splitk(cout, 64, m, dy, cout, cols, 64, slabs, nsplit)
+        tmp = slabs.view(torch.float32)[nsplit * cout * 64:(nsplit + 1) * cout * 64]
+        ops.reduce_slabs(slabs, nsplit, cout * 64, tmp)
+        ops.scale_copy2d(tmp, 64, self.g(conv.weight), k, cout, k, alpha)
+
+    def small_out_backward(self, dy: Tensor, a: Tensor, conv: _Affine, da: Tensor):
+        """Data and weight gradient of a 3x3 stride-1 pad-1 convolution with <= 7 OUTPUT channels (the head)."""
+        co, ci = conv.weight.shape[0], conv.weight.shape[1]
+        b, h, w, _ = dy.shape
+        cols = ops.im2col3x3_small(dy, h, w, 1, 1, flip=True)            # [M][64], column = co*9 + tap (mirrored)
+        m = cols.shape[0]
+
+        def build(prev):                                                  # [ci][co*9 + tap] = w[co][ci][tap]
+            out = prev if prev is not None else torch.zeros((ci, 64), device=conv.weight.device, dtype=torch.float32)
+            for o in range(co):
+                ops.scale_copy2d(conv.weight.detach(), 9, out, 64, ci, 9, src_off=o * ci * 9, dst_off=o * 9)
+            return out
+        wd = self.net._gfrag(conv.weight, "small_out", build)
+        ops.gemm_raw(0, 1, m, ci, 64, cols, 64, 0, wd, 64, 0, da, ci, 0)
+
+        def side():
+            nsplit = _pick_nsplit((ci + 127) // 128, m)
+            slabs = ops.workspace(4 * 64 * ci * (nsplit + 1), dy.device)
+            ops.gemm_tn_splitk(64, ci, m, cols, 64, a, ci, slabs, nsplit)   # [co*9 + tap][ci]
+            tmp = slabs.view(torch.float32)[nsplit * 64 * ci:(nsplit + 1) * 64 * ci]
+            ops.reduce_slabs(slabs, nsplit, 64 * ci, tmp)
+            ops.reduce_slabs(tmp, 1, co * 9 * ci, self.g(conv.weight), layout=1, cout=co, taps=9, cin=ci)
+            self.bias_grad(dy, self.g(conv.bias))
+        self.on_side(side, dy, a, cols)
+
     def dgrad(self, dy: Tensor, conv: _Affine, k: int, stride: int, pad: int, ih: int, iw: int, out: Tensor,
               alpha: float = 1.0, accumulate: bool = False):
         cin = conv.weight.shape[1]
@@ -579,8 +635,13 @@ class _Exec:
         b, fh, fw, cin = xf.shape
         oh, ow = (fh - 3) // 2 + 1, (fw - 3) // 2 + 1
         out = torch.empty((b, oh, ow, cout), device=xf.device, dtype=torch.float32)
-        ops.conv2d_nhwc(xf, None, self.net._packed(conv), cout, 3, 3, 2, 0, 1, oh, ow, out,
-                        ops.epilogue(bias=conv.bias, residual=h.v, ld_residual=cout, out_scale=s))
+        epi = ops.epilogue(bias=conv.bias, residual=h.v, ld_residual=cout, out_scale=s)
+        small = cin * 9 <= 64 and cout % 4 == 0
+        cols = None
+        if small:
+            cols = self.small_in_conv(xf, conv, 2, 0, oh, ow, out, epi)
+        else:
+            ops.conv2d_nhwc(xf, None, self.net._packed(conv), cout, 3, 3, 2, 0, 1, oh, ow, out, epi)
         on = _Node(out)
         if not self.record:
             return on
@@ -591,7 +652,10 @@ class _Exec:
             hg, acc = _gbuf(h)
             ops.axpby(dout, s, None, 0.0, hg, accumulate=acc)
             def side():
-                self.wgrad(dout, xf, conv, 3, 2, 0, alpha=s)
+                if small:
+                    self.small_in_wgrad(dout, cols, conv, alpha=s)
+                else:
+                    self.wgrad(dout, xf, conv, 3, 2, 0, alpha=s)
                 self.bias_grad(dout, self.g(conv.bias), alpha=s)
 
             self.on_side(side, dout, xf)
@@ -650,8 +714,13 @@ class _Exec:
         mi += 1
         b, hh, ww, _ = x_nhwc.shape
         h0 = torch.empty((b, hh, ww, stem.weight.shape[0]), device=x.device, dtype=torch.float32)
-        ops.conv2d_nhwc(x_nhwc, None, net._packed(stem), stem.weight.shape[0], 3, 3, 1, 1, 1, hh, ww, h0,
-                        ops.epilogue(bias=stem.bias))
+        stem_small = x_nhwc.shape[-1] * 9 <= 64 and stem.weight.shape[0] % 4 == 0
+        stem_cols = None
+        if stem_small:
+            stem_cols = self.small_in_conv(x_nhwc, stem, 1, 1, hh, ww, h0, ops.epilogue(bias=stem.bias))
+        else:
+            ops.conv2d_nhwc(x_nhwc, None, net._packed(stem), stem.weight.shape[0], 3, 3, 1, 1, 1, hh, ww, h0,
+                            ops.epilogue(bias=stem.bias))
         n0 = _Node(h0)
         if self.record:
             def stem_bwd():
@@ -659,7 +728,10 @@ class _Exec:
                 n0.g = None
 
                 def side():
-                    self.wgrad(g0, x_nhwc, stem, 3, 1, 1)
+                    if stem_small:
+                        self.small_in_wgrad(g0, stem_cols, stem)
+                    else:
+                        self.wgrad(g0, x_nhwc, stem, 3, 1, 1)
                     self.bias_grad(g0, self.g(stem.bias))
 
                 self.on_side(side, g0, x_nhwc)
@@ -726,13 +798,16 @@ class _Exec:
             def head_bwd():
                 dy = hg.g
 
-                def side():
-                    self.wgrad(dy, af, head, 3, 1, 1)
-                    self.bias_grad(dy, self.g(head.bias))
-
-                self.on_side(side, dy, af)
                 daf = torch.empty_like(af)
-                self.dgrad(dy, head, 3, 1, 1, hh, ww, daf)
+                if oc * 9 <= 64 and af.shape[-1] % 4 == 0:
+                    self.small_out_backward(dy, af, head, daf)
+                else:
+                    def side():
+                        self.wgrad(dy, af, head, 3, 1, 1)
+                        self.bias_grad(dy, self.g(head.bias))
+
+                    self.on_side(side, dy, af)
+                    self.dgrad(dy, head, 3, 1, 1, hh, ww, daf)
                 xg, acc = _gbuf(last)
                 ops.gn_bwd(daf, last.v, stf, gnf.weight, gnf.bias, True, xg, self.g(gnf.weight), self.g(gnf.bias),
                            accumulate_dx=acc)
