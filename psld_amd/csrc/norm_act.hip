@@ -234,21 +234,23 @@ __global__ void gn_bwd_finalize_kernel(const float* __restrict__ part, const flo
     }
 }
 
-// dbeta[c] = sum_n s1[n,c], dgamma[c] = sum_n s2[n,c]: grid (C/64, 2), 64 columns x 4 batch lanes
+// dbeta[c] = sum_n s1[n,c], dgamma[c] = sum_n s2[n,c]: grid (C/64, 2), 64 columns x 16 batch lanes (fixed order)
 __global__ void gn_bwd_param_kernel(const float* __restrict__ sums, int batch, int c, float* __restrict__ dgamma,
                                     float* __restrict__ dbeta) {
-    __shared__ double red[4][64];
+    __shared__ double red[16][64];
     const int which = blockIdx.y;
     const int col = blockIdx.x * 64 + (threadIdx.x & 63);
     const int lane = threadIdx.x >> 6;
     double acc = 0.0;
     if (col < c)
-        for (int n = lane; n < batch; n += 4) acc += (double)sums[((long long)n * 2 + which) * c + col];
+        for (int n = lane; n < batch; n += 16) acc += (double)sums[((long long)n * 2 + which) * c + col];
     red[lane][threadIdx.x & 63] = acc;
     __syncthreads();
     if (lane == 0 && col < c) {
-        const float v = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
-        (which ? dgamma : dbeta)[col] = v;
+        double t = 0.0;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) t += red[l][threadIdx.x];
+        (which ? dgamma : dbeta)[col] = (float)t;
     }
 }
 
@@ -365,7 +367,7 @@ extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(batch), dim3(256), 0, stream, part, rstd, gamma, hw, c, groups,
                        m.chunks, sums, coef);
     PSLD_CHECK_LAUNCH("gn_bwd_finalize_kernel");
-    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(cdiv(c, 64), 2), dim3(256), 0, stream, sums, batch, c, dgamma, dbeta);
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(cdiv(c, 64), 2), dim3(1024), 0, stream, sums, batch, c, dgamma, dbeta);
     PSLD_CHECK_LAUNCH("gn_bwd_param_kernel");
     const Map ma = make_map(batch, hw, c, true);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ma.chunks, batch), dim3(ma.threads), 0, stream, dy, x, mean, rstd,
