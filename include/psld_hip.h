@@ -221,10 +221,15 @@ int psld_colsum_f32(const float* x, int ld, int batch, int hw, int c, float* out
                     void* workspace /* >= psld_colsum_workspace_bytes, NULL = slow scalar path */,
                     hipStream_t stream);
 /* Bias gradient in three launches (two chained psld_colsum_f32 calls take four): out[c] = alpha * sum over (batch, hw) of x[b][p][0..c) (row stride ld), and, when
- * per_image is not NULL, per_image[b][c] = the unscaled per-image sums (the time-embedding gradient needs them,
- * layerspp.py:262-263).  Same workspace as psld_colsum_f32; c % 4 == 0, c <= 1024, 16-byte aligned x. */
-int psld_bias_grad_f32(const float* x, int ld, int batch, int hw, int c, float* per_image, float* out, float alpha,
-                       void* workspace, hipStream_t stream);
+ * per_image is not NULL, per_image[b*ld_per_image + c] = the unscaled per-image sums (ld_per_image = 0 means c; the
+ * time-embedding gradient needs them, layerspp.py:262-263).  Same workspace as psld_colsum_f32; c % 4 == 0, c <= 1024, 16-byte aligned x. */
+int psld_bias_grad_f32(const float* x, int ld, int batch, int hw, int c, float* per_image, int ld_per_image,
+                       float* out, float alpha, void* workspace, hipStream_t stream);
+/* Many contiguous copies in one launch: table_dev = `entries` x 4 int64 {src pointer, dst pointer, float4 count, first
+ * float4 index}; total4 = sum of the counts.  Used to gather the Dense_0 (time-embedding projection,
+ * layerspp.py:225-228) weights of all ResBlocks into one [sum C_out][4*nf] matrix per optimizer step, so that their
+ * 57 forward Linear calls and 57 data gradients become one GEMM each. */
+int psld_copy_batch_f32(const long long* table_dev, int entries, long long total4, hipStream_t stream);
 
 /* dst[r][0:cols] (+)= src[r][0:cols] with row strides: channel concat (ncsnpp.py:374) and its split. */
 int psld_copy2d_f32(const float* src, int ld_src, float* dst, int ld_dst, long long rows, int cols,

@@ -100,7 +100,8 @@ SIGNATURES = {
     "psld_silu_bwd_f32": (I, [P, P, P, LL, P]),
     "psld_colsum_workspace_bytes": (LL, [I, I, I]),
     "psld_colsum_f32": (I, [P, I, I, I, I, P, F, P, P]),
-    "psld_bias_grad_f32": (I, [P, I, I, I, I, P, P, F, P, P]),
+    "psld_bias_grad_f32": (I, [P, I, I, I, I, P, I, P, F, P, P]),
+    "psld_copy_batch_f32": (I, [P, I, LL, P]),
     "psld_copy2d_f32": (I, [P, I, P, I, LL, I, I, P]),
     "psld_im2col3x3_small_f32": (I, [P, I, I, I, I, I, I, I, I, I, P, I, P]),
     "psld_scale_copy2d_f32": (I, [P, I, P, I, LL, I, F, P]),

@@ -129,6 +129,22 @@ __global__ void im2col3x3_small_kernel(const float* __restrict__ x, int ih, int 
     }
 }
 
+// Many contiguous float4-multiple copies in one launch.  tab[4*i ..]: src pointer, dst pointer, float4 count, first
+// float4 index of entry i in the launch-wide numbering (gathers the 57 time-embedding projection weights of the
+// ResBlocks into one matrix once per optimizer step).
+__global__ void copy_batch_kernel(const long long* __restrict__ tab, int ntab, long long total4) {
+    GRID_STRIDE(i, total4) {
+        int lo = 0, hi = ntab - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (tab[4 * mid + 3] <= i) lo = mid; else hi = mid - 1;
+        }
+        const long long* d = tab + 4 * lo;
+        const long long j = i - d[3];
+        reinterpret_cast<f32x4*>(d[1])[j] = reinterpret_cast<const f32x4*>(d[0])[j];
+    }
+}
+
 // dst[r*ld_dst + j] = alpha * src[r*ld_src + j] for j < cols: any column count (padding / un-padding small matrices)
 __global__ void scale_copy2d_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int ld_dst,
                                     long long rows, int cols, float alpha) {
@@ -205,24 +221,24 @@ __global__ void colsum_partial_kernel(const float* __restrict__ x, int ld, int h
     }
 }
 __global__ void colsum_final_kernel(const double* __restrict__ part, int chunks, int c, float* __restrict__ out,
-                                    float alpha) {
+                                    float alpha, int ld_out) {
     const int b = blockIdx.y;
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= c) return;
     double t = 0.0;
     for (int k = 0; k < chunks; ++k) t += part[((long long)b * chunks + k) * c + col];
-    out[(long long)b * c + col] = (float)(t * (double)alpha);
+    out[(long long)b * ld_out + col] = (float)(t * (double)alpha);
 }
 // per-image sums [batch][c] -> batch total: grid c/64, block 1024 = 64 columns x 16 image lanes; every lane adds its
 // images in index order, the lanes are combined in lane order (fixed order, no atomics: bitwise repeatable)
-__global__ void colsum_total_kernel(const float* __restrict__ per_image, int batch, int c, float* __restrict__ out,
-                                    float alpha) {
+__global__ void colsum_total_kernel(const float* __restrict__ per_image, int ld, int batch, int c,
+                                    float* __restrict__ out, float alpha) {
     __shared__ double red[16][64];
     const int col = blockIdx.x * 64 + (threadIdx.x & 63);
     const int bl = threadIdx.x >> 6;
     double tot = 0.0;
     if (col < c)
-        for (int b = bl; b < batch; b += 16) tot += (double)per_image[(long long)b * c + col];
+        for (int b = bl; b < batch; b += 16) tot += (double)per_image[(long long)b * ld + col];
     red[bl][threadIdx.x & 63] = tot;
     __syncthreads();
     if (bl == 0 && col < c) {
@@ -464,6 +480,13 @@ extern "C" int psld_im2col3x3_small_f32(const float* x, int batch, int ih, int i
     return PSLD_OK;
 }
 
+extern "C" int psld_copy_batch_f32(const long long* table_dev, int entries, long long total4, hipStream_t stream) {
+    PSLD_CHECK_ARG(table_dev && entries > 0 && total4 > 0, "psld_copy_batch_f32: bad args");
+    hipLaunchKernelGGL(copy_batch_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, table_dev, entries, total4);
+    PSLD_CHECK_LAUNCH("psld_copy_batch_f32");
+    return PSLD_OK;
+}
+
 extern "C" int psld_scale_copy2d_f32(const float* src, int ld_src, float* dst, int ld_dst, long long rows, int cols,
                                      float alpha, hipStream_t stream) {
     PSLD_CHECK_ARG(src && dst && rows >= 0 && cols > 0 && ld_src >= cols && ld_dst >= cols, "psld_scale_copy2d_f32: bad args");
@@ -534,7 +557,7 @@ extern "C" int psld_colsum_f32(const float* x, int ld, int batch, int hw, int c,
                            stream, x, ld, hw, c, cq, pl, chunk_px, chunks, part);
         PSLD_CHECK_LAUNCH("colsum_partial_kernel");
         hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(c, 128), batch), dim3(128), 0, stream, part, chunks, c, out,
-                           alpha);
+                           alpha, c);
         PSLD_CHECK_LAUNCH("colsum_final_kernel");
         return PSLD_OK;
     }
@@ -544,8 +567,8 @@ extern "C" int psld_colsum_f32(const float* x, int ld, int batch, int hw, int c,
 }
 // out[c] = alpha * sum over (batch, hw) of x; per_image[b][c] (optional, unscaled) = sum over hw.  Three launches
 // (chunk partials, per-image sums, batch total) instead of the four of two chained psld_colsum_f32 calls.
-extern "C" int psld_bias_grad_f32(const float* x, int ld, int batch, int hw, int c, float* per_image, float* out,
-                                  float alpha, void* workspace, hipStream_t stream) {
+extern "C" int psld_bias_grad_f32(const float* x, int ld, int batch, int hw, int c, float* per_image, int ld_per_image,
+                                  float* out, float alpha, void* workspace, hipStream_t stream) {
     PSLD_CHECK_ARG(x && out && workspace && batch > 0 && hw > 0 && c > 0, "psld_bias_grad_f32: bad args");
     PSLD_CHECK_ARG(c % 4 == 0 && ld % 4 == 0 && c / 4 <= 256 && (reinterpret_cast<uintptr_t>(x) & 15) == 0,
                    "psld_bias_grad_f32: needs c %%4 == 0 (<= 1024), ld %%4 == 0 and a 16-byte aligned input");
@@ -564,12 +587,13 @@ extern "C" int psld_bias_grad_f32(const float* x, int ld, int batch, int hw, int
     // without a caller buffer the per-image sums live behind the partials (psld_colsum_workspace_bytes covers
     // 64 chunk rows per image, at most 16 are used)
     float* pim = per_image ? per_image : reinterpret_cast<float*>(part + (long long)batch * 16 * c);
+    const int ldp = per_image && ld_per_image > 0 ? ld_per_image : c;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(chunks, batch), dim3(cq * pl), (size_t)pl * cq * 4 * sizeof(double),
                        stream, x, ld, hw, c, cq, pl, chunk_px, chunks, part);
     PSLD_CHECK_LAUNCH("colsum_partial_kernel");
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(c, 128), batch), dim3(128), 0, stream, part, chunks, c, pim, 1.0f);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(c, 128), batch), dim3(128), 0, stream, part, chunks, c, pim, 1.0f, ldp);
     PSLD_CHECK_LAUNCH("colsum_final_kernel");
-    hipLaunchKernelGGL(colsum_total_kernel, dim3(cdiv(c, 64)), dim3(1024), 0, stream, pim, batch, c, out, alpha);
+    hipLaunchKernelGGL(colsum_total_kernel, dim3(cdiv(c, 64)), dim3(1024), 0, stream, pim, ldp, batch, c, out, alpha);
     PSLD_CHECK_LAUNCH("colsum_total_kernel");
     return PSLD_OK;
 }

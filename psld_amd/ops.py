@@ -60,12 +60,13 @@ def _chk(t: Tensor, dtype=torch.float32):
 
 def epilogue(alpha: float = 1.0, bias: Optional[Tensor] = None, rowbias: Optional[Tensor] = None,
              rows_per_img: int = 1, residual: Optional[Tensor] = None, ld_residual: int = 0,
-             residual_stride_batch: int = 0, out_scale: float = 1.0, accumulate: bool = False) -> Epilogue:
+             residual_stride_batch: int = 0, out_scale: float = 1.0, accumulate: bool = False,
+             ld_rowbias: int = 0) -> Epilogue:
     e = Epilogue()
     e.alpha = alpha
     e.bias = _p(bias)
     e.rowbias = _p(rowbias)
-    e.ld_rowbias = rowbias.shape[-1] if rowbias is not None else 0
+    e.ld_rowbias = (ld_rowbias or rowbias.shape[-1]) if rowbias is not None else 0
     e.rows_per_img = rows_per_img
     e.residual = _p(residual)
     e.ld_residual = ld_residual
@@ -386,12 +387,17 @@ def colsum(x: Tensor, ld: int, batch: int, hw: int, c: int, out: Tensor, alpha: 
 
 
 def bias_grad(x: Tensor, ld: int, batch: int, hw: int, c: int, out: Tensor, alpha: float = 1.0,
-              per_image: Optional[Tensor] = None):
-    """out[c] = alpha * column sums over (batch, hw); per_image[b][c] (optional) = unscaled per-image sums."""
+              per_image: Optional[Tensor] = None, ld_per_image: int = 0):
+    """out[c] = alpha * column sums over (batch, hw); per_image[b*ld_per_image + c] (optional) = unscaled per-image sums."""
     ws = workspace(lib().psld_colsum_workspace_bytes(batch, hw, c), x.device)
-    check(lib().psld_bias_grad_f32(x.data_ptr(), ld, batch, hw, c, _p(per_image), out.data_ptr(), alpha, ws.data_ptr(),
-                                   _stream()), "psld_bias_grad_f32")
+    check(lib().psld_bias_grad_f32(x.data_ptr(), ld, batch, hw, c, _p(per_image), ld_per_image, out.data_ptr(), alpha,
+                                   ws.data_ptr(), _stream()), "psld_bias_grad_f32")
     return out
+
+
+def copy_batch(table: Tensor, entries: int, total4: int):
+    """table rows: [src pointer, dst pointer, float4 count, first float4 index]."""
+    check(lib().psld_copy_batch_f32(table.data_ptr(), entries, total4, _stream()), "psld_copy_batch_f32")
 
 
 def im2col3x3_small(x: Tensor, oh: int, ow: int, stride: int, pad: int, flip: bool = False, ld_out: int = 64) -> Tensor:

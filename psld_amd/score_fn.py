@@ -258,7 +258,8 @@ class _Exec:
         ops.conv2d_wgrad_nhwc(dy, cout, x, k, k, stride, pad, oh, ow, slabs, cin, 0, nsplit)
         ops.reduce_slabs(slabs, nsplit, n, self.g(conv.weight), layout=1, cout=cout, taps=taps, cin=cin, alpha=alpha)
 
-    def bias_grad(self, dy: Tensor, out: Tensor, alpha: float = 1.0, per_image=None, ld: Optional[int] = None):
+    def bias_grad(self, dy: Tensor, out: Tensor, alpha: float = 1.0, per_image=None, ld: Optional[int] = None,
+                  ld_per_image: int = 0):
         """``per_image``: True (or a [b, c] tensor) to also get the per-image sums back; ``ld``: row stride of
         ``dy`` when it is a column slice of a wider buffer."""
         b = dy.shape[0]
@@ -268,8 +269,9 @@ class _Exec:
         if c % 4 == 0 and c <= 1024 and ldx % 4 == 0 and dy.data_ptr() % 16 == 0:
             if per_image is True:
                 per_image = torch.empty((b, c), device=dy.device, dtype=torch.float32)
-            ops.bias_grad(dy, ldx, b, hw, c, out, alpha, per_image)
+            ops.bias_grad(dy, ldx, b, hw, c, out, alpha, per_image, ld_per_image)
             return per_image
+        assert ld_per_image in (0, c), "strided per-image sums need the vector path (c % 4 == 0)"
         tmp = per_image if isinstance(per_image, Tensor) else torch.empty((b, c), device=dy.device, dtype=torch.float32)
         ops.colsum(dy, ldx, b, hw, c, tmp)
         ops.colsum(tmp, c, 1, b, c, out, alpha)
@@ -382,9 +384,26 @@ class _Exec:
         st = _Node(ops.silu(temb))
         self.temb_act = st
         b = t.shape[0]
+        # Dense_0(act(temb)) of EVERY ResBlock in one GEMM against the gathered projection weights
+        # (layerspp.py:262-263 runs one small Linear per block); the blocks read column slices of tp_all
+        plan = net._temb_plan()
+        self.tp_all = self.dtp_all = None
+        if plan is not None:
+            wcat, bcat, total = plan["wcat"], plan["bcat"], plan["total"]
+            self.tp_all = torch.empty((b, total), device=t.device, dtype=torch.float32)
+            ops.gemm_raw(0, 1, b, total, wcat.shape[1], st.v, wcat.shape[1], 0, wcat, wcat.shape[1], 0, self.tp_all,
+                         total, 0, 1, ops.epilogue(bias=bcat))
+            if self.record:
+                self.dtp_all = torch.empty((b, total), device=t.device, dtype=torch.float32)
+        tp_all, dtp_all = self.tp_all, self.dtp_all
 
         def bwd():
-            self.join_side()            # every block accumulated its share of st.g on the side stream
+            self.join_side()            # every block wrote its slice of dtp_all / accumulated into st.g
+            if dtp_all is not None:     # d act(temb) = sum over blocks dtp_i W_i = dtp_all Wcat: one GEMM
+                wcat = plan["wcat"]
+                gb, acc = _gbuf(st)
+                ops.gemm_raw(0, 0, b, wcat.shape[1], plan["total"], dtp_all, plan["total"], 0, wcat, wcat.shape[1], 0, gb,
+                             wcat.shape[1], 0, epi=ops.epilogue(accumulate=True) if acc else None)
             if st.g is None:
                 return
             dtemb = ops.silu_bwd(temb, st.g)
@@ -417,11 +436,16 @@ class _Exec:
         else:
             a0r, xr = a0, x.v
         ho, wo = a0r.shape[1], a0r.shape[2]
-        tp = None
+        tp, tp_ld, tp_off = None, 0, None
         if self.temb_act is not None:
-            tp = ops.linear(self.temb_act.v, mod.Dense_0.weight, mod.Dense_0.bias)
+            tp_off = net._temb_offset(mod) if self.tp_all is not None else None
+            if tp_off is not None:
+                tp, tp_ld = self.tp_all[:, tp_off:tp_off + cout], self.tp_all.shape[1]
+            else:
+                tp = ops.linear(self.temb_act.v, mod.Dense_0.weight, mod.Dense_0.bias)
         h1 = torch.empty((b, ho, wo, cout), device=x.v.device, dtype=torch.float32)
-        self.conv3(a0r, mod.Conv_0, h1, ops.epilogue(bias=mod.Conv_0.bias, rowbias=tp, rows_per_img=ho * wo))
+        self.conv3(a0r, mod.Conv_0, h1, ops.epilogue(bias=mod.Conv_0.bias, rowbias=tp, rows_per_img=ho * wo,
+                                                     ld_rowbias=tp_ld))
         st1 = ops.gn_stats(h1, gn1.weight, gn1.bias)
         drop_p, seed = 0.0, 0
         if self.drop_p > 0:
@@ -445,6 +469,7 @@ class _Exec:
         if not self.record:
             return on
         temb_act = self.temb_act
+        dtp_all = self.dtp_all
         xr_saved = xr if mod.has_shortcut else None
 
         def bwd():
@@ -469,15 +494,26 @@ class _Exec:
             # Conv_0 + time-embedding bias
             def side0():
                 self.wgrad(dh1, a0r, mod.Conv_0, 3, 1, 1)
-                dtp = self.bias_grad(dh1, self.g(mod.Conv_0.bias), per_image=True if temb_act is not None else None)
-                if temb_act is not None:
-                    d0 = mod.Dense_0
-                    kd = d0.weight.shape[1]
-                    ops.colsum(dtp, cout, 1, b, cout, self.g(d0.bias))
+                if temb_act is None:
+                    self.bias_grad(dh1, self.g(mod.Conv_0.bias))
+                    return
+                d0 = mod.Dense_0
+                kd = d0.weight.shape[1]
+                if tp_off is not None and dtp_all is not None:
+                    # per-image sums straight into this block's columns of dtp_all; its share of d act(temb) is added
+                    # by ONE GEMM over all blocks at the end (time_embedding.bwd)
+                    ldt = dtp_all.shape[1]
+                    dtp = dtp_all[:, tp_off:tp_off + cout]
+                    self.bias_grad(dh1, self.g(mod.Conv_0.bias), per_image=dtp, ld_per_image=ldt)
+                    ops.gemm_raw(1, 0, cout, kd, b, dtp, ldt, 0, temb_act.v, kd, 0, self.g(d0.weight), kd, 0)
+                else:
+                    dtp = self.bias_grad(dh1, self.g(mod.Conv_0.bias), per_image=True)
                     ops.gemm_raw(1, 0, cout, kd, b, dtp, cout, 0, temb_act.v, kd, 0, self.g(d0.weight), kd, 0)
                     gb, acc = _gbuf(temb_act)
                     ops.gemm_raw(0, 0, b, kd, cout, dtp, cout, 0, d0.weight, kd, 0, gb, kd, 0,
                                  epi=ops.epilogue(accumulate=True) if acc else None)
+                # d Dense_0.bias = sum over the batch of dtp = the conv bias gradient just computed
+                ops.axpby(self.g(mod.Conv_0.bias), 1.0, None, 0.0, self.g(d0.bias))
 
             self.on_side(side0, dh1, a0r)
             da0r = torch.empty_like(a0r)
@@ -992,6 +1028,7 @@ class NCSNpp(nn.Module):
         self._offsets = None
         self._pack_cache = {}
         self._frag_table = None     # (signature, device table, entries, total work items) of the batched fragment refresh
+        self._temb_plan_cache = None
         self._pack_key = None
         self._epoch = 0
         self._anchor = None
@@ -1161,6 +1198,48 @@ class NCSNpp(nn.Module):
             self._pack_cache[k] = ((self._epoch, w._version, w.data_ptr()), o)
         return True
 
+    def _temb_offset(self, mod) -> Optional[int]:
+        plan = self._temb_plan_cache
+        return None if plan is None else plan["offsets"].get(id(mod))
+
+    def _temb_plan(self):
+        """Gathered time-embedding projections: ``wcat`` [sum C_out][4*nf] and ``bcat`` [sum C_out] hold Dense_0.weight /
+        .bias of every ResBlock back to back (refreshed with ONE batched copy when the weights change), ``offsets`` the
+        first row of each block.  None when the network is not noise-conditioned."""
+        if not self.noise_cond:
+            return None
+        blocks = [m for m in self.all_modules if isinstance(m, ResnetBlockBigGANpp)]
+        dev = blocks[0].Dense_0.weight.device
+        plan = self._temb_plan_cache
+        stamp = (self._epoch, blocks[0].Dense_0.weight._version, blocks[0].Dense_0.weight.data_ptr(), str(dev))
+        if plan is not None and plan["stamp"] == stamp:
+            return plan
+        if plan is None or plan["wcat"].device != dev:
+            total = sum(m.Dense_0.weight.shape[0] for m in blocks)
+            kd = blocks[0].Dense_0.weight.shape[1]
+            plan = {"wcat": torch.empty((total, kd), device=dev, dtype=torch.float32),
+                    "bcat": torch.empty((total,), device=dev, dtype=torch.float32), "total": total, "offsets": {},
+                    "table": None, "sig": None}
+            off = 0
+            for m in blocks:
+                plan["offsets"][id(m)] = off
+                off += m.Dense_0.weight.shape[0]
+        sig = tuple((m.Dense_0.weight.data_ptr(), m.Dense_0.bias.data_ptr()) for m in blocks)
+        if plan["table"] is None or plan["sig"] != sig:
+            rows, first = [], 0
+            for m in blocks:
+                w, bias = m.Dense_0.weight, m.Dense_0.bias
+                o = plan["offsets"][id(m)]
+                for src, dst, n in ((w, plan["wcat"][o], w.numel()), (bias, plan["bcat"][o:], bias.numel())):
+                    assert n % 4 == 0 and src.data_ptr() % 16 == 0 and dst.data_ptr() % 16 == 0
+                    rows.append([src.data_ptr(), dst.data_ptr(), n // 4, first])
+                    first += n // 4
+            plan["table"], plan["sig"], plan["total4"] = torch.tensor(rows, dtype=torch.int64, device=dev), sig, first
+        ops.copy_batch(plan["table"], plan["table"].shape[0], plan["total4"])
+        plan["stamp"] = stamp
+        self._temb_plan_cache = plan
+        return plan
+
     def _gfrag(self, owner: nn.Parameter, tag: str, build):
         """Limb fragments derived from ``owner`` (and possibly sibling parameters), cached until the weights change.
         ``build(prev)`` returns the tensor (or tuple of tensors) to keep and refreshes ``prev`` IN PLACE when given
@@ -1279,6 +1358,7 @@ class NCSNpp(nn.Module):
         graph, sx, st, sy, stamp = ent
         now = (self._epoch, self._flat._version)
         if stamp != now:
+            self._temb_plan()                                   # gathered Dense_0 weights (refreshed in place)
             for ck, cv in list(self._pack_cache.items()):       # refresh, in the same storage, what the graph reads
                 if ck[-1] == "gfrag":
                     self._gfrag(cv[2], ck[1], cv[3])
@@ -1296,7 +1376,7 @@ class NCSNpp(nn.Module):
         cls = self.__class__
         new = cls.__new__(cls)
         memo[id(self)] = new
-        skip = {"_flat", "_flat_grad", "_pack_cache", "_frag_table", "_anchor", "_reducer", "_offsets", "_module_offs", "_posfreq",
+        skip = {"_flat", "_flat_grad", "_pack_cache", "_frag_table", "_temb_plan_cache", "_anchor", "_reducer", "_offsets", "_module_offs", "_posfreq",
                 "_side", "_plist", "_gviews", "_graphs", "_conv_by_weight", "_scratch_grad", "_sviews"}
         for k, v in self.__dict__.items():
             if k in skip:
@@ -1312,6 +1392,7 @@ class NCSNpp(nn.Module):
         new._accumulating = new._grad_stale = False
         new._pack_cache = {}
         new._frag_table = None
+        new._temb_plan_cache = None
         new._pack_key = None
         new._epoch = 0
         # detach copied params from the source's flat buffer (they are re-flattened on first use)
