@@ -85,7 +85,16 @@ __global__ void reduce_slabs4_kernel(const float* __restrict__ slabs, int nsplit
     GRID_STRIDE(q, n4) {
         const f32x4* p = reinterpret_cast<const f32x4*>(slabs) + q;
         f32x4 acc = p[0];
-        for (int s = 1; s < nsplit; ++s) acc += p[(long long)s * n4];
+        int s = 1;
+        for (; s + 3 < nsplit; s += 4) {        // four independent loads in flight; the sum stays in slab order
+            const f32x4 v0 = p[(long long)s * n4], v1 = p[(long long)(s + 1) * n4];
+            const f32x4 v2 = p[(long long)(s + 2) * n4], v3 = p[(long long)(s + 3) * n4];
+            acc += v0;
+            acc += v1;
+            acc += v2;
+            acc += v3;
+        }
+        for (; s < nsplit; ++s) acc += p[(long long)s * n4];
         acc *= alpha;
         const long long i = q << 2;
         if (layout == 1) {  // [co][tap][ci] -> [co][ci][tap]
