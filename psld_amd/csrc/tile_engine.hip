@@ -749,7 +749,19 @@ __global__ void conv_reduce_epilogue_kernel(const float* __restrict__ slabs, int
         const int m = (int)(i / n4);
         const long long off = (long long)m * N + q * 4;
         f32x4 acc = *reinterpret_cast<const f32x4*>(slabs + off);
-        for (int s = 1; s < nsplit; ++s) acc += *reinterpret_cast<const f32x4*>(slabs + (long long)s * M * N + off);
+        const long long slab = (long long)M * N;
+        int s = 1;
+        for (; s + 3 < nsplit; s += 4) {        // four independent loads in flight; the sum stays in slab order
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(slabs + s * slab + off);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(slabs + (s + 1) * slab + off);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(slabs + (s + 2) * slab + off);
+            const f32x4 v3 = *reinterpret_cast<const f32x4*>(slabs + (s + 3) * slab + off);
+            acc += v0;
+            acc += v1;
+            acc += v2;
+            acc += v3;
+        }
+        for (; s < nsplit; ++s) acc += *reinterpret_cast<const f32x4*>(slabs + s * slab + off);
         acc *= e.alpha;
         if (e.bias) acc += *reinterpret_cast<const f32x4*>(e.bias + q * 4);
         if (e.rowbias) acc += *reinterpret_cast<const f32x4*>(e.rowbias + (long long)(m / e.rows_per_img) * e.ld_rowbias + q * 4);
