@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 
-#define PSLD_ABI_VERSION 1
+#define PSLD_ABI_VERSION 2 /* 2: limb-MFMA convolutions, math mode, bias-gradient / batched-copy entry points */
 #define PSLD_COEFF_STRIDE 12
 
 int psld_version(void);

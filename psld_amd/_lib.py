@@ -61,6 +61,8 @@ class SscsCoeffs(C.Structure):
 I, F, D, LL, P = C.c_int, C.c_float, C.c_double, C.c_longlong, C.c_void_p
 EP = C.POINTER(Epilogue)
 
+ABI_VERSION = 2    # PSLD_ABI_VERSION of include/psld_hip.h these signatures were written against
+
 # name -> (restype, argtypes): every symbol include/psld_hip.h declares
 SIGNATURES = {
     "psld_version": (I, []),
@@ -159,6 +161,9 @@ def load() -> C.CDLL:
             raise PsldHipError(f"libpsld_hip.so does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
+    if lib.psld_version() != ABI_VERSION:
+        raise PsldHipError(f"{LIB_PATH} has ABI version {lib.psld_version()}, this package binds version {ABI_VERSION}: "
+                           "rebuild it (`make -C psld_amd/csrc`)")
     _lib = lib
     return lib
 
