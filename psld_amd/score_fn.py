@@ -457,7 +457,7 @@ class _Exec:
         if mod.has_shortcut:
             c2 = mod.Conv_2
             if self.split and ops.gemm_split_supported(cin, 0, b * ho * wo, cout):
-                fr = net._gfrag(c2.weight, "fwd", lambda prev: ops.gemm_frag(c2.weight.detach(), cout, cin, cin, 1, prev))
+                fr = net._pfrag(c2.weight, "fwd", cout, cin, cin, 1)
                 ops.gemm_split(xr, None, b * ho * wo, fr, cout, out, ops.epilogue(bias=c2.bias))
             else:
                 ops.conv2d_nhwc(xr, None, c2.weight, cout, 1, 1, 1, 0, 1, ho, wo, out, ops.epilogue(bias=c2.bias))
@@ -525,8 +525,7 @@ class _Exec:
                 m = b * ho * wo
                 def shortcut_dgrad(dst, epi):
                     if self.split and ops.gemm_split_supported(cout, 0, m, cin):
-                        fr = net._gfrag(c2.weight, "dgrad",
-                                        lambda prev: ops.gemm_frag(c2.weight.detach(), cin, cout, 1, cin, prev))
+                        fr = net._pfrag(c2.weight, "dgrad", cin, cout, 1, cin)
                         ops.gemm_split(dout, None, m, fr, cin, dst, epi)
                     else:
                         ops.gemm_raw(0, 0, m, cin, cout, dout, cout, 0, c2.weight, cin, 0, dst, cin, 0, epi=epi)
@@ -595,7 +594,7 @@ class _Exec:
         out = torch.empty_like(x.v)
         epi_out = ops.epilogue(bias=n3.b, residual=x.v, ld_residual=c, out_scale=s)
         if fused:
-            f_o = net._gfrag(n3.W, "fwd", lambda prev: ops.gemm_frag(n3.W.detach(), c, c, 1, c, prev))
+            f_o = net._pfrag(n3.W, "fwd", c, c, 1, c)
             ops.gemm_split(ho, None, m, f_o, c, out, epi_out)
         else:
             ops.gemm_raw(0, 0, m, c, c, ho, c, 0, n3.W, c, 0, out, c, 0, epi=epi_out)
@@ -617,7 +616,7 @@ class _Exec:
             self.on_side(lambda: nin_wgrad(ho, dout, n3, s, c), ho, dout)
             dho = torch.empty_like(ho)
             if fused:
-                f_od = net._gfrag(n3.W, "dgrad", lambda prev: ops.gemm_frag(n3.W.detach(), c, c, c, 1, prev))
+                f_od = net._pfrag(n3.W, "dgrad", c, c, c, 1)
                 ops.gemm_split(dout, None, m, f_od, c, dho, ops.epilogue(alpha=s))
             else:
                 ops.gemm_raw(0, 1, m, c, c, dout, c, 0, n3.W, c, 0, dho, c, 0, epi=ops.epilogue(alpha=s))
@@ -1176,12 +1175,12 @@ class NCSNpp(nn.Module):
         return out
 
     def _refresh_frags(self) -> bool:
-        """Re-split every registered 3x3 weight into its existing fragment buffer with ONE launch
+        """Re-split every registered 3x3 / pointwise weight into its existing fragment buffer with ONE launch
         (psld_pack_frag_batch).  False when there is nothing to batch."""
-        keys = [k for k in self._pack_cache if len(k) == 3 and k[2] == "frag"]
+        keys = [k for k in self._pack_cache if len(k) == 3 and k[2] in ("frag", "pfrag")]
         if len(keys) < 2:
             return False
-        ws = [self._conv_by_weight[k[0]].weight for k in keys]
+        ws = [self._conv_by_weight[k[0]].weight if k[2] == "frag" else self._pack_cache[k][2] for k in keys]
         outs = [self._pack_cache[k][1] for k in keys]
         if any(o.device != w.device for o, w in zip(outs, ws)):
             return False
@@ -1189,14 +1188,36 @@ class NCSNpp(nn.Module):
         if self._frag_table is None or self._frag_table[0] != sig:
             rows, total = [], 0
             for k, w, o in zip(keys, ws, outs):
-                rows.append(ops.conv3x3_frag_entry(w.detach(), k[1], o) + [total])
-                total += w.shape[0] * w.shape[1] // 8            # work items: one per lane slot
+                if k[2] == "frag":
+                    rows.append(ops.conv3x3_frag_entry(w.detach(), k[1], o) + [total])
+                    total += w.shape[0] * w.shape[1] // 8        # work items: one per lane slot
+                else:
+                    n, kk, sn, sk = self._pack_cache[k][3]
+                    rows.append([w.data_ptr(), o.data_ptr(), n, kk, 1, sn, sk, total])
+                    total += n * kk // 8
             self._frag_table = (sig, torch.tensor(rows, dtype=torch.int64, device=ws[0].device), len(rows), total)
         _, table, n, total = self._frag_table
         ops.pack_frag_batch(table, n, total)
         for k, w, o in zip(keys, ws, outs):
-            self._pack_cache[k] = ((self._epoch, w._version, w.data_ptr()), o)
+            self._pack_cache[k] = ((self._epoch, w._version, w.data_ptr()),) + tuple(self._pack_cache[k][1:])
         return True
+
+    def _pfrag(self, owner: nn.Parameter, tag: str, n: int, k: int, sn: int, sk: int) -> Tensor:
+        """Limb fragments (ops.gemm_frag) of the [n][k] view of ONE parameter (element (i, j) at i*sn + j*sk), cached
+        until the weights change and refreshed together with the 3x3 fragments by the batched launch."""
+        key = (id(owner), tag, "pfrag")
+        ent = self._pack_cache.get(key)
+        stamp = (self._epoch, owner._version, owner.data_ptr())
+        if ent is not None and ent[0] == stamp:
+            return ent[1]
+        if ent is not None and ent[1].device == owner.device and self._refresh_frags():
+            ent = self._pack_cache[key]
+            if ent[0] == stamp:
+                return ent[1]
+        out = ops.gemm_frag(owner.detach(), n, k, sn, sk, ent[1] if ent is not None and ent[1].device == owner.device else None)
+        self._pack_cache[key] = (stamp, out, owner, (n, k, sn, sk))
+        self._frag_table = None
+        return out
 
     def _temb_offset(self, mod) -> Optional[int]:
         plan = self._temb_plan_cache
@@ -1362,6 +1383,9 @@ class NCSNpp(nn.Module):
             for ck, cv in list(self._pack_cache.items()):       # refresh, in the same storage, what the graph reads
                 if ck[-1] == "gfrag":
                     self._gfrag(cv[2], ck[1], cv[3])
+                elif ck[-1] == "pfrag":
+                    if ck[1] == "fwd":
+                        self._pfrag(cv[2], ck[1], *cv[3])
                 elif not ck[1]:
                     (self._frag(self._conv_by_weight[ck[0]], False) if len(ck) == 3
                      else self._packed(self._conv_by_weight[ck[0]]))
