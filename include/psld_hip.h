@@ -143,6 +143,10 @@ int psld_gemm_split_f32(const float* a1, int k1, const float* a2, int k2, int m,
  * of ceil(batch*h*w/32 / nsplit) 32-pixel tiles (every slab must be non-empty); the caller reduces
  * (psld_reduce_slabs_f32).  Shapes: cout, cin multiples of 64, w in {8,16,32,64}, h*w a multiple of 32. */
 int psld_conv3x3_wgrad_split_supported(int cout, int cin, int batch, int h, int w);
+/* Output channels per workgroup the kernel will use for this cout (64 or 128); a launch has
+ * (cout / tile) * (cin / 64) * 3 * nsplit workgroups, 3 (tile 64) or 2 (tile 128) resident per CU: what the caller
+ * needs to pick nsplit. */
+int psld_conv3x3_wgrad_split_cout_tile(int cout);
 int psld_conv3x3_wgrad_split_f32(const float* dy, int lddy, int cout, const float* x, int cin, int batch,
                                  int h, int w, float* slabs, int cin_total, int col0, int nsplit,
                                  hipStream_t stream);

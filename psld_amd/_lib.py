@@ -85,6 +85,7 @@ SIGNATURES = {
     "psld_pack_gemm_frag": (I, [P, P, I, I, LL, LL, P]),
     "psld_gemm_split_f32": (I, [P, I, P, I, I, P, I, P, I, EP, P, LL, P]),
     "psld_conv3x3_wgrad_split_supported": (I, [I, I, I, I, I]),
+    "psld_conv3x3_wgrad_split_cout_tile": (I, [I]),
     "psld_conv3x3_wgrad_split_f32": (I, [P, I, I, P, I, I, I, I, P, I, I, I, P]),
     "psld_reduce_slabs_f32": (I, [P, I, LL, P, I, I, I, I, F, P]),
     "psld_pack_oihw_to_ohwi_f32": (I, [P, P, I, I, I, P]),

@@ -387,10 +387,16 @@ __device__ __forceinline__ u32x2 lds_tr16(const unsigned char* p) {
     return __builtin_bit_cast(u32x2, v);
 }
 
-__global__ void __launch_bounds__(256, 3) dwgrad_kernel(const DWgradArgs a) {
+// CB = 16-channel dy blocks per wave: 2 -> 64-co tile, three workgroups per CU; 4 -> 128-co tile, two per CU (every
+// staged x value and every B fragment then feeds twice the MFMAs).
+template <int CB>
+__global__ void __launch_bounds__(256, CB == 2 ? 3 : 2) dwgrad_kernel(const DWgradArgs a) {
+    constexpr int CO_T = 32 * CB;                // output channels per workgroup
+    constexpr int RSA = CO_T * 2 + 32;           // dy row stride: 160 / 288 B, both conflict-free for the transposed reads
+    constexpr int ALIMB = WG_AROWS * RSA;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* As = smem;                    // [3][32][160]
-    unsigned char* Bs = smem + 3 * WG_ALIMB;     // [3][48][160]
+    unsigned char* As = smem;                    // [3][32][RSA]
+    unsigned char* Bs = smem + 3 * ALIMB;        // [3][48][160]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -402,7 +408,7 @@ __global__ void __launch_bounds__(256, 3) dwgrad_kernel(const DWgradArgs a) {
     const int split = vid / (tiles * 3);
     const int rest = vid - split * tiles * 3;
     const int ky = rest / tiles, tile = rest - ky * tiles;
-    const int co0 = (tile / a.cin_tiles) * 64, ci0 = (tile % a.cin_tiles) * 64;
+    const int co0 = (tile / a.cin_tiles) * CO_T, ci0 = (tile % a.cin_tiles) * 64;
     const int kt_beg = split * a.ktiles_per_split;
     const int kt_end = min(a.ktiles, kt_beg + a.ktiles_per_split);
     const int HW = a.H * a.W;
@@ -414,7 +420,7 @@ __global__ void __launch_bounds__(256, 3) dwgrad_kernel(const DWgradArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int k = 4 * g + 16 * j + q;              // pixel of this lane's row in read j
-        a_base[j] = k * WG_RS + (wr * 32 + 4 * p4) * 2;
+        a_base[j] = k * RSA + (wr * 16 * CB + 4 * p4) * 2;
         const int ry = a.W >= 32 ? 0 : k / a.W;
         const int ox = a.W >= 32 ? k : k - ry * a.W;
         b_base[j] = (ry * a.hw_w + ox) * WG_RS + (wc * 32 + 4 * p4) * 2;
@@ -439,8 +445,10 @@ __global__ void __launch_bounds__(256, 3) dwgrad_kernel(const DWgradArgs a) {
         xrow[i] = hr < a.hrows ? hr : 31;
         xcol[i] = ((hc >= 1 && hc <= a.W) ? 1 : 0) | ((hc + 31 < a.W) ? 2 : 0);
     }
-    const unsigned aoff = (unsigned)((ra * a.lddy + qa * 4) * 4);
-    f32x4 va[2], vb[WG_NB];
+    unsigned aoff[CB];      // dy items: pixel ra + 16*(i & 1), channel quad qa + 16*(i >> 1)
+#pragma unroll
+    for (int i = 0; i < CB; ++i) aoff[i] = (unsigned)(((ra + 16 * (i & 1)) * a.lddy + (qa + 16 * (i >> 1)) * 4) * 4);
+    f32x4 va[CB], vb[WG_NB];
     auto load_tile = [&](int kt) {
         const int p0 = kt * 32;
         const int img = p0 / HW;
@@ -455,19 +463,18 @@ __global__ void __launch_bounds__(256, 3) dwgrad_kernel(const DWgradArgs a) {
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(a.dy + ((long long)p0 * a.lddy + co0)), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            va[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, aoff + i * 16 * a.lddy * 4, 0, 0));
+        for (int i = 0; i < CB; ++i)
+            va[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, aoff[i], 0, 0));
 #pragma unroll
         for (int i = 0; i < WG_NB; ++i) {
             const bool ok = ((rowmask >> xrow[i]) & (unsigned)(xcol[i] >> colsel) & 1u) != 0;
             vb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xoff[i] : 0xffffffffu, 0, 0));
         }
     };
-    auto store_rows = [&](unsigned char* img, int limb_stride, const f32x4& v, int row) {
+    auto store_rows = [&](unsigned char* d, int limb_stride, const f32x4& v) {
         unsigned h0, m0, l0, h1, m1, l1;
         split3(v[0], v[1], h0, m0, l0);
         split3(v[2], v[3], h1, m1, l1);
-        unsigned char* d = img + row * WG_RS + qa * 8;
         *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
         *reinterpret_cast<u32x2*>(d + limb_stride) = u32x2{m0, m1};
         *reinterpret_cast<u32x2*>(d + 2 * limb_stride) = u32x2{l0, l1};
@@ -477,27 +484,27 @@ __global__ void __launch_bounds__(256, 3) dwgrad_kernel(const DWgradArgs a) {
         return u32x4{lo[0], lo[1], hi[0], hi[1]};
     };
 
-    f32x4v acc[3][2][2];
+    f32x4v acc[3][CB][2];
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < CB; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
     if (kt_beg < kt_end) load_tile(kt_beg);
     for (int kt = kt_beg; kt < kt_end; ++kt) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) store_rows(As, WG_ALIMB, va[i], ra + 16 * i);
+        for (int i = 0; i < CB; ++i) store_rows(As + (ra + 16 * (i & 1)) * RSA + (qa + 16 * (i >> 1)) * 8, ALIMB, va[i]);
 #pragma unroll
-        for (int i = 0; i < WG_NB; ++i) store_rows(Bs, WG_BLIMB, vb[i], ra + 16 * i);
+        for (int i = 0; i < WG_NB; ++i) store_rows(Bs + (ra + 16 * i) * WG_RS + qa * 8, WG_BLIMB, vb[i]);
         __syncthreads();
         if (kt + 1 < kt_end) load_tile(kt + 1);
-        u32x4 fa[2][3];
+        u32x4 fa[CB][3];
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int l = 0; l < 3; ++l) fa[cb][l] = frag(As, a_base, l * WG_ALIMB + cb * 32);
+            for (int l = 0; l < 3; ++l) fa[cb][l] = frag(As, a_base, l * ALIMB + cb * 32);
 #pragma unroll
         for (int tx = 0; tx < 3; ++tx) {
             u32x4 fb[2][3];
@@ -509,7 +516,7 @@ __global__ void __launch_bounds__(256, 3) dwgrad_kernel(const DWgradArgs a) {
 #pragma unroll
             for (int u = 0; u < 6; ++u)
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
+                for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb)
                         acc[tx][cb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
@@ -524,14 +531,33 @@ __global__ void __launch_bounds__(256, 3) dwgrad_kernel(const DWgradArgs a) {
 #pragma unroll
     for (int tx = 0; tx < 3; ++tx)
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    const int co = co0 + wr * 32 + cb * 16 + 4 * g + v;
+                    const int co = co0 + wr * 16 * CB + cb * 16 + 4 * g + v;
                     S[((long long)co * 9 + ky * 3 + tx) * a.ld_tap + ci0 + wc * 32 + nb * 16 + i16] = acc[tx][cb][nb][v];
                 }
+}
+
+template <int CB>
+int launch_dwgrad(const DWgradArgs& a, int nsplit, hipStream_t stream) {
+    constexpr size_t LDS = (size_t)3 * (WG_AROWS * (64 * CB + 32) + WG_BLIMB);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dwgrad_kernel<CB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        if (e != hipSuccess) {
+            psld_set_error("psld_conv3x3_wgrad_split_f32: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return PSLD_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL(dwgrad_kernel<CB>, dim3((unsigned)(a.cout_tiles * a.cin_tiles * 3 * nsplit)), dim3(256), LDS,
+                       stream, a);
+    PSLD_CHECK_LAUNCH("psld_conv3x3_wgrad_split_f32");
+    return PSLD_OK;
 }
 
 template <int NH, int TAPS, bool PW>
@@ -673,6 +699,15 @@ extern "C" int psld_conv3x3_wgrad_split_supported(int cout, int cin, int batch, 
            (w == 8 || w == 16 || w == 32 || w == 64) && (h * w) % 32 == 0;
 }
 
+extern "C" int psld_conv3x3_wgrad_split_cout_tile(int cout) {
+    static const int forced = [] {
+        const char* e = getenv("PSLD_WGRAD_COUT_TILE");      // tuning aid: 64 or 128
+        return e ? atoi(e) : 0;
+    }();
+    if (forced == 64 || cout % 128) return 64;
+    return 128;
+}
+
 extern "C" int psld_conv3x3_wgrad_split_f32(const float* dy, int lddy, int cout, const float* x, int cin, int batch,
                                             int h, int w, float* slabs, int cin_total, int col0, int nsplit,
                                             hipStream_t stream) {
@@ -683,7 +718,8 @@ extern "C" int psld_conv3x3_wgrad_split_f32(const float* dy, int lddy, int cout,
     DWgradArgs a{};
     a.dy = dy; a.lddy = lddy; a.x = x; a.cin = cin;
     a.B = batch; a.H = h; a.W = w;
-    a.cout_tiles = cout / 64; a.cin_tiles = cin / 64;
+    const int co_tile = psld_conv3x3_wgrad_split_cout_tile(cout);
+    a.cout_tiles = cout / co_tile; a.cin_tiles = cin / 64;
     a.ktiles = batch * h * w / 32;
     a.ktiles_per_split = cdiv(a.ktiles, nsplit);
     PSLD_CHECK_ARG(cdiv(a.ktiles, a.ktiles_per_split) == nsplit, "psld_conv3x3_wgrad_split_f32: nsplit %d leaves empty slabs", nsplit);
@@ -692,20 +728,7 @@ extern "C" int psld_conv3x3_wgrad_split_f32(const float* dy, int lddy, int cout,
     a.slab_stride = (long long)cout * 9 * cin_total;
     a.hw_w = (w < 32 ? w : 32) + 2;
     a.hrows = w >= 32 ? 1 : 32 / w;
-    constexpr size_t LDS = (size_t)3 * (WG_ALIMB + WG_BLIMB);
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dwgrad_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-        if (e != hipSuccess) {
-            psld_set_error("psld_conv3x3_wgrad_split_f32: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-            return PSLD_ERR_LAUNCH;
-        }
-        configured = true;
-    }
-    hipLaunchKernelGGL(dwgrad_kernel, dim3((unsigned)(a.cout_tiles * a.cin_tiles * 3 * nsplit)), dim3(256), LDS, stream, a);
-    PSLD_CHECK_LAUNCH("psld_conv3x3_wgrad_split_f32");
-    return PSLD_OK;
+    return co_tile == 128 ? launch_dwgrad<4>(a, nsplit, stream) : launch_dwgrad<2>(a, nsplit, stream);
 }
 
 // ---- pointwise (NT GEMM with pre-split B) -------------------------------------------------------------------

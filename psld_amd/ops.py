@@ -198,6 +198,10 @@ def conv3x3_wgrad_split_supported(cout: int, cin: int, b: int, h: int, w: int) -
     return bool(lib().psld_conv3x3_wgrad_split_supported(cout, cin, b, h, w))
 
 
+def conv3x3_wgrad_split_cout_tile(cout: int) -> int:
+    return lib().psld_conv3x3_wgrad_split_cout_tile(cout)
+
+
 def conv3x3_wgrad_split(dy: Tensor, cout: int, x: Tensor, slabs: Tensor, cin_total: int, col0: int, nsplit: int):
     b, h, w, cin = x.shape
     check(lib().psld_conv3x3_wgrad_split_f32(dy.data_ptr(), cout, cout, x.data_ptr(), cin, b, h, w, slabs.data_ptr(),

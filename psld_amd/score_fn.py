@@ -245,7 +245,9 @@ class _Exec:
                 ops.conv3x3_wgrad_split_supported(cout, cin, b, oh, ow):
             ktiles = b * oh * ow // 32
             # 64x64 tiles x 3 filter rows, 3 workgroups (46 KB LDS) resident per CU
-            nsplit = _pick_nsplit((cout // 64) * (cin // 64) * 3, ktiles * 32, min_k=128, resident=768)
+            co_tile = ops.conv3x3_wgrad_split_cout_tile(cout)
+            nsplit = _pick_nsplit((cout // co_tile) * (cin // 64) * 3, ktiles * 32, min_k=128,
+                                  resident=768 if co_tile == 64 else 512)
             per = -(-ktiles // nsplit)
             nsplit = -(-ktiles // per)                 # every slab non-empty
             slabs = ops.workspace(4 * n * nsplit, dy.device)

@@ -214,6 +214,7 @@ def test_conv3x3_split_wide_dynamic_range(ops):
     dict(b=3, ci=128, co=128, h=16, w=16),
     dict(b=1, ci=256, co=64, h=32, w=32),
     dict(b=1, ci=128, co=64, h=64, w=64),
+    dict(b=2, ci=128, co=256, h=32, w=32),
 ])
 def test_conv3x3_split_dgrad_and_wgrad(ops, cfg):
     b, ci, co, h, w_ = (cfg[n] for n in ("b", "ci", "co", "h", "w"))

@@ -68,9 +68,10 @@ def main():
         t = timeit(lambda: ops.conv2d_wgrad_nhwc(dy, cout, x, 3, 3, 1, 1, s, s, slabs, cin, 0, nsplit), args.iters)
         rows.append((f"conv wgrad {cin}->{cout} @{s} (split {nsplit})", fl / t / 1e12, t * 1e6))
         if ops.conv3x3_wgrad_split_supported(cout, cin, B, s, s):
-            tiles = (cout // 64) * (cin // 64)
+            co_tile = ops.conv3x3_wgrad_split_cout_tile(cout)
+            tiles = (cout // co_tile) * (cin // 64)
             kt = B * s * s // 32
-            ns2 = max(1, min(768 // (3 * tiles), kt // 4))
+            ns2 = max(1, min((768 if co_tile == 64 else 512) // (3 * tiles), kt // 4))
             per = -(-kt // ns2)
             ns2 = -(-kt // per)
             slabs2 = torch.empty(ns2, cout, 9, cin, device=DEV)
