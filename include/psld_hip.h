@@ -151,6 +151,14 @@ int psld_conv3x3_wgrad_split_f32(const float* dy, int lddy, int cout, const floa
                                  int h, int w, float* slabs, int cin_total, int col0, int nsplit,
                                  hipStream_t stream);
 
+/* Pointwise weight gradient on the limb kernels: slabs[s][i][j] (row stride ldc) = sum over the s-th range of
+ * ceil(k/32 / nsplit) 32-row tiles of a[p][i] * b[p][j]  (a: [k][m] rows of lda floats, b: [k][n] rows of ldb floats;
+ * m, n multiples of 128, k of 32; every slab non-empty).  Replaces the dW of the 1x1 convolutions and NIN
+ * projections that autograd computes in the reference (layerspp.py:235,268-270 Conv_2; layers.py:531-540 NIN). */
+int psld_gemm_tn_split_supported(int m, int n, int k);
+int psld_gemm_tn_split_f32(int m, int n, int k, const float* a, int lda, const float* b, int ldb,
+                           float* slabs, int ldc, int nsplit, hipStream_t stream);
+
 /* Weight gradient of the convolution above for one input source:
  * slabs[s][co][tap][col0 + ci] = sum over the s-th range of output pixels of dy[pix][co] * x[pix+tap][ci]. */
 int psld_conv2d_wgrad_nhwc_f32(const float* dy, int lddy, int cout,

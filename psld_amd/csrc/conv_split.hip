@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
 // which the 160-byte row stride spreads over all 64 banks (conflict-free).
 constexpr int WG_RS = 160;           // bytes per pixel row and limb: 64 channels bf16 + 32 pad
 constexpr int WG_AROWS = 32, WG_BROWS = 48;
-constexpr int WG_ALIMB = WG_AROWS * WG_RS, WG_BLIMB = WG_BROWS * WG_RS;
+constexpr int WG_BLIMB = WG_BROWS * WG_RS;
 constexpr int WG_NB = 3;             // x float4 items per thread (48 rows x 16 quads / 256)
 
 struct DWgradArgs {
@@ -539,6 +539,129 @@ __global__ void __launch_bounds__(256, CB == 2 ? 3 : 2) dwgrad_kernel(const DWgr
                     const int co = co0 + wr * 16 * CB + cb * 16 + 4 * g + v;
                     S[((long long)co * 9 + ky * 3 + tx) * a.ld_tap + ci0 + wc * 32 + nb * 16 + i16] = acc[tx][cb][nb][v];
                 }
+}
+
+// ---- pointwise weight gradient (TN GEMM) ---------------------------------------------------------------------
+// C[i][j] = sum_p A[p][i] * B[p][j]: the weight gradient of a 1x1 convolution / NIN projection (A = dy, B = x or the
+// other way round for NIN's [in][out] weights).  Same machinery as dwgrad_kernel without the halo: a workgroup owns
+// a 128 x 128 tile of C, stages 32 rows of A and B per K tile as limb images (288-byte rows) and reads both through
+// ds_read_b64_tr_b16; wave tile 64 x 64, two workgroups per CU.
+struct PWgradArgs {
+    const float* a;
+    int lda;
+    const float* b;
+    int ldb;
+    int tiles_i, tiles_j;
+    int ktiles, ktiles_per_split;
+    float* slabs;
+    int ldc;
+    long long slab_stride;
+};
+
+__global__ void __launch_bounds__(256, 2) pwgrad_kernel(const PWgradArgs a) {
+    constexpr int RS = 288;                      // 128 channels bf16 + 32 pad
+    constexpr int LIMB = 32 * RS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* As = smem;                    // [3][32][288]
+    unsigned char* Bs = smem + 3 * LIMB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tiles = a.tiles_i * a.tiles_j;
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = vid / tiles, tile = vid - split * tiles;
+    const int i0 = (tile / a.tiles_j) * 128, j0 = (tile % a.tiles_j) * 128;
+    const int kt_beg = split * a.ktiles_per_split;
+    const int kt_end = min(a.ktiles, kt_beg + a.ktiles_per_split);
+
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3;
+    int a_base[2], b_base[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = 4 * g + 16 * j + q;
+        a_base[j] = k * RS + (wr * 64 + 4 * p4) * 2;
+        b_base[j] = k * RS + (wc * 64 + 4 * p4) * 2;
+    }
+    const int qa = tid & 15, ra = tid >> 4;     // staging item i: row ra + 16*(i & 1), channel quad qa + 16*(i >> 1)
+    unsigned aoff[4], boff[4];
+    int soff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = ra + 16 * (i & 1), c = qa + 16 * (i >> 1);
+        aoff[i] = (unsigned)((r * a.lda + c * 4) * 4);
+        boff[i] = (unsigned)((r * a.ldb + c * 4) * 4);
+        soff[i] = r * RS + c * 8;
+    }
+    f32x4 va[4], vb[4];
+    auto load_tile = [&](int kt) {
+        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.a + ((long long)kt * 32 * a.lda + i0)), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.b + ((long long)kt * 32 * a.ldb + j0)), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) va[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, aoff[i], 0, 0));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB, boff[i], 0, 0));
+    };
+    auto store_rows = [&](unsigned char* d, const f32x4& v) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        split3(v[0], v[1], h0, m0, l0);
+        split3(v[2], v[3], h1, m1, l1);
+        *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(d + LIMB) = u32x2{m0, m1};
+        *reinterpret_cast<u32x2*>(d + 2 * LIMB) = u32x2{l0, l1};
+    };
+    auto frag = [&](const unsigned char* img, const int (&base)[2], int off) -> u32x4 {
+        const u32x2 lo = lds_tr16(img + base[0] + off), hi = lds_tr16(img + base[1] + off);
+        return u32x4{lo[0], lo[1], hi[0], hi[1]};
+    };
+
+    f32x4v acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    if (kt_beg < kt_end) load_tile(kt_beg);
+    for (int kt = kt_beg; kt < kt_end; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) store_rows(As + soff[i], va[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) store_rows(Bs + soff[i], vb[i]);
+        __syncthreads();
+        if (kt + 1 < kt_end) load_tile(kt + 1);
+        u32x4 fa[4][3];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) fa[cb][l] = frag(As, a_base, l * LIMB + cb * 32);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            u32x4 fb[3];
+#pragma unroll
+            for (int l = 0; l < 3; ++l) fb[l] = frag(Bs, b_base, l * LIMB + nb * 32);
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int u = 0; u < 6; ++u)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    acc[cb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, fa[cb][PA[u]]), __builtin_bit_cast(bf16x8, fb[PB[u]]), acc[cb][nb], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    float* S = a.slabs + (long long)split * a.slab_stride;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int i = i0 + wr * 64 + cb * 16 + 4 * g + v;
+                S[(long long)i * a.ldc + j0 + wc * 64 + nb * 16 + i16] = acc[cb][nb][v];
+            }
 }
 
 template <int CB>
@@ -729,6 +852,41 @@ extern "C" int psld_conv3x3_wgrad_split_f32(const float* dy, int lddy, int cout,
     a.hw_w = (w < 32 ? w : 32) + 2;
     a.hrows = w >= 32 ? 1 : 32 / w;
     return co_tile == 128 ? launch_dwgrad<4>(a, nsplit, stream) : launch_dwgrad<2>(a, nsplit, stream);
+}
+
+// ---- pointwise weight gradient ------------------------------------------------------------------------------
+extern "C" int psld_gemm_tn_split_supported(int m, int n, int k) {
+    return m > 0 && n > 0 && k > 0 && m % 128 == 0 && n % 128 == 0 && k % 32 == 0;
+}
+
+extern "C" int psld_gemm_tn_split_f32(int m, int n, int k, const float* a, int lda, const float* b, int ldb,
+                                      float* slabs, int ldc, int nsplit, hipStream_t stream) {
+    PSLD_CHECK_ARG(a && b && slabs && nsplit >= 1, "psld_gemm_tn_split_f32: bad args");
+    PSLD_CHECK_ARG(psld_gemm_tn_split_supported(m, n, k), "psld_gemm_tn_split_f32: unsupported shape m=%d n=%d k=%d", m, n, k);
+    PSLD_CHECK_ARG(aligned16(a) && aligned16(b) && lda % 4 == 0 && ldb % 4 == 0 && lda >= m && ldb >= n && ldc >= n,
+                   "psld_gemm_tn_split_f32: unaligned operand or short row stride");
+    PWgradArgs p{};
+    p.a = a; p.lda = lda; p.b = b; p.ldb = ldb;
+    p.tiles_i = m / 128; p.tiles_j = n / 128;
+    p.ktiles = k / 32;
+    p.ktiles_per_split = cdiv(p.ktiles, nsplit);
+    PSLD_CHECK_ARG(cdiv(p.ktiles, p.ktiles_per_split) == nsplit, "psld_gemm_tn_split_f32: nsplit %d leaves empty slabs", nsplit);
+    p.slabs = slabs; p.ldc = ldc;
+    p.slab_stride = (long long)m * ldc;
+    constexpr size_t LDS = (size_t)2 * 3 * 32 * 288;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pwgrad_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        if (e != hipSuccess) {
+            psld_set_error("psld_gemm_tn_split_f32: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return PSLD_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL(pwgrad_kernel, dim3((unsigned)(p.tiles_i * p.tiles_j * nsplit)), dim3(256), LDS, stream, p);
+    PSLD_CHECK_LAUNCH("psld_gemm_tn_split_f32");
+    return PSLD_OK;
 }
 
 // ---- pointwise (NT GEMM with pre-split B) -------------------------------------------------------------------

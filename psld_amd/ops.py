@@ -198,6 +198,16 @@ def conv3x3_wgrad_split_supported(cout: int, cin: int, b: int, h: int, w: int) -
     return bool(lib().psld_conv3x3_wgrad_split_supported(cout, cin, b, h, w))
 
 
+def gemm_tn_split_supported(m: int, n: int, k: int) -> bool:
+    return bool(lib().psld_gemm_tn_split_supported(m, n, k))
+
+
+def gemm_tn_split(M: int, N: int, K: int, A: Tensor, lda: int, B: Tensor, ldb: int, slabs: Tensor, ldc: int, nsplit: int):
+    """slabs[s][M][ldc] = per-K-range partial sums of A^T B on the bf16 limb kernel (A: [K][M] rows of lda, B: [K][N] rows of ldb)."""
+    check(lib().psld_gemm_tn_split_f32(M, N, K, A.data_ptr(), lda, B.data_ptr(), ldb, slabs.data_ptr(), ldc, nsplit,
+                                       _stream()), "psld_gemm_tn_split_f32")
+
+
 def conv3x3_wgrad_split_cout_tile(cout: int) -> int:
     return lib().psld_conv3x3_wgrad_split_cout_tile(cout)
 

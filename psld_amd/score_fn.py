@@ -254,11 +254,25 @@ class _Exec:
             ops.conv3x3_wgrad_split(dy, cout, x, slabs, cin, 0, nsplit)
             ops.reduce_slabs(slabs, nsplit, n, self.g(conv.weight), layout=1, cout=cout, taps=taps, cin=cin, alpha=alpha)
             return
+        if self.split and k == 1 and stride == 1 and pad == 0 and ops.gemm_tn_split_supported(cout, cin, b * oh * ow):
+            nsplit = self._tn_split(cout, cin, b * oh * ow)
+            slabs = ops.workspace(4 * n * nsplit, dy.device)
+            ops.gemm_tn_split(cout, cin, b * oh * ow, dy, cout, x, cin, slabs, cin, nsplit)
+            ops.reduce_slabs(slabs, nsplit, n, self.g(conv.weight), alpha=alpha)
+            return
         tiles = ((cout + 127) // 128) * ((cin + 127) // 128) * taps
         nsplit = _pick_nsplit(tiles, b * oh * ow)
         slabs = ops.workspace(4 * n * nsplit, dy.device)
         ops.conv2d_wgrad_nhwc(dy, cout, x, k, k, stride, pad, oh, ow, slabs, cin, 0, nsplit)
         ops.reduce_slabs(slabs, nsplit, n, self.g(conv.weight), layout=1, cout=cout, taps=taps, cin=cin, alpha=alpha)
+
+    @staticmethod
+    def _tn_split(m: int, n: int, k: int) -> int:
+        """K ranges of a pointwise limb weight gradient (128x128 tiles, two workgroups resident per CU)."""
+        ktiles = k // 32
+        nsplit = _pick_nsplit((m // 128) * (n // 128), k, min_k=128, resident=512)
+        per = -(-ktiles // nsplit)
+        return -(-ktiles // per)                       # every slab non-empty
 
     def bias_grad(self, dy: Tensor, out: Tensor, alpha: float = 1.0, per_image=None, ld: Optional[int] = None,
                   ld_per_image: int = 0):
@@ -606,9 +620,14 @@ class _Exec:
 
         def nin_wgrad(a_in: Tensor, dy: Tensor, nin: NIN, alpha: float, ldd: int):
             # dW[in,out] = a_in^T dy  (K = B*HW -> split-K slabs); dy may be a column slice (row stride ldd)
-            nsplit = _pick_nsplit(((c + 127) // 128) ** 2, m)
-            slabs = ops.workspace(4 * c * c * nsplit, dev)
-            ops.gemm_tn_splitk(c, c, m, a_in, c, dy, ldd, slabs, nsplit)
+            if self.split and ops.gemm_tn_split_supported(c, c, m):
+                nsplit = self._tn_split(c, c, m)
+                slabs = ops.workspace(4 * c * c * nsplit, dev)
+                ops.gemm_tn_split(c, c, m, a_in, c, dy, ldd, slabs, c, nsplit)
+            else:
+                nsplit = _pick_nsplit(((c + 127) // 128) ** 2, m)
+                slabs = ops.workspace(4 * c * c * nsplit, dev)
+                ops.gemm_tn_splitk(c, c, m, a_in, c, dy, ldd, slabs, nsplit)
             ops.reduce_slabs(slabs, nsplit, c * c, self.g(nin.W), alpha=alpha)
             self.bias_grad(dy.view(b, hw, 1, c) if ldd == c else dy, self.g(nin.b), alpha=alpha, ld=ldd)
 

@@ -242,6 +242,25 @@ def test_conv3x3_split_dgrad_and_wgrad(ops, cfg):
     assert torch.count_nonzero(slabs[:, :, :, :col0]) == 0
 
 
+@pytest.mark.parametrize("m,n,k,lda,ldb,ldc,nsplit", [(128, 128, 64, 128, 128, 128, 1), (256, 128, 2048, 256, 384, 128, 3),
+                                                       (128, 256, 8192, 128, 256, 320, 7), (768, 256, 1024, 768, 256, 256, 32)])
+def test_gemm_tn_split(ops, m, n, k, lda, ldb, ldc, nsplit):
+    """Pointwise weight gradient on the limb kernel: slabs sum to A^T B; strided operands and output."""
+    a, bm = gen(k, lda, seed=75), gen(k, ldb, seed=76)
+    ref = a[:, :m].double().t() @ bm[:, ldb - n:].double()
+    assert ops.gemm_tn_split_supported(m, n, k)
+    kt = k // 32
+    per = -(-kt // nsplit)
+    nsplit = -(-kt // per)
+    slabs = torch.full((nsplit, m, ldc), float("nan"), device=DEV)
+    bd = bm.to(DEV)
+    ops.gemm_tn_split(m, n, k, a.to(DEV), lda, bd.view(-1)[ldb - n:], ldb, slabs, ldc, nsplit)
+    assert rel_l2(slabs[:, :, :n].sum(0), ref) < 3e-6
+    if ldc > n:
+        assert torch.isnan(slabs[:, :, n:]).all()           # columns beyond n untouched
+    assert not ops.gemm_tn_split_supported(64, 128, 64) and not ops.gemm_tn_split_supported(128, 128, 48)
+
+
 @pytest.mark.parametrize("m,n,k1,k2", [(256, 128, 64, 0), (1000, 256, 256, 0), (640, 128, 96, 32), (4096, 768, 256, 0),
                                        (130, 128, 512, 0)])
 def test_gemm_split(ops, m, n, k1, k2):

@@ -55,3 +55,16 @@ print(f"1x1 512->256 @32 bf16x6: {t*1e6:.1f} us {2*M2*256*512/t/1e12:.1f} TF")
 f2d=ops.gemm_frag(W2, 512, 256, 1, 512)
 t=timeit(lambda: ops.gemm_split(y2, None, M2, f2d, 512, dx))
 print(f"1x1 dgrad bf16x6 {M2}x512x256: {t*1e6:.1f} us {2*M2*256*512/t/1e12:.1f} TF")
+# pointwise weight gradients: fp32 engine (conv2d_wgrad 1x1 / TN split-K) vs the limb kernel
+for (mm, nn_, kk, tag) in ((c, c, M, "NIN wgrad 256x256"), (256, 512, M2, "1x1 wgrad 512->256 @32"), (256, 512, M2 // 4, "1x1 wgrad 512->256 @16")):
+    A = torch.randn(kk, mm, device=DEV); Bm = torch.randn(kk, nn_, device=DEV)
+    tiles = (mm // 128) * (nn_ // 128)
+    kt = kk // 32
+    ns = max(1, min(512 // tiles, kt // 4)); per = -(-kt // ns); ns = -(-kt // per)
+    sl2 = torch.empty(ns, mm, nn_, device=DEV)
+    t = timeit(lambda: ops.gemm_tn_split(mm, nn_, kk, A, mm, Bm, nn_, sl2, nn_, ns))
+    ns0 = 16
+    sl0 = torch.empty(ns0, mm, nn_, device=DEV)
+    t0 = timeit(lambda: ops.gemm_tn_splitk(mm, nn_, kk, A, mm, Bm, nn_, sl0, ns0))
+    err = ((sl2.sum(0) - sl0.sum(0)).norm() / sl0.sum(0).norm()).item()
+    print(f"{tag} TN: fp32 {t0*1e6:.1f} us {2*mm*nn_*kk/t0/1e12:.1f} TF | bf16x6 (split {ns}) {t*1e6:.1f} us {2*mm*nn_*kk/t/1e12:.1f} TF (rel {err:.1e})")
