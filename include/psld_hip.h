@@ -159,6 +159,15 @@ int psld_gemm_tn_split_supported(int m, int n, int k);
 int psld_gemm_tn_split_f32(int m, int n, int k, const float* a, int lda, const float* b, int ldb,
                            float* slabs, int ldc, int nsplit, hipStream_t stream);
 
+/* Batched GEMM on the limb kernels with BOTH operands fp32 activations (split inside the kernel):
+ * c[b][i][j] = alpha * sum_p A(i,p) B(p,j);  ta: a is stored [k][m] (else [m][k]); tb: b is stored [n][k] (else [k][n]);
+ * same operand conventions as psld_gemm_f32, not both transposed.  m, n multiples of 128, k of 32.  Replaces the
+ * einsum contractions of the attention block, layerspp.py:82-86 (QK^T, softmax(QK^T) V) and their gradients. */
+int psld_bgemm_split_supported(int ta, int tb, int m, int n, int k);
+int psld_bgemm_split_f32(int ta, int tb, int m, int n, int k, const float* a, int lda, long long stride_a,
+                         const float* b, int ldb, long long stride_b, float* c, int ldc, long long stride_c,
+                         int batch, float alpha, hipStream_t stream);
+
 /* Weight gradient of the convolution above for one input source:
  * slabs[s][co][tap][col0 + ci] = sum over the s-th range of output pixels of dy[pix][co] * x[pix+tap][ci]. */
 int psld_conv2d_wgrad_nhwc_f32(const float* dy, int lddy, int cout,

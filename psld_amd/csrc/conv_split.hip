@@ -664,6 +664,175 @@ __global__ void __launch_bounds__(256, 2) pwgrad_kernel(const PWgradArgs a) {
             }
 }
 
+// ---- batched GEMM with both operands split in the kernel (attention QK^T, PV and their gradients) -------------------
+// C[b] = alpha * op(A[b]) op(B[b]), 128 x 128 tiles, K tiles of 32.  An operand whose K index is the row index in
+// memory (AT: A stored [k][i]; !BT: B stored [k][j]) is staged like pwgrad_kernel's images and read transposed; an
+// operand with contiguous K (A stored [i][k]; BT: B stored [j][k]) is staged like dconv_kernel's pixel rows (64-byte
+// rows, slot swizzle) and read with ds_read_b128.  The transposed reads deliver K in the order 4g + 16j + q, so the
+// row-major images store their 4-element K groups in that order too (group c at slot c & 3, half c >> 2).
+struct BGemmArgs {
+    const float* a;
+    int lda;
+    long long sa;
+    const float* b;
+    int ldb;
+    long long sb;
+    float* c;
+    int ldc;
+    long long sc;
+    int tiles_i, tiles_j, ktiles;
+    float alpha;
+};
+
+template <bool AT, bool BT>
+__global__ void __launch_bounds__(256, 2) bgemm_kernel(const BGemmArgs a) {
+    constexpr int MC_RS = 288, MC_LIMB = 32 * MC_RS, KC_LIMB = 128 * ROWB;
+    constexpr int A_LIMB = AT ? MC_LIMB : KC_LIMB, B_LIMB = BT ? KC_LIMB : MC_LIMB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + 3 * A_LIMB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tiles = a.tiles_i * a.tiles_j;
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int batch = vid / tiles, tile = vid - batch * tiles;
+    const int i0 = (tile / a.tiles_j) * 128, j0 = (tile % a.tiles_j) * 128;
+    const float* Ab = a.a + batch * a.sa + (AT ? (long long)i0 : (long long)i0 * a.lda);
+    const float* Bb = a.b + batch * a.sb + (BT ? (long long)j0 * a.ldb : (long long)j0);
+
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3;
+    // fragment read addresses
+    int a_rd[2], b_rd[2];
+    if constexpr (AT) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) a_rd[j] = (4 * g + 16 * j + q) * MC_RS + (wr * 64 + 4 * p4) * 2;
+    } else {
+        a_rd[0] = (wr * 64 + i16) * ROWB + ((g ^ lds_swz(i16)) << 4);
+        a_rd[1] = 0;
+    }
+    if constexpr (!BT) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b_rd[j] = (4 * g + 16 * j + q) * MC_RS + (wc * 64 + 4 * p4) * 2;
+    } else {
+        b_rd[0] = (wc * 64 + i16) * ROWB + ((g ^ lds_swz(i16)) << 4);
+        b_rd[1] = 0;
+    }
+    // staging items: global byte offset within a K tile and LDS byte offset
+    unsigned a_go[4], b_go[4];
+    int a_so[4], b_so[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (tid >> 4) + 16 * (i & 1), cq = (tid & 15) + 16 * (i >> 1);      // [k row][channel quad] images
+        const int row = (tid >> 3) + 32 * i, c4 = tid & 7;                            // [row][k quad] images
+        const int kc_so = row * ROWB + ((((c4 & 3) ^ lds_swz(row))) << 4) + (c4 >> 2) * 8;
+        a_go[i] = AT ? (unsigned)((r * a.lda + cq * 4) * 4) : (unsigned)((row * a.lda + c4 * 4) * 4);
+        a_so[i] = AT ? r * MC_RS + cq * 8 : kc_so;
+        b_go[i] = !BT ? (unsigned)((r * a.ldb + cq * 4) * 4) : (unsigned)((row * a.ldb + c4 * 4) * 4);
+        b_so[i] = !BT ? r * MC_RS + cq * 8 : kc_so;
+    }
+    f32x4 va[4], vb[4];
+    auto load_tile = [&](int kt) {
+        const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(Ab + (AT ? (long long)kt * 32 * a.lda : (long long)kt * 32)), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(Bb + (!BT ? (long long)kt * 32 * a.ldb : (long long)kt * 32)), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) va[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, a_go[i], 0, 0));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB, b_go[i], 0, 0));
+    };
+    auto store_item = [&](unsigned char* d, int limb, const f32x4& v) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        split3(v[0], v[1], h0, m0, l0);
+        split3(v[2], v[3], h1, m1, l1);
+        *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(d + limb) = u32x2{m0, m1};
+        *reinterpret_cast<u32x2*>(d + 2 * limb) = u32x2{l0, l1};
+    };
+    auto frag_a = [&](int l, int blk) -> u32x4 {
+        if constexpr (AT) {
+            const u32x2 lo = lds_tr16(As + a_rd[0] + l * A_LIMB + blk * 32), hi = lds_tr16(As + a_rd[1] + l * A_LIMB + blk * 32);
+            return u32x4{lo[0], lo[1], hi[0], hi[1]};
+        } else {
+            return *reinterpret_cast<const u32x4*>(As + a_rd[0] + l * A_LIMB + blk * 16 * ROWB);
+        }
+    };
+    auto frag_b = [&](int l, int blk) -> u32x4 {
+        if constexpr (!BT) {
+            const u32x2 lo = lds_tr16(Bs + b_rd[0] + l * B_LIMB + blk * 32), hi = lds_tr16(Bs + b_rd[1] + l * B_LIMB + blk * 32);
+            return u32x4{lo[0], lo[1], hi[0], hi[1]};
+        } else {
+            return *reinterpret_cast<const u32x4*>(Bs + b_rd[0] + l * B_LIMB + blk * 16 * ROWB);
+        }
+    };
+
+    f32x4v acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    load_tile(0);
+    for (int kt = 0; kt < a.ktiles; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) store_item(As + a_so[i], A_LIMB, va[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) store_item(Bs + b_so[i], B_LIMB, vb[i]);
+        __syncthreads();
+        if (kt + 1 < a.ktiles) load_tile(kt + 1);
+        u32x4 fa[4][3];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) fa[cb][l] = frag_a(l, cb);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            u32x4 fb[3];
+#pragma unroll
+            for (int l = 0; l < 3; ++l) fb[l] = frag_b(l, nb);
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int u = 0; u < 6; ++u)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    acc[cb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, fa[cb][PA[u]]), __builtin_bit_cast(bf16x8, fb[PB[u]]), acc[cb][nb], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    float* Cb = a.c + batch * a.sc;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int i = i0 + wr * 64 + cb * 16 + 4 * g + v;
+                Cb[(long long)i * a.ldc + j0 + wc * 64 + nb * 16 + i16] = a.alpha * acc[cb][nb][v];
+            }
+}
+
+template <bool AT, bool BT>
+int launch_bgemm(const BGemmArgs& a, int batch, hipStream_t stream) {
+    constexpr size_t LDS = (size_t)3 * ((AT ? 32 * 288 : 128 * ROWB) + (BT ? 128 * ROWB : 32 * 288));
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm_kernel<AT, BT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        if (e != hipSuccess) {
+            psld_set_error("psld_bgemm_split_f32: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return PSLD_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL((bgemm_kernel<AT, BT>), dim3((unsigned)(a.tiles_i * a.tiles_j * batch)), dim3(256), LDS, stream, a);
+    PSLD_CHECK_LAUNCH("psld_bgemm_split_f32");
+    return PSLD_OK;
+}
+
 template <int CB>
 int launch_dwgrad(const DWgradArgs& a, int nsplit, hipStream_t stream) {
     constexpr size_t LDS = (size_t)3 * (WG_AROWS * (64 * CB + 32) + WG_BLIMB);
@@ -887,6 +1056,30 @@ extern "C" int psld_gemm_tn_split_f32(int m, int n, int k, const float* a, int l
     hipLaunchKernelGGL(pwgrad_kernel, dim3((unsigned)(p.tiles_i * p.tiles_j * nsplit)), dim3(256), LDS, stream, p);
     PSLD_CHECK_LAUNCH("psld_gemm_tn_split_f32");
     return PSLD_OK;
+}
+
+// ---- batched GEMM, both operands fp32 activations --------------------------------------------------------------
+extern "C" int psld_bgemm_split_supported(int ta, int tb, int m, int n, int k) {
+    return !(ta && tb) && m > 0 && n > 0 && k > 0 && m % 128 == 0 && n % 128 == 0 && k % 32 == 0;
+}
+
+extern "C" int psld_bgemm_split_f32(int ta, int tb, int m, int n, int k, const float* a, int lda, long long stride_a,
+                                    const float* b, int ldb, long long stride_b, float* c, int ldc, long long stride_c,
+                                    int batch, float alpha, hipStream_t stream) {
+    PSLD_CHECK_ARG(a && b && c && batch >= 1, "psld_bgemm_split_f32: bad args");
+    PSLD_CHECK_ARG(psld_bgemm_split_supported(ta, tb, m, n, k), "psld_bgemm_split_f32: unsupported ta=%d tb=%d m=%d n=%d k=%d",
+                   ta, tb, m, n, k);
+    PSLD_CHECK_ARG(aligned16(a) && aligned16(b) && lda % 4 == 0 && ldb % 4 == 0 && stride_a % 4 == 0 && stride_b % 4 == 0,
+                   "psld_bgemm_split_f32: unaligned operand");
+    BGemmArgs p{};
+    p.a = a; p.lda = lda; p.sa = stride_a;
+    p.b = b; p.ldb = ldb; p.sb = stride_b;
+    p.c = c; p.ldc = ldc; p.sc = stride_c;
+    p.tiles_i = m / 128; p.tiles_j = n / 128; p.ktiles = k / 32;
+    p.alpha = alpha;
+    if (ta) return launch_bgemm<true, false>(p, batch, stream);
+    if (tb) return launch_bgemm<false, true>(p, batch, stream);
+    return launch_bgemm<false, false>(p, batch, stream);
 }
 
 // ---- pointwise (NT GEMM with pre-split B) -------------------------------------------------------------------

@@ -208,6 +208,17 @@ def gemm_tn_split(M: int, N: int, K: int, A: Tensor, lda: int, B: Tensor, ldb: i
                                        _stream()), "psld_gemm_tn_split_f32")
 
 
+def bgemm_split_supported(ta: int, tb: int, m: int, n: int, k: int) -> bool:
+    return bool(lib().psld_bgemm_split_supported(ta, tb, m, n, k))
+
+
+def bgemm_split(ta: int, tb: int, M: int, N: int, K: int, A: Tensor, lda: int, sa: int, B: Tensor, ldb: int, sb: int,
+                Cc: Tensor, ldc: int, sc: int, batch: int = 1, alpha: float = 1.0):
+    """gemm_raw's operand conventions on the limb kernel, both operands split in the kernel (alpha is the only epilogue)."""
+    check(lib().psld_bgemm_split_f32(ta, tb, M, N, K, A.data_ptr(), lda, sa, B.data_ptr(), ldb, sb, Cc.data_ptr(), ldc, sc,
+                                     batch, alpha, _stream()), "psld_bgemm_split_f32")
+
+
 def conv3x3_wgrad_split_cout_tile(cout: int) -> int:
     return lib().psld_conv3x3_wgrad_split_cout_tile(cout)
 

@@ -266,6 +266,15 @@ class _Exec:
         ops.conv2d_wgrad_nhwc(dy, cout, x, k, k, stride, pad, oh, ow, slabs, cin, 0, nsplit)
         ops.reduce_slabs(slabs, nsplit, n, self.g(conv.weight), layout=1, cout=cout, taps=taps, cin=cin, alpha=alpha)
 
+    def bmm(self, ta: int, tb: int, M: int, N: int, K: int, A: Tensor, lda: int, sa: int, B: Tensor, ldb: int, sb: int,
+            Cc: Tensor, ldc: int, sc: int, batch: int, alpha: float = 1.0):
+        """Batched activation x activation product (attention): limb kernel when the shape allows, fp32 engine otherwise."""
+        if self.split and ops.bgemm_split_supported(ta, tb, M, N, K) and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0:
+            ops.bgemm_split(ta, tb, M, N, K, A, lda, sa, B, ldb, sb, Cc, ldc, sc, batch, alpha)
+        else:
+            ops.gemm_raw(ta, tb, M, N, K, A, lda, sa, B, ldb, sb, Cc, ldc, sc, batch,
+                         ops.epilogue(alpha=alpha) if alpha != 1.0 else None)
+
     @staticmethod
     def _tn_split(m: int, n: int, k: int) -> int:
         """K ranges of a pointwise limb weight gradient (128x128 tiles, two workgroups resident per CU)."""
@@ -603,10 +612,10 @@ class _Exec:
             q, k, v = qkv
             ld = c
         p = torch.empty((b, hw, hw), device=dev, dtype=torch.float32)
-        ops.gemm_raw(0, 1, hw, hw, c, q, ld, hw * ld, k, ld, hw * ld, p, hw, hw * hw, b, ops.epilogue(alpha=scale))
+        self.bmm(0, 1, hw, hw, c, q, ld, hw * ld, k, ld, hw * ld, p, hw, hw * hw, b, scale)
         ops.softmax_rows(p, p, b * hw, hw)
         ho = torch.empty((b, hw, c), device=dev, dtype=torch.float32)
-        ops.gemm_raw(0, 0, hw, c, hw, p, hw, hw * hw, v, ld, hw * ld, ho, c, hw * c, b)
+        self.bmm(0, 0, hw, c, hw, p, hw, hw * hw, v, ld, hw * ld, ho, c, hw * c, b)
         out = torch.empty_like(x.v)
         epi_out = ops.epilogue(bias=n3.b, residual=x.v, ld_residual=c, out_scale=s)
         if fused:
@@ -643,17 +652,17 @@ class _Exec:
                 ops.gemm_raw(0, 1, m, c, c, dout, c, 0, n3.W, c, 0, dho, c, 0, epi=ops.epilogue(alpha=s))
             # dP = dho v^T ; dv = P^T dho
             dp = torch.empty_like(p)
-            ops.gemm_raw(0, 1, hw, hw, c, dho, c, hw * c, v, ld, hw * ld, dp, hw, hw * hw, b)
+            self.bmm(0, 1, hw, hw, c, dho, c, hw * c, v, ld, hw * ld, dp, hw, hw * hw, b)
             if fused:
                 dqkv = torch.empty_like(qkv)
                 dq, dk, dv = dqkv[..., :c], dqkv[..., c:2 * c], dqkv[..., 2 * c:]
             else:
                 dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-            ops.gemm_raw(1, 0, hw, c, hw, p, hw, hw * hw, dho, c, hw * c, dv, ld, hw * ld, b)
+            self.bmm(1, 0, hw, c, hw, p, hw, hw * hw, dho, c, hw * c, dv, ld, hw * ld, b)
             ds = dp
             ops.softmax_rows_bwd(p, dp, ds, b * hw, hw)
-            ops.gemm_raw(0, 0, hw, c, hw, ds, hw, hw * hw, k, ld, hw * ld, dq, ld, hw * ld, b, ops.epilogue(alpha=scale))
-            ops.gemm_raw(1, 0, hw, c, hw, ds, hw, hw * hw, q, ld, hw * ld, dk, ld, hw * ld, b, ops.epilogue(alpha=scale))
+            self.bmm(0, 0, hw, c, hw, ds, hw, hw * hw, k, ld, hw * ld, dq, ld, hw * ld, b, scale)
+            self.bmm(1, 0, hw, c, hw, ds, hw, hw * hw, q, ld, hw * ld, dk, ld, hw * ld, b, scale)
             dhn = torch.empty_like(hn)
             for nin, d in ((n0, dq), (n1, dk), (n2, dv)):
                 self.on_side(lambda nin=nin, d=d: nin_wgrad(hn, d, nin, 1.0, ld), hn, d)

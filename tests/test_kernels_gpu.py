@@ -242,6 +242,29 @@ def test_conv3x3_split_dgrad_and_wgrad(ops, cfg):
     assert torch.count_nonzero(slabs[:, :, :, :col0]) == 0
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0)])
+@pytest.mark.parametrize("m,n,k,batch,pad", [(128, 128, 32, 1, 0), (256, 128, 96, 3, 0), (256, 256, 256, 5, 64)])
+def test_bgemm_split(ops, ta, tb, m, n, k, batch, pad):
+    """Batched limb GEMM, both operands split in the kernel: NT / NN / TN, strided operands (column slices) and output."""
+    A = gen(batch, *((k, m + pad) if ta else (m, k + pad)), seed=77)
+    B = gen(batch, *((n, k + pad) if tb else (k, n + pad)), seed=78)
+    a_use = A[:, :, pad:] if pad else A
+    b_use = B[:, :, pad:] if pad else B
+    opa = a_use.double().transpose(1, 2) if ta else a_use.double()
+    opb = b_use.double().transpose(1, 2) if tb else b_use.double()
+    ref = 0.25 * opa @ opb
+    assert ops.bgemm_split_supported(ta, tb, m, n, k)
+    Ad, Bd = A.to(DEV), B.to(DEV)
+    out = torch.full((batch, m, n + pad), float("nan"), device=DEV)
+    lda, ldb = A.shape[2], B.shape[2]
+    ops.bgemm_split(ta, tb, m, n, k, Ad.view(-1)[pad:], lda, A.shape[1] * lda, Bd.view(-1)[pad:], ldb, B.shape[1] * ldb,
+                    out.view(-1)[pad:], n + pad, m * (n + pad), batch, 0.25)
+    assert rel_l2(out[:, :, pad:], ref) < 3e-6
+    if pad:
+        assert torch.isnan(out[:, :, :pad]).all()
+    assert not ops.bgemm_split_supported(1, 1, m, n, k) and not ops.bgemm_split_supported(ta, tb, 64, n, k)
+
+
 @pytest.mark.parametrize("m,n,k,lda,ldb,ldc,nsplit", [(128, 128, 64, 128, 128, 128, 1), (256, 128, 2048, 256, 384, 128, 3),
                                                        (128, 256, 8192, 128, 256, 320, 7), (768, 256, 1024, 768, 256, 256, 32)])
 def test_gemm_tn_split(ops, m, n, k, lda, ldb, ldc, nsplit):

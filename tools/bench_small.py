@@ -68,3 +68,12 @@ for (mm, nn_, kk, tag) in ((c, c, M, "NIN wgrad 256x256"), (256, 512, M2, "1x1 w
     t0 = timeit(lambda: ops.gemm_tn_splitk(mm, nn_, kk, A, mm, Bm, nn_, sl0, ns0))
     err = ((sl2.sum(0) - sl0.sum(0)).norm() / sl0.sum(0).norm()).item()
     print(f"{tag} TN: fp32 {t0*1e6:.1f} us {2*mm*nn_*kk/t0/1e12:.1f} TF | bf16x6 (split {ns}) {t*1e6:.1f} us {2*mm*nn_*kk/t/1e12:.1f} TF (rel {err:.1e})")
+# attention products: fp32 engine vs limb kernel (both operands split in the kernel)
+hw_ = 256; bb = M // hw_
+qq = torch.randn(bb, hw_, c, device=DEV); kk_ = torch.randn(bb, hw_, c, device=DEV); pp = torch.empty(bb, hw_, hw_, device=DEV); pp2 = torch.empty_like(pp)
+for (ta, tb, tag) in ((0, 1, "QK^T NT"), (0, 0, "PV NN"), (1, 0, "P^T dHo TN")):
+    t0 = timeit(lambda: ops.gemm_raw(ta, tb, hw_, hw_, c, qq, c, hw_ * c, kk_, c, hw_ * c, pp, hw_, hw_ * hw_, bb))
+    t = timeit(lambda: ops.bgemm_split(ta, tb, hw_, hw_, c, qq, c, hw_ * c, kk_, c, hw_ * c, pp2, hw_, hw_ * hw_, bb))
+    err = ((pp2 - pp).norm() / pp.norm()).item()
+    fl = 2 * bb * hw_ * hw_ * c
+    print(f"{tag} batched: fp32 {t0*1e6:.1f} us {fl/t0/1e12:.1f} TF | bf16x6 {t*1e6:.1f} us {fl/t/1e12:.1f} TF (rel {err:.1e})")
