@@ -248,8 +248,9 @@ def main():
             "value": total_imgs / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "math": ("f32 in / f32 accumulate; 3x3 convolutions and 1x1 / NIN projections as exact 3-limb bf16 splits, 6 bf16 MFMA products per "
-                     "fp32 product (dropped terms < 2^-23 of the product); everything else fp32 MFMA / fp32 VALU"
+            "math": ("f32 in / f32 accumulate; 3x3 convolutions, 1x1 / NIN projections, attention products and their gradients as exact "
+                     "3-limb bf16 splits, 6 bf16 MFMA products per fp32 product (dropped terms < 2^-23 of the product); "
+                     "everything else fp32 MFMA / fp32 VALU"
                      if ops.math_mode() == "bf16x6" else "f32 MFMA (v_mfma_f32_32x32x2_f32)"),
             "config": {"workload": "C10-SOTA NCSN++ (nf=128, ch_mult=[2,2,2], nres=8, attn@16, fir, fourier, "
                                    "dropout 0.15) full HSM train step: perturb+fwd+loss+bwd+clip+Adam+EMA",
