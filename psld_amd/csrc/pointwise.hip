@@ -238,22 +238,33 @@ __global__ void colsum_final_kernel(const double* __restrict__ part, int chunks,
     for (int k = 0; k < chunks; ++k) t += part[((long long)b * chunks + k) * c + col];
     out[(long long)b * ld_out + col] = (float)(t * (double)alpha);
 }
-// per-image sums [batch][c] -> batch total: grid c/64, block 1024 = 64 columns x 16 image lanes; every lane adds its
-// images in index order, the lanes are combined in lane order (fixed order, no atomics: bitwise repeatable)
-__global__ void colsum_total_kernel(const float* __restrict__ per_image, int ld, int batch, int c,
-                                    float* __restrict__ out, float alpha) {
-    __shared__ double red[16][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int bl = threadIdx.x >> 6;
+// chunk partials -> per-image sums [batch][c] (unscaled) AND the batch total, one launch: grid c/16, block 1024 =
+// 16 columns x 64 image lanes (two images per lane at B=128, their chunk loads all in flight together: a version
+// with 4 blocks and 128 dependent loads per thread took 57 us); every lane adds its images in index order, the lanes
+// are combined in lane order (fixed order, no atomics: bitwise repeatable)
+__global__ void __launch_bounds__(1024) colsum_final_total_kernel(const double* __restrict__ part, int chunks, int batch,
+                                                                  int c, float* __restrict__ per_image, int ld,
+                                                                  float* __restrict__ out, float alpha) {
+    __shared__ double red[64][16];
+    const int cl = threadIdx.x & 15, bl = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + cl;
     double tot = 0.0;
     if (col < c)
-        for (int b = bl; b < batch; b += 16) tot += (double)per_image[(long long)b * ld + col];
-    red[bl][threadIdx.x & 63] = tot;
+        for (int b = bl; b < batch; b += 64) {
+            const double* p = part + (long long)b * chunks * c + col;
+            double t = 0.0;
+#pragma unroll 8
+            for (int k = 0; k < chunks; ++k) t += p[(long long)k * c];
+            const float f = (float)t;                 // the total is the sum of the ROUNDED per-image sums
+            per_image[(long long)b * ld + col] = f;
+            tot += (double)f;
+        }
+    red[bl][cl] = tot;
     __syncthreads();
     if (bl == 0 && col < c) {
         double t = 0.0;
 #pragma unroll
-        for (int l = 0; l < 16; ++l) t += red[l][threadIdx.x];
+        for (int l = 0; l < 64; ++l) t += red[l][cl];
         out[col] = (float)(t * (double)alpha);
     }
 }
@@ -574,8 +585,8 @@ extern "C" int psld_colsum_f32(const float* x, int ld, int batch, int hw, int c,
     PSLD_CHECK_LAUNCH("psld_colsum_f32");
     return PSLD_OK;
 }
-// out[c] = alpha * sum over (batch, hw) of x; per_image[b][c] (optional, unscaled) = sum over hw.  Three launches
-// (chunk partials, per-image sums, batch total) instead of the four of two chained psld_colsum_f32 calls.
+// out[c] = alpha * sum over (batch, hw) of x; per_image[b][c] (optional, unscaled) = sum over hw.  Two launches
+// (chunk partials; per-image sums + batch total) instead of the four of two chained psld_colsum_f32 calls.
 extern "C" int psld_bias_grad_f32(const float* x, int ld, int batch, int hw, int c, float* per_image, int ld_per_image,
                                   float* out, float alpha, void* workspace, hipStream_t stream) {
     PSLD_CHECK_ARG(x && out && workspace && batch > 0 && hw > 0 && c > 0, "psld_bias_grad_f32: bad args");
@@ -600,10 +611,9 @@ extern "C" int psld_bias_grad_f32(const float* x, int ld, int batch, int hw, int
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(chunks, batch), dim3(cq * pl), (size_t)pl * cq * 4 * sizeof(double),
                        stream, x, ld, hw, c, cq, pl, chunk_px, chunks, part);
     PSLD_CHECK_LAUNCH("colsum_partial_kernel");
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(c, 128), batch), dim3(128), 0, stream, part, chunks, c, pim, 1.0f, ldp);
-    PSLD_CHECK_LAUNCH("colsum_final_kernel");
-    hipLaunchKernelGGL(colsum_total_kernel, dim3(cdiv(c, 64)), dim3(1024), 0, stream, pim, ldp, batch, c, out, alpha);
-    PSLD_CHECK_LAUNCH("colsum_total_kernel");
+    hipLaunchKernelGGL(colsum_final_total_kernel, dim3(cdiv(c, 16)), dim3(1024), 0, stream, part, chunks, batch, c, pim, ldp,
+                       out, alpha);
+    PSLD_CHECK_LAUNCH("colsum_final_total_kernel");
     return PSLD_OK;
 }
 // Cross entropy of [rows][n] logits against int64 labels (nn.CrossEntropyLoss, losses.py:147-173) with its gradient:
