@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 
-#define PSLD_ABI_VERSION 2 /* 2: limb-MFMA convolutions, math mode, bias-gradient / batched-copy entry points */
+#define PSLD_ABI_VERSION 3 /* 2: limb-MFMA convolutions, math mode, bias-gradient / batched-copy entry points; 3: pointwise weight gradient and batched activation GEMM on limb kernels */
 #define PSLD_COEFF_STRIDE 12
 
 int psld_version(void);
