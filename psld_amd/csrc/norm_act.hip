@@ -7,7 +7,7 @@
 // its pixels.  Thread -> (channel quad q = tid % CQ, pixel lane pl = tid / CQ), CQ = C/4, so a
 // wave reads whole 16-byte-per-lane contiguous runs of the NHWC row (coalesced float4).
 // Reductions: per-thread fp32 partials over <= ~64 pixels, then fp64 across threads (LDS) and
-// across chunks (finalize kernel) — deterministic, no global atomics.
+// across chunks (finalize kernel) — deterministic, no atomics.
 #include "common.h"
 #include "psld_hip.h"
 
@@ -45,11 +45,9 @@ inline Map make_map(int batch, int hw, int c, bool elementwise = false) {
 // ---- forward statistics -------------------------------------------------------------------
 __global__ void gn_partial_kernel(const float* __restrict__ x, int hw, int c, int groups, int cq, int pl,
                                   int chunk_px, int chunks, double* __restrict__ part) {
-    __shared__ double gs[MAXG][2];
+    __shared__ double ts[MAXT][2];               // per-thread (sum, sum of squares), combined in thread order
     const int n = blockIdx.y, chunk = blockIdx.x;
     const int tid = threadIdx.x;
-    if (tid < 2 * MAXG) (&gs[0][0])[tid] = 0.0;
-    __syncthreads();
     const int q = tid % cq, l = tid / cq;
     const int p0 = chunk * chunk_px, p1 = min(hw, p0 + chunk_px);
     const float* base = x + ((long long)n * hw) * c + q * 4;
@@ -64,20 +62,35 @@ __global__ void gn_partial_kernel(const float* __restrict__ x, int hw, int c, in
         }
     }
     const int cpg = c / groups;
+    double* out = part + (((long long)n * chunks + chunk) * groups) * 2;
     if (cpg % 4 == 0) {
-        const int g = (q * 4) / cpg;
-        atomicAdd(&gs[g][0], (double)s[0] + (double)s[1] + (double)s[2] + (double)s[3]);
-        atomicAdd(&gs[g][1], (double)ss[0] + (double)ss[1] + (double)ss[2] + (double)ss[3]);
-    } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int g = (q * 4 + e) / cpg;
-            atomicAdd(&gs[g][0], (double)s[e]);
-            atomicAdd(&gs[g][1], (double)ss[e]);
+        // a channel quad lies in one group: group g = quads [g*cpg/4, (g+1)*cpg/4) x all pixel lanes
+        ts[tid][0] = (double)s[0] + (double)s[1] + (double)s[2] + (double)s[3];
+        ts[tid][1] = (double)ss[0] + (double)ss[1] + (double)ss[2] + (double)ss[3];
+        __syncthreads();
+        if (tid < groups * 2) {
+            const int g = tid >> 1, w = tid & 1, qpg = cpg / 4;
+            double t = 0.0;
+            for (int ll = 0; ll < pl; ++ll)
+                for (int qq = g * qpg; qq < (g + 1) * qpg; ++qq) t += ts[ll * cq + qq][w];
+            out[tid] = t;
         }
+    } else {
+        double t = 0.0;                          // thread (g, w) accumulates over the four element rounds
+        for (int e = 0; e < 4; ++e) {
+            ts[tid][0] = (double)s[e];
+            ts[tid][1] = (double)ss[e];
+            __syncthreads();
+            if (tid < groups * 2) {
+                const int g = tid >> 1, w = tid & 1;
+                for (int ll = 0; ll < pl; ++ll)
+                    for (int qq = 0; qq < cq; ++qq)
+                        if ((qq * 4 + e) / cpg == g) t += ts[ll * cq + qq][w];
+            }
+            __syncthreads();
+        }
+        if (tid < groups * 2) out[tid] = t;
     }
-    __syncthreads();
-    if (tid < groups * 2) part[(((long long)n * chunks + chunk) * groups) * 2 + tid] = (&gs[0][0])[tid];
 }
 
 __global__ void gn_finalize_kernel(const double* __restrict__ part, int hw, int c, int groups, int chunks,
@@ -198,30 +211,63 @@ __global__ void gn_bwd_partial_kernel(const float* __restrict__ dy, const float*
     }
 }
 
-// pass 2: per image: sum chunks -> s1[n,c], s2[n,c]; group means m1, m2; write coefficient rows
+// pass 2, one launch with two block roles.
+// blocks [0, batch): per image: sum chunks -> s1[c], s2[c]; group means m1, m2; write coefficient rows
 //   coef[n][0][c] = rstd*gamma  (multiplies dz)
 //   coef[n][1][c] = rstd*m1_g   (subtracted)
 //   coef[n][2][c] = rstd*m2_g   (multiplies xhat, subtracted)
-// and sums[n][2][c] (s1, s2) for the dgamma/dbeta reduction over n.
-__global__ void gn_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ rstd,
-                                       const float* __restrict__ gamma, int hw, int c, int groups, int chunks,
-                                       float* __restrict__ sums, float* __restrict__ coef) {
+// blocks [batch, batch + 2*ceil(c/64)): dbeta[c] = sum_n s1[n,c] / dgamma[c] = sum_n s2[n,c] straight from the chunk
+// partials: 64 columns x 16 image lanes, every lane adds its (image, chunk) terms in index order, lanes combined in
+// lane order.  No atomics anywhere: bitwise repeatable.
+__global__ void __launch_bounds__(1024) gn_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ rstd,
+                                                               const float* __restrict__ gamma, int batch, int hw, int c,
+                                                               int groups, int chunks, float* __restrict__ coef,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double sh[2 * MAXT * 4];          // image role: s1*gamma, s2*gamma per channel; param role: [16][64]
     __shared__ double g1[MAXG], g2[MAXG];
-    const int n = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= batch) {
+        const int r = blockIdx.x - batch;
+        const int which = r & 1;
+        const int col = (r >> 1) * 64 + (tid & 63);
+        const int lane = tid >> 6;
+        double acc = 0.0;
+        if (col < c)
+            for (int n = lane; n < batch; n += 16) {
+                const float* p = part + (((long long)n * chunks) * 2 + which) * c + col;
+#pragma unroll 8
+                for (int k = 0; k < chunks; ++k) acc += (double)p[(long long)k * 2 * c];
+            }
+        sh[lane * 64 + (tid & 63)] = acc;
+        __syncthreads();
+        if (lane == 0 && col < c) {
+            double t = 0.0;
+#pragma unroll
+            for (int l = 0; l < 16; ++l) t += sh[l * 64 + tid];
+            (which ? dgamma : dbeta)[col] = (float)t;
+        }
+        return;
+    }
+    const int n = blockIdx.x;
     const int cpg = c / groups;
-    if (tid < MAXG) g1[tid] = g2[tid] = 0.0;
-    __syncthreads();
     for (int ch = tid; ch < c; ch += blockDim.x) {
         double a = 0, b = 0;
         for (int k = 0; k < chunks; ++k) {
             a += (double)part[(((long long)n * chunks + k) * 2 + 0) * c + ch];
             b += (double)part[(((long long)n * chunks + k) * 2 + 1) * c + ch];
         }
-        sums[((long long)n * 2 + 0) * c + ch] = (float)a;
-        sums[((long long)n * 2 + 1) * c + ch] = (float)b;
-        const int g = ch / cpg;
-        atomicAdd(&g1[g], a * (double)gamma[ch]);
-        atomicAdd(&g2[g], b * (double)gamma[ch]);
+        sh[ch] = a * (double)gamma[ch];
+        sh[MAXT * 4 + ch] = b * (double)gamma[ch];
+    }
+    __syncthreads();
+    if (tid < groups) {
+        double a = 0, b = 0;
+        for (int i = 0; i < cpg; ++i) {
+            a += sh[tid * cpg + i];
+            b += sh[MAXT * 4 + tid * cpg + i];
+        }
+        g1[tid] = a;
+        g2[tid] = b;
     }
     __syncthreads();
     const double cnt = (double)cpg * hw;
@@ -231,26 +277,6 @@ __global__ void gn_bwd_finalize_kernel(const float* __restrict__ part, const flo
         coef[((long long)n * 3 + 0) * c + ch] = r * gamma[ch];
         coef[((long long)n * 3 + 1) * c + ch] = (float)((double)r * g1[g] / cnt);
         coef[((long long)n * 3 + 2) * c + ch] = (float)((double)r * g2[g] / cnt);
-    }
-}
-
-// dbeta[c] = sum_n s1[n,c], dgamma[c] = sum_n s2[n,c]: grid (C/64, 2), 64 columns x 16 batch lanes (fixed order)
-__global__ void gn_bwd_param_kernel(const float* __restrict__ sums, int batch, int c, float* __restrict__ dgamma,
-                                    float* __restrict__ dbeta) {
-    __shared__ double red[16][64];
-    const int which = blockIdx.y;
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int lane = threadIdx.x >> 6;
-    double acc = 0.0;
-    if (col < c)
-        for (int n = lane; n < batch; n += 16) acc += (double)sums[((long long)n * 2 + which) * c + col];
-    red[lane][threadIdx.x & 63] = acc;
-    __syncthreads();
-    if (lane == 0 && col < c) {
-        double t = 0.0;
-#pragma unroll
-        for (int l = 0; l < 16; ++l) t += red[l][threadIdx.x];
-        (which ? dgamma : dbeta)[col] = (float)t;
     }
 }
 
@@ -357,18 +383,15 @@ extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float
     char* ws = reinterpret_cast<char*>(workspace);
     float* part = reinterpret_cast<float*>(ws);
     ws += align256((size_t)batch * m.chunks * 2 * c * sizeof(float));
-    float* sums = reinterpret_cast<float*>(ws);
-    ws += align256((size_t)batch * 2 * c * sizeof(float));
+    ws += align256((size_t)batch * 2 * c * sizeof(float));      // (formerly the per-image sums; the size query is unchanged)
     float* coef = reinterpret_cast<float*>(ws);
     const size_t lds = (size_t)m.pl * m.cq * 8 * sizeof(float);
     hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(m.chunks, batch), dim3(m.threads), lds, stream, dy, x, mean, rstd,
                        gamma, beta, hw, c, groups, m.cq, m.pl, m.chunk_px, m.chunks, act, drop_p, seed, part);
     PSLD_CHECK_LAUNCH("gn_bwd_partial_kernel");
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(batch), dim3(256), 0, stream, part, rstd, gamma, hw, c, groups,
-                       m.chunks, sums, coef);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(batch + 2 * cdiv(c, 64)), dim3(1024), 0, stream, part, rstd, gamma,
+                       batch, hw, c, groups, m.chunks, coef, dgamma, dbeta);
     PSLD_CHECK_LAUNCH("gn_bwd_finalize_kernel");
-    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3(cdiv(c, 64), 2), dim3(1024), 0, stream, sums, batch, c, dgamma, dbeta);
-    PSLD_CHECK_LAUNCH("gn_bwd_param_kernel");
     const Map ma = make_map(batch, hw, c, true);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ma.chunks, batch), dim3(ma.threads), 0, stream, dy, x, mean, rstd,
                        gamma, beta, coef, hw, c, groups, ma.cq, ma.pl, ma.chunk_px, act, drop_p, seed, accumulate_dx, dx);
