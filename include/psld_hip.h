@@ -141,23 +141,25 @@ int psld_gemm_split_f32(const float* a1, int k1, const float* a2, int k2, int m,
 /* Weight gradient of the same convolution, same slab contract as psld_conv2d_wgrad_nhwc_f32 (kh = kw = 3,
  * stride = pad = 1): slabs[s][cout][9][cin_total] restricted to columns [col0, col0 + cin), one slab per K range
  * of ceil(batch*h*w/32 / nsplit) 32-pixel tiles (every slab must be non-empty); the caller reduces
- * (psld_reduce_slabs_f32).  Shapes: cout, cin multiples of 64, w in {8,16,32,64}, h*w a multiple of 32. */
+ * (psld_reduce_slabs_f32).  x2 / cin2 (null / 0 for none): second source of a channel concatenation, filling columns
+ * [col0 + cin, col0 + cin + cin2).  Shapes: cout, cin, cin2 multiples of 64, w in {8,16,32,64}, h*w a multiple of 32. */
 int psld_conv3x3_wgrad_split_supported(int cout, int cin, int batch, int h, int w);
 /* Output channels per workgroup the kernel will use for this cout (64 or 128); a launch has
  * (cout / tile) * (cin / 64) * 3 * nsplit workgroups, 3 (tile 64) or 2 (tile 128) resident per CU: what the caller
  * needs to pick nsplit. */
 int psld_conv3x3_wgrad_split_cout_tile(int cout);
-int psld_conv3x3_wgrad_split_f32(const float* dy, int lddy, int cout, const float* x, int cin, int batch,
-                                 int h, int w, float* slabs, int cin_total, int col0, int nsplit,
-                                 hipStream_t stream);
+int psld_conv3x3_wgrad_split_f32(const float* dy, int lddy, int cout, const float* x, int cin,
+                                 const float* x2, int cin2, int batch, int h, int w, float* slabs,
+                                 int cin_total, int col0, int nsplit, hipStream_t stream);
 
 /* Pointwise weight gradient on the limb kernels: slabs[s][i][j] (row stride ldc) = sum over the s-th range of
  * ceil(k/32 / nsplit) 32-row tiles of a[p][i] * b[p][j]  (a: [k][m] rows of lda floats, b: [k][n] rows of ldb floats;
- * m, n multiples of 128, k of 32; every slab non-empty).  Replaces the dW of the 1x1 convolutions and NIN
+ * b2 / ldb2 / n2 (null / 0 / 0 for none): further columns [n, n + n2) of B from a second tensor (concatenation);
+ * m, n, n2 multiples of 128, k of 32; every slab non-empty).  Replaces the dW of the 1x1 convolutions and NIN
  * projections that autograd computes in the reference (layerspp.py:235,268-270 Conv_2; layers.py:531-540 NIN). */
 int psld_gemm_tn_split_supported(int m, int n, int k);
 int psld_gemm_tn_split_f32(int m, int n, int k, const float* a, int lda, const float* b, int ldb,
-                           float* slabs, int ldc, int nsplit, hipStream_t stream);
+                           const float* b2, int ldb2, int n2, float* slabs, int ldc, int nsplit, hipStream_t stream);
 
 /* Batched GEMM on the limb kernels with BOTH operands fp32 activations (split inside the kernel):
  * c[b][i][j] = alpha * sum_p A(i,p) B(p,j);  ta: a is stored [k][m] (else [m][k]); tb: b is stored [n][k] (else [k][n]);

@@ -86,9 +86,9 @@ SIGNATURES = {
     "psld_gemm_split_f32": (I, [P, I, P, I, I, P, I, P, I, EP, P, LL, P]),
     "psld_conv3x3_wgrad_split_supported": (I, [I, I, I, I, I]),
     "psld_conv3x3_wgrad_split_cout_tile": (I, [I]),
-    "psld_conv3x3_wgrad_split_f32": (I, [P, I, I, P, I, I, I, I, P, I, I, I, P]),
+    "psld_conv3x3_wgrad_split_f32": (I, [P, I, I, P, I, P, I, I, I, I, P, I, I, I, P]),
     "psld_gemm_tn_split_supported": (I, [I, I, I]),
-    "psld_gemm_tn_split_f32": (I, [I, I, I, P, I, P, I, P, I, I, P]),
+    "psld_gemm_tn_split_f32": (I, [I, I, I, P, I, P, I, P, I, I, P, I, I, P]),
     "psld_bgemm_split_supported": (I, [I, I, I, I, I]),
     "psld_bgemm_split_f32": (I, [I, I, I, I, I, P, I, LL, P, I, LL, P, I, LL, I, F, P]),
     "psld_reduce_slabs_f32": (I, [P, I, LL, P, I, I, I, I, F, P]),

@@ -369,6 +369,8 @@ struct DWgradArgs {
     int lddy;
     const float* x;
     int cin;                // channels of x (row stride)
+    const float* x2;        // second source of a channel concatenation (or null): c_in tiles beyond cin read it
+    int cin2;
     int B, H, W;
     int cout_tiles, cin_tiles;
     int ktiles, ktiles_per_split;
@@ -408,7 +410,12 @@ __global__ void __launch_bounds__(256, CB == 2 ? 3 : 2) dwgrad_kernel(const DWgr
     const int split = vid / (tiles * 3);
     const int rest = vid - split * tiles * 3;
     const int ky = rest / tiles, tile = rest - ky * tiles;
-    const int co0 = (tile / a.cin_tiles) * CO_T, ci0 = (tile % a.cin_tiles) * 64;
+    const int co0 = (tile / a.cin_tiles) * CO_T;
+    const int ci_out = (tile % a.cin_tiles) * 64;                // column of the slab
+    const bool second = ci_out >= a.cin;
+    const float* xsrc = second ? a.x2 : a.x;
+    const int xc = second ? a.cin2 : a.cin;                      // row stride of the source
+    const int ci0 = second ? ci_out - a.cin : ci_out;            // channel within the source
     const int kt_beg = split * a.ktiles_per_split;
     const int kt_end = min(a.ktiles, kt_beg + a.ktiles_per_split);
     const int HW = a.H * a.W;
@@ -441,7 +448,7 @@ __global__ void __launch_bounds__(256, CB == 2 ? 3 : 2) dwgrad_kernel(const DWgr
     for (int i = 0; i < WG_NB; ++i) {
         const int px = ra + 16 * i;
         const int hr = px / a.hw_w, hc = px - hr * a.hw_w;
-        xoff[i] = (unsigned)(((hr * a.W + hc) * a.cin + qa * 4) * 4);
+        xoff[i] = (unsigned)(((hr * a.W + hc) * xc + qa * 4) * 4);
         xrow[i] = hr < a.hrows ? hr : 31;
         xcol[i] = ((hc >= 1 && hc <= a.W) ? 1 : 0) | ((hc + 31 < a.W) ? 2 : 0);
     }
@@ -458,7 +465,7 @@ __global__ void __launch_bounds__(256, CB == 2 ? 3 : 2) dwgrad_kernel(const DWgr
         unsigned rowmask = 0;                       // bit r: staged row r lies inside the image
         for (int rr = 0; rr < a.hrows; ++rr) rowmask |= (iy0 + rr >= 0 && iy0 + rr < a.H) ? 1u << rr : 0u;
         const int colsel = ox0 >> 5;
-        const float* xb = a.x + ((long long)((img * a.H + iy0) * a.W + ox0 - 1) * a.cin + ci0);
+        const float* xb = xsrc + ((long long)((img * a.H + iy0) * a.W + ox0 - 1) * xc + ci0);
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, 0x7fffffff, 0x00020000);
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(a.dy + ((long long)p0 * a.lddy + co0)), 0, 0x7fffffff, 0x00020000);
@@ -537,7 +544,7 @@ __global__ void __launch_bounds__(256, CB == 2 ? 3 : 2) dwgrad_kernel(const DWgr
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int co = co0 + wr * 16 * CB + cb * 16 + 4 * g + v;
-                    S[((long long)co * 9 + ky * 3 + tx) * a.ld_tap + ci0 + wc * 32 + nb * 16 + i16] = acc[tx][cb][nb][v];
+                    S[((long long)co * 9 + ky * 3 + tx) * a.ld_tap + ci_out + wc * 32 + nb * 16 + i16] = acc[tx][cb][nb][v];
                 }
 }
 
@@ -551,6 +558,8 @@ struct PWgradArgs {
     int lda;
     const float* b;
     int ldb;
+    const float* b2;        // second source of a column concatenation of B (or null): columns >= n1 read it
+    int ldb2, n1;
     int tiles_i, tiles_j;
     int ktiles, ktiles_per_split;
     float* slabs;
@@ -572,6 +581,10 @@ __global__ void __launch_bounds__(256, 2) pwgrad_kernel(const PWgradArgs a) {
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
     const int split = vid / tiles, tile = vid - split * tiles;
     const int i0 = (tile / a.tiles_j) * 128, j0 = (tile % a.tiles_j) * 128;
+    const bool second = j0 >= a.n1;
+    const float* bsrc = second ? a.b2 : a.b;
+    const int ldb = second ? a.ldb2 : a.ldb;
+    const int jb = second ? j0 - a.n1 : j0;
     const int kt_beg = split * a.ktiles_per_split;
     const int kt_end = min(a.ktiles, kt_beg + a.ktiles_per_split);
 
@@ -590,7 +603,7 @@ __global__ void __launch_bounds__(256, 2) pwgrad_kernel(const PWgradArgs a) {
     for (int i = 0; i < 4; ++i) {
         const int r = ra + 16 * (i & 1), c = qa + 16 * (i >> 1);
         aoff[i] = (unsigned)((r * a.lda + c * 4) * 4);
-        boff[i] = (unsigned)((r * a.ldb + c * 4) * 4);
+        boff[i] = (unsigned)((r * ldb + c * 4) * 4);
         soff[i] = r * RS + c * 8;
     }
     f32x4 va[4], vb[4];
@@ -598,7 +611,7 @@ __global__ void __launch_bounds__(256, 2) pwgrad_kernel(const PWgradArgs a) {
         const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(a.a + ((long long)kt * 32 * a.lda + i0)), 0, 0x7fffffff, 0x00020000);
         const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(a.b + ((long long)kt * 32 * a.ldb + j0)), 0, 0x7fffffff, 0x00020000);
+            const_cast<float*>(bsrc + ((long long)kt * 32 * ldb + jb)), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int i = 0; i < 4; ++i) va[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rA, aoff[i], 0, 0));
 #pragma unroll
@@ -1000,18 +1013,20 @@ extern "C" int psld_conv3x3_wgrad_split_cout_tile(int cout) {
     return 128;
 }
 
-extern "C" int psld_conv3x3_wgrad_split_f32(const float* dy, int lddy, int cout, const float* x, int cin, int batch,
-                                            int h, int w, float* slabs, int cin_total, int col0, int nsplit,
-                                            hipStream_t stream) {
-    PSLD_CHECK_ARG(dy && x && slabs && nsplit >= 1, "psld_conv3x3_wgrad_split_f32: bad args");
-    PSLD_CHECK_ARG(psld_conv3x3_wgrad_split_supported(cout, cin, batch, h, w),
-                   "psld_conv3x3_wgrad_split_f32: unsupported shape cout=%d cin=%d %dx%d", cout, cin, h, w);
-    PSLD_CHECK_ARG(aligned16(dy) && aligned16(x) && lddy % 4 == 0, "psld_conv3x3_wgrad_split_f32: unaligned operand");
+extern "C" int psld_conv3x3_wgrad_split_f32(const float* dy, int lddy, int cout, const float* x, int cin,
+                                            const float* x2, int cin2, int batch, int h, int w, float* slabs,
+                                            int cin_total, int col0, int nsplit, hipStream_t stream) {
+    PSLD_CHECK_ARG(dy && x && slabs && nsplit >= 1 && cin2 >= 0 && (cin2 == 0 || x2), "psld_conv3x3_wgrad_split_f32: bad args");
+    PSLD_CHECK_ARG(psld_conv3x3_wgrad_split_supported(cout, cin, batch, h, w) &&
+                       (cin2 == 0 || psld_conv3x3_wgrad_split_supported(cout, cin2, batch, h, w)),
+                   "psld_conv3x3_wgrad_split_f32: unsupported shape cout=%d cin=%d+%d %dx%d", cout, cin, cin2, h, w);
+    PSLD_CHECK_ARG(aligned16(dy) && aligned16(x) && (cin2 == 0 || aligned16(x2)) && lddy % 4 == 0,
+                   "psld_conv3x3_wgrad_split_f32: unaligned operand");
     DWgradArgs a{};
-    a.dy = dy; a.lddy = lddy; a.x = x; a.cin = cin;
+    a.dy = dy; a.lddy = lddy; a.x = x; a.cin = cin; a.x2 = x2; a.cin2 = cin2;
     a.B = batch; a.H = h; a.W = w;
     const int co_tile = psld_conv3x3_wgrad_split_cout_tile(cout);
-    a.cout_tiles = cout / co_tile; a.cin_tiles = cin / 64;
+    a.cout_tiles = cout / co_tile; a.cin_tiles = (cin + cin2) / 64;
     a.ktiles = batch * h * w / 32;
     a.ktiles_per_split = cdiv(a.ktiles, nsplit);
     PSLD_CHECK_ARG(cdiv(a.ktiles, a.ktiles_per_split) == nsplit, "psld_conv3x3_wgrad_split_f32: nsplit %d leaves empty slabs", nsplit);
@@ -1029,13 +1044,17 @@ extern "C" int psld_gemm_tn_split_supported(int m, int n, int k) {
 }
 
 extern "C" int psld_gemm_tn_split_f32(int m, int n, int k, const float* a, int lda, const float* b, int ldb,
-                                      float* slabs, int ldc, int nsplit, hipStream_t stream) {
-    PSLD_CHECK_ARG(a && b && slabs && nsplit >= 1, "psld_gemm_tn_split_f32: bad args");
-    PSLD_CHECK_ARG(psld_gemm_tn_split_supported(m, n, k), "psld_gemm_tn_split_f32: unsupported shape m=%d n=%d k=%d", m, n, k);
-    PSLD_CHECK_ARG(aligned16(a) && aligned16(b) && lda % 4 == 0 && ldb % 4 == 0 && lda >= m && ldb >= n && ldc >= n,
+                                      const float* b2, int ldb2, int n2, float* slabs, int ldc, int nsplit,
+                                      hipStream_t stream) {
+    PSLD_CHECK_ARG(a && b && slabs && nsplit >= 1 && n2 >= 0 && (n2 == 0 || b2), "psld_gemm_tn_split_f32: bad args");
+    PSLD_CHECK_ARG(psld_gemm_tn_split_supported(m, n, k) && n2 % 128 == 0,
+                   "psld_gemm_tn_split_f32: unsupported shape m=%d n=%d+%d k=%d", m, n, n2, k);
+    PSLD_CHECK_ARG(aligned16(a) && aligned16(b) && lda % 4 == 0 && ldb % 4 == 0 && lda >= m && ldb >= n && ldc >= n + n2 &&
+                       (n2 == 0 || (aligned16(b2) && ldb2 % 4 == 0 && ldb2 >= n2)),
                    "psld_gemm_tn_split_f32: unaligned operand or short row stride");
     PWgradArgs p{};
-    p.a = a; p.lda = lda; p.b = b; p.ldb = ldb;
+    p.a = a; p.lda = lda; p.b = b; p.ldb = ldb; p.b2 = b2; p.ldb2 = ldb2; p.n1 = n;
+    n += n2;
     p.tiles_i = m / 128; p.tiles_j = n / 128;
     p.ktiles = k / 32;
     p.ktiles_per_split = cdiv(p.ktiles, nsplit);

@@ -202,10 +202,12 @@ def gemm_tn_split_supported(m: int, n: int, k: int) -> bool:
     return bool(lib().psld_gemm_tn_split_supported(m, n, k))
 
 
-def gemm_tn_split(M: int, N: int, K: int, A: Tensor, lda: int, B: Tensor, ldb: int, slabs: Tensor, ldc: int, nsplit: int):
-    """slabs[s][M][ldc] = per-K-range partial sums of A^T B on the bf16 limb kernel (A: [K][M] rows of lda, B: [K][N] rows of ldb)."""
-    check(lib().psld_gemm_tn_split_f32(M, N, K, A.data_ptr(), lda, B.data_ptr(), ldb, slabs.data_ptr(), ldc, nsplit,
-                                       _stream()), "psld_gemm_tn_split_f32")
+def gemm_tn_split(M: int, N: int, K: int, A: Tensor, lda: int, B: Tensor, ldb: int, slabs: Tensor, ldc: int, nsplit: int,
+                  B2: Optional[Tensor] = None, ldb2: int = 0, N2: int = 0):
+    """slabs[s][M][ldc] = per-K-range partial sums of A^T [B | B2] on the bf16 limb kernel (A: [K][M] rows of lda,
+    B: [K][N] rows of ldb, optional B2: [K][N2] rows of ldb2 filling columns N .. N+N2)."""
+    check(lib().psld_gemm_tn_split_f32(M, N, K, A.data_ptr(), lda, B.data_ptr(), ldb, _p(B2), ldb2, N2, slabs.data_ptr(),
+                                       ldc, nsplit, _stream()), "psld_gemm_tn_split_f32")
 
 
 def bgemm_split_supported(ta: int, tb: int, m: int, n: int, k: int) -> bool:
@@ -223,10 +225,13 @@ def conv3x3_wgrad_split_cout_tile(cout: int) -> int:
     return lib().psld_conv3x3_wgrad_split_cout_tile(cout)
 
 
-def conv3x3_wgrad_split(dy: Tensor, cout: int, x: Tensor, slabs: Tensor, cin_total: int, col0: int, nsplit: int):
+def conv3x3_wgrad_split(dy: Tensor, cout: int, x: Tensor, slabs: Tensor, cin_total: int, col0: int, nsplit: int,
+                        x2: Optional[Tensor] = None):
     b, h, w, cin = x.shape
-    check(lib().psld_conv3x3_wgrad_split_f32(dy.data_ptr(), cout, cout, x.data_ptr(), cin, b, h, w, slabs.data_ptr(),
-                                             cin_total, col0, nsplit, _stream()), "psld_conv3x3_wgrad_split_f32")
+    cin2 = x2.shape[-1] if x2 is not None else 0
+    check(lib().psld_conv3x3_wgrad_split_f32(dy.data_ptr(), cout, cout, x.data_ptr(), cin, _p(x2), cin2, b, h, w,
+                                             slabs.data_ptr(), cin_total, col0, nsplit, _stream()),
+          "psld_conv3x3_wgrad_split_f32")
 
 
 def conv2d_wgrad_nhwc(dy: Tensor, cout: int, x: Tensor, kh: int, kw: int, stride: int, pad: int, oh: int, ow: int,
@@ -299,9 +304,10 @@ def gn_groups(c: int) -> int:
     return min(c // 4, 32)
 
 
-def gn_stats(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-6) -> GNStats:
+def gn_stats(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-6, groups: Optional[int] = None) -> GNStats:
+    """``groups``: override for a tensor that is one source of a concatenation (its share of the groups)."""
     b, h, w, c = x.shape
-    g = gn_groups(c)
+    g = groups if groups is not None else gn_groups(c)
     st = GNStats(b, g, c, x.device)
     ws = workspace(lib().psld_gn_workspace_bytes(b, h * w, c, g), x.device)
     check(lib().psld_gn_stats_nhwc_f32(x.data_ptr(), b, h * w, c, g, eps, gamma.data_ptr(), beta.data_ptr(),
@@ -321,9 +327,9 @@ def gn_apply(x: Tensor, st: GNStats, act: bool, out: Optional[Tensor] = None, dr
 
 
 def gn_bwd(dy: Tensor, x: Tensor, st: GNStats, gamma: Tensor, beta: Tensor, act: bool, dx: Tensor, dgamma: Tensor,
-           dbeta: Tensor, accumulate_dx: bool = False, drop_p: float = 0.0, seed: int = 0):
+           dbeta: Tensor, accumulate_dx: bool = False, drop_p: float = 0.0, seed: int = 0, groups: Optional[int] = None):
     b, h, w, c = x.shape
-    g = gn_groups(c)
+    g = groups if groups is not None else gn_groups(c)
     ws = workspace(lib().psld_gn_workspace_bytes(b, h * w, c, g), x.device)
     check(lib().psld_gn_bwd_nhwc_f32(dy.data_ptr(), x.data_ptr(), st.mean.data_ptr(), st.rstd.data_ptr(),
                                      gamma.data_ptr(), beta.data_ptr(), b, h * w, c, g, 1 if act else 0,

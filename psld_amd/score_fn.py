@@ -148,6 +148,17 @@ class _Node:
         self.g = None
 
 
+class _CatNode:
+    """torch.cat([a, b], dim=channels) that is never materialised: the consuming residual block reads both sources
+    (two-source convolution kernels, per-source GroupNorm over each source's share of the groups) and writes the
+    gradients straight into the sources' buffers."""
+    __slots__ = ("a", "b")
+
+    def __init__(self, a: _Node, b: _Node):
+        self.a = a
+        self.b = b
+
+
 def _gbuf(node: _Node):
     """Gradient buffer of a node and whether it already holds a partial sum."""
     if node.g is None:
@@ -234,15 +245,21 @@ class _Exec:
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
 
-    def wgrad(self, dy: Tensor, x: Tensor, conv: _Affine, k: int, stride: int, pad: int, alpha: float = 1.0):
+    def wgrad(self, dy: Tensor, x: Tensor, conv: _Affine, k: int, stride: int, pad: int, alpha: float = 1.0,
+              x2: Optional[Tensor] = None):
         """dW (OIHW, scaled by alpha) of ``conv`` from the output gradient and the conv's input: split-K partial
-        slabs in the stream's workspace, then one deterministic reduction straight into the flat gradient."""
+        slabs in the stream's workspace, then one deterministic reduction straight into the flat gradient.
+        ``x2``: second source when the input is an unmaterialised concatenation (limb kernels only)."""
         b, oh, ow, cout = dy.shape
-        cin = x.shape[-1]
+        c1 = x.shape[-1]
+        c2 = x2.shape[-1] if x2 is not None else 0
+        cin = c1 + c2
         taps = k * k
         n = cout * taps * cin
+        assert x2 is None or self.split, "two-source weight gradients exist on the limb kernels only"
         if self.split and k == 3 and stride == 1 and pad == 1 and \
-                ops.conv3x3_wgrad_split_supported(cout, cin, b, oh, ow):
+                ops.conv3x3_wgrad_split_supported(cout, c1, b, oh, ow) and \
+                (x2 is None or ops.conv3x3_wgrad_split_supported(cout, c2, b, oh, ow)):
             ktiles = b * oh * ow // 32
             # 64x64 tiles x 3 filter rows, 3 workgroups (46 KB LDS) resident per CU
             co_tile = ops.conv3x3_wgrad_split_cout_tile(cout)
@@ -251,15 +268,17 @@ class _Exec:
             per = -(-ktiles // nsplit)
             nsplit = -(-ktiles // per)                 # every slab non-empty
             slabs = ops.workspace(4 * n * nsplit, dy.device)
-            ops.conv3x3_wgrad_split(dy, cout, x, slabs, cin, 0, nsplit)
+            ops.conv3x3_wgrad_split(dy, cout, x, slabs, cin, 0, nsplit, x2)
             ops.reduce_slabs(slabs, nsplit, n, self.g(conv.weight), layout=1, cout=cout, taps=taps, cin=cin, alpha=alpha)
             return
-        if self.split and k == 1 and stride == 1 and pad == 0 and ops.gemm_tn_split_supported(cout, cin, b * oh * ow):
+        if self.split and k == 1 and stride == 1 and pad == 0 and ops.gemm_tn_split_supported(cout, c1, b * oh * ow) and \
+                c2 % 128 == 0:
             nsplit = self._tn_split(cout, cin, b * oh * ow)
             slabs = ops.workspace(4 * n * nsplit, dy.device)
-            ops.gemm_tn_split(cout, cin, b * oh * ow, dy, cout, x, cin, slabs, cin, nsplit)
+            ops.gemm_tn_split(cout, c1, b * oh * ow, dy, cout, x, c1, slabs, cin, nsplit, x2, c2, c2)
             ops.reduce_slabs(slabs, nsplit, n, self.g(conv.weight), alpha=alpha)
             return
+        assert x2 is None, "unsupported two-source weight gradient"
         tiles = ((cout + 127) // 128) * ((cin + 127) // 128) * taps
         nsplit = _pick_nsplit(tiles, b * oh * ow)
         slabs = ops.workspace(4 * n * nsplit, dy.device)
@@ -302,14 +321,15 @@ class _Exec:
         ops.colsum(tmp, c, 1, b, c, out, alpha)
         return tmp
 
-    def conv3(self, x: Tensor, conv: _Affine, out: Tensor, epi):
-        """3x3 stride-1 pad-1 convolution of an NHWC tensor."""
+    def conv3(self, x: Tensor, conv: _Affine, out: Tensor, epi, x2: Optional[Tensor] = None):
+        """3x3 stride-1 pad-1 convolution of an NHWC tensor (or of the channel concatenation of x and x2)."""
         b, h, w, c = x.shape
+        c2 = x2.shape[-1] if x2 is not None else 0
         cout = conv.weight.shape[0]
-        if self.split and ops.conv3x3_split_supported(c, 0, b, h, w, cout):
-            ops.conv3x3_split(x, None, self.net._frag(conv, False), cout, out, epi)
+        if self.split and ops.conv3x3_split_supported(c, c2, b, h, w, cout):
+            ops.conv3x3_split(x, x2, self.net._frag(conv, False), cout, out, epi)
         else:
-            ops.conv2d_nhwc(x, None, self.net._packed(conv), cout, 3, 3, 1, 1, 1, h, w, out, epi)
+            ops.conv2d_nhwc(x, x2, self.net._packed(conv), cout, 3, 3, 1, 1, 1, h, w, out, epi)
 
     # -- few-channel 3x3 convolutions (6-channel stem / first pyramid level in, 6-channel head out) as K = 64 GEMMs ----
     # K = 9*6 = 54 does not fit the tile engine's 32-channel chunking, so these convolutions used its scalar-gather
@@ -446,13 +466,28 @@ class _Exec:
         return i + 2
 
     # -- ResnetBlockBigGANpp.forward (layerspp.py:242-274) -------------------------------------------
-    def resblock(self, x: _Node, mod: ResnetBlockBigGANpp) -> _Node:
+    def resblock(self, x, mod: ResnetBlockBigGANpp) -> _Node:
+        """``x``: a node, or a _CatNode (see concat): then every consumer below reads the two sources side by side."""
         net, s = self.net, self.s
-        b, h, w, cin = x.v.shape
+        gn0, gn1 = mod.GroupNorm_0, mod.GroupNorm_1
+        xb: Optional[_Node] = None
+        if isinstance(x, _CatNode):
+            x, xb = x.a, x.b
+        b, h, w, c1 = x.v.shape
+        cin = c1 + (xb.v.shape[-1] if xb is not None else 0)
         cout = mod.out_ch
         up, down = mod.up, mod.down
-        gn0, gn1 = mod.GroupNorm_0, mod.GroupNorm_1
-        st0 = ops.gn_stats(x.v, gn0.weight, gn0.bias)
+        a0b, st0b, g1, g2 = None, None, None, None
+        if xb is None:
+            st0 = ops.gn_stats(x.v, gn0.weight, gn0.bias)
+        else:
+            # GroupNorm over the concatenation = each source normalised over its own share of the groups
+            cpg = cin // ops.gn_groups(cin)
+            g1, g2 = c1 // cpg, (cin - c1) // cpg
+            gam, bet = gn0.weight.detach(), gn0.bias.detach()
+            st0 = ops.gn_stats(x.v, gam[:c1], bet[:c1], groups=g1)
+            st0b = ops.gn_stats(xb.v, gam[c1:], bet[c1:], groups=g2)
+            a0b = ops.gn_apply(xb.v, st0b, True)
         a0 = ops.gn_apply(x.v, st0, True)
         if up or down:
             a0r = self.resample(a0, up)
@@ -470,7 +505,7 @@ class _Exec:
                 tp = ops.linear(self.temb_act.v, mod.Dense_0.weight, mod.Dense_0.bias)
         h1 = torch.empty((b, ho, wo, cout), device=x.v.device, dtype=torch.float32)
         self.conv3(a0r, mod.Conv_0, h1, ops.epilogue(bias=mod.Conv_0.bias, rowbias=tp, rows_per_img=ho * wo,
-                                                     ld_rowbias=tp_ld))
+                                                     ld_rowbias=tp_ld), x2=a0b)
         st1 = ops.gn_stats(h1, gn1.weight, gn1.bias)
         drop_p, seed = 0.0, 0
         if self.drop_p > 0:
@@ -481,11 +516,12 @@ class _Exec:
         out = torch.empty((b, ho, wo, cout), device=x.v.device, dtype=torch.float32)
         if mod.has_shortcut:
             c2 = mod.Conv_2
-            if self.split and ops.gemm_split_supported(cin, 0, b * ho * wo, cout):
+            if self.split and ops.gemm_split_supported(c1, cin - c1, b * ho * wo, cout):
                 fr = net._pfrag(c2.weight, "fwd", cout, cin, cin, 1)
-                ops.gemm_split(xr, None, b * ho * wo, fr, cout, out, ops.epilogue(bias=c2.bias))
+                ops.gemm_split(xr, xb.v if xb is not None else None, b * ho * wo, fr, cout, out, ops.epilogue(bias=c2.bias))
             else:
-                ops.conv2d_nhwc(xr, None, c2.weight, cout, 1, 1, 1, 0, 1, ho, wo, out, ops.epilogue(bias=c2.bias))
+                ops.conv2d_nhwc(xr, xb.v if xb is not None else None, c2.weight, cout, 1, 1, 1, 0, 1, ho, wo, out,
+                                ops.epilogue(bias=c2.bias))
             res = out
         else:
             res = xr
@@ -496,6 +532,7 @@ class _Exec:
         temb_act = self.temb_act
         dtp_all = self.dtp_all
         xr_saved = xr if mod.has_shortcut else None
+        xb_v = xb.v if xb is not None else None
 
         def bwd():
             dout = on.g
@@ -505,10 +542,10 @@ class _Exec:
                 self.wgrad(dout, a1, mod.Conv_1, 3, 1, 1, alpha=s)
                 self.bias_grad(dout, self.g(mod.Conv_1.bias), alpha=s)
                 if mod.has_shortcut:
-                    self.wgrad(dout, xr_saved, mod.Conv_2, 1, 1, 0, alpha=s)
+                    self.wgrad(dout, xr_saved, mod.Conv_2, 1, 1, 0, alpha=s, x2=xb_v)
                     self.bias_grad(dout, self.g(mod.Conv_2.bias), alpha=s)
 
-            self.on_side(side1, dout, a1, xr_saved)
+            self.on_side(side1, dout, a1, xr_saved, xb_v)
             da1 = torch.empty_like(a1)
             self.dgrad(dout, mod.Conv_1, 3, 1, 1, ho, wo, da1, alpha=s)
             dh1 = torch.empty_like(h1)
@@ -518,7 +555,7 @@ class _Exec:
 
             # Conv_0 + time-embedding bias
             def side0():
-                self.wgrad(dh1, a0r, mod.Conv_0, 3, 1, 1)
+                self.wgrad(dh1, a0r, mod.Conv_0, 3, 1, 1, x2=a0b)
                 if temb_act is None:
                     self.bias_grad(dh1, self.g(mod.Conv_0.bias))
                     return
@@ -540,7 +577,10 @@ class _Exec:
                 # d Dense_0.bias = sum over the batch of dtp = the conv bias gradient just computed
                 ops.axpby(self.g(mod.Conv_0.bias), 1.0, None, 0.0, self.g(d0.bias))
 
-            self.on_side(side0, dh1, a0r)
+            self.on_side(side0, dh1, a0r, a0b)
+            if xb is not None:
+                self._resblock_cat_bwd(mod, x, xb, dout, dh1, st0, st0b, g1, g2)
+                return
             da0r = torch.empty_like(a0r)
             self.dgrad(dh1, mod.Conv_0, 3, 1, 1, ho, wo, da0r)
             del dh1
@@ -574,6 +614,32 @@ class _Exec:
 
         self.push(bwd, mod)
         return on
+
+    def _resblock_cat_bwd(self, mod, xa: _Node, xb: _Node, dout: Tensor, dh1: Tensor, sta, stb, g1: int, g2: int):
+        """Input side of the backward of a residual block fed by an unmaterialised concatenation: the data gradients
+        of Conv_0 and of the 1x1 shortcut are computed per source (the fragments of a data gradient are ordered by
+        output-channel tile, so each source's share is a contiguous slice) and GroupNorm_0's backward runs per source
+        over its groups; everything accumulates straight into the two sources' gradient buffers."""
+        net, s = self.net, self.s
+        gn0, c2 = mod.GroupNorm_0, mod.Conv_2
+        b, h, w, cout = dout.shape
+        m = b * h * w
+        c1 = xa.v.shape[-1]
+        cin = c1 + xb.v.shape[-1]
+        f3 = net._frag(mod.Conv_0, True)                        # [cin/128 tiles][...]: data gradient of the 3x3
+        f1 = net._pfrag(c2.weight, "dgrad", cin, cout, 1, cin)  # same for the shortcut
+        cut3, cut1 = f3.numel() * c1 // cin, f1.numel() * c1 // cin
+        gam, bet = gn0.weight.detach(), gn0.bias.detach()
+        dgam, dbet = self.g(gn0.weight), self.g(gn0.bias)
+        for node, lo, hi, fr3, fr1, st, g in ((xa, 0, c1, f3[:cut3], f1[:cut1], sta, g1),
+                                             (xb, c1, cin, f3[cut3:], f1[cut1:], stb, g2)):
+            c = hi - lo
+            xg, acc = _gbuf(node)
+            ops.gemm_split(dout, None, m, fr1, c, xg, ops.epilogue(alpha=s, accumulate=acc))
+            da0 = torch.empty_like(node.v)
+            ops.conv3x3_split(dh1, None, fr3, c, da0)
+            ops.gn_bwd(da0, node.v, st, gam[lo:hi], bet[lo:hi], True, xg, dgam[lo:hi], dbet[lo:hi], accumulate_dx=True,
+                       groups=g)
 
     # -- AttnBlockpp.forward (layerspp.py:75-91) -----------------------------------------------------
     def attn(self, x: _Node, mod: AttnBlockpp) -> _Node:
@@ -743,8 +809,27 @@ class _Exec:
         self.push(bwd, mod)
         return on
 
-    def concat(self, a: _Node, bnode: _Node) -> _Node:
-        """torch.cat([h, hs.pop()], dim=1) (ncsnpp.py:374) in NHWC."""
+    def _cat_ok(self, a: _Node, bnode: _Node, mod) -> bool:
+        """Can ``mod`` (a residual block) consume the concatenation of a and b without it being materialised?"""
+        if not (self.split and isinstance(mod, ResnetBlockBigGANpp)) or mod.up or mod.down or not mod.has_shortcut:
+            return False
+        b, h, w, c1 = a.v.shape
+        c2 = bnode.v.shape[-1]
+        cout, m = mod.out_ch, b * h * w
+        cpg = (c1 + c2) // ops.gn_groups(c1 + c2)
+        if c1 % 128 or c2 % 128 or c1 % cpg or c2 % cpg or (c1 // 4) > 256 or (c2 // 4) > 256:
+            return False
+        ok = ops.conv3x3_split_supported(c1, c2, b, h, w, cout) and ops.gemm_split_supported(c1, c2, m, cout)
+        if self.record:
+            ok = ok and all(ops.conv3x3_split_supported(cout, 0, b, h, w, c) and ops.gemm_split_supported(cout, 0, m, c) and
+                            ops.conv3x3_wgrad_split_supported(cout, c, b, h, w) for c in (c1, c2)) and \
+                ops.gemm_tn_split_supported(cout, c1, m)
+        return ok
+
+    def concat(self, a: _Node, bnode: _Node, consumer=None):
+        """torch.cat([h, hs.pop()], dim=1) (ncsnpp.py:374) in NHWC; not materialised when ``consumer`` reads two sources."""
+        if consumer is not None and self._cat_ok(a, bnode, consumer):
+            return _CatNode(a, bnode)
         b, h, w, c1 = a.v.shape
         c2 = bnode.v.shape[-1]
         rows = b * h * w
@@ -839,7 +924,7 @@ class _Exec:
             return self.clf_head(hnode, mods[mi])
         for lvl in reversed(range(net.num_resolutions)):
             for _ in range(net.num_res_blocks + 1):
-                hnode = self.resblock(self.concat(hnode, hs.pop()), mods[mi])
+                hnode = self.resblock(self.concat(hnode, hs.pop(), mods[mi]), mods[mi])
                 mi += 1
             if hnode.v.shape[2] in net.attn_resolutions:
                 hnode = self.attn(hnode, mods[mi])

@@ -242,6 +242,31 @@ def test_conv3x3_split_dgrad_and_wgrad(ops, cfg):
     assert torch.count_nonzero(slabs[:, :, :, :col0]) == 0
 
 
+def test_two_source_weight_gradients(ops):
+    """dwgrad / pwgrad reading the input of the convolution from two tensors (unmaterialised concatenation)."""
+    b, c1, c2, co, h, w_ = 2, 128, 256, 128, 16, 16
+    x = gen(b, c1 + c2, h, w_, seed=80)
+    gy = gen(b, co, h, w_, seed=81)
+    xh = _nhwc(x)
+    x1, x2 = xh[..., :c1].contiguous().to(DEV), xh[..., c1:].contiguous().to(DEV)
+    gyd = _nhwc(gy).to(DEV)
+    # 3x3
+    wt = torch.zeros(co, c1 + c2, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wt, padding=1).backward(gy.double())
+    ktiles = b * h * w_ // 32
+    nsplit = 4
+    slabs = torch.full((nsplit, co, 9, c1 + c2), float("nan"), device=DEV)
+    ops.conv3x3_wgrad_split(gyd, co, x1, slabs, c1 + c2, 0, nsplit, x2)
+    dw = slabs.sum(0).reshape(co, 3, 3, c1 + c2).permute(0, 3, 1, 2)
+    assert rel_l2(dw, wt.grad) < 3e-6
+    # 1x1
+    m = b * h * w_
+    ref = gyd.view(m, co).double().t().cpu() @ xh.reshape(m, c1 + c2).double()
+    slabs = torch.full((nsplit, co, c1 + c2), float("nan"), device=DEV)
+    ops.gemm_tn_split(co, c1, m, gyd, co, x1, c1, slabs, c1 + c2, nsplit, x2, c2, c2)
+    assert rel_l2(slabs.sum(0), ref) < 3e-6
+
+
 @pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0)])
 @pytest.mark.parametrize("m,n,k,batch,pad", [(128, 128, 32, 1, 0), (256, 128, 96, 3, 0), (256, 256, 256, 5, 64)])
 def test_bgemm_split(ops, ta, tb, m, n, k, batch, pad):
