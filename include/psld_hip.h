@@ -208,12 +208,14 @@ int psld_gn_stats_nhwc_f32(const float* x, int batch, int hw, int c, int groups,
 int psld_gn_apply_nhwc_f32(const float* x, const float* scale, const float* shift, float* y,
                            int batch, int hw, int c, int act, float drop_p, unsigned long long seed,
                            hipStream_t stream);
-/* Backward of y = act(GN(x)): dx, dgamma[C], dbeta[C] (written, not accumulated). */
+/* Backward of y = act(GN(x)): dgamma[C], dbeta[C] (written, not accumulated) and
+ * dx = d/dx (+ add_scale * add when add != NULL: the gradient of an identity branch parallel to the normalisation,
+ * e.g. the residual `(x + h) / sqrt(2)` of layerspp.py:271-274) (+ the previous dx when accumulate_dx). */
 int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float* mean, const float* rstd,
                          const float* gamma, const float* beta, int batch, int hw, int c, int groups,
                          int act, float drop_p, unsigned long long seed,
                          float* dx, float* dgamma, float* dbeta, int accumulate_dx,
-                         void* workspace, hipStream_t stream);
+                         const float* add, float add_scale, void* workspace, hipStream_t stream);
 
 /* ---- FIR resampling: the replacement of the pybind op upfirdn2d_op.upfirdn2d
  *      (op/upfirdn2d.cpp:12-22, op/upfirdn2d_kernel.cu:209-369).  Same semantics: zero-insert

@@ -286,7 +286,7 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                     const float* __restrict__ coef, int hw, int c, int groups, int cq, int pl,
                                     int chunk_px, int act, float drop_p, unsigned long long seed, int accumulate,
-                                    float* __restrict__ dx) {
+                                    const float* __restrict__ add, float add_scale, float* __restrict__ dx) {
     const int n = blockIdx.y, chunk = blockIdx.x;
     const int q = threadIdx.x % cq, l = threadIdx.x / cq;
     const int p0 = chunk * chunk_px, p1 = min(hw, p0 + chunk_px);
@@ -321,6 +321,11 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
             o[e] = c0[e] * dz - c1[e] - xh * c2[e];
         }
         float* dp = dx + idx;
+        if (add) {                       // gradient of a parallel identity branch: dx += add_scale * add
+            const f32x4 av = *reinterpret_cast<const f32x4*>(add + idx);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += add_scale * av[e];
+        }
         if (accumulate) {
             const f32x4 old = *reinterpret_cast<const f32x4*>(dp);
             o += old;
@@ -374,7 +379,8 @@ extern "C" int psld_gn_apply_nhwc_f32(const float* x, const float* scale, const 
 extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float* mean, const float* rstd,
                                     const float* gamma, const float* beta, int batch, int hw, int c, int groups,
                                     int act, float drop_p, unsigned long long seed, float* dx, float* dgamma,
-                                    float* dbeta, int accumulate_dx, void* workspace, hipStream_t stream) {
+                                    float* dbeta, int accumulate_dx, const float* add, float add_scale,
+                                    void* workspace, hipStream_t stream) {
     PSLD_CHECK_ARG(dy && x && mean && rstd && gamma && beta && dx && dgamma && dbeta && workspace,
                    "psld_gn_bwd: null pointer");
     PSLD_CHECK_ARG(c % 4 == 0 && c / 4 <= MAXT && groups <= MAXG && c % groups == 0,
@@ -394,7 +400,8 @@ extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float
     PSLD_CHECK_LAUNCH("gn_bwd_finalize_kernel");
     const Map ma = make_map(batch, hw, c, true);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ma.chunks, batch), dim3(ma.threads), 0, stream, dy, x, mean, rstd,
-                       gamma, beta, coef, hw, c, groups, ma.cq, ma.pl, ma.chunk_px, act, drop_p, seed, accumulate_dx, dx);
+                       gamma, beta, coef, hw, c, groups, ma.cq, ma.pl, ma.chunk_px, act, drop_p, seed, accumulate_dx, add, add_scale,
+                       dx);
     PSLD_CHECK_LAUNCH("gn_bwd_apply_kernel");
     return PSLD_OK;
 }

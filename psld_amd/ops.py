@@ -327,14 +327,16 @@ def gn_apply(x: Tensor, st: GNStats, act: bool, out: Optional[Tensor] = None, dr
 
 
 def gn_bwd(dy: Tensor, x: Tensor, st: GNStats, gamma: Tensor, beta: Tensor, act: bool, dx: Tensor, dgamma: Tensor,
-           dbeta: Tensor, accumulate_dx: bool = False, drop_p: float = 0.0, seed: int = 0, groups: Optional[int] = None):
+           dbeta: Tensor, accumulate_dx: bool = False, drop_p: float = 0.0, seed: int = 0, groups: Optional[int] = None,
+           add: Optional[Tensor] = None, add_scale: float = 1.0):
+    """``add`` (same shape as x): dx additionally receives add_scale * add (gradient of a parallel identity branch)."""
     b, h, w, c = x.shape
     g = groups if groups is not None else gn_groups(c)
     ws = workspace(lib().psld_gn_workspace_bytes(b, h * w, c, g), x.device)
     check(lib().psld_gn_bwd_nhwc_f32(dy.data_ptr(), x.data_ptr(), st.mean.data_ptr(), st.rstd.data_ptr(),
                                      gamma.data_ptr(), beta.data_ptr(), b, h * w, c, g, 1 if act else 0,
                                      drop_p, seed, dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 1 if accumulate_dx else 0,
-                                     ws.data_ptr(), _stream()), "psld_gn_bwd_nhwc_f32")
+                                     _p(add), add_scale, ws.data_ptr(), _stream()), "psld_gn_bwd_nhwc_f32")
 
 
 # ------------------------------------------------------------------------------------------------

@@ -585,6 +585,7 @@ class _Exec:
             self.dgrad(dh1, mod.Conv_0, 3, 1, 1, ho, wo, da0r)
             del dh1
             xg, acc = _gbuf(x)
+            identity = False
             if mod.has_shortcut:
                 c2 = mod.Conv_2
                 m = b * ho * wo
@@ -603,14 +604,14 @@ class _Exec:
                 else:
                     shortcut_dgrad(xg, ops.epilogue(alpha=s, accumulate=acc))
             else:
-                ops.axpby(dout, s, None, 0.0, xg, accumulate=acc)
+                identity = True          # out = (x + h)/sqrt(2): the x branch's gradient s*dout rides on GroupNorm_0's backward
             if up or down:
                 da0 = torch.empty((b, h, w, cin), device=dout.device, dtype=torch.float32)
                 self.resample_bwd(da0r, up, (h, w), da0, False)
             else:
                 da0 = da0r
             ops.gn_bwd(da0, x.v, st0, gn0.weight, gn0.bias, True, xg, self.g(gn0.weight), self.g(gn0.bias),
-                       accumulate_dx=True)
+                       accumulate_dx=not identity or acc, add=dout if identity else None, add_scale=s)
 
         self.push(bwd, mod)
         return on
@@ -741,9 +742,8 @@ class _Exec:
                                  epi=None if first else ops.epilogue(accumulate=True))
                     first = False
             xg, acc = _gbuf(x)
-            ops.axpby(dout, s, None, 0.0, xg, accumulate=acc)
             ops.gn_bwd(dhn, x.v, st, gn.weight, gn.bias, False, xg, self.g(gn.weight), self.g(gn.bias),
-                       accumulate_dx=True)
+                       accumulate_dx=acc, add=dout, add_scale=s)
 
         self.push(bwd, mod)
         return on

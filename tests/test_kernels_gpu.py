@@ -449,6 +449,19 @@ def test_groupnorm_fwd_bwd(ops, b, c, s, act):
     ops.gn_bwd(_nhwc(gy).to(DEV), xd, st, gd, bd, act, dx, dg, db)
     assert rel_l2(dx.permute(0, 3, 1, 2), x.grad) < 1e-5
     assert rel_l2(dg, gamma.grad) < 1e-5 and rel_l2(db, beta.grad) < 1e-5
+    # identity branch folded in (dx = GN term + 0.5*add), on top of an existing gradient; per-source groups override
+    addt = gen(*x.shape, seed=44)
+    dx2 = dx.clone()
+    ops.gn_bwd(_nhwc(gy).to(DEV), xd, st, gd, bd, act, dx2, dg, db, accumulate_dx=True, add=_nhwc(addt).to(DEV), add_scale=0.5)
+    assert rel_l2(dx2.permute(0, 3, 1, 2), 2 * x.grad + 0.5 * addt.double()) < 1e-5
+    if g % 2 == 0 and (c // 2) % 4 == 0:
+        # GroupNorm of a concatenation = each half normalised over its half of the groups
+        h = c // 2
+        x1, x2 = xd[..., :h].contiguous(), xd[..., h:].contiguous()
+        st1 = ops.gn_stats(x1, gd[:h], bd[:h], groups=g // 2)
+        st2 = ops.gn_stats(x2, gd[h:], bd[h:], groups=g // 2)
+        ycat = torch.cat([ops.gn_apply(x1, st1, act), ops.gn_apply(x2, st2, act)], dim=-1)
+        assert rel_l2(ycat.permute(0, 3, 1, 2), y) < 2e-6
 
 
 # ---------------------------------------------------------------------------------------------------
