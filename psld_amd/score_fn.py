@@ -543,7 +543,8 @@ class _Exec:
                 self.bias_grad(dout, self.g(mod.Conv_1.bias), alpha=s)
                 if mod.has_shortcut:
                     self.wgrad(dout, xr_saved, mod.Conv_2, 1, 1, 0, alpha=s, x2=xb_v)
-                    self.bias_grad(dout, self.g(mod.Conv_2.bias), alpha=s)
+                    # Conv_2.bias sees the same output gradient as Conv_1.bias: copy the sum just computed
+                    ops.axpby(self.g(mod.Conv_1.bias), 1.0, None, 0.0, self.g(mod.Conv_2.bias))
 
             self.on_side(side1, dout, a1, xr_saved, xb_v)
             da1 = torch.empty_like(a1)
