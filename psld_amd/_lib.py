@@ -11,7 +11,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpsld_hip.so")
+# PSLD_HIP_LIB: load another build of the same ABI (kernel experiments); the default is the in-tree library
+LIB_PATH = os.environ.get("PSLD_HIP_LIB") or os.path.join(_HERE, "libpsld_hip.so")
 
 c_f32p = C.c_void_p
 c_f64p = C.c_void_p
