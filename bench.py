@@ -34,6 +34,7 @@ if ROOT not in sys.path:
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak
 LIMB_PRODUCTS = 6               # bf16 MFMA products per fp32 product in PSLD_MATH_BF16X6
+SUSTAINED_BF16_MFMA_TFLOPS = 1900.0   # measured: tools/mfma_peak.hip, 16x16x32 bf16 MFMA on random operands (power-limited)
 
 
 class ConvProbe:
@@ -275,8 +276,10 @@ def main():
                 "peak_note": "fp32-equivalent (algorithmic 2MNK) rate; peak = 2500 TFLOP/s dense bf16 MFMA / 6 limb "
                              "products per fp32 product.  MFMA flops issued = 6 x achieved; the fp32 MFMA peak this "
                              "replaces is 157.3 TFLOP/s.  Under this load the chip holds ~1.65-1.8 GHz (PMC, "
-                             "profiles/r01), i.e. the kernel runs at the power limit.",
+                             "profiles/r01); a register-only loop with random operand data sustains 1.90 PFLOP/s "
+                             "(tools/mfma_peak.hip), i.e. 317 TFLOP/s fp32-equivalent is the practical ceiling.",
                 "mfma_issued_tflops": LIMB_PRODUCTS * ps["tflops"],
+                "frac_of_sustained_mfma": LIMB_PRODUCTS * ps["tflops"] / SUSTAINED_BF16_MFMA_TFLOPS,
                 "frac_of_f32_mfma_peak": ps["tflops"] / PEAK_F32_MFMA_TFLOPS,
                 "traffic": pmc.get("traffic_bytes") if pmc else None,
                 "traffic_note": pmc.get("note") if pmc else None,
