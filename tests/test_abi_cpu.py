@@ -31,3 +31,9 @@ def test_error_reporting_without_gpu():
     # argument validation happens on the host before any launch
     st = lib.psld_axpby_f32(None, 1.0, None, 0.0, None, 4, 0, None)
     assert st != 0 and b"psld_axpby_f32" in lib.psld_last_error()
+
+
+def test_graft_entry_build_runs():
+    """The driver's build check: make (a no-op when the objects are current) + import + symbol binding."""
+    import __graft_entry__ as g
+    g.build()
