@@ -585,6 +585,57 @@ def test_training_overfits_fixed_batch():
     assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
 
 
+@pytest.mark.parametrize("attn", [False, True])
+def test_weight_caches_follow_the_optimizer(attn):
+    """Every derived weight buffer (limb fragments of the 3x3 / pointwise / fused q|k|v weights, packed fp32 weights,
+    the gathered time-embedding projections) must be refreshed after an optimizer step: a network that trained for a
+    few steps with warm caches has to agree BITWISE with a fresh network loaded with its weights — in eval forward,
+    in the captured-graph forward, and in the gradients of one more step."""
+    import psld_amd
+    psld_amd.import_modules_into_registry()
+    from psld_amd.optim import FusedAdam
+    from psld_amd.registry import get_module
+    from tests.synth import synth_inputs
+    # 128 / 256 channels: limb kernels, two-source residual blocks; attention on the 16x16 maps (fused q|k|v, limb
+    # attention products) or on the 8x8 maps (fp32 engine)
+    cfg = C.tiny(nf=128, ch_mult=(1, 1), attn_resolutions=(16,) if attn else (8,))
+    torch.manual_seed(1)
+    net = get_module("score_fn", "ncsnpp")(cfg).to(DEV).train()
+    sde = get_module("sde", "psld")(cfg)
+    crit = get_module("losses", "psld_score_loss")(cfg, sde)
+    opt = FusedAdam(net, lr=1e-3, grad_clip=1.0)
+    x0, eps, t = (v.to(DEV) for v in synth_inputs(4, 3, 16, seed=9))
+    xin = torch.randn(4, 6, 16, 16, device=DEV)
+    tin = torch.rand(4, device=DEV)
+    net.eval()
+    with torch.no_grad():
+        net(xin, tin)                                     # warm the inference-side caches before any update
+    net.train()
+    for _ in range(3):
+        crit(x0, t, net, eps=eps).backward()
+        opt.step()
+    fresh = get_module("score_fn", "ncsnpp")(cfg)
+    fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in net.state_dict().items()})
+    fresh = fresh.to(DEV)
+    net.eval(); fresh.eval()
+    with torch.no_grad():
+        y_warm, y_fresh = net(xin, tin), fresh(xin, tin)
+    assert torch.equal(y_warm, y_fresh)
+    net.enable_graphs(True)
+    with torch.no_grad():
+        y_graph = net(xin, tin)
+        y_graph2 = net(xin, tin)
+    net.enable_graphs(False)
+    assert torch.equal(y_graph, y_fresh) and torch.equal(y_graph2, y_fresh)
+    net.train(); fresh.train()
+    for n_ in (net, fresh):
+        for p_ in n_.parameters():
+            p_.grad = None
+    torch.manual_seed(5); crit(x0, t, net, eps=eps).backward()
+    torch.manual_seed(5); crit(x0, t, fresh, eps=eps).backward()
+    assert torch.equal(net.flat_grad(), fresh.flat_grad())
+
+
 def _dp_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
