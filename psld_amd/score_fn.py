@@ -568,7 +568,11 @@ class _Exec:
                     ldt = dtp_all.shape[1]
                     dtp = dtp_all[:, tp_off:tp_off + cout]
                     self.bias_grad(dh1, self.g(mod.Conv_0.bias), per_image=dtp, ld_per_image=ldt)
-                    ops.gemm_raw(1, 0, cout, kd, b, dtp, ldt, 0, temb_act.v, kd, 0, self.g(d0.weight), kd, 0)
+                    if self.split and ops.gemm_tn_split_supported(cout, kd, b) and dtp.data_ptr() % 16 == 0:
+                        # one "slab" = the gradient itself: K = batch is short enough for a single range
+                        ops.gemm_tn_split(cout, kd, b, dtp, ldt, temb_act.v, kd, self.g(d0.weight), kd, 1)
+                    else:
+                        ops.gemm_raw(1, 0, cout, kd, b, dtp, ldt, 0, temb_act.v, kd, 0, self.g(d0.weight), kd, 0)
                 else:
                     dtp = self.bias_grad(dh1, self.g(mod.Conv_0.bias), per_image=True)
                     ops.gemm_raw(1, 0, cout, kd, b, dtp, cout, 0, temb_act.v, kd, 0, self.g(d0.weight), kd, 0)
