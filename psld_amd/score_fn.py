@@ -447,8 +447,18 @@ class _Exec:
             if dtp_all is not None:     # d act(temb) = sum over blocks dtp_i W_i = dtp_all Wcat: one GEMM
                 wcat = plan["wcat"]
                 gb, acc = _gbuf(st)
-                ops.gemm_raw(0, 0, b, wcat.shape[1], plan["total"], dtp_all, plan["total"], 0, wcat, wcat.shape[1], 0, gb,
-                             wcat.shape[1], 0, epi=ops.epilogue(accumulate=True) if acc else None)
+                total, kd = plan["total"], wcat.shape[1]
+                # M = batch is one tile tall and K = sum of the blocks' C_out is long (14592 for C10): cut K into
+                # ranges that run as the batches of one launch, then add the partial products in range order
+                ks = next((k for k in (256, 128, 64) if total % k == 0), 0)
+                if not acc and ks and total // ks >= 8 and (b * kd) % 4 == 0:
+                    ns = total // ks
+                    slabs = ops.workspace(4 * ns * b * kd, dtp_all.device).view(torch.float32)
+                    ops.gemm_raw(0, 0, b, kd, ks, dtp_all, total, ks, wcat, kd, ks * kd, slabs, kd, b * kd, ns)
+                    ops.reduce_slabs(slabs, ns, b * kd, gb)
+                else:
+                    ops.gemm_raw(0, 0, b, kd, total, dtp_all, total, 0, wcat, kd, 0, gb, kd, 0,
+                                 epi=ops.epilogue(accumulate=True) if acc else None)
             if st.g is None:
                 return
             dtemb = ops.silu_bwd(temb, st.g)
