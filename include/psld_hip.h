@@ -265,6 +265,15 @@ int psld_copy2d_f32(const float* src, int ld_src, float* dst, int ld_dst, long l
  * stores tap 8 - t in the column of tap t (what a data gradient reads).  The column order ch*9 + tap is OIHW's. */
 int psld_im2col3x3_small_f32(const float* x, int batch, int ih, int iw, int c, int oh, int ow, int stride, int pad,
                              int flip, float* out, int ld_out, hipStream_t stream);
+/* 3x3 im2col / col2im of an NHWC tensor with c % 4 == 0 channels, K order (tap, channel) = the OHWI weight order of
+ * psld_pack_oihw_to_ohwi_f32: cols[m][tap*c + ch] = x[n, oy*stride + ky - pad, ox*stride + kx - pad, ch] (zero outside);
+ * col2im is its adjoint (written, fixed summation order).  They turn the stride-2 convolution of the input pyramid
+ * (`Downsample` with fir: up_or_down_sampling.py:177 `F.conv2d(x, w, stride=2)`, layerspp.py:149-163) and its data
+ * gradient into psld_gemm_split_f32 calls. */
+int psld_im2col3x3_f32(const float* x, int batch, int ih, int iw, int c, int oh, int ow, int stride, int pad,
+                       float* cols, hipStream_t stream);
+int psld_col2im3x3_f32(const float* dcols, int batch, int ih, int iw, int c, int oh, int ow, int stride, int pad,
+                       float* dx, hipStream_t stream);
 /* dst[r][j] = alpha * src[r][j], j < cols, arbitrary cols / leading dimensions (pads and un-pads the small K = 54
  * weight matrices of the calls above). */
 int psld_scale_copy2d_f32(const float* src, int ld_src, float* dst, int ld_dst, long long rows, int cols, float alpha,

@@ -112,6 +112,8 @@ SIGNATURES = {
     "psld_copy_batch_f32": (I, [P, I, LL, P]),
     "psld_copy2d_f32": (I, [P, I, P, I, LL, I, I, P]),
     "psld_im2col3x3_small_f32": (I, [P, I, I, I, I, I, I, I, I, I, P, I, P]),
+    "psld_im2col3x3_f32": (I, [P, I, I, I, I, I, I, I, I, P, P]),
+    "psld_col2im3x3_f32": (I, [P, I, I, I, I, I, I, I, I, P, P]),
     "psld_scale_copy2d_f32": (I, [P, I, P, I, LL, I, F, P]),
     "psld_softmax_rows_f32": (I, [P, P, LL, I, P]),
     "psld_softmax_rows_bwd_f32": (I, [P, P, P, LL, I, P]),

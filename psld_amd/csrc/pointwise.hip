@@ -138,6 +138,61 @@ __global__ void im2col3x3_small_kernel(const float* __restrict__ x, int ih, int 
     }
 }
 
+// 3x3 im2col / col2im of a many-channel NHWC tensor (c % 4 == 0) in the tile engine's K order (tap, channel):
+// cols[m][tap*c + ch] = x[n, oy*stride + ky - pad, ox*stride + kx - pad, ch].  One float4 per thread; a (row, tap)
+// pair is one contiguous run of c floats on both sides.  With it the stride-2 convolution of the input pyramid
+// (layerspp.py:149-163, up_or_down_sampling.py:177) and its data gradient run as pointwise limb GEMMs.
+__global__ void im2col3x3_kernel(const float* __restrict__ x, int ih, int iw, int c4, int oh, int ow, int stride, int pad,
+                                 float* __restrict__ cols, long long total4) {
+    GRID_STRIDE(i, total4) {
+        const int q = (int)(i % c4);
+        long long r = i / c4;
+        const int t = (int)(r % 9);
+        const long long m = r / 9;
+        const int ky = t / 3, kx = t - ky * 3;
+        const int ox = (int)(m % ow);
+        const long long rr = m / ow;
+        const int oy = (int)(rr % oh);
+        const long long n = rr / oh;
+        const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < ih && ix >= 0 && ix < iw)
+            v = reinterpret_cast<const f32x4*>(x)[((n * ih + iy) * iw + ix) * c4 + q];
+        reinterpret_cast<f32x4*>(cols)[i] = v;
+    }
+}
+// dx[n, iy, ix, ch] = sum over the (output pixel, tap) pairs that read this input pixel of dcols[m][tap*c + ch]
+// (gather form: fixed summation order ky, kx; no atomics)
+__global__ void col2im3x3_kernel(const float* __restrict__ dcols, int ih, int iw, int c4, int oh, int ow, int stride,
+                                 int pad, float* __restrict__ dx, long long total4) {
+    GRID_STRIDE(i, total4) {
+        const int q = (int)(i % c4);
+        long long r = i / c4;
+        const int ix = (int)(r % iw);
+        r /= iw;
+        const int iy = (int)(r % ih);
+        const long long n = r / ih;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ty = iy + pad - ky;
+            if (ty < 0 || ty % stride) continue;
+            const int oy = ty / stride;
+            if (oy >= oh) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tx = ix + pad - kx;
+                if (tx < 0 || tx % stride) continue;
+                const int ox = tx / stride;
+                if (ox >= ow) continue;
+                const long long m = (n * oh + oy) * ow + ox;
+                acc += reinterpret_cast<const f32x4*>(dcols)[(m * 9 + ky * 3 + kx) * c4 + q];
+            }
+        }
+        reinterpret_cast<f32x4*>(dx)[i] = acc;
+    }
+}
+
 // Many contiguous float4-multiple copies in one launch.  tab[4*i ..]: src pointer, dst pointer, float4 count, first
 // float4 index of entry i in the launch-wide numbering (gathers the 57 time-embedding projection weights of the
 // ResBlocks into one matrix once per optimizer step).
@@ -497,6 +552,30 @@ extern "C" int psld_im2col3x3_small_f32(const float* x, int batch, int ih, int i
     hipLaunchKernelGGL(im2col3x3_small_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, ih, iw, c, oh, ow, stride,
                        pad, flip, out, ld_out, total);
     PSLD_CHECK_LAUNCH("psld_im2col3x3_small_f32");
+    return PSLD_OK;
+}
+
+extern "C" int psld_im2col3x3_f32(const float* x, int batch, int ih, int iw, int c, int oh, int ow, int stride, int pad,
+                                  float* cols, hipStream_t stream) {
+    PSLD_CHECK_ARG(x && cols && batch > 0 && c > 0 && c % 4 == 0 && oh > 0 && ow > 0 && stride >= 1 && pad >= 0 &&
+                       (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(cols) & 15) == 0,
+                   "psld_im2col3x3_f32: bad args (c=%d)", c);
+    const long long total4 = (long long)batch * oh * ow * 9 * (c / 4);
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, x, ih, iw, c / 4, oh, ow, stride, pad,
+                       cols, total4);
+    PSLD_CHECK_LAUNCH("psld_im2col3x3_f32");
+    return PSLD_OK;
+}
+
+extern "C" int psld_col2im3x3_f32(const float* dcols, int batch, int ih, int iw, int c, int oh, int ow, int stride, int pad,
+                                  float* dx, hipStream_t stream) {
+    PSLD_CHECK_ARG(dcols && dx && batch > 0 && c > 0 && c % 4 == 0 && oh > 0 && ow > 0 && stride >= 1 && pad >= 0 &&
+                       (reinterpret_cast<uintptr_t>(dx) & 15) == 0 && (reinterpret_cast<uintptr_t>(dcols) & 15) == 0,
+                   "psld_col2im3x3_f32: bad args (c=%d)", c);
+    const long long total4 = (long long)batch * ih * iw * (c / 4);
+    hipLaunchKernelGGL(col2im3x3_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, dcols, ih, iw, c / 4, oh, ow, stride,
+                       pad, dx, total4);
+    PSLD_CHECK_LAUNCH("psld_col2im3x3_f32");
     return PSLD_OK;
 }
 

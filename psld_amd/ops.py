@@ -442,6 +442,25 @@ def im2col3x3_small(x: Tensor, oh: int, ow: int, stride: int, pad: int, flip: bo
     return out
 
 
+def im2col3x3(x: Tensor, stride: int, pad: int, oh: int, ow: int) -> Tensor:
+    """[b*oh*ow][9*c] patch matrix of an NHWC tensor, K order (tap, channel)."""
+    b, ih, iw, c = x.shape
+    cols = torch.empty((b * oh * ow, 9 * c), device=x.device, dtype=torch.float32)
+    check(lib().psld_im2col3x3_f32(x.data_ptr(), b, ih, iw, c, oh, ow, stride, pad, cols.data_ptr(), _stream()),
+          "psld_im2col3x3_f32")
+    return cols
+
+
+def col2im3x3(dcols: Tensor, shape, stride: int, pad: int, oh: int, ow: int, out: Optional[Tensor] = None) -> Tensor:
+    """Adjoint of im2col3x3: ``shape`` = (b, ih, iw, c) of the input tensor."""
+    b, ih, iw, c = shape
+    if out is None:
+        out = torch.empty(tuple(shape), device=dcols.device, dtype=torch.float32)
+    check(lib().psld_col2im3x3_f32(dcols.data_ptr(), b, ih, iw, c, oh, ow, stride, pad, out.data_ptr(), _stream()),
+          "psld_col2im3x3_f32")
+    return out
+
+
 def scale_copy2d(src: Tensor, ld_src: int, dst: Tensor, ld_dst: int, rows: int, cols: int, alpha: float = 1.0,
                  src_off: int = 0, dst_off: int = 0):
     check(lib().psld_scale_copy2d_f32(src.data_ptr() + 4 * src_off, ld_src, dst.data_ptr() + 4 * dst_off, ld_dst, rows,

@@ -784,8 +784,19 @@ class _Exec:
         epi = ops.epilogue(bias=conv.bias, residual=h.v, ld_residual=cout, out_scale=s)
         small = cin * 9 <= 64 and cout % 4 == 0
         cols = None
+        net = self.net
+        m = b * oh * ow
+        # many-channel levels on the limb kernels: explicit im2col (K order = the packed OHWI weights') + pointwise GEMM
+        limb = self.split and not small and cin % 4 == 0 and ops.gemm_split_supported(9 * cin, 0, m, cout) and \
+            ops.gemm_split_supported(cout, 0, m, 9 * cin)
         if small:
             cols = self.small_in_conv(xf, conv, 2, 0, oh, ow, out, epi)
+        elif limb:
+            patches = ops.im2col3x3(xf, 2, 0, oh, ow)
+            fr = net._gfrag(conv.weight, "s2fwd",
+                            lambda prev: ops.gemm_frag(net._packed(conv), cout, 9 * cin, 9 * cin, 1, prev))
+            ops.gemm_split(patches, None, m, fr, cout, out, epi)
+            del patches
         else:
             ops.conv2d_nhwc(xf, None, self.net._packed(conv), cout, 3, 3, 2, 0, 1, oh, ow, out, epi)
         on = _Node(out)
@@ -807,7 +818,15 @@ class _Exec:
             self.on_side(side, dout, xf)
             if not first:
                 dxf = torch.empty_like(xf)
-                self.dgrad(dout, conv, 3, 2, 0, fh, fw, dxf, alpha=s)
+                if limb:
+                    frd = net._gfrag(conv.weight, "s2dgrad",
+                                     lambda prev: ops.gemm_frag(net._packed(conv), 9 * cin, cout, 1, 9 * cin, prev))
+                    dpatches = torch.empty((m, 9 * cin), device=dout.device, dtype=torch.float32)
+                    ops.gemm_split(dout, None, m, frd, 9 * cin, dpatches, ops.epilogue(alpha=s))
+                    ops.col2im3x3(dpatches, xf.shape, 2, 0, oh, ow, out=dxf)
+                    del dpatches
+                else:
+                    self.dgrad(dout, conv, 3, 2, 0, fh, fw, dxf, alpha=s)
                 pg, pacc = _gbuf(pyr)
                 ops.upfirdn2d_bwd_raw(dxf, k, 1, 1, pad, (pyr.v.shape[1], pyr.v.shape[2]), 1, out=pg, accumulate=pacc)
             elif self.want_dx:

@@ -242,6 +242,22 @@ def test_conv3x3_split_dgrad_and_wgrad(ops, cfg):
     assert torch.count_nonzero(slabs[:, :, :, :col0]) == 0
 
 
+@pytest.mark.parametrize("b,c,ih,stride,pad", [(2, 8, 9, 2, 0), (1, 64, 17, 2, 0), (2, 16, 8, 1, 1)])
+def test_im2col_col2im(ops, b, c, ih, stride, pad):
+    """Many-channel 3x3 im2col in (tap, channel) order and its adjoint (gather form) against F.unfold / F.fold."""
+    oh = (ih + 2 * pad - 3) // stride + 1
+    x = gen(b, c, ih, ih, seed=90)
+    cols = ops.im2col3x3(_nhwc(x).to(DEV), stride, pad, oh, oh)
+    ref = F.unfold(x, 3, padding=pad, stride=stride)                         # [b][c*9][L], row = ch*9 + tap
+    ref = ref.view(b, c, 9, oh * oh).permute(0, 3, 2, 1).reshape(b * oh * oh, 9 * c)
+    assert torch.equal(cols.cpu(), ref)
+    d = gen(b * oh * oh, 9 * c, seed=91)
+    dx = ops.col2im3x3(d.to(DEV), (b, ih, ih, c), stride, pad, oh, oh)
+    dref = F.fold(d.view(b, oh * oh, 9, c).permute(0, 3, 2, 1).reshape(b, c * 9, oh * oh).double(), (ih, ih), 3,
+                  padding=pad, stride=stride)
+    assert rel_l2(dx.permute(0, 3, 1, 2), dref) < 1e-6
+
+
 def test_two_source_weight_gradients(ops):
     """dwgrad / pwgrad reading the input of the convolution from two tensors (unmaterialised concatenation)."""
     b, c1, c2, co, h, w_ = 2, 128, 256, 128, 16, 16
