@@ -274,6 +274,12 @@ int psld_im2col3x3_f32(const float* x, int batch, int ih, int iw, int c, int oh,
                        float* cols, hipStream_t stream);
 int psld_col2im3x3_f32(const float* dcols, int batch, int ih, int iw, int c, int oh, int ow, int stride, int pad,
                        float* dx, hipStream_t stream);
+/* y[n,oy,ox,o] = bias[o] + sum_{tap,c} x[n,oy+ky-1,ox+kx-1,c] * w_ohwi[o][tap][c]: 3x3 stride-1 pad-1 convolution with
+ * 3 or 6 output channels (the network head `conv3x3(in_ch, channels)`, ncsnpp.py:430), exact fp32 fmaf chains + a
+ * fixed cross-lane sum; cin % 4 == 0, cin <= 256, weights in the OHWI order of psld_pack_oihw_to_ohwi_f32. */
+int psld_conv3x3_fewout_supported(int cin, int cout);
+int psld_conv3x3_fewout_f32(const float* x, const float* w_ohwi, const float* bias, float* y, int batch,
+                            int h, int w, int cin, int cout, hipStream_t stream);
 /* dst[r][j] = alpha * src[r][j], j < cols, arbitrary cols / leading dimensions (pads and un-pads the small K = 54
  * weight matrices of the calls above). */
 int psld_scale_copy2d_f32(const float* src, int ld_src, float* dst, int ld_dst, long long rows, int cols, float alpha,

@@ -114,6 +114,8 @@ SIGNATURES = {
     "psld_im2col3x3_small_f32": (I, [P, I, I, I, I, I, I, I, I, I, P, I, P]),
     "psld_im2col3x3_f32": (I, [P, I, I, I, I, I, I, I, I, P, P]),
     "psld_col2im3x3_f32": (I, [P, I, I, I, I, I, I, I, I, P, P]),
+    "psld_conv3x3_fewout_supported": (I, [I, I]),
+    "psld_conv3x3_fewout_f32": (I, [P, P, P, P, I, I, I, I, I, P]),
     "psld_scale_copy2d_f32": (I, [P, I, P, I, LL, I, F, P]),
     "psld_softmax_rows_f32": (I, [P, P, LL, I, P]),
     "psld_softmax_rows_bwd_f32": (I, [P, P, P, LL, I, P]),

@@ -193,6 +193,88 @@ __global__ void col2im3x3_kernel(const float* __restrict__ dcols, int ih, int iw
     }
 }
 
+// 3x3 stride-1 pad-1 convolution with FEW output channels (the 6-channel head, ncsnpp.py:430): a GEMM tile would be
+// 95 % padding (609 us on the tile engine), so this is a dot-product kernel.  A wave owns four horizontally adjacent
+// pixels; lane l holds channels 4l..4l+3 of the shared 3 x 6 input window (18 float4) and, per (tap, output), the
+// matching weight float4 from LDS ([tap][out][c], OHWI order); 4 x COUT fp32 partial sums per lane (fmaf chains in tap
+// order) are combined across the lanes by a fixed butterfly.  c = 256 only uses all 64 lanes; c < 256 idles the rest.
+template <int COUT>
+__global__ void __launch_bounds__(256) conv3x3_fewout_kernel(const float* __restrict__ x, const float* __restrict__ w_ohwi,
+                                                            const float* __restrict__ bias, float* __restrict__ y,
+                                                            int batch, int h, int w, int c) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];      // [9][COUT][c]
+    for (int i = threadIdx.x; i < 9 * COUT * c; i += blockDim.x) {
+        const int ch = i % c, r = i / c;
+        const int o = r % COUT, t = r / COUT;
+        wl[i] = w_ohwi[((long long)o * 9 + t) * c + ch];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c4 = c >> 2;
+    const bool live = lane < c4;
+    const int wq = (w + 3) >> 2;                                     // groups of four pixels per image row
+    const long long groups = (long long)batch * h * wq;
+    for (long long gidx = (long long)blockIdx.x * 4 + wave; gidx < groups; gidx += (long long)gridDim.x * 4) {
+        const int gx = (int)(gidx % wq);
+        const long long r = gidx / wq;
+        const int oy = (int)(r % h);
+        const long long n = r / h;
+        const int ox0 = gx * 4;
+        f32x4 win[3][6];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 6; ++dx) {
+                const int iy = oy + dy - 1, ix = ox0 + dx - 1;
+                const bool ok = live && iy >= 0 && iy < h && ix >= 0 && ix < w;
+                win[dy][dx] = ok ? reinterpret_cast<const f32x4*>(x)[((n * h + iy) * w + ix) * c4 + lane]
+                                 : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        float acc[4][COUT];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) acc[p][o] = 0.f;
+        if (live) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ky = t / 3, kx = t - ky * 3;
+#pragma unroll
+                for (int o = 0; o < COUT; ++o) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + ((t * COUT + o) * c) + lane * 4);
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const f32x4 xv = win[ky][p + kx];
+                        float a = acc[p][o];
+                        a = fmaf(xv[0], wv[0], a);
+                        a = fmaf(xv[1], wv[1], a);
+                        a = fmaf(xv[2], wv[2], a);
+                        a = fmaf(xv[3], wv[3], a);
+                        acc[p][o] = a;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) {
+                float v = acc[p][o];
+#pragma unroll
+                for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft, 64);
+                acc[p][o] = v;
+            }
+        if (lane < 4 && ox0 + lane < w) {
+            float* yo = y + (((n * h + oy) * w + ox0 + lane) * COUT);
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) {
+                float v = lane == 0 ? acc[0][o] : lane == 1 ? acc[1][o] : lane == 2 ? acc[2][o] : acc[3][o];
+                yo[o] = v + (bias ? bias[o] : 0.f);
+            }
+        }
+    }
+}
+
 // Many contiguous float4-multiple copies in one launch.  tab[4*i ..]: src pointer, dst pointer, float4 count, first
 // float4 index of entry i in the launch-wide numbering (gathers the 57 time-embedding projection weights of the
 // ResBlocks into one matrix once per optimizer step).
@@ -576,6 +658,42 @@ extern "C" int psld_col2im3x3_f32(const float* dcols, int batch, int ih, int iw,
     hipLaunchKernelGGL(col2im3x3_kernel, dim3(grid_for(total4)), dim3(256), 0, stream, dcols, ih, iw, c / 4, oh, ow, stride,
                        pad, dx, total4);
     PSLD_CHECK_LAUNCH("psld_col2im3x3_f32");
+    return PSLD_OK;
+}
+
+extern "C" int psld_conv3x3_fewout_supported(int cin, int cout) {
+    return cin > 0 && cin % 4 == 0 && cin <= 256 && (cout == 3 || cout == 6) && 9 * cout * cin * 4 <= 64 * 1024;
+}
+
+extern "C" int psld_conv3x3_fewout_f32(const float* x, const float* w_ohwi, const float* bias, float* y, int batch,
+                                       int h, int w, int cin, int cout, hipStream_t stream) {
+    PSLD_CHECK_ARG(x && w_ohwi && y && batch > 0 && h > 0 && w > 0, "psld_conv3x3_fewout_f32: bad args");
+    PSLD_CHECK_ARG(psld_conv3x3_fewout_supported(cin, cout), "psld_conv3x3_fewout_f32: unsupported cin=%d cout=%d", cin, cout);
+    PSLD_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0, "psld_conv3x3_fewout_f32: unaligned input");
+    const size_t lds = (size_t)9 * cout * cin * sizeof(float);
+    const long long groups = (long long)batch * h * ((w + 3) / 4);
+    long long blocks = (groups + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    if (cout == 6) {
+        static bool configured = false;
+        if (!configured) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_fewout_kernel<6>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            configured = true;
+        }
+        hipLaunchKernelGGL(conv3x3_fewout_kernel<6>, dim3((unsigned)blocks), dim3(256), lds, stream, x, w_ohwi, bias, y, batch,
+                           h, w, cin);
+    } else {
+        static bool configured = false;
+        if (!configured) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_fewout_kernel<3>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            configured = true;
+        }
+        hipLaunchKernelGGL(conv3x3_fewout_kernel<3>, dim3((unsigned)blocks), dim3(256), lds, stream, x, w_ohwi, bias, y, batch,
+                           h, w, cin);
+    }
+    PSLD_CHECK_LAUNCH("psld_conv3x3_fewout_f32");
     return PSLD_OK;
 }
 

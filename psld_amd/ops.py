@@ -461,6 +461,17 @@ def col2im3x3(dcols: Tensor, shape, stride: int, pad: int, oh: int, ow: int, out
     return out
 
 
+def conv3x3_fewout_supported(cin: int, cout: int) -> bool:
+    return bool(lib().psld_conv3x3_fewout_supported(cin, cout))
+
+
+def conv3x3_fewout(x: Tensor, w_ohwi: Tensor, bias: Optional[Tensor], cout: int, y: Tensor):
+    """3x3 stride-1 pad-1 convolution with 3 / 6 output channels (dot-product kernel; weights packed OHWI)."""
+    b, h, w, c = x.shape
+    check(lib().psld_conv3x3_fewout_f32(x.data_ptr(), w_ohwi.data_ptr(), _p(bias), y.data_ptr(), b, h, w, c, cout,
+                                        _stream()), "psld_conv3x3_fewout_f32")
+
+
 def scale_copy2d(src: Tensor, ld_src: int, dst: Tensor, ld_dst: int, rows: int, cols: int, alpha: float = 1.0,
                  src_off: int = 0, dst_off: int = 0):
     check(lib().psld_scale_copy2d_f32(src.data_ptr() + 4 * src_off, ld_src, dst.data_ptr() + 4 * dst_off, ld_dst, rows,

@@ -973,7 +973,10 @@ class _Exec:
         af = ops.gn_apply(hnode.v, stf, True)
         oc = head.weight.shape[0]
         y = torch.empty((b, hh, ww, oc), device=x.device, dtype=torch.float32)
-        ops.conv2d_nhwc(af, None, net._packed(head), oc, 3, 3, 1, 1, 1, hh, ww, y, ops.epilogue(bias=head.bias))
+        if ops.conv3x3_fewout_supported(af.shape[-1], oc):
+            ops.conv3x3_fewout(af, net._packed(head), head.bias, oc, y)
+        else:
+            ops.conv2d_nhwc(af, None, net._packed(head), oc, 3, 3, 1, 1, 1, hh, ww, y, ops.epilogue(bias=head.bias))
         if self.record:
             last = hnode
             self.head_grad = _Node(y)

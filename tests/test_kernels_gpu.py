@@ -258,6 +258,22 @@ def test_im2col_col2im(ops, b, c, ih, stride, pad):
     assert rel_l2(dx.permute(0, 3, 1, 2), dref) < 1e-6
 
 
+@pytest.mark.parametrize("b,c,co,h,w_", [(2, 256, 6, 8, 8), (1, 128, 6, 5, 7), (3, 32, 3, 16, 16), (1, 256, 6, 32, 32)])
+def test_conv3x3_fewout(ops, b, c, co, h, w_):
+    """Head convolution (few output channels) as a dot-product kernel; ragged widths (w % 4 != 0) included."""
+    x = gen(b, c, h, w_, seed=95)
+    w = gen(co, c, 3, 3, seed=96, scale=0.1)
+    bias = gen(co, seed=97)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    assert ops.conv3x3_fewout_supported(c, co)
+    wp = torch.empty(co, 3, 3, c, device=DEV)
+    ops.pack_ohwi(w.to(DEV), wp)
+    y = torch.full((b, h, w_, co), float("nan"), device=DEV)
+    ops.conv3x3_fewout(_nhwc(x).to(DEV), wp, bias.to(DEV), co, y)
+    assert rel_l2(y.permute(0, 3, 1, 2), ref) < 2e-6
+    assert not ops.conv3x3_fewout_supported(512, 6) and not ops.conv3x3_fewout_supported(256, 8)
+
+
 def test_two_source_weight_gradients(ops):
     """dwgrad / pwgrad reading the input of the convolution from two tensors (unmaterialised concatenation)."""
     b, c1, c2, co, h, w_ = 2, 128, 256, 128, 16, 16
