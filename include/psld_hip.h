@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 
-#define PSLD_ABI_VERSION 3 /* 2: limb-MFMA convolutions, math mode, bias-gradient / batched-copy entry points; 3: pointwise weight gradient and batched activation GEMM on limb kernels */
+#define PSLD_ABI_VERSION 4 /* 2: limb-MFMA convolutions, math mode, bias-gradient / batched-copy entry points; 3: pointwise weight gradient and batched activation GEMM on limb kernels; 4: GroupNorm statistics from the limb kernels' epilogue */
 #define PSLD_COEFF_STRIDE 12
 
 int psld_version(void);
@@ -61,6 +61,14 @@ typedef struct psld_epilogue {
     long long residual_stride_batch;
     float out_scale;
     int accumulate;
+    /* Optional (limb kernels psld_conv3x3_split_f32 / psld_gemm_split_f32 only; the call then never splits its K
+     * range): GroupNorm statistics of the OUTPUT as a by-product, for the GroupNorm that reads it next
+     * (layerspp.py:258,264 GroupNorm_0/1; :77 of the attention block).  gn_part[((img*chunks + chunk)*(N/8) + f)*2 + {0,1}]
+     * = sum / sum of squares of the 8 channels 8f..8f+7 over the chunk-th run of 64 rows of image img
+     * (chunks = gn_hw / 64, gn_hw = rows per image, a multiple of 64; N a multiple of 128).
+     * psld_gn_stats_from_partials_f32 turns them into the statistics of any group size that is a multiple of 8. */
+    double* gn_part;
+    int gn_hw;
 } psld_epilogue_t;
 
 /* C[b] = epilogue(op(A[b]) * op(B[b])), fp32 MFMA (v_mfma_f32_32x32x2_f32), batched.
@@ -201,6 +209,11 @@ int psld_gn_stats_nhwc_f32(const float* x, int batch, int hw, int c, int groups,
                            const float* gamma, const float* beta,
                            float* mean, float* rstd, float* scale, float* shift,
                            void* workspace, hipStream_t stream);
+/* Second half of psld_gn_stats_nhwc_f32 on partial sums a limb kernel's epilogue produced (psld_epilogue_t.gn_part):
+ * fine = channels per group / 8. */
+int psld_gn_stats_from_partials_f32(const double* gn_part, int batch, int hw, int c, int groups, float eps,
+                                    const float* gamma, const float* beta, float* mean, float* rstd,
+                                    float* scale, float* shift, hipStream_t stream);
 /* y = dropout(act(x*scale[n,c] + shift[n,c])); act: 0 = identity, 1 = SiLU.  Dropout
  * (nn.Dropout, layerspp.py:265): element i of the NHWC tensor is kept iff
  * psld_dropout_keep(seed, i, p) (counter-based hash, reproducible in the backward pass, no mask

@@ -33,6 +33,8 @@ class Epilogue(C.Structure):
         ("residual_stride_batch", C.c_longlong),
         ("out_scale", C.c_float),
         ("accumulate", C.c_int),
+        ("gn_part", C.c_void_p),
+        ("gn_hw", C.c_int),
     ]
 
 
@@ -62,7 +64,7 @@ class SscsCoeffs(C.Structure):
 I, F, D, LL, P = C.c_int, C.c_float, C.c_double, C.c_longlong, C.c_void_p
 EP = C.POINTER(Epilogue)
 
-ABI_VERSION = 3    # PSLD_ABI_VERSION of include/psld_hip.h these signatures were written against
+ABI_VERSION = 4    # PSLD_ABI_VERSION of include/psld_hip.h these signatures were written against
 
 # name -> (restype, argtypes): every symbol include/psld_hip.h declares
 SIGNATURES = {
@@ -99,6 +101,7 @@ SIGNATURES = {
     "psld_nhwc_to_nchw_f32": (I, [P, P, I, I, I, P]),
     "psld_gn_workspace_bytes": (LL, [I, I, I, I]),
     "psld_gn_stats_nhwc_f32": (I, [P, I, I, I, I, F, P, P, P, P, P, P, P, P]),
+    "psld_gn_stats_from_partials_f32": (I, [P, I, I, I, I, F, P, P, P, P, P, P, P]),
     "psld_gn_apply_nhwc_f32": (I, [P, P, P, P, I, I, I, I, F, C.c_ulonglong, P]),
     "psld_gn_bwd_nhwc_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, F, C.c_ulonglong, P, P, P, I, P, F, P, P]),
     "psld_upfirdn2d_f32": (I, [P, P, I, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, P]),

@@ -325,6 +325,9 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
     float* Cb = a.C + (long long)split * a.c_stride_split;
     const PsldEpilogue& e = a.e;
     const bool rb_uniform = e.rowbias && (e.rows_per_img % 16 == 0);
+    float gs[4], gss[4];                 // GroupNorm by-product: this lane's column sums over the wave's 64 rows
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) gs[nb] = gss[nb] = 0.f;
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
         const int row_base = m0 + wr * 64 + mb * 16;
@@ -345,6 +348,37 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
                 float* cp = Cb + (long long)gm * a.ldc + gn;
                 if (e.accumulate) x += *cp;
                 *cp = x;
+                gs[nb] += x;
+                gss[nb] += x * x;
+            }
+        }
+    }
+    if (e.gn_part) {
+        // 64 rows x 64 columns of one image per wave: sums over the 8 channels of a fine group = lanes r16 & 8 equal,
+        // all four row groups kq.  Fixed butterfly, one writer per (wave, fine group): repeatable.
+        const int row0 = m0 + wr * 64;
+        if (row0 < a.M) {
+            const int img = row0 / e.gn_hw, chunk = (row0 - img * e.gn_hw) >> 6, chunks = e.gn_hw >> 6;
+            const int fine = a.N >> 3;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                float s1 = gs[nb], s2 = gss[nb];
+#pragma unroll
+                for (int sft = 1; sft <= 4; sft <<= 1) {
+                    s1 += __shfl_xor(s1, sft, 64);
+                    s2 += __shfl_xor(s2, sft, 64);
+                }
+#pragma unroll
+                for (int sft = 16; sft <= 32; sft <<= 1) {
+                    s1 += __shfl_xor(s1, sft, 64);
+                    s2 += __shfl_xor(s2, sft, 64);
+                }
+                if ((lane & 0x37) == 0) {        // lanes 0 and 8
+                    const int f = ((n0 + wc * 64 + nb * 16) >> 3) + (r16 >> 3);
+                    double* pp = e.gn_part + (((long long)img * chunks + chunk) * fine + f) * 2;
+                    pp[0] = (double)s1;
+                    pp[1] = (double)s2;
+                }
             }
         }
     }
@@ -889,7 +923,7 @@ int launch_dconv(const DConvArgs& a, int nsplit, hipStream_t stream, const char*
 int plan_split(DConvArgs& a, const PsldEpilogue& e, float* y, int ldy, void* workspace, long long ws_bytes) {
     const long long tiles = (long long)cdiv(a.M, 128) * (a.N / 128);
     int ns = 1;
-    if (workspace && tiles < 384 && ldy % 4 == 0 && aligned16(y) && (!e.bias || aligned16(e.bias)) &&
+    if (workspace && tiles < 384 && !e.gn_part && ldy % 4 == 0 && aligned16(y) && (!e.bias || aligned16(e.bias)) &&
         (!e.rowbias || (aligned16(e.rowbias) && e.ld_rowbias % 4 == 0)) && (!e.res || (aligned16(e.res) && e.ldres % 4 == 0))) {
         ns = (int)(512 / tiles);
         if (ns > 8) ns = 8;
@@ -987,6 +1021,8 @@ extern "C" int psld_conv3x3_split_f32(const float* x1, int c1, const float* x2, 
     a.zero = psld_detail_zero_page("psld_conv3x3_split_f32");
     if (!a.zero) return PSLD_ERR_LAUNCH;
     const PsldEpilogue e = make_epilogue(epi);
+    PSLD_CHECK_ARG(!e.gn_part || (e.gn_hw == h * w && e.gn_hw % 64 == 0 && !e.accumulate),
+                   "psld_conv3x3_split_f32: gn_part needs gn_hw = h*w, a multiple of 64, and no accumulation");
     const int ns = plan_split(a, e, y, ldy, workspace, ws_bytes);
     const int nh = cdiv((long long)halo_px * 8, 256);
     const char* name = "psld_conv3x3_split_f32";
@@ -1131,6 +1167,8 @@ extern "C" int psld_gemm_split_f32(const float* a1, int k1, const float* a2, int
     a.zero = psld_detail_zero_page("psld_gemm_split_f32");
     if (!a.zero) return PSLD_ERR_LAUNCH;
     const PsldEpilogue e = make_epilogue(epi);
+    PSLD_CHECK_ARG(!e.gn_part || (e.gn_hw > 0 && e.gn_hw % 64 == 0 && m % e.gn_hw == 0 && !e.accumulate),
+                   "psld_gemm_split_f32: gn_part needs gn_hw (rows per image) a multiple of 64 dividing m, and no accumulation");
     const int ns = plan_split(a, e, y, ldy, workspace, ws_bytes);
     const int st = launch_dconv<8, 2, true>(a, ns, stream, "psld_gemm_split_f32");
     if (st != PSLD_OK) return st;

@@ -93,7 +93,9 @@ __global__ void gn_partial_kernel(const float* __restrict__ x, int hw, int c, in
     }
 }
 
-__global__ void gn_finalize_kernel(const double* __restrict__ part, int hw, int c, int groups, int chunks,
+// fine: partial sums per group in `part` (1 from gn_partial_kernel; channels-per-group / 8 for the 8-channel sums a
+// limb kernel's epilogue wrote), added in index order
+__global__ void gn_finalize_kernel(const double* __restrict__ part, int hw, int c, int groups, int chunks, int fine,
                                    float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ mean, float* __restrict__ rstd,
                                    float* __restrict__ scale, float* __restrict__ shift) {
@@ -103,9 +105,11 @@ __global__ void gn_finalize_kernel(const double* __restrict__ part, int hw, int 
     if (tid < groups) {
         double s = 0, ss = 0;
         for (int k = 0; k < chunks; ++k) {
-            const double* pp = part + (((long long)n * chunks + k) * groups + tid) * 2;
-            s += pp[0];
-            ss += pp[1];
+            const double* pp = part + (((long long)n * chunks + k) * groups + tid) * fine * 2;
+            for (int f = 0; f < fine; ++f) {
+                s += pp[2 * f];
+                ss += pp[2 * f + 1];
+            }
         }
         const double cnt = (double)cpg * hw;
         const double mu = s / cnt;
@@ -358,8 +362,20 @@ extern "C" int psld_gn_stats_nhwc_f32(const float* x, int batch, int hw, int c, 
     hipLaunchKernelGGL(gn_partial_kernel, dim3(m.chunks, batch), dim3(m.threads), 0, stream, x, hw, c, groups, m.cq,
                        m.pl, m.chunk_px, m.chunks, part);
     PSLD_CHECK_LAUNCH("gn_partial_kernel");
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, stream, part, hw, c, groups, m.chunks, eps,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, stream, part, hw, c, groups, m.chunks, 1, eps,
                        gamma, beta, mean, rstd, scale, shift);
+    PSLD_CHECK_LAUNCH("gn_finalize_kernel");
+    return PSLD_OK;
+}
+
+extern "C" int psld_gn_stats_from_partials_f32(const double* gn_part, int batch, int hw, int c, int groups, float eps,
+                                               const float* gamma, const float* beta, float* mean, float* rstd,
+                                               float* scale, float* shift, hipStream_t stream) {
+    PSLD_CHECK_ARG(gn_part && gamma && beta && mean && rstd && scale && shift, "psld_gn_stats_from_partials: null pointer");
+    PSLD_CHECK_ARG(groups > 0 && groups <= MAXG && c % groups == 0 && (c / groups) % 8 == 0 && hw % 64 == 0 && hw > 0,
+                   "psld_gn_stats_from_partials: unsupported C=%d groups=%d hw=%d", c, groups, hw);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, stream, gn_part, hw, c, groups, hw / 64,
+                       (c / groups) / 8, eps, gamma, beta, mean, rstd, scale, shift);
     PSLD_CHECK_LAUNCH("gn_finalize_kernel");
     return PSLD_OK;
 }

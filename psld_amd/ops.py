@@ -61,7 +61,8 @@ def _chk(t: Tensor, dtype=torch.float32):
 def epilogue(alpha: float = 1.0, bias: Optional[Tensor] = None, rowbias: Optional[Tensor] = None,
              rows_per_img: int = 1, residual: Optional[Tensor] = None, ld_residual: int = 0,
              residual_stride_batch: int = 0, out_scale: float = 1.0, accumulate: bool = False,
-             ld_rowbias: int = 0) -> Epilogue:
+             ld_rowbias: int = 0, gn_part: Optional[Tensor] = None, gn_hw: int = 0) -> Epilogue:
+    """``gn_part`` (limb kernels only; see gn_part_buffer): GroupNorm partial sums of the output as a by-product."""
     e = Epilogue()
     e.alpha = alpha
     e.bias = _p(bias)
@@ -73,7 +74,9 @@ def epilogue(alpha: float = 1.0, bias: Optional[Tensor] = None, rowbias: Optiona
     e.residual_stride_batch = residual_stride_batch
     e.out_scale = out_scale
     e.accumulate = 1 if accumulate else 0
-    e._keep = (bias, rowbias, residual)  # the struct holds raw pointers: keep the tensors alive
+    e.gn_part = _p(gn_part)
+    e.gn_hw = gn_hw if gn_part is not None else 0
+    e._keep = (bias, rowbias, residual, gn_part)  # the struct holds raw pointers: keep the tensors alive
     return e
 
 
@@ -313,6 +316,30 @@ def gn_stats(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-6, groups: 
     check(lib().psld_gn_stats_nhwc_f32(x.data_ptr(), b, h * w, c, g, eps, gamma.data_ptr(), beta.data_ptr(),
                                        st.mean.data_ptr(), st.rstd.data_ptr(), st.scale.data_ptr(),
                                        st.shift.data_ptr(), ws.data_ptr(), _stream()), "psld_gn_stats_nhwc_f32")
+    return st
+
+
+def gn_part_supported(b: int, hw: int, c: int) -> bool:
+    """Can a limb kernel's epilogue produce the GroupNorm partial sums of its [b, hw, c] output?  (Whole 64-row
+    runs per image, groups made of 8-channel fine groups, and a grid large enough that the kernel does not split
+    its K range.)"""
+    return hw % 64 == 0 and c % 128 == 0 and (c // gn_groups(c)) % 8 == 0 and ((b * hw + 127) // 128) * (c // 128) >= 384
+
+
+def gn_part_buffer(b: int, hw: int, c: int, device) -> Tensor:
+    """[b][hw/64][c/8][2] float64: sum / sum of squares per 64-row run and 8-channel fine group."""
+    return torch.empty((b, hw // 64, c // 8, 2), device=device, dtype=torch.float64)
+
+
+def gn_stats_from_part(part: Tensor, shape, gamma: Tensor, beta: Tensor, eps: float = 1e-6,
+                       groups: Optional[int] = None) -> GNStats:
+    """gn_stats of a tensor of ``shape`` = (b, h, w, c) whose producer left the partial sums in ``part``."""
+    b, h, w, c = shape
+    g = groups if groups is not None else gn_groups(c)
+    st = GNStats(b, g, c, part.device)
+    check(lib().psld_gn_stats_from_partials_f32(part.data_ptr(), b, h * w, c, g, eps, gamma.data_ptr(), beta.data_ptr(),
+                                                st.mean.data_ptr(), st.rstd.data_ptr(), st.scale.data_ptr(),
+                                                st.shift.data_ptr(), _stream()), "psld_gn_stats_from_partials_f32")
     return st
 
 

@@ -141,11 +141,14 @@ class Downsample(nn.Module):
 # executor
 # ----------------------------------------------------------------------------------------------
 class _Node:
-    __slots__ = ("v", "g")
+    """``gp``: GroupNorm partial sums of ``v`` left behind by the limb kernel that produced it (ops.gn_part_buffer),
+    or None: the GroupNorm that reads the node then skips its statistics pass over the tensor."""
+    __slots__ = ("v", "g", "gp")
 
-    def __init__(self, v):
+    def __init__(self, v, gp=None):
         self.v = v
         self.g = None
+        self.gp = gp
 
 
 class _CatNode:
@@ -284,6 +287,22 @@ class _Exec:
         slabs = ops.workspace(4 * n * nsplit, dy.device)
         ops.conv2d_wgrad_nhwc(dy, cout, x, k, k, stride, pad, oh, ow, slabs, cin, 0, nsplit)
         ops.reduce_slabs(slabs, nsplit, n, self.g(conv.weight), layout=1, cout=cout, taps=taps, cin=cin, alpha=alpha)
+
+    @staticmethod
+    def node_stats(node: _Node, gamma: Tensor, beta: Tensor, groups: Optional[int] = None):
+        """GroupNorm statistics of a node: from the producer's partial sums when it left some and the group size is a
+        multiple of their 8 channels, else by a pass over the tensor."""
+        c = node.v.shape[-1]
+        g = groups if groups is not None else ops.gn_groups(c)
+        if node.gp is not None and (c // g) % 8 == 0:
+            return ops.gn_stats_from_part(node.gp, node.v.shape, gamma, beta, groups=groups)
+        return ops.gn_stats(node.v, gamma, beta, groups=groups)
+
+    def part_for(self, b: int, hw: int, c: int, device, limb_kernel: bool):
+        """Partial-sum buffer for the epilogue of a limb kernel writing a [b, hw, c] output (None: not applicable)."""
+        if self.split and limb_kernel and ops.gn_part_supported(b, hw, c):
+            return ops.gn_part_buffer(b, hw, c, device)
+        return None
 
     def bmm(self, ta: int, tb: int, M: int, N: int, K: int, A: Tensor, lda: int, sa: int, B: Tensor, ldb: int, sb: int,
             Cc: Tensor, ldc: int, sc: int, batch: int, alpha: float = 1.0):
@@ -489,14 +508,14 @@ class _Exec:
         up, down = mod.up, mod.down
         a0b, st0b, g1, g2 = None, None, None, None
         if xb is None:
-            st0 = ops.gn_stats(x.v, gn0.weight, gn0.bias)
+            st0 = self.node_stats(x, gn0.weight, gn0.bias)
         else:
             # GroupNorm over the concatenation = each source normalised over its own share of the groups
             cpg = cin // ops.gn_groups(cin)
             g1, g2 = c1 // cpg, (cin - c1) // cpg
             gam, bet = gn0.weight.detach(), gn0.bias.detach()
-            st0 = ops.gn_stats(x.v, gam[:c1], bet[:c1], groups=g1)
-            st0b = ops.gn_stats(xb.v, gam[c1:], bet[c1:], groups=g2)
+            st0 = self.node_stats(x, gam[:c1], bet[:c1], groups=g1)
+            st0b = self.node_stats(xb, gam[c1:], bet[c1:], groups=g2)
             a0b = ops.gn_apply(xb.v, st0b, True)
         a0 = ops.gn_apply(x.v, st0, True)
         if up or down:
@@ -514,9 +533,12 @@ class _Exec:
             else:
                 tp = ops.linear(self.temb_act.v, mod.Dense_0.weight, mod.Dense_0.bias)
         h1 = torch.empty((b, ho, wo, cout), device=x.v.device, dtype=torch.float32)
+        c0_in2 = a0b.shape[-1] if a0b is not None else 0
+        h1p = self.part_for(b, ho * wo, cout, h1.device,
+                            ops.conv3x3_split_supported(a0r.shape[-1], c0_in2, b, ho, wo, cout))
         self.conv3(a0r, mod.Conv_0, h1, ops.epilogue(bias=mod.Conv_0.bias, rowbias=tp, rows_per_img=ho * wo,
-                                                     ld_rowbias=tp_ld), x2=a0b)
-        st1 = ops.gn_stats(h1, gn1.weight, gn1.bias)
+                                                     ld_rowbias=tp_ld, gn_part=h1p, gn_hw=ho * wo), x2=a0b)
+        st1 = self.node_stats(_Node(h1, h1p), gn1.weight, gn1.bias)
         drop_p, seed = 0.0, 0
         if self.drop_p > 0:
             drop_p = self.drop_p
@@ -535,8 +557,10 @@ class _Exec:
             res = out
         else:
             res = xr
-        self.conv3(a1, mod.Conv_1, out, ops.epilogue(bias=mod.Conv_1.bias, residual=res, ld_residual=cout, out_scale=s))
-        on = _Node(out)
+        outp = self.part_for(b, ho * wo, cout, out.device, ops.conv3x3_split_supported(cout, 0, b, ho, wo, cout))
+        self.conv3(a1, mod.Conv_1, out, ops.epilogue(bias=mod.Conv_1.bias, residual=res, ld_residual=cout, out_scale=s,
+                                                     gn_part=outp, gn_hw=ho * wo))
+        on = _Node(out, outp)
         if not self.record:
             return on
         temb_act = self.temb_act
@@ -665,7 +689,7 @@ class _Exec:
         m = b * hw
         dev = x.v.device
         gn = mod.GroupNorm_0
-        st = ops.gn_stats(x.v, gn.weight, gn.bias)
+        st = self.node_stats(x, gn.weight, gn.bias)
         hn = ops.gn_apply(x.v, st, False)
         n0, n1, n2, n3 = mod.NIN_0, mod.NIN_1, mod.NIN_2, mod.NIN_3
         scale = float(int(c) ** (-0.5))
@@ -699,7 +723,8 @@ class _Exec:
         ho = torch.empty((b, hw, c), device=dev, dtype=torch.float32)
         self.bmm(0, 0, hw, c, hw, p, hw, hw * hw, v, ld, hw * ld, ho, c, hw * c, b)
         out = torch.empty_like(x.v)
-        epi_out = ops.epilogue(bias=n3.b, residual=x.v, ld_residual=c, out_scale=s)
+        outp = self.part_for(b, hw, c, dev, fused)
+        epi_out = ops.epilogue(bias=n3.b, residual=x.v, ld_residual=c, out_scale=s, gn_part=outp, gn_hw=hw)
         if fused:
             f_o = net._pfrag(n3.W, "fwd", c, c, 1, c)
             ops.gemm_split(ho, None, m, f_o, c, out, epi_out)
@@ -969,7 +994,7 @@ class _Exec:
         assert not hs
         gnf, head = mods[mi], mods[mi + 1]
         assert mi + 2 == len(mods)
-        stf = ops.gn_stats(hnode.v, gnf.weight, gnf.bias)
+        stf = self.node_stats(hnode, gnf.weight, gnf.bias)
         af = ops.gn_apply(hnode.v, stf, True)
         oc = head.weight.shape[0]
         y = torch.empty((b, hh, ww, oc), device=x.device, dtype=torch.float32)

@@ -274,6 +274,44 @@ def test_conv3x3_fewout(ops, b, c, co, h, w_):
     assert not ops.conv3x3_fewout_supported(512, 6) and not ops.conv3x3_fewout_supported(256, 8)
 
 
+@pytest.mark.parametrize("b,c,co,h", [(24, 128, 256, 32), (96, 128, 256, 16)])
+def test_gn_partials_from_conv_epilogue(ops, b, c, co, h):
+    """GroupNorm statistics of a limb convolution's output as a by-product of its epilogue == gn_stats of the output,
+    for the consumer's own group size and for the coarser groups of a concatenation source; same for the pointwise form."""
+    x = gen(b, c, h, h, seed=110)
+    w = gen(co, c, 3, 3, seed=111, scale=0.1)
+    bias, res = gen(co, seed=112), gen(b, h, h, co, seed=113)
+    gamma, beta = (1 + 0.2 * gen(co, seed=114)).to(DEV), (0.1 * gen(co, seed=115)).to(DEV)
+    xd = _nhwc(x).to(DEV)
+    assert ops.gn_part_supported(b, h * h, co)
+    part = ops.gn_part_buffer(b, h * h, co, DEV)
+    part.fill_(float("nan"))
+    y = torch.empty(b, h, h, co, device=DEV)
+    epi = ops.epilogue(bias=bias.to(DEV), residual=res.to(DEV), ld_residual=co, out_scale=0.7, gn_part=part, gn_hw=h * h)
+    ops.conv3x3_split(xd, None, ops.conv3x3_frag(w.to(DEV), False), co, y, epi)
+    y_ref = torch.empty_like(y)
+    ops.conv3x3_split(xd, None, ops.conv3x3_frag(w.to(DEV), False), co, y_ref,
+                      ops.epilogue(bias=bias.to(DEV), residual=res.to(DEV), ld_residual=co, out_scale=0.7))
+    assert torch.equal(y, y_ref)
+    assert not ops.gn_part_supported(b, h * h, 128)              # 32 groups of 4 channels: finer than the 8-channel sums
+    for groups in (None, ops.gn_groups(2 * co) // 2):            # own GroupNorm / as one half of a concatenation
+        ref = ops.gn_stats(y, gamma, beta, groups=groups)
+        got = ops.gn_stats_from_part(part, y.shape, gamma, beta, groups=groups)
+        assert (got.mean - ref.mean).abs().max() < 2e-6 * ref.mean.abs().max() + 1e-7
+        assert rel_l2(got.rstd, ref.rstd) < 2e-6 and rel_l2(got.scale, ref.scale) < 2e-6
+        assert (got.shift - ref.shift).abs().max() < 1e-5
+    # pointwise form
+    m = b * h * h
+    wmat = gen(co, c, seed=116, scale=0.1)
+    part.fill_(float("nan"))
+    y2 = torch.empty(m, co, device=DEV)
+    ops.gemm_split(xd.view(m, c), None, m, ops.gemm_frag(wmat.to(DEV), co, c, c, 1), co, y2,
+                   ops.epilogue(bias=bias.to(DEV), gn_part=part, gn_hw=h * h))
+    ref = ops.gn_stats(y2.view(b, h, h, co), gamma, beta)
+    got = ops.gn_stats_from_part(part, (b, h, h, co), gamma, beta)
+    assert rel_l2(got.rstd, ref.rstd) < 2e-6 and rel_l2(got.scale, ref.scale) < 2e-6 and (got.shift - ref.shift).abs().max() < 1e-5
+
+
 def test_two_source_weight_gradients(ops):
     """dwgrad / pwgrad reading the input of the convolution from two tensors (unmaterialised concatenation)."""
     b, c1, c2, co, h, w_ = 2, 128, 256, 128, 16, 16
