@@ -157,6 +157,87 @@ struct DConvArgs {
     const float* zero;
 };
 
+// Fused epilogue of a 64 x 64 wave tile (4 x 4 accumulators of v_mfma_f32_16x16x32_bf16) at (m0 + wr*64, n0 + wc*64).
+__device__ __forceinline__ void dconv_epilogue(const DConvArgs& a, f32x4v (&acc)[4][4], int m0, int n0, int wr, int wc,
+                                               int lane, int split) {
+    const int r16 = lane & 15, kq = lane >> 4;
+    // fused epilogue; C/D layout of the 16x16 MFMA: col = lane & 15, row = 4*(lane >> 4) + v
+    float* Cb = a.C + (long long)split * a.c_stride_split;
+    const PsldEpilogue& e = a.e;
+    const bool rb_uniform = e.rowbias && (e.rows_per_img % 16 == 0);
+    float gs[4], gss[4];                 // GroupNorm by-product: this lane's column sums over the wave's 64 rows
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) gs[nb] = gss[nb] = 0.f;
+    // Residual / previous-output values are loaded for a whole 16-row block (16 loads in flight) BEFORE its stores: a
+    // load placed after a store to memory the compiler cannot tell apart waits out its own latency (measured: the
+    // residual epilogue cost +138 us on a 161 us GEMM, +53 us on a 650 us convolution when it was interleaved).
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const int row_base = m0 + wr * 64 + mb * 16;
+        float rv[4][4], cv[4][4];       // residual, previous output
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const int gn = n0 + wc * 64 + nb * 16 + r16;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int gm = row_base + 4 * kq + v;
+                const bool ok = gm < a.M;
+                rv[nb][v] = (e.res && ok) ? e.res[(long long)gm * e.ldres + gn] : 0.f;
+                cv[nb][v] = (e.accumulate && ok) ? Cb[(long long)gm * a.ldc + gn] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const int gn = n0 + wc * 64 + nb * 16 + r16;
+            float bias = e.bias ? e.bias[gn] : 0.f;
+            // time-embedding bias: one value per (image, channel); a 16-row block never straddles images
+            if (rb_uniform && row_base < a.M) bias += e.rowbias[(long long)(row_base / e.rows_per_img) * e.ld_rowbias + gn];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int gm = row_base + 4 * kq + v;
+                if (gm >= a.M) continue;
+                float x = acc[mb][nb][v] * e.alpha + bias;
+                if (e.rowbias && !rb_uniform) x += e.rowbias[(long long)(gm / e.rows_per_img) * e.ld_rowbias + gn];
+                if (e.res) x += rv[nb][v];
+                x *= e.out_scale;
+                if (e.accumulate) x += cv[nb][v];
+                Cb[(long long)gm * a.ldc + gn] = x;
+                gs[nb] += x;
+                gss[nb] += x * x;
+            }
+        }
+    }
+    if (e.gn_part) {
+        // 64 rows x 64 columns of one image per wave: sums over the 8 channels of a fine group = lanes r16 & 8 equal,
+        // all four row groups kq.  Fixed butterfly, one writer per (wave, fine group): repeatable.
+        const int row0 = m0 + wr * 64;
+        if (row0 < a.M) {
+            const int img = row0 / e.gn_hw, chunk = (row0 - img * e.gn_hw) >> 6, chunks = e.gn_hw >> 6;
+            const int fine = a.N >> 3;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                float s1 = gs[nb], s2 = gss[nb];
+#pragma unroll
+                for (int sft = 1; sft <= 4; sft <<= 1) {
+                    s1 += __shfl_xor(s1, sft, 64);
+                    s2 += __shfl_xor(s2, sft, 64);
+                }
+#pragma unroll
+                for (int sft = 16; sft <= 32; sft <<= 1) {
+                    s1 += __shfl_xor(s1, sft, 64);
+                    s2 += __shfl_xor(s2, sft, 64);
+                }
+                if ((lane & 0x37) == 0) {        // lanes 0 and 8
+                    const int f = ((n0 + wc * 64 + nb * 16) >> 3) + (r16 >> 3);
+                    double* pp = e.gn_part + (((long long)img * chunks + chunk) * fine + f) * 2;
+                    pp[0] = (double)s1;
+                    pp[1] = (double)s2;
+                }
+            }
+        }
+    }
+}
+
 // NH = float4 staging items per thread and stage: the LDS image has NH*32 pixel rows per limb.
 // TAPS = K steps (of 32 channels) served by one staged image: the 9 filter taps of a 3x3 convolution (PW = false:
 // the image is the halo tile of ONE 32-channel chunk, >= nseg*(rps+2)*(W+2) rows), or, for the pointwise kernel
@@ -321,67 +402,7 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
         if (sigma + 1 < sig_end) step(sigma + 1, std::integral_constant<int, 1>{});
     }
 
-    // fused epilogue; C/D layout of the 16x16 MFMA: col = lane & 15, row = 4*(lane >> 4) + v
-    float* Cb = a.C + (long long)split * a.c_stride_split;
-    const PsldEpilogue& e = a.e;
-    const bool rb_uniform = e.rowbias && (e.rows_per_img % 16 == 0);
-    float gs[4], gss[4];                 // GroupNorm by-product: this lane's column sums over the wave's 64 rows
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) gs[nb] = gss[nb] = 0.f;
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-        const int row_base = m0 + wr * 64 + mb * 16;
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            const int gn = n0 + wc * 64 + nb * 16 + r16;
-            float bias = e.bias ? e.bias[gn] : 0.f;
-            // time-embedding bias: one value per (image, channel); a 16-row block never straddles images
-            if (rb_uniform && row_base < a.M) bias += e.rowbias[(long long)(row_base / e.rows_per_img) * e.ld_rowbias + gn];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int gm = row_base + 4 * kq + v;
-                if (gm >= a.M) continue;
-                float x = acc[mb][nb][v] * e.alpha + bias;
-                if (e.rowbias && !rb_uniform) x += e.rowbias[(long long)(gm / e.rows_per_img) * e.ld_rowbias + gn];
-                if (e.res) x += e.res[(long long)gm * e.ldres + gn];
-                x *= e.out_scale;
-                float* cp = Cb + (long long)gm * a.ldc + gn;
-                if (e.accumulate) x += *cp;
-                *cp = x;
-                gs[nb] += x;
-                gss[nb] += x * x;
-            }
-        }
-    }
-    if (e.gn_part) {
-        // 64 rows x 64 columns of one image per wave: sums over the 8 channels of a fine group = lanes r16 & 8 equal,
-        // all four row groups kq.  Fixed butterfly, one writer per (wave, fine group): repeatable.
-        const int row0 = m0 + wr * 64;
-        if (row0 < a.M) {
-            const int img = row0 / e.gn_hw, chunk = (row0 - img * e.gn_hw) >> 6, chunks = e.gn_hw >> 6;
-            const int fine = a.N >> 3;
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                float s1 = gs[nb], s2 = gss[nb];
-#pragma unroll
-                for (int sft = 1; sft <= 4; sft <<= 1) {
-                    s1 += __shfl_xor(s1, sft, 64);
-                    s2 += __shfl_xor(s2, sft, 64);
-                }
-#pragma unroll
-                for (int sft = 16; sft <= 32; sft <<= 1) {
-                    s1 += __shfl_xor(s1, sft, 64);
-                    s2 += __shfl_xor(s2, sft, 64);
-                }
-                if ((lane & 0x37) == 0) {        // lanes 0 and 8
-                    const int f = ((n0 + wc * 64 + nb * 16) >> 3) + (r16 >> 3);
-                    double* pp = e.gn_part + (((long long)img * chunks + chunk) * fine + f) * 2;
-                    pp[0] = (double)s1;
-                    pp[1] = (double)s2;
-                }
-            }
-        }
-    }
+    dconv_epilogue(a, acc, m0, n0, wr, wc, lane, split);
 }
 
 // ---- weight gradient ---------------------------------------------------------------------------------------

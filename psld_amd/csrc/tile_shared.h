@@ -58,16 +58,25 @@ __device__ __forceinline__ void epilogue_store_block(const f32x16& acc, int row_
     float bias = e.bias ? e.bias[gn] : 0.f;
     // time-embedding bias: one value per (image, channel); a 32-row block never straddles images
     if (rb_uniform && row_base < M) bias += e.rowbias[(long long)(row_base / e.rows_per_img) * e.ld_rowbias + gn];
+    // residual / previous-output values first, all 16 in flight: a load issued after a store the compiler cannot tell
+    // apart from it waits out its own latency (see dconv_epilogue in conv_split.hip)
+    float rv[16], cv[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int gm = row_base + (v & 3) + 8 * (v >> 2) + 4 * h;
+        const bool ok = gm < M;
+        rv[v] = (Rb && ok) ? Rb[(long long)gm * e.ldres + gn] : 0.f;
+        cv[v] = (e.accumulate && ok) ? Cb[(long long)gm * ldc + gn] : 0.f;
+    }
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
         const int gm = row_base + (v & 3) + 8 * (v >> 2) + 4 * h;
         if (gm >= M) continue;
         float x = acc[v] * e.alpha + bias;
         if (e.rowbias && !rb_uniform) x += e.rowbias[(long long)(gm / e.rows_per_img) * e.ld_rowbias + gn];
-        if (Rb) x += Rb[(long long)gm * e.ldres + gn];
+        if (Rb) x += rv[v];
         x *= e.out_scale;
-        float* cp = Cb + (long long)gm * ldc + gn;
-        if (e.accumulate) x += *cp;
-        *cp = x;
+        if (e.accumulate) x += cv[v];
+        Cb[(long long)gm * ldc + gn] = x;
     }
 }
