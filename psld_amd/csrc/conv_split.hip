@@ -174,16 +174,26 @@ __device__ __forceinline__ void dconv_epilogue(const DConvArgs& a, f32x4v (&acc)
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
         const int row_base = m0 + wr * 64 + mb * 16;
+        if (row_base >= a.M) continue;                      // wave-uniform
+        const bool full = row_base + 16 <= a.M;             // wave-uniform: no per-element bounds checks
+        long long coff[4], roff[4];                         // row offsets of this lane's four rows
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int gm = row_base + 4 * kq + v;
+            coff[v] = (long long)gm * a.ldc;
+            roff[v] = (long long)gm * e.ldres;
+        }
         float rv[4][4], cv[4][4];       // residual, previous output
+        if (e.res || e.accumulate) {
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            const int gn = n0 + wc * 64 + nb * 16 + r16;
+            for (int nb = 0; nb < 4; ++nb) {
+                const int gn = n0 + wc * 64 + nb * 16 + r16;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int gm = row_base + 4 * kq + v;
-                const bool ok = gm < a.M;
-                rv[nb][v] = (e.res && ok) ? e.res[(long long)gm * e.ldres + gn] : 0.f;
-                cv[nb][v] = (e.accumulate && ok) ? Cb[(long long)gm * a.ldc + gn] : 0.f;
+                for (int v = 0; v < 4; ++v) {
+                    const bool ok = full || row_base + 4 * kq + v < a.M;
+                    rv[nb][v] = (e.res && ok) ? e.res[roff[v] + gn] : 0.f;
+                    cv[nb][v] = (e.accumulate && ok) ? Cb[coff[v] + gn] : 0.f;
+                }
             }
         }
 #pragma unroll
@@ -191,17 +201,17 @@ __device__ __forceinline__ void dconv_epilogue(const DConvArgs& a, f32x4v (&acc)
             const int gn = n0 + wc * 64 + nb * 16 + r16;
             float bias = e.bias ? e.bias[gn] : 0.f;
             // time-embedding bias: one value per (image, channel); a 16-row block never straddles images
-            if (rb_uniform && row_base < a.M) bias += e.rowbias[(long long)(row_base / e.rows_per_img) * e.ld_rowbias + gn];
+            if (rb_uniform) bias += e.rowbias[(long long)(row_base / e.rows_per_img) * e.ld_rowbias + gn];
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int gm = row_base + 4 * kq + v;
-                if (gm >= a.M) continue;
+                if (!full && gm >= a.M) continue;
                 float x = acc[mb][nb][v] * e.alpha + bias;
                 if (e.rowbias && !rb_uniform) x += e.rowbias[(long long)(gm / e.rows_per_img) * e.ld_rowbias + gn];
                 if (e.res) x += rv[nb][v];
                 x *= e.out_scale;
                 if (e.accumulate) x += cv[nb][v];
-                Cb[(long long)gm * a.ldc + gn] = x;
+                Cb[coff[v] + gn] = x;
                 gs[nb] += x;
                 gss[nb] += x * x;
             }
