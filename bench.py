@@ -4,6 +4,10 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 128]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`--gpus N` with N > 1 and no launcher in the environment (WORLD_SIZE unset) starts the N ranks itself: the parent
+spawns `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process before it has touched the
+GPU and exits with the child's code.  A world size that differs from --gpus is an error, never a silent 1-rank run.
+
 One step = the reference's full training step (main/models/wrapper.py:64-91 + callbacks.py:42-64):
 t ~ U[eps,1] -> PSLD perturb -> NCSN++ forward -> HSM loss -> backward (-> RCCL bucketed all-reduce
 when N>1) -> global-norm clip -> Adam -> LambdaLR -> EMA, dropout 0.15 on, fp32, per-GPU batch 128,
@@ -86,11 +90,31 @@ class ConvProbe:
                 "avg_us": 1e3 * ms / len(recs), "tflops": fl / (ms * 1e-3) / 1e12}
 
 
-def cpu_baseline(cfg, batch=16):
-    """Oracle (kind 'port') on the host cores: one full HSM train step at B=16 (configs[0])."""
+def physical_cores():
+    """One logical CPU per physical core among the CPUs this process may run on (SMT siblings dropped)."""
+    allowed = sorted(os.sched_getaffinity(0))
+    seen, keep = set(), []
+    for c in allowed:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as fh:
+                sib = fh.read().strip()
+        except OSError:
+            sib = str(c)
+        if sib not in seen:
+            seen.add(sib)
+            keep.append(c)
+    return keep
+
+
+def cpu_baseline(cfg, batch=16, timed=3):
+    """Oracle (kind 'port') on the host cores, configs[0] exactly (B=16, fp32, one process): threads pinned one per
+    physical core, 1 warm-up + `timed` full HSM train steps (median) and the eval-mode forward."""
     from oracle import psld_oracle as O
     from psld_amd.score_fn import NCSNpp
     from tests.synth import synth_inputs
+    cores = physical_cores()
+    os.sched_setaffinity(0, cores)
+    torch.set_num_threads(len(cores))
     torch.manual_seed(0)
     net = NCSNpp(cfg)
     sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
@@ -120,41 +144,107 @@ def cpu_baseline(cfg, batch=16):
                 O.resblock_biggan = orig
             shapes = rec
         masks = [(torch.rand(batch, *s[1:], generator=g) >= p).float() / (1 - p) for s in shapes]
-    t0 = time.perf_counter()
-    O.train_step(sde, sd, cfg, x0, t, eps, {}, 1, ema_sd={k: v.clone() for k, v in sd.items()},
-                 dropout_masks=masks)
-    dt = time.perf_counter() - t0
-    return {"value": batch / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 HSM train step (fwd+bwd+clip+Adam+EMA), B={batch}, C10-SOTA NCSN++, fp32, "
-                      f"{dt:.1f} s on {torch.get_num_threads()} threads"}
+    ema_sd = {k: v.clone() for k, v in sd.items()}
+    opt_state = {}
+    times = []
+    for i in range(1 + timed):                 # step 0 = warm-up (allocator, thread pool, oneDNN primitive caches)
+        t0 = time.perf_counter()
+        O.train_step(sde, sd, cfg, x0, t, eps, opt_state, i + 1, ema_sd=ema_sd, dropout_masks=masks)
+        times.append(time.perf_counter() - t0)
+    steps = sorted(times[1:])
+    dt = steps[len(steps) // 2]
+    z = torch.randn(batch, 6, cfg.data.image_size, cfg.data.image_size)
+    tt = torch.rand(batch) * 0.98 + 0.01
+    fwd = []
+    with torch.no_grad():
+        for i in range(3):
+            t0 = time.perf_counter()
+            O.ncsnpp_forward(sd, cfg, z, tt)
+            fwd.append(time.perf_counter() - t0)
+    fdt = sorted(fwd[1:])[0]
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), "")
+    except OSError:
+        pass
+    return {"value": batch / dt, "unit": "images/s", "cores": len(cores), "kind": "port",
+            "eval_forward_images_per_s": batch / fdt,
+            "train_step_s": [round(x, 2) for x in times], "host": model, "torch": torch.__version__,
+            "sample": f"{timed} HSM train steps after 1 warm-up (median; fwd+bwd+clip+Adam+EMA), B={batch}, C10-SOTA "
+                      f"NCSN++, fp32, {dt:.1f} s/step on {len(cores)} threads pinned to physical cores; eval forward "
+                      f"{fdt:.2f} s (best of 2 after 1 warm-up)"}
 
 
-def sampling_probe(cfg, ema_net, sde, dev, batch, steps):
-    """Second half of BASELINE.json's metric: EM reverse-SDE sampling (configs[4]: 1000 steps, 512/GPU).
-    Times `steps` full predictor updates (network forward + fused EM kernel) of the EMA network in eval
-    mode and extrapolates the 50k-sample wall-clock for 8 GPUs (ceil(50000/(8*512)) = 13 batches/GPU)."""
+def sampling_run(cfg, ema_net, sde, dev, batch, n_discrete_steps):
+    """Second half of BASELINE.json's metric, measured: ONE full per-GPU batch of configs[4] end to end —
+    prior sampling -> (n_discrete_steps - 1) EM predictor steps + the denoising step on the EMA network at B=512
+    (main/eval/sample.py:59-109 -> wrapper.py:101-122 -> samplers/sde.py:38-58) -> uint8 conversion of the position
+    half (callbacks.py:103-107, util.py:147-158) -> host.  50 000 samples on 8 GPUs = ceil(50000 / (8*512)) = 13 such
+    batches per GPU (the last one partial), no collective."""
+    from psld_amd import ops
     from psld_amd.registry import get_module
     ema_net.eval()
-    sampler = get_module("samplers", "em_sde")(cfg, sde, ema_net)
-    x = sde.prior_sampling((batch, 3, 32, 32), device=dev)
-    n = 1000
-    ts = torch.linspace(0, sde.T - cfg.evaluation.eval_eps, n, device=dev, dtype=torch.float64)
+    cfg.evaluation.n_discrete_steps = n_discrete_steps
+    wrapper = get_module("pl_modules", "sde_wrapper")(cfg, sde, ema_net, ema_score_fn=ema_net,
+                                                      sampler_cls=get_module("samplers", "em_sde"))
     with torch.no_grad():
-        sampler.sample(x, ts[:2], 1, denoise=False)          # warm-up
+        warm = sde.prior_sampling((batch, 3, 32, 32), device=dev)
+        wrapper.sampler.sample(warm, wrapper.sampling_times(dev)[:3], 2, denoise=True, eps=cfg.evaluation.eval_eps)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        sampler.sample(x, ts[: steps + 1], steps, denoise=False)
+        x = sde.prior_sampling((batch, 3, 32, 32), device=dev)
+        xs = wrapper.predict_step(x, 0)
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
+        t1 = time.perf_counter()
+        u8 = ops.samples_to_uint8(xs, is_augmented=True)
+        host = u8.cpu()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
     ema_net.train()
+    assert host.shape[0] == batch and host.dtype == torch.uint8
+    batch_s = t2 - t0
+    evals = n_discrete_steps                      # n-1 predictor steps + 1 denoising step, one network call each
     batches = -(-50000 // (8 * batch))
-    return {"batch_per_gpu": batch, "ms_per_em_step": 1e3 * dt, "network_evals_per_s": batch / dt,
-            "fwd_tflops": 76.46e9 * batch / dt / 1e12,
-            "est_50k_samples_1000_steps_8gpu_s": batches * 1000 * dt,
-            "note": "measured on 1 GPU; 8-GPU figure assumes the collective-free sharding of SURVEY 8(e)"}
+    full = n_discrete_steps == 1000
+    return {"batch_per_gpu": batch, "n_discrete_steps": n_discrete_steps, "network_evals": evals,
+            "measured_batch_s": batch_s, "sampler_s": t1 - t0, "uint8_and_d2h_s": t2 - t1,
+            "finite": bool(torch.isfinite(xs).all()),
+            "network_evals_per_s": batch * evals / (t1 - t0), "ms_per_em_step": 1e3 * (t1 - t0) / evals,
+            "fwd_tflops": 76.46e9 * batch * evals / (t1 - t0) / 1e12,
+            "per_gpu_50k_samples_8gpu_s": batches * batch_s * (1000.0 / n_discrete_steps),
+            "note": ("ONE full batch measured end to end on 1 GPU (prior -> 999 EM steps + denoise -> uint8 -> host); "
+                     if full else
+                     f"SHORTENED run ({n_discrete_steps} of 1000 discretisation steps) scaled by 1000/{n_discrete_steps}; ") +
+                    f"per_gpu_50k = {batches} batches/GPU x measured_batch_s: each of 8 GPUs samples its own shard, no "
+                    "collective (SURVEY 8(e)); the last batch of the real run is partial (50000 - 12*4096 = 848 samples "
+                    "over 8 GPUs)"}
 
 
-def main():
+def pmc_traffic_record():
+    """HBM bytes per launch of the dominant convolution from the committed PMC passes (profiles/r02/pmc_traffic.json,
+    written by tools/pmc_traffic.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs).  The record carries the hash of
+    the kernel sources it was measured on; a record measured on other sources is refused (traffic = null)."""
+    import hashlib
+    path = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            rec = json.load(fh)
+    except Exception:  # noqa: BLE001
+        return None, "no PMC record (profiles/r02/pmc_traffic.json)"
+    h = hashlib.sha256()
+    for f in rec.get("sources", []):
+        try:
+            with open(os.path.join(ROOT, f), "rb") as fh:
+                h.update(fh.read())
+        except OSError:
+            return None, f"PMC record names a missing source file {f}"
+    if h.hexdigest() != rec.get("sources_sha256"):
+        return None, "PMC record is stale: the kernel sources changed since it was measured (re-run tools/pmc_traffic.py)"
+    return rec, None
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -165,9 +255,40 @@ def main():
     ap.add_argument("--bucket-mb", type=int, default=64)
     ap.add_argument("--config", default="c10_sota", choices=["c10_sota", "celeba64_sota"],
                     help="c10_sota = BASELINE.json configs[0..2] (headline); celeba64_sota = configs[3] (extra data point)")
-    ap.add_argument("--sample-batch", type=int, default=512, help="per-GPU batch of the EM sampling probe (0 = skip)")
-    ap.add_argument("--sample-steps", type=int, default=4)
-    args = ap.parse_args()
+    ap.add_argument("--sample-batch", type=int, default=512, help="per-GPU batch of the EM sampling run (0 = skip)")
+    ap.add_argument("--sample-steps", type=int, default=1000,
+                    help="n_discrete_steps of the sampling run (1000 = configs[4], ~3 min at B=512; fewer = scaled estimate)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="form the process group, all-reduce ones, print the JSON line and exit (no model work; runs on "
+                         "CPU with gloo: how the self-launch path is tested without a GPU)")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args()
+
+
+def self_launch(args) -> int:
+    """--gpus N > 1 without a launcher: start N ranks as a child `torch.distributed.run` and return its exit code.
+    The parent has made no HIP call (importing torch does not initialise the GPU)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main():
+    args = parse_args()
+    if args.cpu_baseline_only:
+        from psld_amd import config as C
+        print(json.dumps(cpu_baseline(C.c10_sota())), flush=True)
+        return 0
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
 
     import psld_amd
     from psld_amd import config as C, ops
@@ -181,10 +302,56 @@ def main():
     # GPU (RCCL needs one device per rank; gloo stages through the host)
     backend = os.environ.get("PSLD_DIST_BACKEND") or None
     share_gpu = os.environ.get("PSLD_SHARE_GPU", "0") == "1"
+    if args.launch_check and backend is None and torch.cuda.device_count() < max(1, args.gpus):
+        backend = "gloo"
     rank, local, world = init_distributed(backend=backend, force=force_pg)
     if share_gpu:
         local = 0
-    assert world == max(1, args.gpus) or world == 1, (world, args.gpus)
+    if world != max(1, args.gpus):
+        print(f"bench.py: --gpus {args.gpus} but the launcher provides WORLD_SIZE={world}; refusing to report a "
+              f"{world}-rank run as a {args.gpus}-GPU number", file=sys.stderr)
+        return 2
+    dist_on = world > 1 or force_pg
+    backend_name = dist.get_backend() if dist_on else None
+
+    def barrier():
+        if dist_on:
+            dist.barrier(device_ids=[local]) if backend_name == "nccl" else dist.barrier()
+
+    ones_ok = None
+    if dist_on:        # the group really spans `world` ranks: an all-reduce of ones must give world
+        on_dev = backend_name == "nccl"
+        if on_dev:
+            torch.cuda.set_device(local)
+        one = torch.ones(1, device=torch.device("cuda", local) if on_dev else "cpu")
+        dist.all_reduce(one)
+        ones_ok = float(one.item()) == float(world)
+        if not ones_ok:
+            print(f"bench.py: all-reduce of ones gave {one.item()} on a world of {world}", file=sys.stderr)
+            return 3
+    if args.launch_check:
+        barrier()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "backend": backend_name,
+                              "allreduce_ones_ok": ones_ok, "parallelism": f"dp{world}",
+                              "self_launched": os.environ.get("TORCHELASTIC_RUN_ID") is not None}), flush=True)
+        if dist_on:
+            dist.destroy_process_group()
+        return 0
+
+    # the CPU baseline runs FIRST, in a child process with its own thread pool pinned to physical cores, before this
+    # process has touched the GPU; nothing else is running on the box while it is timed
+    cpu_base = None
+    if world == 1 and not args.no_cpu_baseline and args.config == "c10_sota":
+        import subprocess
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"],
+                               capture_output=True, text=True, timeout=900)
+            cpu_base = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else \
+                {"error": (r.stderr or r.stdout)[-400:]}
+        except Exception as e:  # noqa: BLE001
+            cpu_base = {"error": repr(e)}
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -205,8 +372,10 @@ def main():
     crit = get_module("losses", "psld_score_loss")(cfg, sde)
     wrapper = get_module("pl_modules", "sde_wrapper")(cfg, sde, net, ema_score_fn=ema, criterion=crit)
     ema_cb = EMAWeightUpdate(cfg.training.ema_decay)
-    if world > 1 or force_pg:
-        net.set_reducer(BucketReducer(bucket_bytes=args.bucket_mb << 20, force_collective=force_pg))
+    reducer = None
+    if dist_on:
+        reducer = BucketReducer(bucket_bytes=args.bucket_mb << 20, force_collective=force_pg, profile=True)
+        net.set_reducer(reducer)
     g = torch.Generator(device=dev).manual_seed(rank)         # per-rank data
     data = [torch.rand(args.batch, 3, size, size, device=dev, generator=g) * 2 - 1 for _ in range(4)]
 
@@ -223,11 +392,12 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1 or force_pg:
-            dist.barrier(device_ids=[local]) if dist.get_backend() == "nccl" else dist.barrier()
+        barrier()
         torch.cuda.synchronize()
 
     fence()
+    if reducer is not None:
+        reducer.stats()                                       # drop the warm-up steps' events
     probe.enabled = not args.no_probe
     t0 = time.perf_counter()
     last = None
@@ -237,10 +407,19 @@ def main():
     dt = time.perf_counter() - t0
     probe.enabled = False
     if world > 1:
-        tt = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if backend_name == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     loss_val = float(last.item())
+    # replicas stay identical: same seed, same averaged gradient -> same parameters on every rank
+    in_sync = None
+    if world > 1:
+        chk = net.flatten_parameters().double().sum().reshape(1)
+        chk = chk if backend_name == "nccl" else chk.cpu()
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        in_sync = bool(lo.item() == hi.item())
 
     if rank == 0:
         total_imgs = world * args.batch * args.steps
@@ -260,14 +439,16 @@ def main():
             "images_per_sec_per_gpu": total_imgs / dt / world,
             "final_loss": loss_val,
         }
+        if dist_on:
+            st = reducer.stats()
+            out["distributed"] = {"backend": ("rccl" if backend_name == "nccl" else backend_name), "world": world,
+                                  "allreduce_ones_ok": ones_ok, "replicas_in_sync": in_sync,
+                                  "gradient_bytes_per_step": int(net.flat_grad().numel()) * 4,
+                                  "shared_gpu_rehearsal": share_gpu}
+            out["overlap"] = st if st is not None else {"note": "no collective ran"}
         ps = probe.summary("split")
         pt = probe.summary("tile")
-        pmc = None
-        try:   # HBM bytes of the dominant launch shape from the committed PMC passes (profiles/r01/pmc_traffic.json)
-            with open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")) as fh:
-                pmc = json.load(fh)
-        except Exception:  # noqa: BLE001
-            pmc = None
+        pmc, pmc_err = pmc_traffic_record()
         if ps is not None:
             peak = PEAK_BF16_MFMA_TFLOPS / LIMB_PRODUCTS
             out["roofline"] = {
@@ -276,13 +457,13 @@ def main():
                 "peak_note": "fp32-equivalent (algorithmic 2MNK) rate; peak = 2500 TFLOP/s dense bf16 MFMA / 6 limb "
                              "products per fp32 product.  MFMA flops issued = 6 x achieved; the fp32 MFMA peak this "
                              "replaces is 157.3 TFLOP/s.  Under this load the chip holds ~1.65-1.8 GHz (PMC, "
-                             "profiles/r01); a register-only loop with random operand data sustains 1.90 PFLOP/s "
+                             "profiles/); a register-only loop with random operand data sustains 1.90 PFLOP/s "
                              "(tools/mfma_peak.hip), i.e. 317 TFLOP/s fp32-equivalent is the practical ceiling.",
                 "mfma_issued_tflops": LIMB_PRODUCTS * ps["tflops"],
                 "frac_of_sustained_mfma": LIMB_PRODUCTS * ps["tflops"] / SUSTAINED_BF16_MFMA_TFLOPS,
                 "frac_of_f32_mfma_peak": ps["tflops"] / PEAK_F32_MFMA_TFLOPS,
                 "traffic": pmc.get("traffic_bytes") if pmc else None,
-                "traffic_note": pmc.get("note") if pmc else None,
+                "traffic_note": pmc.get("note") if pmc else pmc_err,
                 "launches": ps["launches"], "avg_launch_us": ps["avg_us"],
                 "share_of_step": ps["total_ms"] / (1e3 * dt)}
         elif pt is not None:        # PSLD_MATH=f32: the fp32 MFMA tile engine carries the convolutions
@@ -304,19 +485,14 @@ def main():
             out["config"]["workload"] = f"{args.config} NCSN++ full HSM train step"
             out["config"]["image"] = f"6x{size}x{size}"
         if world == 1 and args.sample_batch > 0 and args.config == "c10_sota":
-            out["sampling"] = sampling_probe(cfg, ema, sde, dev, args.sample_batch, args.sample_steps)
-        if world == 1 and not args.no_cpu_baseline and args.config == "c10_sota":
-            try:
-                out["cpu_baseline"] = cpu_baseline(C.c10_sota())
-            except Exception as e:  # noqa: BLE001
-                out["cpu_baseline"] = {"error": repr(e)}
-        else:
-            out["cpu_baseline"] = None
+            out["sampling"] = sampling_run(cfg, ema, sde, dev, args.sample_batch, max(3, args.sample_steps))
+        out["cpu_baseline"] = cpu_base
         print(json.dumps(out), flush=True)
-    if world > 1 or force_pg:
-        dist.barrier(device_ids=[local]) if dist.get_backend() == "nccl" else dist.barrier()
+    if dist_on:
+        barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

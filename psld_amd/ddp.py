@@ -41,8 +41,13 @@ def init_distributed(backend: Optional[str] = None, force: bool = False) -> Tupl
 
 class BucketReducer:
     def __init__(self, process_group=None, bucket_bytes: int = 64 << 20, average: bool = True,
-                 force_collective: bool = False):
+                 force_collective: bool = False, profile: bool = False):
         self.pg = process_group
+        # profile: bracket every collective with HIP events on the side stream and the join in finish() with events
+        # on the compute stream -> stats(): how much of the exchange ran hidden under backward (bench.py "overlap")
+        self.profile = profile
+        self._prof = []          # per finished backward: ([(start, end) per bucket], (join0, join1)) or host seconds
+        self._cur = None
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.average = average
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -65,6 +70,7 @@ class BucketReducer:
         self._next = len(self._bounds) - 1
         self._works = []
         self.launched = []
+        self._cur = [] if self.profile else None
         if flat_grad.is_cuda and self._side is None:
             self._side = torch.cuda.Stream(device=flat_grad.device)
 
@@ -82,19 +88,32 @@ class BucketReducer:
                 pe.record(ps)
                 self._side.wait_event(pe)
             with torch.cuda.stream(self._side):
-                w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-                if self.average:
-                    w.wait()             # stream-level wait on the side stream only
-                    view.mul_(1.0 / self.world)
+                if self._cur is not None:
+                    s0 = torch.cuda.Event(enable_timing=True)
+                    s0.record(self._side)
+                # RCCL averages inside the collective (ReduceOp.AVG): no separate scaling pass over the bucket
+                op = dist.ReduceOp.AVG if self.average else dist.ReduceOp.SUM
+                w = dist.all_reduce(view, op=op, group=self.pg, async_op=True)
+                w.wait()                 # stream-level: orders the side stream after the collective, no host wait
+                if self._cur is not None:
+                    s1 = torch.cuda.Event(enable_timing=True)
+                    s1.record(self._side)
+                    self._cur.append((s0, s1))
             self._works.append(w)
         else:
+            import time as _time
             if self._flat.is_cuda:
                 torch.cuda.current_stream().synchronize()   # gloo reads the buffer from the host side
                 for ps in self.producer_streams:
                     ps.synchronize()
-            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)
+            t0 = _time.perf_counter()
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg)   # gloo has no AVG
             if self.average:
                 view.mul_(1.0 / self.world)
+            if self._cur is not None:
+                if self._flat.is_cuda:
+                    torch.cuda.current_stream().synchronize()
+                self._cur.append(_time.perf_counter() - t0)
 
     def ready_from(self, offset: int):
         """All gradients at flat offsets >= ``offset`` are final."""
@@ -109,10 +128,44 @@ class BucketReducer:
             self._launch(lo, hi)
             self._next -= 1
         if self._flat is not None and self._flat.is_cuda and (self.world > 1 or self.force) and self._works:
-            for w in self._works:
-                w.wait()
-            torch.cuda.current_stream().wait_stream(self._side)
+            cur = torch.cuda.current_stream()
+            j0 = j1 = None
+            if self._cur is not None:
+                j0 = torch.cuda.Event(enable_timing=True)
+                j0.record(cur)
+            cur.wait_stream(self._side)
+            if self._cur is not None:
+                j1 = torch.cuda.Event(enable_timing=True)
+                j1.record(cur)
+                self._prof.append((self._cur, (j0, j1)))
+        elif self._cur:
+            self._prof.append((self._cur, None))
+        self._cur = None
         self._works = []
+
+    def stats(self, reset: bool = True):
+        """Exchange timing over the backward passes since the last reset (``profile=True``): per step the number of
+        buckets, the time the collectives occupied the side stream (``comm_ms``), the time the compute stream
+        stood waiting for them at the join (``exposed_ms``) and the difference (``hidden_ms``: ran under backward).
+        Host-synchronous backends (gloo) expose everything.  Call after a device synchronize."""
+        steps = len(self._prof)
+        if steps == 0:
+            return None
+        buckets = comm = exposed = 0.0
+        for evs, join in self._prof:
+            buckets += len(evs)
+            if join is None:
+                c = 1e3 * sum(evs)
+                comm += c
+                exposed += c
+            else:
+                comm += sum(a.elapsed_time(b) for a, b in evs)
+                exposed += join[0].elapsed_time(join[1])
+        if reset:
+            self._prof = []
+        return {"steps": steps, "buckets_per_step": buckets / steps, "bucket_mb": self.bucket_elems * 4 / 2 ** 20,
+                "comm_ms_per_step": comm / steps, "exposed_ms_per_step": exposed / steps,
+                "hidden_ms_per_step": max(0.0, comm - exposed) / steps}
 
 
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:

@@ -25,6 +25,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.ema_decay = float(ema_decay)
         self._step = 0
         self._m = self._v = self._norm = None
+        self._backward_seen = -1     # module._backward_count at the last zero_grad()/step(): step() needs a newer one
 
     def _state_buffers(self):
         flat = self.module.flatten_parameters()
@@ -44,6 +45,11 @@ class FusedAdam(torch.optim.Optimizer):
         self.module.mark_grads_stale()
         if not set_to_none:
             self.module.flat_grad().zero_()
+        elif self.module._params_visible():
+            # gradients arrive through autograd's AccumulateGrad (torch DDP): a populated .grad would be added to
+            for p in self.module._trainable():
+                p.grad = None
+        self._backward_seen = self.module._backward_count
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -51,17 +57,28 @@ class FusedAdam(torch.optim.Optimizer):
         group = self.param_groups[0]
         flat = self._state_buffers()
         grad = self.module.flat_grad()
+        if self.module._backward_count == self._backward_seen:
+            raise RuntimeError("FusedAdam.step(): no backward pass has run since the last zero_grad()/step(); the gradient "
+                               "buffer holds the previous step's (consumed) gradient")
+        self.module.adopt_foreign_grads()     # a foreign reducer may have replaced .grad (DDP bucket views)
         self._step += 1
         if self.grad_clip > 0:
             ops.grad_norm(grad, self._norm)
         ema_flat = None
         if self.ema_module is not None:
             ema_flat = self.ema_module.flatten_parameters()
+        # torch.optim.Adam skips parameters without a gradient; the kernel sweeps the whole flat buffer, where frozen
+        # parameters (GaussianFourierProjection.W) see g = 0: a no-op unless weight decay is on -> keep them aside
+        frozen = [p for p in self.module._params() if not p.requires_grad] if group["weight_decay"] != 0 else []
+        kept = [p.detach().clone() for p in frozen]
         ops.adam_ema(flat, grad, self._m, self._v, ema_flat, self._norm if self.grad_clip > 0 else None,
                      self.grad_clip, group["lr"], group["betas"][0], group["betas"][1], group["eps"],
                      group["weight_decay"], self._step, self.ema_decay)
+        for p, k in zip(frozen, kept):
+            p.detach().copy_(k)
         self.module.weights_changed()
         self.module.mark_grads_stale()      # consumed: a following backward starts a fresh gradient
+        self._backward_seen = self.module._backward_count
         if self.ema_module is not None:
             self.ema_module.weights_changed()
 

@@ -1108,6 +1108,37 @@ class _NCSNppFn(torch.autograd.Function):
         return ex.dx_nchw, None, None, None
 
 
+class _NCSNppParamFn(torch.autograd.Function):
+    """Same executor, with every trainable parameter an INPUT of the autograd node: backward hands their gradients
+    (views of the flat gradient buffer) to autograd, which runs each parameter's AccumulateGrad node - the place where
+    torch ``DistributedDataParallel`` (Lightning ``strategy="ddp"``, train_sde.py:114) hangs its reducer hooks.
+    ``_NCSNppFn`` assigns ``p.grad`` itself and never reaches those nodes."""
+
+    @staticmethod
+    def forward(ctx, x, t, net, *params):
+        ex = _Exec(net, record=True)
+        ex.want_dx = bool(x.requires_grad)
+        y = ex.run(x, t)
+        ctx.ex = ex
+        ctx.net = net
+        ctx.pending = _Pending(net)
+        ctx.n_params = len(params)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        ex, net = ctx.ex, ctx.net
+        if ex is None:
+            raise RuntimeError("psld_amd.NCSNpp: backward through the same forward pass twice is not supported")
+        ctx.ex = None
+        net._begin_backward(visible=True)
+        ex.backward(gy)
+        grads = net._end_backward_visible()
+        ctx.pending.release()
+        assert len(grads) == ctx.n_params
+        return (ex.dx_nchw, None, None) + grads
+
+
 @register_module(category="score_fn", name="ncsnpp")
 class NCSNpp(nn.Module):
     """NCSN++ (ncsnpp.py:35-285 for the module list; forward in ``_Exec.run``)."""
@@ -1215,9 +1246,16 @@ class NCSNpp(nn.Module):
         # per-kernel HIP-event timings are not inflated by a concurrent MFMA kernel)
         import os as _os
         self.overlap_wgrad = _os.environ.get("PSLD_OVERLAP_WGRAD", "0") == "1"
+        # None (auto): parameters become inputs of the autograd node (gradients delivered through AccumulateGrad, so
+        # torch DDP / Lightning's ddp strategy can reduce them) when a multi-rank process group exists and no
+        # BucketReducer is attached; True / False (or PSLD_AUTOGRAD_PARAMS=1 / 0) force it.
+        _ap = _os.environ.get("PSLD_AUTOGRAD_PARAMS")
+        self.autograd_params = None if _ap is None else _ap == "1"
         self._plist = None
+        self._tlist = None
         self._gviews = None
         self._pending = 0
+        self._backward_count = 0    # finished backward passes (FusedAdam.step refuses to re-apply a consumed gradient)
         self._accumulating = False
         self._grad_stale = False
         self._scratch_grad = None
@@ -1464,12 +1502,29 @@ class NCSNpp(nn.Module):
         """The next backward overwrites the gradient buffer (what ``zero_grad`` means for this module)."""
         self._grad_stale = True
 
-    def _begin_backward(self):
+    def _trainable(self) -> List[nn.Parameter]:
+        if self._tlist is None or len(self._tlist[1]) != sum(p.requires_grad for p in self._params()):
+            self._tlist = (None, [p for p in self._params() if p.requires_grad])
+        return self._tlist[1]
+
+    def _params_visible(self) -> bool:
+        """Should this forward hand the parameters to autograd (see ``autograd_params``)?"""
+        if self.autograd_params is not None:
+            return self.autograd_params
+        import torch.distributed as dist
+        return self._reducer is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def _begin_backward(self, visible: bool = False):
         self.flat_grad()
         # torch semantics: a populated .grad is accumulated into.  Kernels WRITE their results, so in that
         # case this pass goes to a scratch buffer that is added afterwards (one extra 0.4 GB pass).
         probe = next((p for p in self._params() if p.requires_grad), None)
-        self._accumulating = probe is not None and (probe.grad is not None) and not self._grad_stale
+        if visible:
+            # autograd adds what backward returns INTO a populated .grad: it must not be handed the very memory
+            # .grad aliases, whatever zero_grad() marked
+            self._accumulating = probe is not None and probe.grad is not None
+        else:
+            self._accumulating = probe is not None and (probe.grad is not None) and not self._grad_stale
         self._grad_stale = False
         target = self._flat_grad
         if self._accumulating:
@@ -1487,6 +1542,7 @@ class NCSNpp(nn.Module):
             self._reducer.ready_from(offset)
 
     def _end_backward(self):
+        self._backward_count += 1
         if self._reducer is not None:
             self._reducer.finish()
         if self._accumulating:
@@ -1500,6 +1556,38 @@ class NCSNpp(nn.Module):
                 p.grad = gv
             else:
                 p.grad.add_(gv)  # caller kept a foreign .grad tensor: accumulate like autograd would
+
+    def _end_backward_visible(self):
+        """Gradients of the trainable parameters, in ``_trainable()`` order, for autograd to accumulate: fresh view
+        objects of the buffer this pass wrote (a view nobody else references is adopted by AccumulateGrad as ``.grad``
+        without a copy, so ``p.grad`` keeps aliasing the flat gradient buffer the fused optimiser reads)."""
+        src = self._scratch_grad if self._accumulating else self._flat_grad
+        self._accumulating = False
+        self._backward_count += 1
+        offs = self._offsets
+        return tuple(src[offs[id(p)]:offs[id(p)] + p.numel()].view(p.shape) for p in self._trainable())
+
+    def adopt_foreign_grads(self) -> int:
+        """Copy every ``p.grad`` that does NOT alias the flat gradient buffer into its slot (a reducer that swaps
+        ``.grad`` for its own bucket views - DDP ``gradient_as_bucket_view=True`` - leaves the reduced values there);
+        returns how many were copied.  Called by ``FusedAdam.step``."""
+        self.flat_grad()
+        if self._gviews is None:
+            self._gviews = self._views_of(self._flat_grad)
+        tr = self._trainable()
+        # probe three parameters first: a reducer that swaps .grad does so for all of them
+        if not any(q.grad is not None and q.grad.data_ptr() != self._gviews[id(q)].data_ptr()
+                   for q in (tr[0], tr[len(tr) // 2], tr[-1])):
+            return 0
+        dst, src = [], []
+        for p in tr:
+            gv = self._gviews[id(p)]
+            if p.grad is not None and p.grad.data_ptr() != gv.data_ptr():
+                dst.append(gv)
+                src.append(p.grad)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        return len(dst)
 
     def set_reducer(self, reducer):
         """Attach a gradient reducer (psld_amd.ddp.BucketReducer) fed during backward."""
@@ -1521,6 +1609,11 @@ class NCSNpp(nn.Module):
             self.flat_grad()
             if self._anchor is None or self._anchor.device != x.device:
                 self._anchor = torch.zeros(1, device=x.device, requires_grad=True)
+            if need_grad and self._params_visible():
+                if self._reducer is not None:
+                    raise RuntimeError("psld_amd.NCSNpp: autograd_params (gradients through AccumulateGrad, for torch DDP) "
+                                       "and a BucketReducer are two gradient exchanges: detach one of them")
+                return _NCSNppParamFn.apply(x, t, self, *self._trainable())
             return _NCSNppFn.apply(x, t, self._anchor, self)
         if self.use_graphs and not self.training:
             return self._graph_forward(x, t)
@@ -1578,17 +1671,18 @@ class NCSNpp(nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         skip = {"_flat", "_flat_grad", "_pack_cache", "_frag_table", "_temb_plan_cache", "_anchor", "_reducer", "_offsets", "_module_offs", "_posfreq",
-                "_side", "_plist", "_gviews", "_graphs", "_conv_by_weight", "_scratch_grad", "_sviews"}
+                "_side", "_plist", "_tlist", "_gviews", "_graphs", "_conv_by_weight", "_scratch_grad", "_sviews"}
         for k, v in self.__dict__.items():
             if k in skip:
                 continue
             new.__dict__[k] = copy.deepcopy(v, memo)
         new._flat = new._flat_grad = new._offsets = new._anchor = new._reducer = new._posfreq = new._side = None
         new._module_offs = None
-        new._plist = new._gviews = None
+        new._plist = new._tlist = new._gviews = None
         new._graphs = {}
         new._conv_by_weight = {}
         new._pending = 0
+        new._backward_count = 0
         new._scratch_grad = new._sviews = None
         new._accumulating = new._grad_stale = False
         new._pack_cache = {}

@@ -11,6 +11,8 @@ import torch.multiprocessing as mp
 
 from psld_amd.ddp import BucketReducer, shard_range
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def _free_port():
     with socket.socket() as s:
@@ -29,7 +31,7 @@ def _worker_buckets(rank, world, port, q):
     _init(rank, world, port)
     n = 1000
     flat = torch.arange(n, dtype=torch.float32) * (rank + 1)
-    red = BucketReducer(bucket_bytes=4 * 256)          # 256-element buckets -> 4 buckets
+    red = BucketReducer(bucket_bytes=4 * 256, profile=True)   # 256-element buckets -> 4 buckets
     red.begin(flat)
     for off in (900, 600, 512, 300, 0):                # watermarks as the backward tape would report them
         red.ready_from(off)
@@ -39,6 +41,9 @@ def _worker_buckets(rank, world, port, q):
     red.finish()
     expect = torch.arange(n, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
     ok = torch.allclose(flat, expect) and red.launched == [(768, 1000), (512, 768), (256, 512), (0, 256)]
+    st = red.stats()                                   # host-synchronous backend: all of the exchange is exposed
+    ok = ok and st["steps"] == 1 and st["buckets_per_step"] == 4 and st["hidden_ms_per_step"] == 0.0 and \
+        st["comm_ms_per_step"] > 0 and red.stats() is None
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
@@ -102,3 +107,29 @@ def test_shard_range_partitions_samples():
     assert spans[0][0] == 0 and spans[-1][1] == n
     assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
     assert shard_range(5, 7, 8) == (5, 5)
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` without torchrun must start 2 ranks itself: the launch check forms
+    the process group (gloo here: no GPUs), all-reduces ones and reports the world it really ran on."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = next(ln for ln in reversed(r.stdout.strip().splitlines()) if ln.startswith("{"))
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["allreduce_ones_ok"] is True and out["parallelism"] == "dp2"
+    assert out["self_launched"] is True and out["backend"] == "gloo"
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """A launcher that provides fewer ranks than --gpus asks for is an error, not a silent 1-rank number."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--launch-check"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 2 and "refusing" in r.stderr

@@ -689,6 +689,132 @@ def test_data_parallel_gradients_two_ranks_one_gpu():
     assert res[0][2] >= 4 and res[0][2] == res[1][2]
 
 
+def _torch_ddp_worker(rank, world, port, q, as_bucket_view):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        from psld_amd.optim import FusedAdam
+        from psld_amd.ddp import shard_range
+        from psld_amd.registry import get_module
+        from tests.synth import synth_inputs
+        net, cfg, _ = _build("tiny", train=True)
+        sde = get_module("sde", "psld")(cfg)
+        crit = get_module("losses", "psld_score_loss")(cfg, sde)
+        x0, eps, t = (v.to(DEV) for v in synth_inputs(4, 3, 16, seed=77))
+        # single-process large-batch reference on every rank (parameters hidden from autograd: the fast path)
+        net.autograd_params = False
+        crit(x0, t, net, eps=eps).backward()
+        ref = net.flat_grad().clone()
+        for p in net.parameters():
+            p.grad = None
+        net.autograd_params = None          # auto: a 2-rank group without a BucketReducer -> gradients through autograd
+        assert net._params_visible()
+        ddp = DDP(net, device_ids=[0], find_unused_parameters=True, gradient_as_bucket_view=as_bucket_view)
+        opt = FusedAdam(net, lr=1e-3, grad_clip=1.0)
+        lo, hi = shard_range(4, rank, world)
+        errs = []
+        for it in range(2):                 # second iteration: .grad populated by the first -> zero_grad path
+            opt.zero_grad()
+            crit(x0[lo:hi].contiguous(), t[lo:hi].contiguous(), ddp, eps=eps[lo:hi].contiguous()).backward()
+            torch.cuda.synchronize()
+            copied = net.adopt_foreign_grads()
+            g = net.flat_grad()
+            if it == 0:
+                errs.append(((g - ref).double().norm() / ref.double().norm()).item())
+                errs.append(copied)
+                # every trainable parameter got a gradient through its AccumulateGrad node
+                assert all(p.grad is not None for p in net.parameters() if p.requires_grad)
+                before = net.flatten_parameters().clone()
+                opt.step()
+                torch.cuda.synchronize()
+                assert not torch.equal(before, net.flatten_parameters())
+        # the two ranks applied the same update: parameters stay in sync without any further exchange
+        flat = net.flatten_parameters().detach().cpu()
+        gathered = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        errs.append(float((gathered[0] - gathered[1]).abs().max()))
+        q.put((rank, errs))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("as_bucket_view", [False, True])
+def test_torch_ddp_wrapper_reduces_the_gradients(as_bucket_view):
+    """The reference's DP is Lightning strategy="ddp" = torch DistributedDataParallel (train_sde.py:114,
+    wrapper.py:77-86).  Wrapping NCSNpp in DDP(find_unused_parameters=True) must give the rank-averaged gradient:
+    the parameters are inputs of the network's autograd node whenever a multi-rank group exists and no BucketReducer
+    is attached, so DDP's AccumulateGrad hooks fire.  2 gloo ranks share this GPU, half a batch of 4 each."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_torch_ddp_worker, args=(r, 2, port, q, as_bucket_view)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, (err, copied, drift) in res:
+        print(f"rank {rank}: DDP gradient vs large-batch {err:.3e}; foreign grads adopted {copied}; param drift {drift:.1e}")
+        assert err < 2e-5
+        assert (copied > 0) == as_bucket_view      # bucket views replace .grad: the optimiser must pick them up
+        assert drift == 0.0
+
+
+def test_bucket_reducer_and_autograd_params_are_exclusive():
+    from psld_amd.ddp import BucketReducer
+    net, cfg, _ = _build("tiny", train=True)
+    net.autograd_params = True
+    net.set_reducer(BucketReducer())
+    with pytest.raises(RuntimeError, match="two gradient exchanges"):
+        net(torch.zeros(1, 6, 16, 16, device=DEV), torch.ones(1, device=DEV))
+
+
+def test_autograd_params_single_process_matches_fast_path():
+    """Gradients delivered through autograd (the DDP-compatible path) are bitwise those of the fast path, and a
+    populated .grad is accumulated into like autograd does."""
+    from psld_amd.registry import get_module
+    from tests.synth import synth_inputs
+    net, cfg, _ = _build("tiny", train=True)
+    sde = get_module("sde", "psld")(cfg)
+    crit = get_module("losses", "psld_score_loss")(cfg, sde)
+    x0, eps, t = (v.to(DEV) for v in synth_inputs(3, 3, 16, seed=5))
+    crit(x0, t, net, eps=eps).backward()
+    ref = net.flat_grad().clone()
+    for p in net.parameters():
+        p.grad = None
+    net.autograd_params = True
+    crit(x0, t, net, eps=eps).backward()
+    assert torch.equal(net.flat_grad(), ref)
+    p0 = next(p for p in net.parameters() if p.requires_grad)
+    assert p0.grad.data_ptr() == net._gviews[id(p0)].data_ptr()      # adopted without a copy
+    crit(x0, t, net, eps=eps).backward()                                # second pass: accumulate
+    assert torch.allclose(net.flat_grad(), 2 * ref, rtol=1e-6, atol=0)
+
+
+def test_fused_adam_refuses_a_consumed_gradient():
+    from psld_amd.optim import FusedAdam
+    from psld_amd.registry import get_module
+    from tests.synth import synth_inputs
+    net, cfg, _ = _build("tiny", train=True)
+    sde = get_module("sde", "psld")(cfg)
+    crit = get_module("losses", "psld_score_loss")(cfg, sde)
+    opt = FusedAdam(net, lr=1e-3, weight_decay=0.1)
+    x0, eps, t = (v.to(DEV) for v in synth_inputs(2, 3, 16, seed=5))
+    w_before = net.all_modules[0].W.detach().clone()
+    crit(x0, t, net, eps=eps).backward()
+    opt.step()
+    assert torch.equal(net.all_modules[0].W, w_before)       # frozen Fourier frequencies: no weight decay
+    with pytest.raises(RuntimeError, match="no backward pass"):
+        opt.step()
+
+
 @pytest.mark.parametrize("name", ["c10_sota", "celeba64"])
 def test_full_size_network_gradients_against_live_oracle(name):
     """North-star scale backward: every parameter gradient of the 97.6 M (C10-SOTA) / 62.8 M (CelebA-64)

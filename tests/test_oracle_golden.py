@@ -261,6 +261,31 @@ def test_em_sampler(golden, tag):
     np.testing.assert_array_equal(torch.stack(seen).numpy(), g[f"seen_t_{tag}"])
 
 
+@pytest.mark.parametrize("stride", ["uniform", "quadratic"])
+def test_em_sampler_c10_sota(golden, stride):
+    """BASELINE configs[4] on its own network: the oracle's EM loop over the C10-SOTA NCSN++ against the
+    reference's EulerMaruyamaSampler (tools/gen_golden.py em_c10_section), 3 predictor steps + denoise."""
+    g = golden("em_c10_sota.npz")
+    cfg = C.c10_sota()
+    sde = O.PSLDOracle.from_config(cfg)
+    meta = _net_meta()["c10_sota"]
+    sd = synth_state_dict([(k, tuple(s)) for k, s in meta["keys"]], meta["seed"])
+    seen = []
+
+    def score_fn(u, tt):
+        assert u.dtype == torch.float32 and tt.dtype == torch.float32
+        seen.append(tt[0].clone())
+        return O.ncsnpp_forward(sd, cfg, u, tt)
+
+    ts, n = O.sampling_times(sde.T, cfg.evaluation.eval_eps, 4, True, stride)
+    np.testing.assert_array_equal(ts.numpy(), g[f"ts_{stride}"])
+    x = O.em_sample(sde, score_fn, T(g[f"batch_{stride}"]), ts, n, True, cfg.evaluation.eval_eps,
+                    noise=list(T(g[f"noise_{stride}"])))
+    assert x.dtype == torch.float64
+    assert rel_l2(x, T(g[f"x_{stride}"])) < 2e-6
+    np.testing.assert_array_equal(torch.stack(seen).numpy(), g[f"seen_t_{stride}"])
+
+
 @pytest.mark.parametrize("tag", ["xm_3", "xm_6", "m_3", "m_6"])
 def test_sscs_sampler(golden, tag):
     """symmetric-splitting sampler, default (score_xm) and gamma=0 (score_m, out_ch=3)."""

@@ -164,11 +164,55 @@ def clf_section(get, C):
         json.dump({"seed": 5000, "keys": [[k, list(s)] for k, s in cks], "clf_temp": 2.5}, fh)
 
 
+def em_c10_section(get, C):
+    """configs[4] on its own network: the reference's EulerMaruyamaSampler over the C10-SOTA NCSN++ (seed-2000 synthetic
+    weights), B=2, n_discrete_steps=4 (3 predictor steps + the denoising step), noise replayed."""
+    print("EM sampler (C10-SOTA)")
+    cfg = C.c10_sota()
+    sde = get("sde", "psld")(cfg)
+    net = get("score_fn", "ncsnpp")(cfg)
+    load_synth(net, 2000)
+    net.eval()
+    seen_t = []
+
+    def score_fn(u, tt):
+        seen_t.append(tt.detach().clone())
+        return net(u, tt)
+
+    sampler = get("samplers", "em_sde")(cfg, sde, score_fn)
+    out = {}
+    for stride in ("uniform", "quadratic"):
+        g = torch.Generator().manual_seed(4242)
+        batch = torch.cat([torch.randn(2, 3, 32, 32, generator=g),
+                           torch.randn(2, 3, 32, 32, generator=g) * np.sqrt(sde.m)], dim=1)
+        n = 3
+        t_final = sde.T - cfg.evaluation.eval_eps
+        tsx = torch.linspace(0, t_final, n + 1, dtype=torch.float64)
+        if stride == "quadratic":
+            tsx = t_final * torch.flip(1 - (tsx / t_final) ** 2.0, dims=[0])
+        noises = [torch.randn(2, 6, 32, 32, generator=g, dtype=torch.float64) for _ in range(n)]
+        it = iter(noises)
+        orig = torch.randn_like
+        torch.randn_like = lambda x_, **kw: next(it).to(x_.dtype)
+        seen_t.clear()
+        try:
+            xf = sampler.sample(batch, tsx, n, denoise=True, eps=cfg.evaluation.eval_eps)
+        finally:
+            torch.randn_like = orig
+        assert xf.dtype == torch.float64
+        out[f"batch_{stride}"] = batch
+        out[f"noise_{stride}"] = torch.stack(noises)
+        out[f"x_{stride}"] = xf
+        out[f"ts_{stride}"] = tsx
+        out[f"seen_t_{stride}"] = torch.stack([s[0] for s in seen_t])
+    save("em_c10_sota.npz", **out)
+
+
 def main():
     util = import_reference()
     if "--only" in sys.argv:
         which = sys.argv[sys.argv.index("--only") + 1]
-        {"inpaint": inpaint_section, "clf": clf_section}[which](util.get_module, C)
+        {"inpaint": inpaint_section, "clf": clf_section, "em_c10": em_c10_section}[which](util.get_module, C)
         return
     get = util.get_module
     PSLD = get("sde", "psld")
@@ -535,6 +579,7 @@ def main():
         json.dump({"seed": 4000, "keys": [[k, list(s)] for k, s in vks]}, fh)
     inpaint_section(get, C)
     clf_section(get, C)
+    em_c10_section(get, C)
     print("done")
 
 
