@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 
-#define PSLD_ABI_VERSION 4 /* 2: limb-MFMA convolutions, math mode, bias-gradient / batched-copy entry points; 3: pointwise weight gradient and batched activation GEMM on limb kernels; 4: GroupNorm statistics from the limb kernels' epilogue */
+#define PSLD_ABI_VERSION 6 /* 2: limb-MFMA convolutions, math mode, bias-gradient / batched-copy entry points; 3: pointwise weight gradient and batched activation GEMM on limb kernels; 4: GroupNorm statistics from the limb kernels' epilogue; 5: per-sample-time reverse SDE, ScoreLoss nll / l1; 6: limb-plane activations */
 #define PSLD_COEFF_STRIDE 12
 
 int psld_version(void);
@@ -131,6 +131,18 @@ int psld_pack_frag_batch(const long long* table_dev, int entries, long long tota
 int psld_conv3x3_split_f32(const float* x1, int c1, const float* x2, int c2, int batch, int h, int w,
                            const void* wfrag, int cout, float* y, int ldy, const psld_epilogue_t* epi,
                            void* workspace, long long ws_bytes, hipStream_t stream);
+
+/* "Limb planes": an NHWC activation [rows][c] (c a multiple of 32) stored already decomposed, as bf16
+ * [rows][c/32 chunks][3 limbs hi|mid|lo][32 channels] (6 bytes per element; hi + mid + lo == x bit for bit).  The
+ * producers of a 3x3 convolution's input write this form (psld_gn_apply_nhwc_f32 with y_limb) so that the convolution
+ * stages its halo tile by LDS-DMA without splitting: psld_conv3x3_limb_f32 = psld_conv3x3_split_f32 with x1 / x2
+ * given as limb planes (same weights fragments, same epilogue, bitwise the same result). */
+long long psld_limb_bytes(long long rows, int c);
+int psld_f32_to_limb(const float* x, long long rows, int c, void* y_limb, hipStream_t stream);
+int psld_limb_to_f32(const void* y_limb, long long rows, int c, float* x, hipStream_t stream);
+int psld_conv3x3_limb_f32(const void* x1_limb, int c1, const void* x2_limb, int c2, int batch, int h, int w,
+                          const void* wfrag, int cout, float* y, int ldy, const psld_epilogue_t* epi,
+                          void* workspace, long long ws_bytes, hipStream_t stream);
 
 /* Pointwise sibling of the kernel above: C = epilogue(A * B^T), A = concat(a1[m][k1], a2[m][k2]) row-major fp32,
  * B given as limb fragments of an [n][k] matrix (psld_pack_gemm_frag: element (n, k) is read at
@@ -351,6 +363,14 @@ int psld_em_step_f64(double* x, const float* eps_pred, const double* z, const ps
 /* reverse_sde outputs themselves (f_bar, g_bar) for callers that want them (psld.py:345-364). */
 int psld_reverse_sde_f64(const double* x, const float* eps_pred, const psld_em_coeffs_t* k,
                          int batch, int c, int hw, double* f_bar, double* g_bar, hipStream_t stream);
+/* The same outputs with PER-SAMPLE times, as PSLD.sde / reverse_sde take them (psld.py:330-364, t[B]): t_rev[b] is the
+ * already reversed time T - t of sample b (device f64); beta_t, _cov and get_inv_coeff are evaluated per sample on the
+ * device (no host read of t).  eps_pred NULL: the forward SDE's own (f, g) of psld.py:330-343 (t_rev = t).  nan_flag
+ * as in psld_perturb_coeffs_f64 (psld.py:214-219 raises ValueError).  batch <= 65535. */
+int psld_reverse_sde_rows_f64(const double* x, const float* eps_pred, const double* t_rev,
+                              const psld_sde_params_t* p, double xx_0, double mm_0, int score_mode,
+                              int probability_flow, int batch, int c, int hw, double* f_bar, double* g_bar,
+                              int* nan_flag, hipStream_t stream);
 /* Symmetric-splitting (SSCS) sampler, SURVEY.md 8(f) rank 1 (samplers/sde.py:227-370):
  * analytic half step u <- M u + L z (M = exp-scaled 2x2 mean matrix of :236-263, L = factor of the
  * transition covariance :265-291 through get_coeff) and the Euler score step of :313-329. */
@@ -382,6 +402,13 @@ int psld_scaled_norm_sq_f64(const double* const* v, const double* coef, int nv, 
                             void* workspace /* >= psld_reduce_workspace_bytes(n) */, hipStream_t stream);
 /* VP-SDE baseline (main/models/sde/vpsde.py:9-99): perturbation kernel and the reverse
  * drift / Euler-Maruyama update (mode 0: f_bar = -f + g^2*score; mode 1: x <- x + f_bar*dt + g*sqrt(dt)*z). */
+/* ScoreLoss beyond the eps-MSE (main/losses.py:38-39, 55-63).  mode 1: L1 criterion, loss f32 = mean|sum |eps - eps_pred|;
+ * mode 2: weighting 'nll', loss f64 = mean|sum (score(eps_pred) - score(eps))^2 * beta(t), score = -eps / std(t)
+ * (vpsde.py:26-27, 97-99), t [batch] f64, per = C*H*W.  grad (optional): d loss / d eps_pred * grad_scale, f32.
+ * workspace >= psld_reduce_workspace_bytes(batch*per). */
+int psld_vp_score_loss(const float* eps, const float* eps_pred, const double* t, double beta0, double beta1,
+                       int batch, long long per, int mode, int reduce_mean, void* loss, float* grad,
+                       float grad_scale, void* workspace, hipStream_t stream);
 int psld_vp_perturb_f32(const float* x0, const float* eps, const double* t, double beta0, double beta1,
                         int batch, long long per_image, float* z_f32, double* u_f64, hipStream_t stream);
 int psld_vp_reverse_f64(double* x, const float* eps_pred, const double* z, double beta, double std, double dt,

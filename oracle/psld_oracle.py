@@ -232,11 +232,20 @@ class VPSDEOracle:
         return -f + g ** 2 * score, (torch.zeros_like(g) if probability_flow else g)
 
 
-def score_loss(sde: VPSDEOracle, x_0, t, score_fn, eps, reduce_mean=True):
-    """losses.py:41-65 with weighting='fid', l_type='l2'."""
+def score_loss(sde: VPSDEOracle, x_0, t, score_fn, eps, reduce_mean=True, weighting="fid", l_type="l2"):
+    """losses.py:41-65: eps-prediction criterion (MSE / L1, :38-39,52) or, for weighting='nll', the score error
+    weighted by g(t)^2 = beta(t) (:55-63, vpsde.py:97-99)."""
     x_t = sde.perturb_data(x_0, t, eps)
     eps_pred = score_fn(x_t.type(torch.float32), t.type(torch.float32))
-    return F.mse_loss(eps_pred, eps, reduction="mean" if reduce_mean else "sum")
+    red = "mean" if reduce_mean else "sum"
+    if weighting == "nll":
+        assert l_type == "l2"                                            # losses.py:33-35
+        gt_2 = bcast(sde.beta_t(t), x_0)
+        loss = (sde.get_score(eps_pred, t) - sde.get_score(eps, t)) ** 2 * gt_2
+        return loss.mean() if reduce_mean else loss.sum()
+    if l_type == "l1":
+        return F.l1_loss(eps, eps_pred, reduction=red)
+    return F.mse_loss(eps_pred, eps, reduction=red)
 
 
 # --------------------------------------------------------------------------------------
@@ -724,7 +733,7 @@ def ncsnpp_clf_forward(sd: Dict[str, Tensor], config_clf, x: Tensor, time_cond: 
 def tce_loss(sde: "PSLDOracle", x_0: Tensor, y: Tensor, t: Tensor, clf_fn: Callable, mode: str = "hsm",
              reduce_mean: bool = True, m0_draw: Optional[Tensor] = None, eps: Optional[Tensor] = None):
     """PSLDTimeCELoss.forward (losses.py:150-178): cross entropy of the noise-conditioned classifier on the perturbed
-    state, plus top-1 accuracy in percent.  ``m0_draw`` / ``eps`` replace the two ``randn_like`` draws (:152, :164)."""
+    state, plus top-1 accuracy as a fraction (losses.py:11-15).  ``m0_draw`` / ``eps`` replace the two ``randn_like`` draws (:152, :164)."""
     if m0_draw is None:
         m0_draw = torch.randn_like(x_0)
     m_0 = np.sqrt(sde.mm_0) * m0_draw
@@ -737,7 +746,7 @@ def tce_loss(sde: "PSLDOracle", x_0: Tensor, y: Tensor, t: Tensor, clf_fn: Calla
     u_t, _, _ = sde.perturb_data(x_0, m_0, 0, mm_0, t, eps=eps)
     y_pred = clf_fn(u_t.type(torch.float32), t)
     loss = F.cross_entropy(y_pred, y, reduction="mean" if reduce_mean else "sum")
-    acc = (y_pred.argmax(dim=1) == y).float().mean() * 100.0            # util.compute_top_k(k=1)
+    acc = (y_pred.argmax(dim=1) == y).float().mean()                    # compute_top_k(k=1): a fraction
     return loss, acc
 
 

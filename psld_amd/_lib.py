@@ -64,7 +64,7 @@ class SscsCoeffs(C.Structure):
 I, F, D, LL, P = C.c_int, C.c_float, C.c_double, C.c_longlong, C.c_void_p
 EP = C.POINTER(Epilogue)
 
-ABI_VERSION = 4    # PSLD_ABI_VERSION of include/psld_hip.h these signatures were written against
+ABI_VERSION = 6    # PSLD_ABI_VERSION of include/psld_hip.h these signatures were written against
 
 # name -> (restype, argtypes): every symbol include/psld_hip.h declares
 SIGNATURES = {
@@ -83,6 +83,10 @@ SIGNATURES = {
     "psld_pack_conv3x3_frag": (I, [P, P, I, I, I, P]),
     "psld_pack_frag_batch": (I, [P, I, LL, P]),
     "psld_conv3x3_split_f32": (I, [P, I, P, I, I, I, I, P, I, P, I, EP, P, LL, P]),
+    "psld_limb_bytes": (LL, [LL, I]),
+    "psld_f32_to_limb": (I, [P, LL, I, P, P]),
+    "psld_limb_to_f32": (I, [P, LL, I, P, P]),
+    "psld_conv3x3_limb_f32": (I, [P, I, P, I, I, I, I, P, I, P, I, EP, P, LL, P]),
     "psld_gemm_frag_bytes": (LL, [I, I]),
     "psld_gemm_split_supported": (I, [I, I, I, I]),
     "psld_pack_gemm_frag": (I, [P, P, I, I, LL, LL, P]),
@@ -129,6 +133,8 @@ SIGNATURES = {
     "psld_sqerr_loss_f32": (I, [P, P, LL, I, P, P, F, P, P]),
     "psld_em_step_f64": (I, [P, P, P, C.POINTER(EmCoeffs), I, I, I, P, P]),
     "psld_reverse_sde_f64": (I, [P, P, C.POINTER(EmCoeffs), I, I, I, P, P, P]),
+    "psld_vp_score_loss": (I, [P, P, P, D, D, I, LL, I, I, P, P, F, P, P]),
+    "psld_reverse_sde_rows_f64": (I, [P, P, P, C.POINTER(SdeParams), D, D, I, I, I, I, I, P, P, P, P]),
     "psld_sscs_analytic_f64": (I, [P, P, C.POINTER(SscsCoeffs), I, I, I, P, P]),
     "psld_sscs_score_step_f64": (I, [P, P, C.POINTER(EmCoeffs), I, I, I, P]),
     "psld_samples_to_uint8": (I, [P, P, I, I, I, I, I, P]),

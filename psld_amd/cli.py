@@ -66,7 +66,7 @@ def build(cfg, device):
     return score_fn, ema, sde
 
 
-def save_checkpoint(path, wrapper, optim, step, epoch):
+def save_checkpoint(path, wrapper, optim, step, epoch, sched=None):
     sd = {}
     for k, v in wrapper.score_fn.state_dict().items():
         sd["score_fn." + k] = v.detach().cpu()
@@ -74,22 +74,85 @@ def save_checkpoint(path, wrapper, optim, step, epoch):
         sd["ema_score_fn." + k] = v.detach().cpu()
     os.makedirs(os.path.dirname(path), exist_ok=True)
     torch.save({"state_dict": sd, "global_step": step, "epoch": epoch,
-                "optimizer_states": [optim.state_dict()] if optim is not None else []}, path)
+                "optimizer_states": [optim.state_dict()] if optim is not None else [],
+                "lr_schedulers": [sched.state_dict()] if sched is not None else []}, path)   # Lightning's key
 
 
-def load_checkpoint(path, score_fn, ema, optim=None):
+def adopt_torch_adam_state(optim, state_dict) -> bool:
+    """Moments of a ``torch.optim.Adam`` state_dict (what a reference / Lightning checkpoint carries: per-parameter
+    ``exp_avg`` / ``exp_avg_sq`` / ``step`` keyed by parameter index) -> FusedAdam's flat m / v buffers.  True when
+    every trainable parameter was found with a matching shape."""
+    state = state_dict.get("state", {})
+    params = [p for p in optim.module.parameters()]
+    if not state or any(not isinstance(v, dict) or "exp_avg" not in v for v in state.values()):
+        return False
+    optim._state_buffers()
+    offs = optim.module._offsets
+    steps = set()
+    for i, p in enumerate(params):
+        ent = state.get(i, state.get(str(i)))
+        if ent is None:
+            if p.requires_grad:
+                return False
+            continue
+        if tuple(ent["exp_avg"].shape) != tuple(p.shape):
+            return False
+    for i, p in enumerate(params):
+        ent = state.get(i, state.get(str(i)))
+        if ent is None:
+            continue
+        o = offs[id(p)]
+        optim._m[o:o + p.numel()].copy_(ent["exp_avg"].reshape(-1))
+        optim._v[o:o + p.numel()].copy_(ent["exp_avg_sq"].reshape(-1))
+        steps.add(int(ent["step"]) if "step" in ent else -1)
+    if len(steps) == 1 and next(iter(steps)) >= 0:
+        optim._step = next(iter(steps))
+    return True
+
+
+def load_checkpoint(path, score_fn, ema, optim=None, sched=None):
+    """Returns (global_step, epoch).  The optimiser state is restored from a FusedAdam state (own checkpoints) or
+    converted from a torch.optim.Adam state (reference checkpoints); if neither works the moments restart from zero
+    TOGETHER with the bias-correction step, and that is said loudly.  The LR scheduler state is restored when the
+    checkpoint has one (Lightning's ``lr_schedulers``), else re-derived from the global step."""
+    import warnings
     ck = torch.load(path, map_location="cpu", weights_only=False)
     sd = ck["state_dict"] if "state_dict" in ck else ck
     s1 = {k[len("score_fn."):]: v for k, v in sd.items() if k.startswith("score_fn.")}
     s2 = {k[len("ema_score_fn."):]: v for k, v in sd.items() if k.startswith("ema_score_fn.")}
     score_fn.load_state_dict(s1, strict=True)
     ema.load_state_dict(s2 if s2 else s1, strict=True)
-    if optim is not None and ck.get("optimizer_states"):
-        try:
-            optim.load_state_dict(ck["optimizer_states"][0])
-        except Exception:  # noqa: BLE001  (a reference checkpoint carries torch.optim.Adam state)
-            pass
-    return ck.get("global_step", 0), ck.get("epoch", 0)
+    step = ck.get("global_step", 0)
+    if optim is not None:
+        states = ck.get("optimizer_states") or []
+        restored = False
+        if states:
+            osd = states[0]
+            if "fused" in osd:
+                optim.load_state_dict(dict(osd))
+                restored = True
+            else:
+                restored = adopt_torch_adam_state(optim, osd)
+                if restored and optim._step == 0:
+                    optim._step = step
+        if not restored:
+            warnings.warn(f"{path}: no usable optimizer state - Adam moments AND the bias-correction step restart from "
+                          "zero (weights, EMA and the LR schedule position are restored)", RuntimeWarning, stacklevel=2)
+            optim._step = 0
+            if optim._m is not None:
+                optim._m.zero_(), optim._v.zero_()
+    if sched is not None:
+        scheds = ck.get("lr_schedulers") or []
+        if scheds:
+            sched.load_state_dict(scheds[0])
+        else:
+            sched.last_epoch = step
+            sched._step_count = step + 1
+        for group, lr in zip(sched.optimizer.param_groups, [base * lmbda(sched.last_epoch) for lmbda, base in
+                                                            zip(sched.lr_lambdas, sched.base_lrs)]):
+            group["lr"] = lr
+        sched._last_lr = [g["lr"] for g in sched.optimizer.param_groups]
+    return step, ck.get("epoch", 0)
 
 
 def _dataset(cfg, args, device, rank):
@@ -99,8 +162,23 @@ def _dataset(cfg, args, device, rank):
         arr = np.load(args.data, mmap_mode="r")
         assert arr.dtype == np.uint8 and arr.shape[1:] == (size, size, 3), arr.shape
         return torch.from_numpy(np.ascontiguousarray(arr)).to(device)
-    g = torch.Generator().manual_seed(1234 + rank)
+    g = torch.Generator().manual_seed(1234)          # ONE dataset, the same on every rank; ranks take shards of it
     return torch.randint(0, 256, (args.synthetic_size, size, size, 3), generator=g, dtype=torch.uint8).to(device)
+
+
+def epoch_indices(n_items: int, batch_size: int, seed: int, epoch: int, rank: int, world: int) -> torch.Tensor:
+    """Indices this rank trains on in ``epoch``, in order: what Lightning's strategy="ddp" gives the reference
+    (train_sde.py:100-114) - a ``DistributedSampler(shuffle=True)`` over the dataset (one permutation per epoch from
+    ``seed + epoch``, identical on every rank, padded to a multiple of ``world`` by wrapping around, rank r takes
+    every world-th element from r) under a ``DataLoader(drop_last=True)``.  Every rank gets the same number of
+    batches, so the per-step collectives cannot deadlock; an epoch is ONE pass over the data in total."""
+    g = torch.Generator().manual_seed(seed + epoch)
+    perm = torch.randperm(n_items, generator=g)
+    total = -(-n_items // world) * world
+    if total > n_items:
+        perm = torch.cat([perm, perm[:total - n_items]])
+    mine = perm[rank:total:world]
+    return mine[:mine.numel() // batch_size * batch_size]
 
 
 def train(args, overrides):
@@ -122,19 +200,20 @@ def train(args, overrides):
     if world > 1:
         score_fn.set_reducer(BucketReducer())
     optim = wrapper.optimizers()
+    sched = wrapper.lr_schedulers()
     step, epoch0 = 0, 0
     if cfg.training.restore_path:
-        step, epoch0 = load_checkpoint(cfg.training.restore_path, score_fn, ema, optim)
+        score_fn.flatten_parameters()
+        step, epoch0 = load_checkpoint(cfg.training.restore_path, score_fn, ema, optim, sched)
         score_fn.to(dev), ema.to(dev)
-        optim._step = step
     data = _dataset(cfg, args, dev, rank)
-    bs = cfg.training.batch_size
-    n = data.shape[0] // bs * bs                                          # drop_last (train_sde.py:100-110)
-    gen = torch.Generator(device=dev).manual_seed(cfg.training.seed + rank)
+    bs = min(cfg.training.batch_size, data.shape[0])                      # train_sde.py:101-102
+    gen = torch.Generator(device=dev).manual_seed(cfg.training.seed + rank)   # horizontal flips: per-rank stream
     ckdir = os.path.join(cfg.training.results_dir or "psld_results", "checkpoints")
     t0 = time.perf_counter()
     for epoch in range(epoch0, cfg.training.epochs):
-        perm = torch.randperm(data.shape[0], device=dev, generator=gen)[:n]
+        perm = epoch_indices(data.shape[0], bs, cfg.training.seed, epoch, rank, world).to(dev)
+        n = perm.numel()
         for i in range(0, n, bs):
             idx = perm[i:i + bs]
             flip = (torch.rand(bs, device=dev, generator=gen) < 0.5).to(torch.uint8) if cfg.data.hflip else None
@@ -150,8 +229,8 @@ def train(args, overrides):
                 break
         if rank == 0 and ((epoch + 1) % cfg.training.chkpt_interval == 0 or (args.max_steps and step >= args.max_steps)):
             name = f"{cfg.model.sde.name}-{cfg.training.chkpt_prefix}-epoch={epoch:02d}-loss={loss.item():.4f}.ckpt"
-            save_checkpoint(os.path.join(ckdir, name), wrapper, optim, step, epoch + 1)
-            save_checkpoint(os.path.join(ckdir, "last.ckpt"), wrapper, optim, step, epoch + 1)
+            save_checkpoint(os.path.join(ckdir, name), wrapper, optim, step, epoch + 1, sched)
+            save_checkpoint(os.path.join(ckdir, "last.ckpt"), wrapper, optim, step, epoch + 1, sched)
         if args.max_steps and step >= args.max_steps:
             break
     if world > 1:
@@ -257,15 +336,15 @@ def train_clf(args, overrides):
         labels = torch.from_numpy(np.load(args.labels).astype(np.int64)).to(dev)
     else:
         labels = torch.randint(0, cc.model.clf_fn.n_cls, (data.shape[0],),
-                               generator=torch.Generator().manual_seed(4321 + rank)).to(dev)
+                               generator=torch.Generator().manual_seed(4321)).to(dev)     # one label set for all ranks
     assert labels.shape[0] == data.shape[0]
     bs = min(cc.training.batch_size, data.shape[0])
-    n = data.shape[0] // bs * bs
     gen = torch.Generator(device=dev).manual_seed(cc.training.seed + rank)
     ckdir = os.path.join(cc.training.results_dir or "psld_clf_results", "checkpoints")
     step = 0
     for epoch in range(cc.training.epochs):
-        perm = torch.randperm(data.shape[0], device=dev, generator=gen)[:n]
+        perm = epoch_indices(data.shape[0], bs, cc.training.seed, epoch, rank, world).to(dev)   # DistributedSampler shard
+        n = perm.numel()
         for i in range(0, n, bs):
             idx = perm[i:i + bs]
             flip = (torch.rand(bs, device=dev, generator=gen) < 0.5).to(torch.uint8) if cc.data.hflip else None
@@ -273,7 +352,7 @@ def train_clf(args, overrides):
             loss = wrapper.training_step((x0, labels[idx].contiguous()), step)
             step += 1
             if rank == 0 and step % max(1, cc.training.log_step * args.log_every) == 0:
-                print(f"epoch {epoch} step {step} loss {loss.item():.4f} top1 {float(wrapper.logged['Top1-Acc']):.1f}%", flush=True)
+                print(f"epoch {epoch} step {step} loss {loss.item():.4f} top1 {100 * float(wrapper.logged['Top1-Acc']):.1f}%", flush=True)
             if args.max_steps and step >= args.max_steps:
                 break
         done = args.max_steps and step >= args.max_steps

@@ -415,6 +415,226 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
     dconv_epilogue(a, acc, m0, n0, wr, wc, lane, split);
 }
 
+// ---- forward / data-gradient on pre-split activations ("limb planes") ----------------------------------------------
+// The producers of a 3x3 convolution's input (GroupNorm+SiLU apply, GroupNorm backward) can write the activation
+// already decomposed: bf16 limb planes [pixel][C/32 chunks][3 limbs][32 channels] (6 bytes per element instead of 4).
+// A chunk of a pixel is then 3 x 64 contiguous bytes in exactly the form the LDS image wants, so the halo tile is
+// staged by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no split3, no ds_write) into one of TWO images:
+// the next chunk's image fills while the current chunk's nine taps run, one barrier per chunk.  The XOR slot
+// swizzle of the image is applied on the SOURCE address (the DMA destination is lane-linear).
+// RG = 16-row groups per image (>= halo pixels / 16); wave w moves row groups w, w + 4, ...
+constexpr int LP_PIX_BYTES_PER_CH = 6;     // bytes per element of a limb-plane tensor
+
+template <int RG, bool DB>
+__global__ void __launch_bounds__(256, 2) dconv_lp_kernel(const DConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int LIMB = RG * 16 * ROWB;
+    constexpr int BUF = 3 * LIMB;
+    constexpr int TAPS = 9;
+    constexpr int NRG = (RG + 3) / 4;            // row groups per wave (upper bound)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: uniform branches below
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int tiles_n = a.N >> 7;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    const int m0 = tile_m * 128, n0 = tile_n * 128;
+    const int split = blockIdx.y;
+    const int c_beg = split * a.chunks_per_split;
+    const int c_end = min(a.chunks, c_beg + a.chunks_per_split);
+
+    const int W2 = a.W + 2;
+    const unsigned char* zp = reinterpret_cast<const unsigned char*>(a.zero);
+    const unsigned char* p1 = reinterpret_cast<const unsigned char*>(a.x1);
+    const unsigned char* p2 = reinterpret_cast<const unsigned char*>(a.x2);
+
+    // items this lane moves: image row rg*16 + (lane >> 2), 16-byte slot lane & 3 (the image's XOR swizzle is applied
+    // on the source side).  hpix = source pixel, or -1 for padding: such items read the 16-byte zero page three times.
+    // Everything below is arithmetic on integers (no per-lane branch: a branch around a DMA makes hipcc drain vmcnt).
+    int hpix[NRG];
+    int sslot[NRG];
+    {
+        const int HW = a.H * a.W;
+        const int img0 = m0 / HW;
+        const int oy0 = (m0 - img0 * HW) / a.W;
+        const int seg_px = (a.rps + 2) * W2;
+#pragma unroll
+        for (int i = 0; i < NRG; ++i) {
+            const int px = (wave + 4 * i) * 16 + (lane >> 2);
+            const int seg = px / seg_px;
+            const int rem = px - seg * seg_px;
+            const int hr = rem / W2, hx = rem - hr * W2;
+            const int img = img0 + seg, iy = oy0 + hr - 1, ix = hx - 1;
+            const bool ok = seg < a.nseg && img < a.B && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            hpix[i] = ok ? (img * a.H + iy) * a.W + ix : -1;
+            sslot[i] = ((lane & 3) ^ lds_swz(px)) << 4;
+        }
+    }
+    // row group i of this wave (three DMAs: one per limb) of chunk c into image buf
+    auto issue_dma = [&](int c, int buf, int i) {
+        const int c0 = c * 32;
+        const bool second = c0 >= a.C1;
+        const unsigned char* src = second ? p2 : p1;
+        const long long ps = (long long)(second ? a.C2 : a.C1) * LP_PIX_BYTES_PER_CH;
+        const long long coff = ((second ? c0 - a.C1 : c0) >> 5) * 192;
+        const long long zdelta = zp - src;       // scalar: where the zero page sits relative to this source
+        const int rg = wave + 4 * i;
+        if (rg < RG) {                            // scalar branch
+            const bool ok = hpix[i] >= 0;
+            const long long off = ok ? hpix[i] * ps + coff + sslot[i] : zdelta;
+            const long long lstep = ok ? 64 : 0;
+            const unsigned char* g = src + off;
+            unsigned char* d = smem + buf * BUF + rg * 1024;
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + l * lstep),
+                                                 (__attribute__((address_space(3))) void*)(d + l * LIMB), 16, 0, 0);
+        }
+    };
+
+    const int r16 = lane & 15, kq = lane >> 4;
+    int abase[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const int ml = wr * 64 + mb * 16 + r16;
+        const int seg = ml / (a.rps * a.W);
+        const int rem = ml - seg * (a.rps * a.W);
+        const int ry = rem / a.W, ox = rem - ry * a.W;
+        abase[mb] = (seg * (a.rps + 2) + ry) * W2 + ox;
+    }
+
+    const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
+    const u32x4* wp = a.wfrag + ((long long)(tile_n * 2 + wc) * a.chunks * TAPS) * TAP_U4 + lane;
+    const int sig_beg = c_beg * TAPS, sig_end = c_end * TAPS;
+    u32x4 bq[2][4][3];
+    auto load_b = [&](int sigma, u32x4 (&dst)[4][3]) {
+        const u32x4* p = wp + (long long)min(sigma, sig_end - 1) * TAP_U4;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) dst[nb][l] = p[(nb * 3 + l) * 64];
+    };
+
+    f32x4v acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int i = 0; i < NRG; ++i) issue_dma(c_beg, 0, i);
+    load_b(sig_beg, bq[0]);
+    __syncthreads();                         // vmcnt(0) + barrier: image 0 has landed for every wave
+
+    int c = c_beg, tap = 0, tap_off = 0, kx = 0, buf = 0;
+    // Next chunk's image: one row group per tap, taps ISSUE_TAP0 .. ISSUE_TAP0 + NRG - 1.  While an LDS-DMA is in flight
+    // hipcc waits vmcnt(0) (not a counted vmcnt) for every B fragment, and vmcnt retires in order: a DMA is therefore
+    // issued right AFTER an explicit wait for the B fragments this tap needs anyway, and has the tap's 96 MFMAs to land
+    // before the next tap's wait reaches it.
+    constexpr int ISSUE_TAP0 = 9 - 1 - NRG;
+    auto step = [&](int sigma, auto PP) {
+        constexpr int pp = decltype(PP)::value;
+        const bool more = (c + 1) < c_end;
+        // ONE vector-memory wait per tap, here: it retires this tap's B fragments and the row group issued a tap ago.
+        // Everything issued below (a row group of the next image, the next tap's B fragments) has this tap's 96 MFMAs
+        // to land.  (With a DMA in flight hipcc can only wait vmcnt(0), never a counted vmcnt: any later wait of its
+        // own would drain the prefetch it sits behind.)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        if (DB && more && tap >= ISSUE_TAP0 && tap < ISSUE_TAP0 + NRG) issue_dma(c + 1, buf ^ 1, tap - ISSUE_TAP0);
+        load_b(sigma + 1, bq[pp ^ 1]);
+        // A fragments by inline-asm ds_read_b128: to hipcc an LDS read it can see may alias the image an in-flight DMA is
+        // filling (same array), and it would wait vmcnt(0) in front of every one of them.  Issue order = use order
+        // (limb lo, hi, mid: the six products are lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi), counted lgkmcnt waits.
+        u32x4 fa[4][3];
+        unsigned addr[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const int prow = abase[mb] + tap_off;
+            addr[mb] = lds_base + buf * BUF + prow * ROWB + ((kq ^ lds_swz(prow)) << 4);
+        }
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[mb][2]) : "v"(addr[mb]), "n"(2 * LIMB) : "memory");
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+            asm volatile("ds_read_b128 %0, %1" : "=v"(fa[mb][0]) : "v"(addr[mb]) : "memory");
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[mb][1]) : "v"(addr[mb]), "n"(LIMB) : "memory");
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            if (t == 0) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            if (t == 1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            if (t == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (t <= 2) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, fa[mb][PA[t]]), __builtin_bit_cast(bf16x8, bq[pp][nb][PB[t]]),
+                        acc[mb][nb], 0, 0, 0);
+        }
+        if (++tap == TAPS) {
+            tap = 0; tap_off = 0; kx = 0;
+            if constexpr (DB) {
+                // everyone is done with image buf; every wave's row groups of image buf^1 were issued by tap 7 and
+                // retired by its own vmcnt(0) at the top of tap 8: a bare barrier (no vmcnt drain: the next tap's B
+                // fragments stay in flight across it)
+                __builtin_amdgcn_s_barrier();
+                buf ^= 1;
+            } else {
+                __syncthreads();
+                if (more) {
+#pragma unroll
+                    for (int i = 0; i < NRG; ++i) issue_dma(c + 1, 0, i);
+                    __syncthreads();
+                }
+            }
+            ++c;
+        } else {
+            if (++kx == 3) { kx = 0; tap_off += W2 - 2; } else { tap_off += 1; }
+        }
+    };
+    for (int sigma = sig_beg; sigma < sig_end; sigma += 2) {
+        step(sigma, std::integral_constant<int, 0>{});
+        if (sigma + 1 < sig_end) step(sigma + 1, std::integral_constant<int, 1>{});
+    }
+
+    dconv_epilogue(a, acc, m0, n0, wr, wc, lane, split);
+}
+
+// fp32 NHWC [rows][c] -> limb planes [rows][c/32][3][32] (tests, and producers without a fused writer)
+__global__ void f32_to_limb_kernel(const float* __restrict__ x, long long rows, int c, unsigned char* __restrict__ y) {
+    const long long n4 = rows * (c >> 2);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / (c >> 2);
+        const int q = (int)(i - r * (c >> 2));
+        const f32x4 v = ld4(x + r * c + q * 4);
+        unsigned h0, m0, l0, h1, m1, l1;
+        split3(v[0], v[1], h0, m0, l0);
+        split3(v[2], v[3], h1, m1, l1);
+        unsigned char* d = y + r * (long long)c * LP_PIX_BYTES_PER_CH + (q >> 3) * 192 + (q & 7) * 8;
+        *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(d + 64) = u32x2{m0, m1};
+        *reinterpret_cast<u32x2*>(d + 128) = u32x2{l0, l1};
+    }
+}
+__global__ void limb_to_f32_kernel(const unsigned char* __restrict__ y, long long rows, int c, float* __restrict__ x) {
+    const long long n = rows * c;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / c;
+        const int ch = (int)(i - r * c);
+        const unsigned short* d = reinterpret_cast<const unsigned short*>(y + r * (long long)c * LP_PIX_BYTES_PER_CH +
+                                                                          (ch >> 5) * 192) + (ch & 31);
+        x[i] = (__uint_as_float((unsigned)d[0] << 16) + __uint_as_float((unsigned)d[32] << 16)) +
+               __uint_as_float((unsigned)d[64] << 16);
+    }
+}
+
 // ---- weight gradient ---------------------------------------------------------------------------------------
 // dW[co][tap][ci] = sum_p dy[p][co] * x[p + tap][ci].  One workgroup owns a 64 (co) x 64 (ci) tile for the three
 // taps of ONE filter row ky (each wave 32 x 32 x 3 taps = twelve 16x16 accumulators, 48 VGPRs, so four waves fit
@@ -949,6 +1169,25 @@ int launch_dconv(const DConvArgs& a, int nsplit, hipStream_t stream, const char*
     return PSLD_OK;
 }
 
+template <int RG, bool DB>
+int launch_dconv_lp(const DConvArgs& a, int nsplit, hipStream_t stream, const char* name) {
+    constexpr size_t LDS = (size_t)(DB ? 2 : 1) * 3 * RG * 16 * ROWB;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv_lp_kernel<RG, DB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        if (e != hipSuccess) {
+            psld_set_error("%s: hipFuncSetAttribute failed: %s", name, hipGetErrorString(e));
+            return PSLD_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    dim3 grid((unsigned)(cdiv(a.M, 128) * (a.N / 128)), (unsigned)nsplit);
+    hipLaunchKernelGGL((dconv_lp_kernel<RG, DB>), grid, dim3(256), LDS, stream, a);
+    PSLD_CHECK_LAUNCH(name);
+    return PSLD_OK;
+}
+
 // split the K stages over extra workgroups when the output grid cannot fill 256 CUs x 2 slots; returns the number
 // of slabs (1 = write the output directly) and fills the slab fields of `a`
 int plan_split(DConvArgs& a, const PsldEpilogue& e, float* y, int ldy, void* workspace, long long ws_bytes) {
@@ -1061,6 +1300,60 @@ extern "C" int psld_conv3x3_split_f32(const float* x1, int c1, const float* x2, 
     if (nh <= 6) st = launch_dconv<6, 9, false>(a, ns, stream, name);
     else if (nh <= 7) st = launch_dconv<7, 9, false>(a, ns, stream, name);
     else st = launch_dconv<9, 9, false>(a, ns, stream, name);
+    if (st != PSLD_OK) return st;
+    if (ns >= 2) return psld_detail_conv_reduce_epilogue(a.C, ns, a.M, cout, y, ldy, e, stream);
+    return PSLD_OK;
+}
+
+extern "C" long long psld_limb_bytes(long long rows, int c) { return rows * (long long)c * LP_PIX_BYTES_PER_CH; }
+
+extern "C" int psld_f32_to_limb(const float* x, long long rows, int c, void* y, hipStream_t stream) {
+    PSLD_CHECK_ARG(x && y && rows > 0 && c > 0 && c % 32 == 0 && aligned16(x) && aligned16(y), "psld_f32_to_limb: bad args");
+    const long long n4 = rows * (c / 4);
+    const int blocks = (int)((n4 + 255) / 256 < 16384 ? (n4 + 255) / 256 : 16384);
+    hipLaunchKernelGGL(f32_to_limb_kernel, dim3(blocks), dim3(256), 0, stream, x, rows, c, reinterpret_cast<unsigned char*>(y));
+    PSLD_CHECK_LAUNCH("psld_f32_to_limb");
+    return PSLD_OK;
+}
+
+extern "C" int psld_limb_to_f32(const void* y, long long rows, int c, float* x, hipStream_t stream) {
+    PSLD_CHECK_ARG(x && y && rows > 0 && c > 0 && c % 32 == 0, "psld_limb_to_f32: bad args");
+    const long long n = rows * c;
+    const int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+    hipLaunchKernelGGL(limb_to_f32_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<const unsigned char*>(y), rows, c, x);
+    PSLD_CHECK_LAUNCH("psld_limb_to_f32");
+    return PSLD_OK;
+}
+
+extern "C" int psld_conv3x3_limb_f32(const void* x1, int c1, const void* x2, int c2, int batch, int h, int w,
+                                     const void* wfrag, int cout, float* y, int ldy, const psld_epilogue_t* epi,
+                                     void* workspace, long long ws_bytes, hipStream_t stream) {
+    PSLD_CHECK_ARG(x1 && wfrag && y && (c2 == 0 || x2), "psld_conv3x3_limb_f32: null pointer");
+    PSLD_CHECK_ARG(psld_conv3x3_split_supported(c1, c2, batch, h, w, cout),
+                   "psld_conv3x3_limb_f32: unsupported shape c1=%d c2=%d %dx%d cout=%d", c1, c2, h, w, cout);
+    PSLD_CHECK_ARG(aligned16(x1) && (!x2 || aligned16(x2)) && aligned16(wfrag), "psld_conv3x3_limb_f32: unaligned pointer");
+    DConvArgs a{};
+    a.x1 = reinterpret_cast<const float*>(x1); a.x2 = reinterpret_cast<const float*>(x2); a.C1 = c1; a.C2 = c2;
+    a.B = batch; a.H = h; a.W = w;
+    a.wfrag = reinterpret_cast<const u32x4*>(wfrag);
+    a.N = cout; a.M = batch * h * w;
+    a.chunks = (c1 + c2) / 32;
+    int halo_px = 0;
+    dconv_geometry(h, w, &a.nseg, &a.rps, &halo_px);
+    a.zero = psld_detail_zero_page("psld_conv3x3_limb_f32");
+    if (!a.zero) return PSLD_ERR_LAUNCH;
+    const PsldEpilogue e = make_epilogue(epi);
+    PSLD_CHECK_ARG(!e.gn_part || (e.gn_hw == h * w && e.gn_hw % 64 == 0 && !e.accumulate),
+                   "psld_conv3x3_limb_f32: gn_part needs gn_hw = h*w, a multiple of 64, and no accumulation");
+    const int ns = plan_split(a, e, y, ldy, workspace, ws_bytes);
+    const int rg = cdiv(halo_px, 16);
+    const char* name = "psld_conv3x3_limb_f32";
+    static const int single = [] { const char* v = getenv("PSLD_LP_SINGLE_BUFFER"); return v ? atoi(v) : 0; }();
+    int st;
+    // two images of RG <= 13 row groups (79,872 B) leave room for two workgroups per CU (163,840 B of LDS)
+    if (rg <= 12) st = single ? launch_dconv_lp<12, false>(a, ns, stream, name) : launch_dconv_lp<12, true>(a, ns, stream, name);
+    else if (rg <= 13) st = single ? launch_dconv_lp<13, false>(a, ns, stream, name) : launch_dconv_lp<13, true>(a, ns, stream, name);
+    else st = launch_dconv_lp<18, false>(a, ns, stream, name);
     if (st != PSLD_OK) return st;
     if (ns >= 2) return psld_detail_conv_reduce_epilogue(a.C, ns, a.M, cout, y, ldy, e, stream);
     return PSLD_OK;

@@ -209,6 +209,51 @@ __global__ void reverse_sde_kernel(const double* __restrict__ x, const float* __
     }
 }
 
+// Per-sample times (psld.py:330-364 take t[B]): every thread derives its sample's scalars from t[b] on the device -
+// no host read of t.  beta_t (psld.py:38-40), _cov (:86-152) and get_inv_coeff (:188-220) in f64, the inverse
+// coefficients cast to f32 before they touch eps (:253-258) exactly like the one-time path's host scalars.
+__global__ void reverse_sde_rows_kernel(const double* __restrict__ x, const float* __restrict__ eps,
+                                        const double* __restrict__ t_rev, const psld_sde_params_t p, double xx_0,
+                                        double mm_0, int score_mode, int probability_flow, int forward_only,
+                                        int c, int hw, double* __restrict__ fbar, double* __restrict__ gbar,
+                                        int* __restrict__ nan_flag) {
+    const int b = blockIdx.y;
+    const double tt = t_rev[b];
+    psld_em_coeffs_t k;
+    k.beta = p.beta_0 + tt * (p.beta_1 - p.beta_0);
+    k.m_inv = p.m_inv; k.gamma = p.gamma; k.nu = p.nu; k.m = 1.0 / p.m_inv;
+    k.dt = 0.0; k.score_mode = score_mode; k.probability_flow = probability_flow;
+    k.c11 = k.c12 = k.c21 = k.c22 = 0.f;
+    if (!forward_only) {
+        const double bt = p.beta_0 * tt + 0.5 * (tt * tt) * (p.beta_1 - p.beta_0);
+        double xx, xm, mm;
+        psld_cov(p, xx_0, mm_0, bt, xx, xm, mm);
+        const double det = xx * mm - xm * xm;
+        double c11, c12, c21, c22;
+        if (p.decomp_lower) {   // psld.py:194-199
+            c11 = sqrt(1 / xx); c12 = -xm / (sqrt(xx) * sqrt(det)); c21 = 0.0; c22 = sqrt(xx / det);
+        } else {                // psld.py:207-212
+            c11 = sqrt(mm / det); c12 = 0.0; c21 = -xm / (sqrt(mm) * sqrt(det)); c22 = sqrt(1 / mm);
+        }
+        if ((isnan(c11) || isnan(c12) || isnan(c21) || isnan(c22)) && threadIdx.x == 0 && blockIdx.x == 0)
+            atomicExch(nan_flag, 1);
+        k.c11 = (float)c11; k.c12 = (float)c12; k.c21 = (float)c21; k.c22 = (float)c22;
+    }
+    const long long n = (long long)c * hw;
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (long long)gridDim.x * blockDim.x) {
+        const long long ox = (long long)b * 2 * c * hw + r, om = ox + (long long)c * hw;
+        float ex = 0.f, em = 0.f;
+        if (!forward_only) fetch_eps(eps, k, b, r, c, hw, ex, em);
+        const RevOut o = reverse_terms(k, x[ox], x[om], ex, em, true);
+        if (forward_only) {     // sde(): (f, g) themselves; -(-f + 0) is exact
+            fbar[ox] = -o.fbx; fbar[om] = -o.fbm;
+        } else {
+            fbar[ox] = o.fbx; fbar[om] = o.fbm;
+        }
+        if (gbar) { gbar[ox] = o.gx; gbar[om] = o.gm; }
+    }
+}
+
 // ---- symmetric-splitting sampler (samplers/sde.py:227-370) ----------------------------------------
 // analytic half step: u' = M u + L z with host-computed 2x2 mean matrix (incl. exp scaling) and
 // Cholesky factor of the transition covariance (sde.py:236-311)
@@ -504,5 +549,80 @@ extern "C" int psld_reverse_sde_f64(const double* x, const float* eps_pred, cons
     hipLaunchKernelGGL(reverse_sde_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x, eps_pred, *k, batch, c, hw,
                        f_bar, g_bar);
     PSLD_CHECK_LAUNCH("psld_reverse_sde_f64");
+    return PSLD_OK;
+}
+
+extern "C" int psld_reverse_sde_rows_f64(const double* x, const float* eps_pred, const double* t_rev,
+                                         const psld_sde_params_t* p, double xx_0, double mm_0, int score_mode,
+                                         int probability_flow, int batch, int c, int hw, double* f_bar, double* g_bar,
+                                         int* nan_flag, hipStream_t stream) {
+    PSLD_CHECK_ARG(x && t_rev && p && f_bar && nan_flag && batch > 0 && c > 0 && hw > 0 && batch <= 65535,
+                   "psld_reverse_sde_rows_f64: bad args");
+    const long long n = (long long)c * hw;
+    int bx = (int)((n + 255) / 256);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(reverse_sde_rows_kernel, dim3(bx, batch), dim3(256), 0, stream, x, eps_pred, t_rev, *p, xx_0, mm_0,
+                       score_mode, probability_flow, eps_pred ? 0 : 1, c, hw, f_bar, g_bar, nan_flag);
+    PSLD_CHECK_LAUNCH("psld_reverse_sde_rows_f64");
+    return PSLD_OK;
+}
+
+// ---- ScoreLoss beyond the eps-MSE (main/losses.py:38-39, 55-63) --------------------------------------------
+// mode 1: L1 criterion |eps - eps_pred| (f32 like nn.L1Loss); mode 2: 'nll' weighting, per element
+// (score(eps_pred) - score(eps))^2 * g(t)^2 with score = -eps / std(t) (vpsde.py:26-27) and g(t)^2 = beta(t)
+// (vpsde.py:97-99), evaluated in f64 like the reference (t is f64 there).
+__global__ void vp_score_loss_kernel(const float* __restrict__ e, const float* __restrict__ ep,
+                                     const double* __restrict__ t, double beta0, double beta1, long long per,
+                                     long long n, int mode, double* __restrict__ part, float* __restrict__ grad,
+                                     double gscale) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    GRID_STRIDE(i, n) {
+        if (mode == 1) {
+            const float d = e[i] - ep[i];
+            acc += (double)fabsf(d);
+            if (grad) grad[i] = (float)(gscale * (d > 0.f ? -1.0 : (d < 0.f ? 1.0 : 0.0)));
+        } else {
+            const double tt = t[i / per];
+            const double lmc = -0.25 * (tt * tt) * (beta1 - beta0) - 0.5 * tt * beta0;   // vpsde.py:74-76
+            const double sd = sqrt(1.0 - exp(2.0 * lmc));
+            const double g2 = beta0 + tt * (beta1 - beta0);
+            const double d = (-(double)ep[i] / sd) - (-(double)e[i] / sd);
+            acc += d * d * g2;
+            if (grad) grad[i] = (float)(gscale * 2.0 * d * g2 * (-1.0 / sd));
+        }
+    }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void scaled_final_kernel(const double* __restrict__ part, int nparts, double denom, double* __restrict__ out64,
+                                    float* __restrict__ out32) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 64) acc += part[i];
+    acc = wave_sum_d(acc);
+    if (threadIdx.x == 0) {
+        if (out64) out64[0] = acc / denom;
+        if (out32) out32[0] = (float)(acc / denom);
+    }
+}
+
+extern "C" int psld_vp_score_loss(const float* eps, const float* eps_pred, const double* t, double beta0, double beta1,
+                                  int batch, long long per, int mode, int reduce_mean, void* loss, float* grad,
+                                  float grad_scale, void* workspace, hipStream_t stream) {
+    PSLD_CHECK_ARG(eps && eps_pred && loss && workspace && batch > 0 && per > 0 && (mode == 1 || (mode == 2 && t)),
+                   "psld_vp_score_loss: bad args");
+    const long long n = (long long)batch * per;
+    int blocks = grid_for(n);
+    double* part = reinterpret_cast<double*>(workspace);
+    const double denom = reduce_mean ? (double)n : 1.0;
+    hipLaunchKernelGGL(vp_score_loss_kernel, dim3(blocks), dim3(256), 0, stream, eps, eps_pred, t, beta0, beta1, per, n,
+                       mode, part, grad, (double)grad_scale / denom);
+    PSLD_CHECK_LAUNCH("vp_score_loss_kernel");
+    hipLaunchKernelGGL(scaled_final_kernel, dim3(1), dim3(64), 0, stream, part, blocks, denom,
+                       mode == 2 ? reinterpret_cast<double*>(loss) : nullptr,
+                       mode == 1 ? reinterpret_cast<float*>(loss) : nullptr);
+    PSLD_CHECK_LAUNCH("scaled_final_kernel");
     return PSLD_OK;
 }

@@ -46,10 +46,13 @@ class PSLDScoreLoss(nn.Module):
     def forward(self, x_0, t, score_fn, eps=None):
         sde = self.sde
         # losses.py:96-102: DSM samples the momentum, HSM marginalises it
+        # losses.py:96-102: the momentum is drawn in BOTH modes (HSM discards it), so a seeded run consumes the device
+        # RNG stream exactly like the reference
+        m_draw = torch.randn_like(x_0)
         if self.mode == "hsm":
             m_0, mm_0 = None, sde.mm_0
         else:
-            m_0, mm_0 = np.sqrt(sde.mm_0) * torch.randn_like(x_0), 0.0
+            m_0, mm_0 = np.sqrt(sde.mm_0) * m_draw, 0.0
         if eps is None:
             eps = torch.randn(x_0.shape[0], 2 * x_0.shape[1], *x_0.shape[2:], device=x_0.device)
         assert eps.shape[1] == 2 * x_0.shape[1]
@@ -67,18 +70,34 @@ class PSLDScoreLoss(nn.Module):
         return _SqErr.apply(eps_pred, target, self.reduce_strategy == "mean")
 
 
+class _VpScoreLoss(torch.autograd.Function):
+    """L1 criterion (mode 1) / g(t)^2-weighted score error (mode 2); the kernel also emits d loss / d pred."""
+
+    @staticmethod
+    def forward(ctx, pred, target, t, beta0, beta1, mode, reduce_mean):
+        loss, grad = ops.vp_score_loss(target, pred.contiguous(), t, beta0, beta1, mode, reduce_mean, want_grad=True)
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g.to(grad.dtype), None, None, None, None, None, None
+
+
 @register_module(category="losses", name="score_loss")
 class ScoreLoss(nn.Module):
-    """Loss for non-augmented score models (VP-SDE), main/losses.py:21-65 — the 'fid' (eps-MSE) weighting."""
+    """Loss for non-augmented score models (VP-SDE), main/losses.py:21-65: the eps-prediction criterion (MSE, or L1
+    for ``l_type='l1'``) for weighting 'fid', the g(t)^2-weighted score error for weighting 'nll'."""
 
     def __init__(self, config, sde):
         super().__init__()
         assert config.training.loss.weighting in ["nll", "fid"]
-        if config.training.loss.weighting != "fid" or config.training.loss.l_type != "l2":
-            raise NotImplementedError("ScoreLoss: only weighting='fid' with l_type='l2' is implemented")
         self.sde = sde
         self.l_type = config.training.loss.l_type
         self.weighting = config.training.loss.weighting
+        if self.weighting == "nll" and self.l_type != "l2":
+            raise ValueError("l_type can only be `l2` when using nll weighting")       # losses.py:33-35
         self.reduce_strategy = "mean" if config.training.loss.reduce_mean else "sum"
 
     def forward(self, x_0, t, score_fn, eps=None):
@@ -89,7 +108,13 @@ class ScoreLoss(nn.Module):
         x_t = self.sde.perturb_f32(x_0, t, eps)                          # losses.py:48-49
         t32 = ops.f64_to_f32(t.contiguous()) if t.dtype == torch.float64 else t.float()
         eps_pred = score_fn(x_t, t32)
-        return _SqErr.apply(eps_pred, eps, self.reduce_strategy == "mean")
+        mean = self.reduce_strategy == "mean"
+        if self.weighting == "nll":                                      # losses.py:55-63 (f64 loss: t is f64)
+            return _VpScoreLoss.apply(eps_pred, eps, t.to(torch.float64).contiguous(), self.sde.beta_0, self.sde.beta_1,
+                                      2, mean)
+        if self.l_type != "l2":                                          # losses.py:38-39: nn.L1Loss
+            return _VpScoreLoss.apply(eps_pred, eps, None, 0.0, 0.0, 1, mean)
+        return _SqErr.apply(eps_pred, eps, mean)
 
 
 class _SoftmaxXent(torch.autograd.Function):
@@ -112,7 +137,7 @@ class _SoftmaxXent(torch.autograd.Function):
 @register_module(category="losses", name="tce_loss")
 class PSLDTimeCELoss(nn.Module):
     """Loss of the noise-conditioned classifier used for guidance (main/losses.py:132-178).
-    ``forward(x_0, y, t, clf_fn) -> (loss, top-1 accuracy in percent)``; ``config`` is the root node holding
+    ``forward(x_0, y, t, clf_fn) -> (loss, top-1 accuracy as a fraction in [0, 1] like util.compute_top_k)``; ``config`` is the root node holding
     ``.diffusion`` and ``.clf``.  Both ``randn_like`` draws of the reference are made, in its order (the momentum
     draw is discarded in HSM mode, exactly like there)."""
 
@@ -139,4 +164,4 @@ class PSLDTimeCELoss(nn.Module):
         t32 = ops.f64_to_f32(t.contiguous()) if t.dtype == torch.float64 else t.float()   # layers.py: timesteps.float()
         y_pred = clf_fn(u_t, t32)
         loss, correct = _SoftmaxXent.apply(y_pred, y, self.reduce_strategy == "mean")
-        return loss, correct * (100.0 / y_pred.shape[0])                # util.compute_top_k(k=1)
+        return loss, correct * (1.0 / y_pred.shape[0])                  # losses.py:11-15 compute_top_k(k=1): a fraction

@@ -165,9 +165,52 @@ def conv3x3_split(x1: Tensor, x2: Optional[Tensor], wfrag: Tensor, cout: int, y:
     if b * h * w <= 32768:
         wsb = lib().psld_conv2d_workspace_bytes(b, h, w, cout)
         ws = workspace(wsb, x1.device).data_ptr()
+    if isinstance(x1, LimbPlanes):       # pre-split input(s): the LDS-DMA kernel
+        assert x2 is None or isinstance(x2, LimbPlanes)
+        check(lib().psld_conv3x3_limb_f32(x1.data_ptr(), c1, x2.data_ptr() if x2 is not None else None, c2, b, h, w,
+                                          wfrag.data_ptr(), cout, y.data_ptr(), ldy if ldy is not None else cout,
+                                          C.byref(epi) if epi is not None else None, ws, wsb, _stream()),
+              "psld_conv3x3_limb_f32")
+        return
     check(lib().psld_conv3x3_split_f32(x1.data_ptr(), c1, _p(x2), c2, b, h, w, wfrag.data_ptr(), cout, y.data_ptr(),
                                        ldy if ldy is not None else cout, C.byref(epi) if epi is not None else None,
                                        ws, wsb, _stream()), "psld_conv3x3_split_f32")
+
+
+class LimbPlanes:
+    """An NHWC activation stored as bf16 limb planes [rows][c/32][3][32] (include/psld_hip.h): ``t`` is the raw int16
+    storage, ``shape`` the logical (b, h, w, c)."""
+    __slots__ = ("t", "shape")
+
+    def __init__(self, shape, device=None, t: Optional[Tensor] = None):
+        self.shape = tuple(shape)
+        b, h, w, c = self.shape
+        assert c % 32 == 0, c
+        self.t = t if t is not None else torch.empty((b * h * w * c * 3,), device=device, dtype=torch.int16)
+
+    @property
+    def device(self):
+        return self.t.device
+
+    def data_ptr(self):
+        return self.t.data_ptr()
+
+    def record_stream(self, s):
+        self.t.record_stream(s)
+
+
+def f32_to_limb(x: Tensor, out: Optional[LimbPlanes] = None) -> LimbPlanes:
+    b, h, w, c = x.shape
+    out = out if out is not None else LimbPlanes(x.shape, x.device)
+    check(lib().psld_f32_to_limb(_chk(x).data_ptr(), b * h * w, c, out.data_ptr(), _stream()), "psld_f32_to_limb")
+    return out
+
+
+def limb_to_f32(x: LimbPlanes) -> Tensor:
+    b, h, w, c = x.shape
+    out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    check(lib().psld_limb_to_f32(x.data_ptr(), b * h * w, c, out.data_ptr(), _stream()), "psld_limb_to_f32")
+    return out
 
 
 def gemm_split_supported(k1: int, k2: int, m: int, n: int) -> bool:
@@ -577,6 +620,21 @@ def sqerr_loss(eps: Tensor, eps_pred: Tensor, reduce_mean: bool, want_grad: bool
     return loss, grad
 
 
+def vp_score_loss(eps: Tensor, eps_pred: Tensor, t: Optional[Tensor], beta0: float, beta1: float, mode: int,
+                  reduce_mean: bool, want_grad: bool):
+    """ScoreLoss criteria beyond the eps-MSE: mode 1 = L1 (f32 loss), mode 2 = 'nll' weighting (f64 loss)."""
+    b = eps.shape[0]
+    per = eps.numel() // b
+    loss = torch.empty((), device=eps.device, dtype=torch.float64 if mode == 2 else torch.float32)
+    grad = torch.empty_like(eps_pred) if want_grad else None
+    ws = workspace(lib().psld_reduce_workspace_bytes(eps.numel()), eps.device)
+    check(lib().psld_vp_score_loss(_chk(eps).data_ptr(), _chk(eps_pred).data_ptr(),
+                                   _chk(t, torch.float64).data_ptr() if t is not None else None, float(beta0), float(beta1),
+                                   b, per, mode, 1 if reduce_mean else 0, loss.data_ptr(), _p(grad), 1.0, ws.data_ptr(),
+                                   _stream()), "psld_vp_score_loss")
+    return loss, grad
+
+
 def em_step(x: Tensor, eps_pred: Tensor, z: Optional[Tensor], k: EmCoeffs, x_f32: Optional[Tensor]):
     b, c2, h, w = x.shape
     check(lib().psld_em_step_f64(_chk(x, torch.float64).data_ptr(), _chk(eps_pred).data_ptr(), _p(z), C.byref(k), b,
@@ -589,6 +647,20 @@ def reverse_sde(x: Tensor, eps_pred: Tensor, k: EmCoeffs):
     g = torch.empty_like(x)
     check(lib().psld_reverse_sde_f64(_chk(x, torch.float64).data_ptr(), _chk(eps_pred).data_ptr(), C.byref(k), b,
                                      c2 // 2, h * w, f.data_ptr(), g.data_ptr(), _stream()), "psld_reverse_sde_f64")
+    return f, g
+
+
+def reverse_sde_rows(x: Tensor, eps_pred: Optional[Tensor], t_rev: Tensor, params: SdeParams, xx_0: float, mm_0: float,
+                     score_mode: int, probability_flow: bool, nan_flag: Tensor):
+    """(f_bar, g_bar) - or (f, g) of the forward SDE when ``eps_pred`` is None - with one time per sample."""
+    b, c2, h, w = x.shape
+    f = torch.empty_like(x)
+    g = torch.empty_like(x)
+    check(lib().psld_reverse_sde_rows_f64(_chk(x, torch.float64).data_ptr(), _p(eps_pred),
+                                          _chk(t_rev, torch.float64).data_ptr(), C.byref(params), float(xx_0), float(mm_0),
+                                          int(score_mode), 1 if probability_flow else 0, b, c2 // 2, h * w,
+                                          f.data_ptr(), g.data_ptr(), nan_flag.data_ptr(), _stream()),
+          "psld_reverse_sde_rows_f64")
     return f, g
 
 

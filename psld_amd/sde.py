@@ -198,13 +198,23 @@ class PSLD:
         return z
 
     # ---- score / drift (psld.py:230-260, 330-364) ----------------------------------------------------------
-    def _uniform_time(self, t) -> float:
-        if torch.is_tensor(t):
-            vals = t.detach().reshape(-1).to(torch.float64).tolist()
-            if any(v != vals[0] for v in vals):
-                raise NotImplementedError("per-sample times in sde()/reverse_sde(): call once per distinct t")
-            return float(vals[0])
-        return float(t)
+    def _score_mode(self) -> int:
+        if self.decomp_mode == "lower" and self.mode == "score_m":
+            return 1
+        if self.decomp_mode == "upper" and self.mode == "score_x":
+            return 2
+        return 0
+
+    def _rows(self, u_t, t):
+        """Device tensors for the per-sample-time kernels: f64 state, f64 t[B] (a 0-d / 1-element t is broadcast)."""
+        if not u_t.is_cuda:
+            raise RuntimeError("psld_amd.PSLD needs device tensors (no CPU fallback)")
+        b = u_t.shape[0]
+        tt = t.detach().to(device=u_t.device, dtype=torch.float64).reshape(-1)
+        if tt.numel() == 1 and b != 1:
+            tt = tt.expand(b)
+        assert tt.numel() == b, (tuple(t.shape), b)
+        return u_t.to(torch.float64).contiguous(), tt.contiguous()
 
     def get_score(self, eps, xx_0, mm_0, t):
         """score = -L_t^{-T} eps, f32 (psld.py:230-260) — host composition over tiny tensors."""
@@ -220,7 +230,12 @@ class PSLD:
         return torch.cat([-r(c11, ex) * ex - r(c12, em) * em, -r(c21, ex) * ex - r(c22, em) * em], dim=1)
 
     def sde(self, u_t, t):
-        tt = self._uniform_time(t)
+        """(f, g) of psld.py:330-343.  ``t``: a float, or a tensor with one time per sample (stays on the device)."""
+        if torch.is_tensor(t):
+            u64, tt = self._rows(u_t, t)
+            flag = torch.zeros(1, dtype=torch.int32, device=u64.device)
+            return ops.reverse_sde_rows(u64, None, tt, self._params, 0.0, self.mm_0, self._score_mode(), False, flag)
+        tt = float(t)
         k = self.em_coeffs(tt, 0.0)
         k.c11 = k.c12 = k.c21 = k.c22 = 0.0   # score := 0 -> f_bar = -f
         zeros = torch.zeros(u_t.shape[0], u_t.shape[1] if k.score_mode == 0 else u_t.shape[1] // 2, *u_t.shape[2:],
@@ -229,7 +244,21 @@ class PSLD:
         return -fb, g
 
     def reverse_sde(self, u_t, t, score_fn: Callable, probability_flow=False):
-        tt = self.T - self._uniform_time(t)
+        """(f_bar, g_bar) of psld.py:345-364.  ``t``: a float (one host-computed coefficient set, the samplers' path),
+        or a tensor with one time per sample: then nothing is read back from ``t`` - the network gets
+        ``(T - t).float()`` and the kernel derives each sample's coefficients from its own time."""
+        if torch.is_tensor(t):
+            u64, tt = self._rows(u_t, t)
+            t_rev = self.T - tt                                          # psld.py:348
+            u32 = ops.f64_to_f32(u64) if u_t.dtype != torch.float32 else u_t.contiguous()
+            eps_pred = score_fn(u32, ops.f64_to_f32(t_rev))              # psld.py:354
+            flag = torch.zeros(1, dtype=torch.int32, device=u64.device)
+            out = ops.reverse_sde_rows(u64, eps_pred.contiguous(), t_rev, self._params, 0.0, self.mm_0,
+                                       self._score_mode(), probability_flow, flag)
+            if self.check_nan and int(flag.item()) != 0:
+                raise ValueError("Numerical precision error.")
+            return out
+        tt = self.T - float(t)
         u64 = u_t.to(torch.float64).contiguous()
         u32 = ops.f64_to_f32(u64) if u_t.dtype != torch.float32 else u_t.contiguous()
         t32 = torch.full((u_t.shape[0],), float(np.float32(tt)), device=u_t.device, dtype=torch.float32)

@@ -102,3 +102,88 @@ def test_cpu_tensor_is_rejected_without_touching_the_gpu():
     net = NCSNpp(C.tiny())
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         net(torch.zeros(1, 6, 16, 16), torch.ones(1))
+
+
+def test_epoch_indices_match_torch_distributed_sampler():
+    """The CLI's per-rank epoch shard is what Lightning strategy="ddp" gives the reference (train_sde.py:100-114):
+    torch's DistributedSampler(shuffle=True, seed, set_epoch) under DataLoader(drop_last=True)."""
+    from torch.utils.data import DistributedSampler
+    from psld_amd.cli import epoch_indices
+    n, bs, seed = 1003, 16, 7
+    ds = list(range(n))
+    for world in (1, 2, 8):
+        seen = []
+        for rank in range(world):
+            smp = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True, seed=seed)
+            for epoch in (0, 3):
+                smp.set_epoch(epoch)
+                ref = torch.tensor(list(iter(smp)))
+                ref = ref[:ref.numel() // bs * bs]
+                mine = epoch_indices(n, bs, seed, epoch, rank, world)
+                assert torch.equal(mine, ref), (world, rank, epoch)
+            seen.append(epoch_indices(n, bs, seed, 0, rank, world))
+        # one epoch = one pass: ranks see disjoint indices (up to the wrap-around padding) and equal step counts
+        assert len({s.numel() for s in seen}) == 1
+        allidx = torch.cat(seen)
+        assert allidx.unique().numel() >= allidx.numel() - world
+
+
+def test_checkpoint_resume_restores_scheduler_and_adopts_torch_adam_state(tmp_path, recwarn):
+    """Resume: the LambdaLR position is restored (not re-warmed from 0) and a torch.optim.Adam state -
+    what a reference checkpoint carries - is converted into FusedAdam's flat moments; with no usable state the
+    bias-correction step restarts together with the moments, loudly."""
+    import copy
+    from psld_amd import cli
+    from psld_amd.optim import FusedAdam
+    from psld_amd.score_fn import NCSNpp
+
+    cfg = C.tiny(image_size=8, nf=16, ch_mult=(1,), num_res_blocks=1, attn_resolutions=(8,))
+    net = NCSNpp(cfg)
+    ema = copy.deepcopy(net)
+
+    class W:
+        score_fn, ema_score_fn = net, ema
+
+    params = [p for p in net.parameters()]
+    # a reference-style checkpoint: torch.optim.Adam state after 7 steps
+    adam = torch.optim.Adam([p for p in params if p.requires_grad], lr=1e-3)
+    for p in params:
+        if p.requires_grad:
+            p.grad = torch.randn_like(p)
+    for _ in range(7):
+        adam.step()
+    ref_sd = adam.state_dict()
+    # the reference's optimizer indexes only trainable parameters in module order; FusedAdam indexes all parameters
+    idx = [i for i, p in enumerate(params) if p.requires_grad]
+    state = {idx[k]: v for k, v in ref_sd["state"].items()}
+    path = str(tmp_path / "ref.ckpt")
+    sd = {"score_fn." + k: v for k, v in net.state_dict().items()}
+    torch.save({"state_dict": sd, "global_step": 7, "epoch": 1,
+                "optimizer_states": [{"state": state, "param_groups": ref_sd["param_groups"]}]}, path)
+    opt = FusedAdam(net, lr=2e-4)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: min(s / 5000, 1.0))
+    step, epoch = cli.load_checkpoint(path, net, ema, opt, sched)
+    assert (step, epoch) == (7, 1) and opt._step == 7
+    p0 = next(p for p in params if p.requires_grad)
+    o = net._offsets[id(p0)]
+    assert torch.equal(opt._m[o:o + p0.numel()].view(p0.shape), adam.state[p0]["exp_avg"])
+    assert torch.equal(opt._v[o:o + p0.numel()].view(p0.shape), adam.state[p0]["exp_avg_sq"])
+    assert sched.last_epoch == 7 and abs(opt.param_groups[0]["lr"] - 2e-4 * 7 / 5000) < 1e-12
+    # own checkpoint: round trip incl. the scheduler state
+    for _ in range(3):
+        sched.step()
+    own = str(tmp_path / "own.ckpt")
+    cli.save_checkpoint(own, W, opt, 10, 2, sched)
+    opt2 = FusedAdam(net, lr=2e-4)
+    sched2 = torch.optim.lr_scheduler.LambdaLR(opt2, lambda s: min(s / 5000, 1.0))
+    assert cli.load_checkpoint(own, net, ema, opt2, sched2) == (10, 2)
+    assert opt2._step == 7 and torch.equal(opt2._m, opt._m) and sched2.last_epoch == 10
+    assert abs(opt2.param_groups[0]["lr"] - 2e-4 * 10 / 5000) < 1e-12
+    # no optimizer state at all: loud, and the step restarts with the moments
+    bare = str(tmp_path / "bare.ckpt")
+    torch.save({"state_dict": sd, "global_step": 9, "epoch": 1}, bare)
+    opt3 = FusedAdam(net, lr=2e-4)
+    opt3._step = 5
+    with pytest.warns(RuntimeWarning, match="restart from"):
+        cli.load_checkpoint(bare, net, ema, opt3, None)
+    assert opt3._step == 0

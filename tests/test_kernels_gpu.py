@@ -196,6 +196,56 @@ def test_conv3x3_split_forward(ops, cfg):
     assert rel_l2(y, y32) < 3e-6
 
 
+def test_limb_planes_roundtrip_is_exact(ops):
+    """fp32 -> bf16 limb planes [rows][c/32][3][32] -> fp32: hi + mid + lo reproduces every value bit for bit, over a
+    wide dynamic range, and the plane layout is the documented one."""
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(2, 4, 8, 96, generator=g) * torch.exp(torch.randn(2, 4, 8, 96, generator=g) * 8.0)).to(DEV)
+    x[0, 0, 0, :4] = torch.tensor([0.0, -0.0, 1.0, -3.5e-30], device=DEV)
+    lp = ops.f32_to_limb(x)
+    assert torch.equal(ops.limb_to_f32(lp), x)
+    raw = lp.t.view(2 * 4 * 8, 3, 3, 32).cpu()                                     # [row][chunk][limb][32]
+    rec = (raw.to(torch.int32) << 16).view(torch.float32).double().sum(dim=2).reshape(2, 4, 8, 96)
+    assert torch.equal(rec, x.double().cpu())
+    hi = (raw[:, :, 0].to(torch.int32) << 16).view(torch.float32).reshape(2, 4, 8, 96)
+    assert torch.equal(hi, x.cpu().bfloat16().float())                              # hi limb = round-to-nearest-even bf16
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(b=2, c1=64, c2=0, co=128, h=8, w=8),
+    dict(b=3, c1=32, c2=0, co=128, h=8, w=8),
+    dict(b=2, c1=64, c2=32, co=128, h=16, w=16),
+    dict(b=1, c1=32, c2=0, co=256, h=32, w=32),
+    dict(b=5, c1=96, c2=0, co=128, h=32, w=32),      # 13 row groups, odd chunk count, several tiles per image
+    dict(b=1, c1=32, c2=0, co=128, h=64, w=64),      # CelebA-64 resolution: single-image (non double-buffered) variant
+    dict(b=1, c1=256, c2=256, co=256, h=8, w=8),     # split over the channel chunks
+    dict(b=2, c1=32, c2=0, co=128, h=4, w=8),
+])
+def test_conv3x3_limb_input_is_bitwise_the_split_kernel(ops, cfg):
+    """psld_conv3x3_limb_f32 (input as bf16 limb planes, halo tile staged by LDS-DMA into two images) computes the
+    same limb products in the same order as psld_conv3x3_split_f32 (fp32 input split in the kernel): bitwise equal
+    outputs, with the full epilogue; and both against fp64."""
+    b, c1, c2, co, h, w_ = (cfg[n] for n in ("b", "c1", "c2", "co", "h", "w"))
+    x = gen(b, c1 + c2, h, w_, seed=40)
+    w = gen(co, c1 + c2, 3, 3, seed=41, scale=0.1)
+    bias, res = gen(co, seed=42), gen(b, co, h, w_, seed=43)
+    temb = gen(b, co, seed=44)
+    ref = (F.conv2d(x.double(), w.double(), bias.double(), padding=1) + temb.double()[:, :, None, None]
+           + res.double()) * 0.7
+    x1 = _nhwc(x[:, :c1]).to(DEV)
+    x2 = _nhwc(x[:, c1:]).to(DEV) if c2 else None
+    wf = ops.conv3x3_frag(w.to(DEV), False)
+    epi = ops.epilogue(bias=bias.to(DEV), rowbias=temb.to(DEV), rows_per_img=h * w_, residual=_nhwc(res).to(DEV),
+                       ld_residual=co, out_scale=0.7)
+    y = torch.full((b, h, w_, co), float("nan"), device=DEV)
+    ops.conv3x3_split(x1, x2, wf, co, y, epi)
+    for rep in range(3):        # repeated: a DMA that has not landed when it is read shows up as a run-to-run difference
+        yl = torch.full((b, h, w_, co), float("nan"), device=DEV)
+        ops.conv3x3_split(ops.f32_to_limb(x1), ops.f32_to_limb(x2) if x2 is not None else None, wf, co, yl, epi)
+        assert torch.equal(yl, y), (cfg, rep, rel_l2(yl, y))
+    assert rel_l2(yl.permute(0, 3, 1, 2), ref) < 3e-6
+
+
 def test_conv3x3_split_wide_dynamic_range(ops):
     """Limb products keep fp32 accuracy when operands span many binades (gradients late in training are ~1e-8)."""
     b, c, co, s = 2, 64, 128, 8

@@ -449,14 +449,31 @@ def test_sde_interface_matches_oracle(golden):
         bad = get_module("sde", "psld")(cfg)
         bad._params.numerical_eps = -1.0
         bad.perturb_data(x0, None, 0, bad.mm_0, torch.full((4,), 1e-5, dtype=torch.float64, device=DEV), eps=eps)
-    # reverse_sde through the generic (reference-shaped) entry point, uniform t
-    uu = T(g["u"])[:1].to(DEV)
+    # sde() / reverse_sde() through the reference-shaped entry points with ONE TIME PER SAMPLE (psld.py:330-364 take
+    # t[B]): t = [1e-5, 1.0, two random]; the times never leave the device (coefficients are derived in the kernel)
+    uu, tt = T(g["u"]).to(DEV), T(g["t"]).to(DEV)
     fake = lambda a, b: 0.1 * a + b.view(-1, 1, 1, 1)
-    fb, gb = sde.reverse_sde(uu, T(g["t"])[:1].to(DEV), fake)
-    np.testing.assert_allclose(fb.cpu().numpy(), g["f_bar"][:1], rtol=1e-12, atol=1e-14)
-    np.testing.assert_allclose(gb.cpu().numpy(), g["g_bar"][:1], rtol=1e-14)
-    f, gg = sde.sde(uu, T(g["t"])[:1].to(DEV))
-    np.testing.assert_allclose(f.cpu().numpy(), g["f"][:1], rtol=1e-12, atol=1e-14)
+    for pf, tag in ((False, ""), (True, "_pf")):
+        fb, gb = sde.reverse_sde(uu, tt, fake, probability_flow=pf)
+        assert fb.dtype == torch.float64 and gb.dtype == torch.float64
+        np.testing.assert_allclose(fb.cpu().numpy(), g["f_bar" + tag], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(gb.cpu().numpy(), g["g_bar" + tag], rtol=1e-14)
+    f, gg = sde.sde(uu, tt)
+    np.testing.assert_allclose(f.cpu().numpy(), g["f"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(gg.cpu().numpy(), g["g"], rtol=1e-14)
+    # float32 state at entry (the sampler's first call) and a one-element t broadcast over the batch
+    fb1, _ = sde.reverse_sde(uu.float(), tt[2:3], fake)
+    fb2, _ = sde.reverse_sde(uu.float(), float(tt[2].item()), fake)          # the samplers' host-scalar path
+    np.testing.assert_allclose(fb1.cpu().numpy(), fb2.cpu().numpy(), rtol=1e-12, atol=1e-14)
+    # host-scalar path against the golden, row by row
+    for i in range(uu.shape[0]):
+        fbi, gbi = sde.reverse_sde(uu[i:i + 1], float(g["t"][i]), fake)
+        np.testing.assert_allclose(fbi.cpu().numpy(), g["f_bar"][i:i + 1], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(gbi.cpu().numpy(), g["g_bar"][i:i + 1], rtol=1e-14)
+    with pytest.raises(ValueError, match="Numerical precision error"):
+        bad = get_module("sde", "psld")(cfg)
+        bad._params.numerical_eps = -1.0
+        bad.reverse_sde(uu, torch.full((4,), 1.0, dtype=torch.float64, device=DEV), fake)   # T - t = 0: xx = -1
 
 
 def test_dropout_mask_statistics_and_gradient_consistency():
@@ -999,6 +1016,39 @@ def test_vpsde_baseline_matches_reference(golden):
     # generic reverse_sde entry (used by the BB-ODE sampler)
     fb, gb = sde.reverse_sde(T(g["batch"]).to(DEV), 0.3, net, probability_flow=True)
     assert fb.dtype == torch.float64 and float(gb.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("tag", ["nll_l2_mean", "nll_l2_sum", "fid_l1_mean", "fid_l1_sum"])
+def test_vpsde_score_loss_weightings_match_reference(golden, tag):
+    """ScoreLoss weighting='nll' (main/losses.py:55-63: g(t)^2-weighted score error, f64 loss) and the L1 criterion of
+    weighting='fid' (:38-39), against the reference's loss values and parameter gradients."""
+    import psld_amd
+    psld_amd.import_modules_into_registry()
+    from psld_amd.registry import get_module
+    from tests.test_oracle_golden import _vp_setup
+    g = golden("vploss_tiny.npz")
+    cfg, sd = _vp_setup()
+    weighting, l_type, red = tag.split("_")
+    cfg.training.loss.weighting, cfg.training.loss.l_type, cfg.training.loss.reduce_mean = weighting, l_type, red == "mean"
+    net = get_module("score_fn", "ncsnpp")(cfg)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV).train()
+    sde = get_module("sde", "vpsde")(cfg)
+    loss = get_module("losses", "score_loss")(cfg, sde)(T(g["x0"]).to(DEV), T(g["t"]).to(DEV), net, eps=T(g["eps"]).to(DEV))
+    ref = float(g["loss_" + tag])
+    assert loss.dtype == T(g["loss_" + tag]).dtype                 # nll: f64 like the reference; l1: f32
+    assert abs(loss.item() - ref) < 2e-5 * abs(ref), (loss.item(), ref)
+    loss.backward()
+    pd = dict(net.named_parameters())
+    total = torch.stack([p.grad.double().norm() for p in pd.values() if p.grad is not None]).norm().item()
+    assert abs(total - float(g["gnorm_" + tag])) < 1e-4 * float(g["gnorm_" + tag])
+    for k in g.files:
+        if k.startswith(f"g_{tag}:"):
+            e = rel_l2(pd[k.split(":", 1)[1]].grad, T(g[k]))
+            assert e < 1e-4, (k, e)
+    with pytest.raises(ValueError, match="l_type can only be"):
+        cfg.training.loss.weighting, cfg.training.loss.l_type = "nll", "l1"
+        get_module("losses", "score_loss")(cfg, sde)
 
 
 def test_gradient_accumulation_semantics():

@@ -432,3 +432,22 @@ def test_vpsde_baseline(golden):
         x = O.em_sample(sde, lambda u, tt: O.ncsnpp_forward(sd, cfg, u, tt), T(g["batch"]), T(g["ts"]), 4, True,
                         cfg.evaluation.eval_eps, noise=list(T(g["noise"])))
     assert rel_l2(x, T(g["x_em"])) < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["nll_l2_mean", "nll_l2_sum", "fid_l1_mean", "fid_l1_sum"])
+def test_vpsde_score_loss_weightings(golden, tag):
+    """ScoreLoss 'nll' weighting (losses.py:55-63) and the L1 criterion (:38-39) vs the reference, with gradients."""
+    g = golden("vploss_tiny.npz")
+    cfg, sd = _vp_setup()
+    sde = O.VPSDEOracle(cfg.model.sde.beta_min, cfg.model.sde.beta_max)
+    weighting, l_type, red = tag.split("_")
+    p = {k: v.requires_grad_(True) for k, v in sd.items()}
+    loss = O.score_loss(sde, T(g["x0"]), T(g["t"]), lambda u, tt: O.ncsnpp_forward(p, cfg, u, tt), T(g["eps"]),
+                        reduce_mean=red == "mean", weighting=weighting, l_type=l_type)
+    ref = float(g["loss_" + tag])
+    assert loss.dtype == T(g["loss_" + tag]).dtype
+    assert abs(loss.item() - ref) < 2e-6 * abs(ref)
+    loss.backward()
+    for k in g.files:
+        if k.startswith(f"g_{tag}:"):
+            assert rel_l2(p[k.split(":", 1)[1]].grad, T(g[k])) < 2e-5, k

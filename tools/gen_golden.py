@@ -208,11 +208,42 @@ def em_c10_section(get, C):
     save("em_c10_sota.npz", **out)
 
 
+def vp_loss_section(get, C):
+    """ScoreLoss beyond the eps-MSE: weighting='nll' (g(t)^2-weighted score error, losses.py:55-63) and the L1 criterion
+    of weighting='fid' (losses.py:38-39), mean and sum reductions, with parameter gradients."""
+    print("VP-SDE ScoreLoss: nll weighting / l1")
+    vcfg = C.tiny_vpsde()
+    vsde = get("sde", "vpsde")(vcfg)
+    net = get("score_fn", "ncsnpp")(vcfg)
+    load_synth(net, 4000)
+    net.train()
+    g = torch.Generator().manual_seed(93)
+    x0 = torch.rand(4, 3, 16, 16, generator=g) * 2 - 1
+    eps = torch.randn(4, 3, 16, 16, generator=g)
+    t = torch.rand(4, generator=g, dtype=torch.float64) * (1 - 1e-3) + 1e-3
+    out = {"x0": x0, "eps": eps, "t": t}
+    names = [k for k, _ in net.named_parameters()]
+    for weighting, l_type in (("nll", "l2"), ("fid", "l1")):
+        for red in (True, False):
+            cfg = C.tiny_vpsde()
+            cfg.training.loss.weighting, cfg.training.loss.l_type, cfg.training.loss.reduce_mean = weighting, l_type, red
+            for p_ in net.parameters():
+                p_.grad = None
+            loss = get("losses", "score_loss")(cfg, vsde)(x0, t, net, eps=eps)
+            loss.backward()
+            tag = f"{weighting}_{l_type}_{'mean' if red else 'sum'}"
+            out["loss_" + tag] = loss.detach()
+            out["gnorm_" + tag] = torch.stack([p_.grad.double().norm() for p_ in net.parameters() if p_.grad is not None]).norm()
+            for k in (names[0], names[5], names[-1]):
+                out[f"g_{tag}:{k}"] = dict(net.named_parameters())[k].grad.clone()
+    save("vploss_tiny.npz", **out)
+
+
 def main():
     util = import_reference()
     if "--only" in sys.argv:
         which = sys.argv[sys.argv.index("--only") + 1]
-        {"inpaint": inpaint_section, "clf": clf_section, "em_c10": em_c10_section}[which](util.get_module, C)
+        {"inpaint": inpaint_section, "clf": clf_section, "em_c10": em_c10_section, "vp_loss": vp_loss_section}[which](util.get_module, C)
         return
     get = util.get_module
     PSLD = get("sde", "psld")
@@ -580,6 +611,7 @@ def main():
     inpaint_section(get, C)
     clf_section(get, C)
     em_c10_section(get, C)
+    vp_loss_section(get, C)
     print("done")
 
 
