@@ -171,7 +171,6 @@ int psld_conv3x3_wgrad_split_cout_tile(int cout);
 int psld_conv3x3_wgrad_split_f32(const float* dy, int lddy, int cout, const float* x, int cin,
                                  const float* x2, int cin2, int batch, int h, int w, float* slabs,
                                  int cin_total, int col0, int nsplit, hipStream_t stream);
-
 /* Pointwise weight gradient on the limb kernels: slabs[s][i][j] (row stride ldc) = sum over the s-th range of
  * ceil(k/32 / nsplit) 32-row tiles of a[p][i] * b[p][j]  (a: [k][m] rows of lda floats, b: [k][n] rows of ldb floats;
  * b2 / ldb2 / n2 (null / 0 / 0 for none): further columns [n, n + n2) of B from a second tensor (concatenation);
@@ -233,6 +232,11 @@ int psld_gn_stats_from_partials_f32(const double* gn_part, int batch, int hw, in
 int psld_gn_apply_nhwc_f32(const float* x, const float* scale, const float* shift, float* y,
                            int batch, int hw, int c, int act, float drop_p, unsigned long long seed,
                            hipStream_t stream);
+/* The same pass writing bf16 limb planes (see psld_conv3x3_limb_f32) instead of fp32: y_limb holds
+ * psld_limb_bytes(batch*hw, c) bytes; c a multiple of 32.  The dropout mask is the one psld_gn_apply_nhwc_f32 and
+ * psld_gn_bwd_nhwc_f32 derive from (seed, element index). */
+int psld_gn_apply_limb_nhwc(const float* x, const float* scale, const float* shift, void* y_limb, int batch,
+                            int hw, int c, int act, float drop_p, unsigned long long seed, hipStream_t stream);
 /* Backward of y = act(GN(x)): dgamma[C], dbeta[C] (written, not accumulated) and
  * dx = d/dx (+ add_scale * add when add != NULL: the gradient of an identity branch parallel to the normalisation,
  * e.g. the residual `(x + h) / sqrt(2)` of layerspp.py:271-274) (+ the previous dx when accumulate_dx). */

@@ -83,6 +83,7 @@ SIGNATURES = {
     "psld_pack_conv3x3_frag": (I, [P, P, I, I, I, P]),
     "psld_pack_frag_batch": (I, [P, I, LL, P]),
     "psld_conv3x3_split_f32": (I, [P, I, P, I, I, I, I, P, I, P, I, EP, P, LL, P]),
+    "psld_gn_apply_limb_nhwc": (I, [P, P, P, P, I, I, I, I, F, C.c_ulonglong, P]),
     "psld_limb_bytes": (LL, [LL, I]),
     "psld_f32_to_limb": (I, [P, LL, I, P, P]),
     "psld_limb_to_f32": (I, [P, LL, I, P, P]),

@@ -155,71 +155,71 @@ struct DConvArgs {
     int nseg, rps;          // image segments per 128-pixel tile and output rows per segment
     PsldEpilogue e;
     const float* zero;
+    int v4;                 // rows of C / residual / bias / row bias are 16-byte aligned: dwordx4 epilogue (set by plan_split)
 };
 
 // Fused epilogue of a 64 x 64 wave tile (4 x 4 accumulators of v_mfma_f32_16x16x32_bf16) at (m0 + wr*64, n0 + wc*64).
+// The kernels issue the MFMAs with the WEIGHT fragment as the first operand, i.e. they accumulate the transposed
+// block D^T[channel][pixel]: in the 16x16 C/D layout (col = lane & 15, row = 4*(lane >> 4) + v) a lane then holds
+// FOUR CONSECUTIVE CHANNELS of ONE pixel per block - a 16-byte run of the NHWC row - so output, residual, previous
+// output and biases move as dwordx4 (16 memory instructions per block row instead of 64 single-dword ones).  Rows of
+// C / residual / bias / row bias must be 16-byte aligned (checked by the entry points).
 __device__ __forceinline__ void dconv_epilogue(const DConvArgs& a, f32x4v (&acc)[4][4], int m0, int n0, int wr, int wc,
                                                int lane, int split) {
     const int r16 = lane & 15, kq = lane >> 4;
-    // fused epilogue; C/D layout of the 16x16 MFMA: col = lane & 15, row = 4*(lane >> 4) + v
     float* Cb = a.C + (long long)split * a.c_stride_split;
     const PsldEpilogue& e = a.e;
     const bool rb_uniform = e.rowbias && (e.rows_per_img % 16 == 0);
-    float gs[4], gss[4];                 // GroupNorm by-product: this lane's column sums over the wave's 64 rows
+    const int cn0 = n0 + wc * 64 + 4 * kq;           // this lane's first channel in block column nb: cn0 + nb*16
+    const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4v bias4[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+        bias4[nb] = e.bias ? *reinterpret_cast<const f32x4v*>(e.bias + cn0 + nb * 16) : zero4;
+    float gs[4], gss[4];                 // GroupNorm by-product: sums of this lane's 4 channels x 4 pixels per block column
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) gs[nb] = gss[nb] = 0.f;
-    // Residual / previous-output values are loaded for a whole 16-row block (16 loads in flight) BEFORE its stores: a
-    // load placed after a store to memory the compiler cannot tell apart waits out its own latency (measured: the
-    // residual epilogue cost +138 us on a 161 us GEMM, +53 us on a 650 us convolution when it was interleaved).
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
         const int row_base = m0 + wr * 64 + mb * 16;
         if (row_base >= a.M) continue;                      // wave-uniform
-        const bool full = row_base + 16 <= a.M;             // wave-uniform: no per-element bounds checks
-        long long coff[4], roff[4];                         // row offsets of this lane's four rows
+        const int gm = min(row_base + r16, a.M - 1);        // this lane's pixel (clamped: loads stay in range)
+        const bool ok = row_base + r16 < a.M;
+        const long long coff = (long long)gm * a.ldc, roff = (long long)gm * e.ldres;
+        const long long toff = (long long)((rb_uniform ? row_base : gm) / e.rows_per_img) * e.ld_rowbias;
+        // Residual / previous-output values of the whole block row are loaded BEFORE its stores: a load placed after a
+        // store to memory the compiler cannot tell apart waits out its own latency (measured on the scalar form).
+        f32x4v rv[4], cv[4];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int gm = row_base + 4 * kq + v;
-            coff[v] = (long long)gm * a.ldc;
-            roff[v] = (long long)gm * e.ldres;
-        }
-        float rv[4][4], cv[4][4];       // residual, previous output
-        if (e.res || e.accumulate) {
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                const int gn = n0 + wc * 64 + nb * 16 + r16;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const bool ok = full || row_base + 4 * kq + v < a.M;
-                    rv[nb][v] = (e.res && ok) ? e.res[roff[v] + gn] : 0.f;
-                    cv[nb][v] = (e.accumulate && ok) ? Cb[coff[v] + gn] : 0.f;
-                }
-            }
+        for (int nb = 0; nb < 4; ++nb) {
+            const int gn = cn0 + nb * 16;
+            rv[nb] = e.res ? *reinterpret_cast<const f32x4v*>(e.res + roff + gn) : zero4;
+            cv[nb] = e.accumulate ? *reinterpret_cast<const f32x4v*>(Cb + coff + gn) : zero4;
+            const f32x4v tb = e.rowbias ? *reinterpret_cast<const f32x4v*>(e.rowbias + toff + gn) : zero4;
+            // x = ((acc*alpha + bias + rowbias) + res) * out_scale + prev: the additive terms in the scalar form's order
+            acc[mb][nb] = acc[mb][nb] * e.alpha + (bias4[nb] + tb);
         }
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
-            const int gn = n0 + wc * 64 + nb * 16 + r16;
-            float bias = e.bias ? e.bias[gn] : 0.f;
-            // time-embedding bias: one value per (image, channel); a 16-row block never straddles images
-            if (rb_uniform) bias += e.rowbias[(long long)(row_base / e.rows_per_img) * e.ld_rowbias + gn];
+            const int gn = cn0 + nb * 16;
+            f32x4v o = acc[mb][nb];
+            if (e.res) o += rv[nb];
+            o *= e.out_scale;
+            if (e.accumulate) o += cv[nb];
+            if (ok) {
+                *reinterpret_cast<f32x4v*>(Cb + coff + gn) = o;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int gm = row_base + 4 * kq + v;
-                if (!full && gm >= a.M) continue;
-                float x = acc[mb][nb][v] * e.alpha + bias;
-                if (e.rowbias && !rb_uniform) x += e.rowbias[(long long)(gm / e.rows_per_img) * e.ld_rowbias + gn];
-                if (e.res) x += rv[nb][v];
-                x *= e.out_scale;
-                if (e.accumulate) x += cv[nb][v];
-                Cb[coff[v] + gn] = x;
-                gs[nb] += x;
-                gss[nb] += x * x;
+                for (int v = 0; v < 4; ++v) {
+                    gs[nb] += o[v];
+                    gss[nb] += o[v] * o[v];
+                }
             }
         }
     }
     if (e.gn_part) {
-        // 64 rows x 64 columns of one image per wave: sums over the 8 channels of a fine group = lanes r16 & 8 equal,
-        // all four row groups kq.  Fixed butterfly, one writer per (wave, fine group): repeatable.
+        // 64 pixels x 64 channels of one image per wave.  A fine group = 8 channels = the lane pairs kq = (0,1) / (2,3) of
+        // block column nb; pixels run over the 16 lanes r16 (and the 4 block rows already summed per lane).  Fixed
+        // butterfly, one writer per (wave, fine group): repeatable.
         const int row0 = m0 + wr * 64;
         if (row0 < a.M) {
             const int img = row0 / e.gn_hw, chunk = (row0 - img * e.gn_hw) >> 6, chunks = e.gn_hw >> 6;
@@ -228,17 +228,12 @@ __device__ __forceinline__ void dconv_epilogue(const DConvArgs& a, f32x4v (&acc)
             for (int nb = 0; nb < 4; ++nb) {
                 float s1 = gs[nb], s2 = gss[nb];
 #pragma unroll
-                for (int sft = 1; sft <= 4; sft <<= 1) {
+                for (int sft = 1; sft <= 16; sft <<= 1) {        // 16 pixels (1, 2, 4, 8), then the partner channel quad (16)
                     s1 += __shfl_xor(s1, sft, 64);
                     s2 += __shfl_xor(s2, sft, 64);
                 }
-#pragma unroll
-                for (int sft = 16; sft <= 32; sft <<= 1) {
-                    s1 += __shfl_xor(s1, sft, 64);
-                    s2 += __shfl_xor(s2, sft, 64);
-                }
-                if ((lane & 0x37) == 0) {        // lanes 0 and 8
-                    const int f = ((n0 + wc * 64 + nb * 16) >> 3) + (r16 >> 3);
+                if ((lane & 0x1f) == 0) {        // lanes 0 (channels 0-7 of the block column) and 32 (channels 8-15)
+                    const int f = ((n0 + wc * 64 + nb * 16) >> 3) + (lane >> 5);
                     double* pp = e.gn_part + (((long long)img * chunks + chunk) * fine + f) * 2;
                     pp[0] = (double)s1;
                     pp[1] = (double)s2;
@@ -390,8 +385,8 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb)
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8, fa[mb][PA[t]]), __builtin_bit_cast(bf16x8, bq[pp][nb][PB[t]]),
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(       // weights first: D^T (see dconv_epilogue)
+                        __builtin_bit_cast(bf16x8, bq[pp][nb][PB[t]]), __builtin_bit_cast(bf16x8, fa[mb][PA[t]]),
                         acc[mb][nb], 0, 0, 0);
         if (++tap == TAPS) {            // stage done: swap in the next image
             tap = 0; tap_off = 0; kx = 0;
@@ -574,8 +569,8 @@ __global__ void __launch_bounds__(256, 2) dconv_lp_kernel(const DConvArgs a) {
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb)
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8, fa[mb][PA[t]]), __builtin_bit_cast(bf16x8, bq[pp][nb][PB[t]]),
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(       // weights first: D^T (see dconv_epilogue)
+                        __builtin_bit_cast(bf16x8, bq[pp][nb][PB[t]]), __builtin_bit_cast(bf16x8, fa[mb][PA[t]]),
                         acc[mb][nb], 0, 0, 0);
         }
         if (++tap == TAPS) {
@@ -1214,6 +1209,9 @@ int plan_split(DConvArgs& a, const PsldEpilogue& e, float* y, int ldy, void* wor
         a.c_stride_split = 0;
         a.e = e;
     }
+    a.v4 = (a.ldc % 4 == 0) && aligned16(a.C) && (a.c_stride_split % 4 == 0) &&
+           (!a.e.res || (a.e.ldres % 4 == 0 && aligned16(a.e.res))) && (!a.e.bias || aligned16(a.e.bias)) &&
+           (!a.e.rowbias || (a.e.ld_rowbias % 4 == 0 && aligned16(a.e.rowbias)));
     return ns;
 }
 
@@ -1294,6 +1292,7 @@ extern "C" int psld_conv3x3_split_f32(const float* x1, int c1, const float* x2, 
     PSLD_CHECK_ARG(!e.gn_part || (e.gn_hw == h * w && e.gn_hw % 64 == 0 && !e.accumulate),
                    "psld_conv3x3_split_f32: gn_part needs gn_hw = h*w, a multiple of 64, and no accumulation");
     const int ns = plan_split(a, e, y, ldy, workspace, ws_bytes);
+    PSLD_CHECK_ARG(a.v4, "limb kernels: y, residual, bias and rowbias need 16-byte aligned rows (pointer and row stride)");
     const int nh = cdiv((long long)halo_px * 8, 256);
     const char* name = "psld_conv3x3_split_f32";
     int st;
@@ -1346,6 +1345,7 @@ extern "C" int psld_conv3x3_limb_f32(const void* x1, int c1, const void* x2, int
     PSLD_CHECK_ARG(!e.gn_part || (e.gn_hw == h * w && e.gn_hw % 64 == 0 && !e.accumulate),
                    "psld_conv3x3_limb_f32: gn_part needs gn_hw = h*w, a multiple of 64, and no accumulation");
     const int ns = plan_split(a, e, y, ldy, workspace, ws_bytes);
+    PSLD_CHECK_ARG(a.v4, "limb kernels: y, residual, bias and rowbias need 16-byte aligned rows (pointer and row stride)");
     const int rg = cdiv(halo_px, 16);
     const char* name = "psld_conv3x3_limb_f32";
     static const int single = [] { const char* v = getenv("PSLD_LP_SINGLE_BUFFER"); return v ? atoi(v) : 0; }();
@@ -1494,6 +1494,7 @@ extern "C" int psld_gemm_split_f32(const float* a1, int k1, const float* a2, int
     PSLD_CHECK_ARG(!e.gn_part || (e.gn_hw > 0 && e.gn_hw % 64 == 0 && m % e.gn_hw == 0 && !e.accumulate),
                    "psld_gemm_split_f32: gn_part needs gn_hw (rows per image) a multiple of 64 dividing m, and no accumulation");
     const int ns = plan_split(a, e, y, ldy, workspace, ws_bytes);
+    PSLD_CHECK_ARG(a.v4, "limb kernels: y, residual, bias and rowbias need 16-byte aligned rows (pointer and row stride)");
     const int st = launch_dconv<8, 2, true>(a, ns, stream, "psld_gemm_split_f32");
     if (st != PSLD_OK) return st;
     if (ns >= 2) return psld_detail_conv_reduce_epilogue(a.C, ns, m, n, y, ldy, e, stream);

@@ -156,6 +156,55 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, const float* __rest
     }
 }
 
+// The same pass writing bf16 LIMB PLANES [pixel][c/32][3 limbs][32 channels] instead of fp32 (include/psld_hip.h: the
+// 3x3 convolution that consumes the activation stages them by LDS-DMA, no split in the MFMA kernel).  hi = rne_bf16(a),
+// mid = rne_bf16(a - hi), lo = a - hi - mid: exactly the decomposition the convolution kernels apply to fp32 input.
+__device__ __forceinline__ void gn_split3(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const bf16x2_t ph = {(__bf16)x0, (__bf16)x1};
+    hi = __builtin_bit_cast(unsigned, ph);
+    const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+    const bf16x2_t pm = {(__bf16)r0, (__bf16)r1};
+    mid = __builtin_bit_cast(unsigned, pm);
+    const float s0 = r0 - __uint_as_float(mid << 16), s1 = r1 - __uint_as_float(mid & 0xffff0000u);
+    const bf16x2_t pl = {(__bf16)s0, (__bf16)s1};
+    lo = __builtin_bit_cast(unsigned, pl);
+}
+
+__global__ void gn_apply_limb_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, unsigned char* __restrict__ y, int hw, int c, int cq,
+                                     int pl, int chunk_px, int act, float drop_p, unsigned long long seed) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int q = threadIdx.x % cq, l = threadIdx.x / cq;
+    const int p0 = chunk * chunk_px, p1 = min(hw, p0 + chunk_px);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + (long long)n * c + q * 4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + (long long)n * c + q * 4);
+    const long long off = ((long long)n * hw) * c + q * 4;
+    const long long yoff = ((long long)n * hw) * c * 6 + (q >> 3) * 192 + (q & 7) * 8;
+    const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+#pragma unroll 4
+    for (int p = p0 + l; p < p1; p += pl) {
+        const long long idx = off + (long long)p * c;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + idx);
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float z = v[e] * sc[e] + sh[e];
+            float a = act ? silu_f(z) : z;
+            if (drop_p > 0.f) a = psld_dropout_keep(seed, (unsigned long long)(idx + e), drop_p) ? a * keep_scale : 0.f;
+            o[e] = a;
+        }
+        unsigned h0, m0, l0, h1, m1, l1;
+        gn_split3(o[0], o[1], h0, m0, l0);
+        gn_split3(o[2], o[3], h1, m1, l1);
+        unsigned char* d = y + yoff + (long long)p * c * 6;
+        *reinterpret_cast<u32x2_t*>(d) = u32x2_t{h0, h1};
+        *reinterpret_cast<u32x2_t*>(d + 64) = u32x2_t{m0, m1};
+        *reinterpret_cast<u32x2_t*>(d + 128) = u32x2_t{l0, l1};
+    }
+}
+
 // ---- backward -------------------------------------------------------------------------------
 // pass 1: per (n, chunk, channel): s1 = sum dz, s2 = sum dz * xhat      (dz = dy * act'(z))
 __global__ void gn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -389,6 +438,18 @@ extern "C" int psld_gn_apply_nhwc_f32(const float* x, const float* scale, const 
     hipLaunchKernelGGL(gn_apply_kernel, dim3(m.chunks, batch), dim3(m.threads), 0, stream, x, scale, shift, y, hw, c,
                        m.cq, m.pl, m.chunk_px, act, drop_p, seed);
     PSLD_CHECK_LAUNCH("gn_apply_kernel");
+    return PSLD_OK;
+}
+
+extern "C" int psld_gn_apply_limb_nhwc(const float* x, const float* scale, const float* shift, void* y_limb, int batch,
+                                       int hw, int c, int act, float drop_p, unsigned long long seed,
+                                       hipStream_t stream) {
+    PSLD_CHECK_ARG(x && scale && shift && y_limb, "psld_gn_apply_limb: null pointer");
+    PSLD_CHECK_ARG(c % 32 == 0 && c / 4 <= MAXT, "psld_gn_apply_limb: unsupported C=%d (needs a multiple of 32, <= 1024)", c);
+    const Map m = make_map(batch, hw, c, true);
+    hipLaunchKernelGGL(gn_apply_limb_kernel, dim3(m.chunks, batch), dim3(m.threads), 0, stream, x, scale, shift,
+                       reinterpret_cast<unsigned char*>(y_limb), hw, c, m.cq, m.pl, m.chunk_px, act, drop_p, seed);
+    PSLD_CHECK_LAUNCH("gn_apply_limb_kernel");
     return PSLD_OK;
 }
 

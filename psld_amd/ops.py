@@ -396,6 +396,15 @@ def gn_apply(x: Tensor, st: GNStats, act: bool, out: Optional[Tensor] = None, dr
     return out
 
 
+def gn_apply_limb(x: Tensor, st: GNStats, act: bool, drop_p: float = 0.0, seed: int = 0) -> LimbPlanes:
+    """GroupNorm apply (+SiLU, dropout) writing bf16 limb planes for a 3x3 convolution to stage by LDS-DMA."""
+    b, h, w, c = x.shape
+    out = LimbPlanes(x.shape, x.device)
+    check(lib().psld_gn_apply_limb_nhwc(x.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), out.data_ptr(), b,
+                                        h * w, c, 1 if act else 0, drop_p, seed, _stream()), "psld_gn_apply_limb_nhwc")
+    return out
+
+
 def gn_bwd(dy: Tensor, x: Tensor, st: GNStats, gamma: Tensor, beta: Tensor, act: bool, dx: Tensor, dgamma: Tensor,
            dbeta: Tensor, accumulate_dx: bool = False, drop_p: float = 0.0, seed: int = 0, groups: Optional[int] = None,
            add: Optional[Tensor] = None, add_scale: float = 1.0):

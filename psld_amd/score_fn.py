@@ -219,6 +219,8 @@ class _Exec:
         self.side = net._side_stream() if (record and net.overlap_wgrad) else None
         self.want_dx = False        # gradient w.r.t. the network input requested (x.requires_grad)
         self.split = ops.math_mode() == "bf16x6"   # 3x3 convs on the bf16 limb kernels (csrc/conv_split.hip)
+        import os as _os
+        self.limb_planes = _os.environ.get("PSLD_LIMB_PLANES", "1") != "0"    # A/B switch for tools/bench_sample.py
         self.dx_nchw = None
 
     # -- helpers ------------------------------------------------------------------------------
@@ -516,8 +518,18 @@ class _Exec:
             gam, bet = gn0.weight.detach(), gn0.bias.detach()
             st0 = self.node_stats(x, gam[:c1], bet[:c1], groups=g1)
             st0b = self.node_stats(xb, gam[c1:], bet[c1:], groups=g2)
-            a0b = ops.gn_apply(xb.v, st0b, True)
-        a0 = ops.gn_apply(x.v, st0, True)
+        # Forward-only passes (sampling) hand the activations to the 3x3 convolutions as bf16 limb planes: GroupNorm's
+        # apply pass writes them already split (6 B per element instead of 4) and the convolution stages its halo tile
+        # by LDS-DMA with no split in the MFMA kernel (ops.conv3x3_split on LimbPlanes; bitwise the same result).  The
+        # training tape keeps fp32: the weight-gradient kernels read these tensors as fp32 x operands.
+        lp0 = (not self.record) and self.split and self.limb_planes and not (up or down) and \
+            ops.conv3x3_split_supported(c1, cin - c1, b, h, w, cout)
+        lp1 = (not self.record) and self.split and self.limb_planes and ops.conv3x3_split_supported(cout, 0, b, h // 2 if down else (h * 2 if up else h),
+                                                                               w // 2 if down else (w * 2 if up else w), cout)
+        apply0 = ops.gn_apply_limb if lp0 else ops.gn_apply
+        if xb is not None:
+            a0b = apply0(xb.v, st0b, True)
+        a0 = apply0(x.v, st0, True)
         if up or down:
             a0r = self.resample(a0, up)
             xr = self.resample(x.v, up)
@@ -544,7 +556,7 @@ class _Exec:
             drop_p = self.drop_p
             self.n_drop += 1
             seed = (self.seed + self.n_drop * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF
-        a1 = ops.gn_apply(h1, st1, True, drop_p=drop_p, seed=seed)
+        a1 = (ops.gn_apply_limb if lp1 else ops.gn_apply)(h1, st1, True, drop_p=drop_p, seed=seed)
         out = torch.empty((b, ho, wo, cout), device=x.v.device, dtype=torch.float32)
         if mod.has_shortcut:
             c2 = mod.Conv_2

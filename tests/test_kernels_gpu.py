@@ -292,6 +292,20 @@ def test_conv3x3_split_dgrad_and_wgrad(ops, cfg):
     assert torch.count_nonzero(slabs[:, :, :, :col0]) == 0
 
 
+def test_gn_apply_limb_planes_match_the_fp32_pass(ops):
+    """psld_gn_apply_limb_nhwc writes exactly the limb decomposition of what psld_gn_apply_nhwc_f32 writes (same
+    affine, SiLU and dropout mask)."""
+    b, h, c = 3, 8, 256
+    x = torch.randn(b, h, h, c, generator=torch.Generator().manual_seed(5)).to(DEV)
+    gamma = (1 + 0.2 * torch.randn(c, generator=torch.Generator().manual_seed(6))).to(DEV)
+    beta = (0.1 * torch.randn(c, generator=torch.Generator().manual_seed(7))).to(DEV)
+    st = ops.gn_stats(x, gamma, beta)
+    for act, p in ((True, 0.0), (True, 0.15), (False, 0.0)):
+        ref = ops.gn_apply(x, st, act, drop_p=p, seed=1234)
+        got = ops.limb_to_f32(ops.gn_apply_limb(x, st, act, drop_p=p, seed=1234))
+        assert torch.equal(got, ref), (act, p)
+
+
 @pytest.mark.parametrize("b,c,ih,stride,pad", [(2, 8, 9, 2, 0), (1, 64, 17, 2, 0), (2, 16, 8, 1, 1)])
 def test_im2col_col2im(ops, b, c, ih, stride, pad):
     """Many-channel 3x3 im2col in (tap, channel) order and its adjoint (gather form) against F.unfold / F.fold."""

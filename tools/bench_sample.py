@@ -13,7 +13,7 @@ net = get_module("score_fn", "ncsnpp")(cfg).to(dev).eval()
 sde = get_module("sde", "psld")(cfg)
 sampler = get_module("samplers", "em_sde")(cfg, sde, net)
 ts = torch.linspace(0, 0.999, 1000, device=dev, dtype=torch.float64)
-for batch in (16, 64, 512):
+for batch in ((512,) if os.environ.get("ONLY512") else (16, 64, 512)):
     x = sde.prior_sampling((batch, 3, 32, 32), device=dev)
     for graphs in (False, True):
         net.enable_graphs(graphs)
