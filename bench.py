@@ -277,6 +277,8 @@ def parse_args():
     ap.add_argument("--sample-batch", type=int, default=512, help="per-GPU batch of the EM sampling run (0 = skip)")
     ap.add_argument("--sample-steps", type=int, default=1000,
                     help="n_discrete_steps of the sampling run (1000 = configs[4], ~3 min at B=512; fewer = scaled estimate)")
+    ap.add_argument("--graphs", action="store_true",
+                    help="hipGraph-captured training step (SDEWrapper.enable_graphs): for the launch-bound small-batch regime")
     ap.add_argument("--launch-check", action="store_true",
                     help="form the process group, all-reduce ones, print the JSON line and exit (no model work; runs on "
                          "CPU with gloo: how the self-launch path is tested without a GPU)")
@@ -391,6 +393,10 @@ def main():
     crit = get_module("losses", "psld_score_loss")(cfg, sde)
     wrapper = get_module("pl_modules", "sde_wrapper")(cfg, sde, net, ema_score_fn=ema, criterion=crit)
     ema_cb = EMAWeightUpdate(cfg.training.ema_decay)
+    if args.graphs:
+        wrapper.enable_graphs(True)
+        args.no_probe = True          # per-launch HIP-event brackets cannot sit inside a captured graph
+        args.warmup = max(args.warmup, 3)   # two eager steps, then the capture
     reducer = None
     if dist_on:
         reducer = BucketReducer(bucket_bytes=args.bucket_mb << 20, force_collective=force_pg, profile=True)
@@ -457,6 +463,8 @@ def main():
                        "parallelism": f"dp{world}", "image": "6x32x32"},
             "images_per_sec_per_gpu": total_imgs / dt / world,
             "final_loss": loss_val,
+            "captured_step": bool(args.graphs and getattr(wrapper, "_graph_steps", None) and
+                                  any("graph" in e for e in wrapper._graph_steps.values())),
         }
         if dist_on:
             st = reducer.stats()

@@ -229,20 +229,23 @@ int psld_gn_stats_from_partials_f32(const double* gn_part, int batch, int hw, in
  * (nn.Dropout, layerspp.py:265): element i of the NHWC tensor is kept iff
  * psld_dropout_keep(seed, i, p) (counter-based hash, reproducible in the backward pass, no mask
  * tensor) and scaled by 1/(1-p); drop_p = 0 disables it. */
+/* seed_dev (may be NULL): one device word added to `seed` by the kernel - the per-step part of the dropout seed lives
+ * in device memory so that a hipGraph-captured training step draws a fresh mask on every replay. */
 int psld_gn_apply_nhwc_f32(const float* x, const float* scale, const float* shift, float* y,
                            int batch, int hw, int c, int act, float drop_p, unsigned long long seed,
-                           hipStream_t stream);
+                           const unsigned long long* seed_dev, hipStream_t stream);
 /* The same pass writing bf16 limb planes (see psld_conv3x3_limb_f32) instead of fp32: y_limb holds
  * psld_limb_bytes(batch*hw, c) bytes; c a multiple of 32.  The dropout mask is the one psld_gn_apply_nhwc_f32 and
  * psld_gn_bwd_nhwc_f32 derive from (seed, element index). */
 int psld_gn_apply_limb_nhwc(const float* x, const float* scale, const float* shift, void* y_limb, int batch,
-                            int hw, int c, int act, float drop_p, unsigned long long seed, hipStream_t stream);
+                            int hw, int c, int act, float drop_p, unsigned long long seed,
+                            const unsigned long long* seed_dev, hipStream_t stream);
 /* Backward of y = act(GN(x)): dgamma[C], dbeta[C] (written, not accumulated) and
  * dx = d/dx (+ add_scale * add when add != NULL: the gradient of an identity branch parallel to the normalisation,
  * e.g. the residual `(x + h) / sqrt(2)` of layerspp.py:271-274) (+ the previous dx when accumulate_dx). */
 int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float* mean, const float* rstd,
                          const float* gamma, const float* beta, int batch, int hw, int c, int groups,
-                         int act, float drop_p, unsigned long long seed,
+                         int act, float drop_p, unsigned long long seed, const unsigned long long* seed_dev,
                          float* dx, float* dgamma, float* dbeta, int accumulate_dx,
                          const float* add, float add_scale, void* workspace, hipStream_t stream);
 
@@ -446,7 +449,11 @@ int psld_grad_norm_f32(const float* g, long long n, double* norm_out, void* work
 int psld_adam_ema_f32(float* p, const float* g, float* m, float* v, float* ema, long long n,
                       const double* norm, double max_norm, double lr, double beta1, double beta2,
                       double eps, double weight_decay, int step, double ema_tau, int write_clipped_grad,
-                      float* g_mut, hipStream_t stream);
+                      float* g_mut, const float* hyper_dev, hipStream_t stream);
+/* The two per-step scalars of the kernel above, lr / (1 - beta1^step) and 1 / sqrt(1 - beta2^step), formed in
+ * double like the launcher does: what a caller writes into hyper_dev[0..1] (device floats) before replaying a
+ * captured training step (then lr / step of the captured call are ignored). */
+void psld_adam_step_scalars(double lr, double beta1, double beta2, int step, float* out2_host);
 /* target = target*tau + src*(1-tau) (callbacks.py:62-64); hyper-parameters are doubles so that
  * (1 - tau), (1 - beta) are formed in double and rounded once, as torch does for python floats. */
 int psld_ema_f32(float* target, const float* src, long long n, double tau, hipStream_t stream);

@@ -83,7 +83,7 @@ SIGNATURES = {
     "psld_pack_conv3x3_frag": (I, [P, P, I, I, I, P]),
     "psld_pack_frag_batch": (I, [P, I, LL, P]),
     "psld_conv3x3_split_f32": (I, [P, I, P, I, I, I, I, P, I, P, I, EP, P, LL, P]),
-    "psld_gn_apply_limb_nhwc": (I, [P, P, P, P, I, I, I, I, F, C.c_ulonglong, P]),
+    "psld_gn_apply_limb_nhwc": (I, [P, P, P, P, I, I, I, I, F, C.c_ulonglong, P, P]),
     "psld_limb_bytes": (LL, [LL, I]),
     "psld_f32_to_limb": (I, [P, LL, I, P, P]),
     "psld_limb_to_f32": (I, [P, LL, I, P, P]),
@@ -107,8 +107,8 @@ SIGNATURES = {
     "psld_gn_workspace_bytes": (LL, [I, I, I, I]),
     "psld_gn_stats_nhwc_f32": (I, [P, I, I, I, I, F, P, P, P, P, P, P, P, P]),
     "psld_gn_stats_from_partials_f32": (I, [P, I, I, I, I, F, P, P, P, P, P, P, P]),
-    "psld_gn_apply_nhwc_f32": (I, [P, P, P, P, I, I, I, I, F, C.c_ulonglong, P]),
-    "psld_gn_bwd_nhwc_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, F, C.c_ulonglong, P, P, P, I, P, F, P, P]),
+    "psld_gn_apply_nhwc_f32": (I, [P, P, P, P, I, I, I, I, F, C.c_ulonglong, P, P]),
+    "psld_gn_bwd_nhwc_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, F, C.c_ulonglong, P, P, P, P, I, P, F, P, P]),
     "psld_upfirdn2d_f32": (I, [P, P, I, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "psld_fused_bias_act_f32": (I, [P, P, P, LL, I, I, I, F, F, P]),
     "psld_axpby_f32": (I, [P, F, P, F, P, LL, I, P]),
@@ -150,7 +150,8 @@ SIGNATURES = {
     "psld_f64_to_f32": (I, [P, P, LL, P]),
     "psld_f32_to_f64": (I, [P, P, LL, P]),
     "psld_grad_norm_f32": (I, [P, LL, P, P, P]),
-    "psld_adam_ema_f32": (I, [P, P, P, P, P, LL, P, D, D, D, D, D, D, I, D, I, P, P]),
+    "psld_adam_ema_f32": (I, [P, P, P, P, P, LL, P, D, D, D, D, D, D, I, D, I, P, P, P]),
+    "psld_adam_step_scalars": (None, [D, D, D, I, P]),
     "psld_ema_f32": (I, [P, P, LL, D, P]),
 }
 

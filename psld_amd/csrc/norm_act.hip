@@ -132,8 +132,10 @@ __global__ void gn_finalize_kernel(const double* __restrict__ part, int hw, int 
 
 __global__ void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                 const float* __restrict__ shift, float* __restrict__ y, int hw, int c, int cq,
-                                int pl, int chunk_px, int act, float drop_p, unsigned long long seed) {
+                                int pl, int chunk_px, int act, float drop_p, unsigned long long seed,
+                                const unsigned long long* __restrict__ seed_dev) {
     const int n = blockIdx.y, chunk = blockIdx.x;
+    if (seed_dev) seed += seed_dev[0];        // per-step seed kept in device memory (graph-captured training)
     const int q = threadIdx.x % cq, l = threadIdx.x / cq;
     const int p0 = chunk * chunk_px, p1 = min(hw, p0 + chunk_px);
     const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + (long long)n * c + q * 4);
@@ -173,9 +175,11 @@ __device__ __forceinline__ void gn_split3(float x0, float x1, unsigned& hi, unsi
 
 __global__ void gn_apply_limb_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                      const float* __restrict__ shift, unsigned char* __restrict__ y, int hw, int c, int cq,
-                                     int pl, int chunk_px, int act, float drop_p, unsigned long long seed) {
+                                     int pl, int chunk_px, int act, float drop_p, unsigned long long seed,
+                                const unsigned long long* __restrict__ seed_dev) {
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
     const int n = blockIdx.y, chunk = blockIdx.x;
+    if (seed_dev) seed += seed_dev[0];        // per-step seed kept in device memory (graph-captured training)
     const int q = threadIdx.x % cq, l = threadIdx.x / cq;
     const int p0 = chunk * chunk_px, p1 = min(hw, p0 + chunk_px);
     const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + (long long)n * c + q * 4);
@@ -211,9 +215,11 @@ __global__ void gn_bwd_partial_kernel(const float* __restrict__ dy, const float*
                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                       const float* __restrict__ gamma, const float* __restrict__ beta, int hw,
                                       int c, int groups, int cq, int pl, int chunk_px, int chunks, int act,
-                                      float drop_p, unsigned long long seed, float* __restrict__ part) {
+                                      float drop_p, unsigned long long seed,
+                                      const unsigned long long* __restrict__ seed_dev, float* __restrict__ part) {
     extern __shared__ float red[];  // [pl][cq][8]
     const int n = blockIdx.y, chunk = blockIdx.x;
+    if (seed_dev) seed += seed_dev[0];        // per-step seed kept in device memory (graph-captured training)
     const int tid = threadIdx.x;
     const int q = tid % cq, l = tid / cq;
     const int p0 = chunk * chunk_px, p1 = min(hw, p0 + chunk_px);
@@ -338,9 +344,11 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                     const float* __restrict__ coef, int hw, int c, int groups, int cq, int pl,
-                                    int chunk_px, int act, float drop_p, unsigned long long seed, int accumulate,
+                                    int chunk_px, int act, float drop_p, unsigned long long seed,
+                                    const unsigned long long* __restrict__ seed_dev, int accumulate,
                                     const float* __restrict__ add, float add_scale, float* __restrict__ dx) {
     const int n = blockIdx.y, chunk = blockIdx.x;
+    if (seed_dev) seed += seed_dev[0];        // per-step seed kept in device memory (graph-captured training)
     const int q = threadIdx.x % cq, l = threadIdx.x / cq;
     const int p0 = chunk * chunk_px, p1 = min(hw, p0 + chunk_px);
     const int cpg = c / groups;
@@ -431,31 +439,32 @@ extern "C" int psld_gn_stats_from_partials_f32(const double* gn_part, int batch,
 
 extern "C" int psld_gn_apply_nhwc_f32(const float* x, const float* scale, const float* shift, float* y, int batch,
                                       int hw, int c, int act, float drop_p, unsigned long long seed,
-                                      hipStream_t stream) {
+                                      const unsigned long long* seed_dev, hipStream_t stream) {
     PSLD_CHECK_ARG(x && scale && shift && y, "psld_gn_apply: null pointer");
     PSLD_CHECK_ARG(c % 4 == 0 && c / 4 <= MAXT, "psld_gn_apply: unsupported C=%d", c);
     const Map m = make_map(batch, hw, c, true);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(m.chunks, batch), dim3(m.threads), 0, stream, x, scale, shift, y, hw, c,
-                       m.cq, m.pl, m.chunk_px, act, drop_p, seed);
+                       m.cq, m.pl, m.chunk_px, act, drop_p, seed, seed_dev);
     PSLD_CHECK_LAUNCH("gn_apply_kernel");
     return PSLD_OK;
 }
 
 extern "C" int psld_gn_apply_limb_nhwc(const float* x, const float* scale, const float* shift, void* y_limb, int batch,
                                        int hw, int c, int act, float drop_p, unsigned long long seed,
-                                       hipStream_t stream) {
+                                       const unsigned long long* seed_dev, hipStream_t stream) {
     PSLD_CHECK_ARG(x && scale && shift && y_limb, "psld_gn_apply_limb: null pointer");
     PSLD_CHECK_ARG(c % 32 == 0 && c / 4 <= MAXT, "psld_gn_apply_limb: unsupported C=%d (needs a multiple of 32, <= 1024)", c);
     const Map m = make_map(batch, hw, c, true);
     hipLaunchKernelGGL(gn_apply_limb_kernel, dim3(m.chunks, batch), dim3(m.threads), 0, stream, x, scale, shift,
-                       reinterpret_cast<unsigned char*>(y_limb), hw, c, m.cq, m.pl, m.chunk_px, act, drop_p, seed);
+                       reinterpret_cast<unsigned char*>(y_limb), hw, c, m.cq, m.pl, m.chunk_px, act, drop_p, seed, seed_dev);
     PSLD_CHECK_LAUNCH("gn_apply_limb_kernel");
     return PSLD_OK;
 }
 
 extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float* mean, const float* rstd,
                                     const float* gamma, const float* beta, int batch, int hw, int c, int groups,
-                                    int act, float drop_p, unsigned long long seed, float* dx, float* dgamma,
+                                    int act, float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* dx,
+                                    float* dgamma,
                                     float* dbeta, int accumulate_dx, const float* add, float add_scale,
                                     void* workspace, hipStream_t stream) {
     PSLD_CHECK_ARG(dy && x && mean && rstd && gamma && beta && dx && dgamma && dbeta && workspace,
@@ -470,14 +479,14 @@ extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float
     float* coef = reinterpret_cast<float*>(ws);
     const size_t lds = (size_t)m.pl * m.cq * 8 * sizeof(float);
     hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(m.chunks, batch), dim3(m.threads), lds, stream, dy, x, mean, rstd,
-                       gamma, beta, hw, c, groups, m.cq, m.pl, m.chunk_px, m.chunks, act, drop_p, seed, part);
+                       gamma, beta, hw, c, groups, m.cq, m.pl, m.chunk_px, m.chunks, act, drop_p, seed, seed_dev, part);
     PSLD_CHECK_LAUNCH("gn_bwd_partial_kernel");
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(batch + 2 * cdiv(c, 64)), dim3(1024), 0, stream, part, rstd, gamma,
                        batch, hw, c, groups, m.chunks, coef, dgamma, dbeta);
     PSLD_CHECK_LAUNCH("gn_bwd_finalize_kernel");
     const Map ma = make_map(batch, hw, c, true);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ma.chunks, batch), dim3(ma.threads), 0, stream, dy, x, mean, rstd,
-                       gamma, beta, coef, hw, c, groups, ma.cq, ma.pl, ma.chunk_px, act, drop_p, seed, accumulate_dx, add, add_scale,
+                       gamma, beta, coef, hw, c, groups, ma.cq, ma.pl, ma.chunk_px, act, drop_p, seed, seed_dev, accumulate_dx, add, add_scale,
                        dx);
     PSLD_CHECK_LAUNCH("gn_bwd_apply_kernel");
     return PSLD_OK;

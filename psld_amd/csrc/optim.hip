@@ -54,7 +54,12 @@ struct AdamArgs {
 // denom = sqrt(v)/sqrt(bc2) + eps; p -= (lr/bc1) * m/denom.   Clip: g *= min(max_norm/(norm+1e-6), 1).
 __global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                 float* __restrict__ v, float* __restrict__ ema, long long n,
-                                const double* __restrict__ norm, const AdamArgs a, float* __restrict__ g_mut) {
+                                const double* __restrict__ norm, AdamArgs a, float* __restrict__ g_mut,
+                                const float* __restrict__ hyper_dev) {
+    if (hyper_dev) {                 // captured training step: the two step-dependent scalars come from device memory
+        a.step_size = hyper_dev[0];
+        a.inv_sqrt_bc2 = hyper_dev[1];
+    }
     float coef = 1.0f;
     if (a.max_norm > 0.f && norm) {
         const float c = a.max_norm / ((float)norm[0] + 1e-6f);
@@ -100,7 +105,7 @@ extern "C" int psld_grad_norm_f32(const float* g, long long n, double* norm_out,
 extern "C" int psld_adam_ema_f32(float* p, const float* g, float* m, float* v, float* ema, long long n,
                                  const double* norm, double max_norm, double lr, double beta1, double beta2,
                                  double eps, double weight_decay, int step, double ema_tau, int write_clipped_grad,
-                                 float* g_mut, hipStream_t stream) {
+                                 float* g_mut, const float* hyper_dev, hipStream_t stream) {
     PSLD_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "psld_adam_ema_f32: bad args");
     PSLD_CHECK_ARG(max_norm <= 0.f || norm, "psld_adam_ema_f32: clipping needs the norm buffer");
     AdamArgs a;
@@ -113,9 +118,15 @@ extern "C" int psld_adam_ema_f32(float* p, const float* g, float* m, float* v, f
     long long b = (n + 1023) / 1024;
     if (b > 256 * 16) b = 256 * 16;
     hipLaunchKernelGGL(adam_ema_kernel, dim3((int)b), dim3(256), 0, stream, p, g, m, v, ema, n, norm, a,
-                       write_clipped_grad ? g_mut : nullptr);
+                       write_clipped_grad ? g_mut : nullptr, hyper_dev);
     PSLD_CHECK_LAUNCH("adam_ema_kernel");
     return PSLD_OK;
+}
+
+extern "C" void psld_adam_step_scalars(double lr, double beta1, double beta2, int step, float* out2_host) {
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+    out2_host[0] = (float)(lr / bc1);
+    out2_host[1] = (float)(1.0 / sqrt(bc2));
 }
 
 extern "C" int psld_ema_f32(float* target, const float* src, long long n, double tau, hipStream_t stream) {

@@ -66,33 +66,48 @@ __global__ void perturb_coeffs_kernel(const double* __restrict__ t, int batch, c
     o[8] = xx; o[9] = xm; o[10] = mm; o[11] = 0;
 }
 
-// one thread per (b, c, pixel) of the x half; writes both halves
+// one thread per FOUR consecutive pixels of one (b, c) plane of the x half (hw % 4 == 0: 16-byte accesses); writes
+// both halves.  VEC = 1 is the element-wise form for odd plane sizes.
+template <int VEC>
 __global__ void perturb_kernel(const float* __restrict__ x0, const float* __restrict__ m0,
                                const float* __restrict__ eps, const double* __restrict__ coeffs,
                                const psld_sde_params_t p, int batch, int c, int hw, float* __restrict__ z,
                                double* __restrict__ u, double* __restrict__ mu_out) {
-    const long long n = (long long)batch * c * hw;
+    typedef float fv __attribute__((ext_vector_type(VEC)));
+    typedef double dv __attribute__((ext_vector_type(VEC)));
+    const long long n = (long long)batch * c * hw / VEC;
+    const long long plane = (long long)c * hw / VEC;
     const double A1 = (p.nu - p.gamma) / 4, A2 = (p.gamma - p.nu) * (p.gamma - p.nu) / 8;
     const double C1 = -0.5, C2 = (p.gamma - p.nu) / 4;
     GRID_STRIDE(i, n) {
-        const int b = (int)(i / ((long long)c * hw));
-        const long long r = i - (long long)b * c * hw;  // offset inside the half
+        const int b = (int)(i / plane);
+        const long long r = i - (long long)b * plane;  // offset inside the half (in VEC units)
         const double* k = coeffs + (long long)b * COEFF_STRIDE;
         const double bt = k[0], sf = k[1];
-        const double xv = (double)x0[i];
-        const double mv = m0 ? (double)m0[i] : 0.0;
-        // psld.py:76-83
-        const double mu_x = (A1 * xv * bt + A2 * mv * bt + xv) * sf;
-        const double mu_m = (C1 * xv * bt + C2 * mv * bt + mv) * sf;
-        const long long ox = (long long)b * 2 * c * hw + r, om = ox + (long long)c * hw;
-        const double ex = (double)eps[ox], em = (double)eps[om];
-        // psld.py:277-283
-        const double nx = k[4] * ex + k[5] * em;
-        const double nm = k[6] * ex + k[7] * em;
-        const double ux = mu_x + nx, um = mu_m + nm;
-        if (z) { z[ox] = (float)ux; z[om] = (float)um; }
-        if (u) { u[ox] = ux; u[om] = um; }
-        if (mu_out) { mu_out[ox] = mu_x; mu_out[om] = mu_m; }
+        const fv xf = reinterpret_cast<const fv*>(x0)[i];
+        fv mf = 0.f;
+        if (m0) mf = reinterpret_cast<const fv*>(m0)[i];
+        const long long ox = (long long)b * 2 * plane + r, om = ox + plane;
+        const fv exf = reinterpret_cast<const fv*>(eps)[ox], emf = reinterpret_cast<const fv*>(eps)[om];
+        fv zx, zm;
+        dv ux, um, mx, mm;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const double xv = (double)xf[e], mv = (double)mf[e];
+            // psld.py:76-83
+            const double mu_x = (A1 * xv * bt + A2 * mv * bt + xv) * sf;
+            const double mu_m = (C1 * xv * bt + C2 * mv * bt + mv) * sf;
+            const double ex = (double)exf[e], em = (double)emf[e];
+            // psld.py:277-283
+            const double nx = k[4] * ex + k[5] * em;
+            const double nm = k[6] * ex + k[7] * em;
+            ux[e] = mu_x + nx; um[e] = mu_m + nm;
+            mx[e] = mu_x; mm[e] = mu_m;
+            zx[e] = (float)ux[e]; zm[e] = (float)um[e];
+        }
+        if (z) { reinterpret_cast<fv*>(z)[ox] = zx; reinterpret_cast<fv*>(z)[om] = zm; }
+        if (u) { reinterpret_cast<dv*>(u)[ox] = ux; reinterpret_cast<dv*>(u)[om] = um; }
+        if (mu_out) { reinterpret_cast<dv*>(mu_out)[ox] = mx; reinterpret_cast<dv*>(mu_out)[om] = mm; }
     }
 }
 
@@ -103,11 +118,20 @@ __global__ void sqerr_partial_kernel(const float* __restrict__ a, const float* _
     double acc = 0.0;
     float local = 0.f;
     int cnt = 0;
-    GRID_STRIDE(i, n) {
+    // 16 bytes per lane (n4 float4 items), then the < 4 leftover elements
+    const long long n4 = n >> 2;
+    GRID_STRIDE(i, n4) {
+        const f32x4 va = reinterpret_cast<const f32x4*>(a)[i], vb = reinterpret_cast<const f32x4*>(b)[i];
+        const f32x4 d = va - vb;
+        local += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        if (grad) reinterpret_cast<f32x4*>(grad)[i] = d * (-gscale);   // d/d(b) of (a-b)^2 * (gscale/2)
+        if (++cnt == 4) { acc += (double)local; local = 0.f; cnt = 0; }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) {
+        const long long i = (n4 << 2) + threadIdx.x;
         const float d = a[i] - b[i];
         local += d * d;
-        if (grad) grad[i] = -gscale * d;   // d/d(b) of (a-b)^2 * (gscale/2)
-        if (++cnt == 16) { acc += (double)local; local = 0.f; cnt = 0; }
+        if (grad) grad[i] = -gscale * d;
     }
     acc += (double)local;
     acc = wave_sum_d(acc);
@@ -510,8 +534,13 @@ extern "C" int psld_perturb_f32(const float* x0, const float* m0, const float* e
                                    double* mu_f64, hipStream_t stream) {
     PSLD_CHECK_ARG(x0 && eps && coeffs && p && batch > 0 && c > 0 && hw > 0, "psld_perturb_f32: bad args");
     const long long n = (long long)batch * c * hw;
-    hipLaunchKernelGGL(perturb_kernel, dim3(grid_for(n)), dim3(256), 0, stream, x0, m0, eps, coeffs, *p, batch, c, hw,
-                       z_f32, u_f64, mu_f64);
+    auto al = [](const void* q, uintptr_t a) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & (a - 1)) == 0; };
+    if (hw % 4 == 0 && al(x0, 16) && al(m0, 16) && al(eps, 16) && al(z_f32, 16) && al(u_f64, 32) && al(mu_f64, 32))
+        hipLaunchKernelGGL(perturb_kernel<4>, dim3(grid_for(n / 4)), dim3(256), 0, stream, x0, m0, eps, coeffs, *p, batch, c,
+                           hw, z_f32, u_f64, mu_f64);
+    else
+        hipLaunchKernelGGL(perturb_kernel<1>, dim3(grid_for(n)), dim3(256), 0, stream, x0, m0, eps, coeffs, *p, batch, c, hw,
+                           z_f32, u_f64, mu_f64);
     PSLD_CHECK_LAUNCH("psld_perturb_f32");
     return PSLD_OK;
 }
@@ -519,7 +548,9 @@ extern "C" int psld_perturb_f32(const float* x0, const float* m0, const float* e
 extern "C" int psld_sqerr_loss_f32(const float* eps, const float* eps_pred, long long n, int reduce_mean, float* loss,
                                    float* grad, float grad_scale, void* workspace, hipStream_t stream) {
     PSLD_CHECK_ARG(eps && eps_pred && loss && workspace && n > 0, "psld_sqerr_loss_f32: bad args");
-    int blocks = grid_for(n);
+    PSLD_CHECK_ARG(((reinterpret_cast<uintptr_t>(eps) | reinterpret_cast<uintptr_t>(eps_pred) |
+                     reinterpret_cast<uintptr_t>(grad)) & 15) == 0, "psld_sqerr_loss_f32: operands must be 16-byte aligned");
+    int blocks = grid_for((n + 3) / 4);
     if (blocks > 4096) blocks = 4096;
     double* part = reinterpret_cast<double*>(workspace);
     // d loss / d eps_pred = 2*(pred - eps)/denom * upstream  ==  -(gscale) * (eps - pred)

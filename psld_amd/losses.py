@@ -43,12 +43,14 @@ class PSLDScoreLoss(nn.Module):
         self.decomp_mode = config.model.sde.decomp_mode
         self.reduce_strategy = "mean" if config.training.loss.reduce_mean else "sum"
 
-    def forward(self, x_0, t, score_fn, eps=None):
+    def forward(self, x_0, t, score_fn, eps=None, m_draw=None):
+        """``eps`` / ``m_draw``: the two normal draws of losses.py:96,108 when the caller has made them already (tests;
+        the captured training step, which keeps every RNG call outside its hipGraph)."""
         sde = self.sde
-        # losses.py:96-102: DSM samples the momentum, HSM marginalises it
-        # losses.py:96-102: the momentum is drawn in BOTH modes (HSM discards it), so a seeded run consumes the device
-        # RNG stream exactly like the reference
-        m_draw = torch.randn_like(x_0)
+        # losses.py:96-102: DSM samples the momentum, HSM marginalises it; the momentum is drawn in BOTH modes (HSM
+        # discards it), so a seeded run consumes the device RNG stream exactly like the reference
+        if m_draw is None:
+            m_draw = torch.randn_like(x_0)
         if self.mode == "hsm":
             m_0, mm_0 = None, sde.mm_0
         else:

@@ -387,34 +387,39 @@ def gn_stats_from_part(part: Tensor, shape, gamma: Tensor, beta: Tensor, eps: fl
 
 
 def gn_apply(x: Tensor, st: GNStats, act: bool, out: Optional[Tensor] = None, drop_p: float = 0.0,
-             seed: int = 0) -> Tensor:
+             seed: int = 0, seed_dev: Optional[Tensor] = None) -> Tensor:
+    """``seed_dev``: int64 device scalar added to ``seed`` by the kernel (the per-step part of the dropout seed)."""
     b, h, w, c = x.shape
     if out is None:
         out = torch.empty_like(x)
     check(lib().psld_gn_apply_nhwc_f32(x.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), out.data_ptr(), b,
-                                       h * w, c, 1 if act else 0, drop_p, seed, _stream()), "psld_gn_apply_nhwc_f32")
+                                       h * w, c, 1 if act else 0, drop_p, seed, _p(seed_dev), _stream()),
+          "psld_gn_apply_nhwc_f32")
     return out
 
 
-def gn_apply_limb(x: Tensor, st: GNStats, act: bool, drop_p: float = 0.0, seed: int = 0) -> LimbPlanes:
+def gn_apply_limb(x: Tensor, st: GNStats, act: bool, drop_p: float = 0.0, seed: int = 0,
+                  seed_dev: Optional[Tensor] = None) -> LimbPlanes:
     """GroupNorm apply (+SiLU, dropout) writing bf16 limb planes for a 3x3 convolution to stage by LDS-DMA."""
     b, h, w, c = x.shape
     out = LimbPlanes(x.shape, x.device)
     check(lib().psld_gn_apply_limb_nhwc(x.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), out.data_ptr(), b,
-                                        h * w, c, 1 if act else 0, drop_p, seed, _stream()), "psld_gn_apply_limb_nhwc")
+                                        h * w, c, 1 if act else 0, drop_p, seed, _p(seed_dev), _stream()),
+          "psld_gn_apply_limb_nhwc")
     return out
 
 
 def gn_bwd(dy: Tensor, x: Tensor, st: GNStats, gamma: Tensor, beta: Tensor, act: bool, dx: Tensor, dgamma: Tensor,
            dbeta: Tensor, accumulate_dx: bool = False, drop_p: float = 0.0, seed: int = 0, groups: Optional[int] = None,
-           add: Optional[Tensor] = None, add_scale: float = 1.0):
+           add: Optional[Tensor] = None, add_scale: float = 1.0, seed_dev: Optional[Tensor] = None):
     """``add`` (same shape as x): dx additionally receives add_scale * add (gradient of a parallel identity branch)."""
     b, h, w, c = x.shape
     g = groups if groups is not None else gn_groups(c)
     ws = workspace(lib().psld_gn_workspace_bytes(b, h * w, c, g), x.device)
     check(lib().psld_gn_bwd_nhwc_f32(dy.data_ptr(), x.data_ptr(), st.mean.data_ptr(), st.rstd.data_ptr(),
                                      gamma.data_ptr(), beta.data_ptr(), b, h * w, c, g, 1 if act else 0,
-                                     drop_p, seed, dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 1 if accumulate_dx else 0,
+                                     drop_p, seed, _p(seed_dev), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                     1 if accumulate_dx else 0,
                                      _p(add), add_scale, ws.data_ptr(), _stream()), "psld_gn_bwd_nhwc_f32")
 
 
@@ -797,11 +802,21 @@ def grad_norm(g: Tensor, norm_out: Tensor):
 
 def adam_ema(p: Tensor, g: Tensor, m: Tensor, v: Tensor, ema: Optional[Tensor], norm: Optional[Tensor],
              max_norm: float, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float, step: int,
-             ema_tau: float, write_clipped_grad: bool = False):
+             ema_tau: float, write_clipped_grad: bool = False, hyper_dev: Optional[Tensor] = None):
+    """``hyper_dev``: float32[2] device tensor holding (lr / bias_correction1, 1 / sqrt(bias_correction2)) of THIS step
+    (``adam_step_scalars``); then ``lr`` / ``step`` of the call are ignored (captured training step)."""
     check(lib().psld_adam_ema_f32(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(ema), p.numel(),
                                   _p(norm), max_norm, lr, beta1, beta2, eps, weight_decay, step, ema_tau,
                                   1 if write_clipped_grad else 0, g.data_ptr() if write_clipped_grad else None,
-                                  _stream()), "psld_adam_ema_f32")
+                                  _p(hyper_dev), _stream()), "psld_adam_ema_f32")
+
+
+def adam_step_scalars(lr: float, beta1: float, beta2: float, step: int, out: Tensor) -> Tensor:
+    """(lr / (1 - beta1^step), 1 / sqrt(1 - beta2^step)) as the launcher of psld_adam_ema_f32 forms them, into the
+    2-element float32 HOST tensor ``out``."""
+    assert out.dtype == torch.float32 and out.numel() == 2 and not out.is_cuda
+    lib().psld_adam_step_scalars(float(lr), float(beta1), float(beta2), int(step), out.data_ptr())
+    return out
 
 
 def ema(target: Tensor, src: Tensor, tau: float):

@@ -51,17 +51,12 @@ class FusedAdam(torch.optim.Optimizer):
                 p.grad = None
         self._backward_seen = self.module._backward_count
 
-    @torch.no_grad()
-    def step(self, closure=None):
-        assert closure is None
+    def _launch(self, hyper_dev=None):
+        """The kernels of one step (norm, clip + Adam (+ EMA)) against the current ``self._step`` / lr; with
+        ``hyper_dev`` the two step-dependent scalars are read from device memory instead (captured training step)."""
         group = self.param_groups[0]
         flat = self._state_buffers()
         grad = self.module.flat_grad()
-        if self.module._backward_count == self._backward_seen:
-            raise RuntimeError("FusedAdam.step(): no backward pass has run since the last zero_grad()/step(); the gradient "
-                               "buffer holds the previous step's (consumed) gradient")
-        self.module.adopt_foreign_grads()     # a foreign reducer may have replaced .grad (DDP bucket views)
-        self._step += 1
         if self.grad_clip > 0:
             ops.grad_norm(grad, self._norm)
         ema_flat = None
@@ -73,14 +68,29 @@ class FusedAdam(torch.optim.Optimizer):
         kept = [p.detach().clone() for p in frozen]
         ops.adam_ema(flat, grad, self._m, self._v, ema_flat, self._norm if self.grad_clip > 0 else None,
                      self.grad_clip, group["lr"], group["betas"][0], group["betas"][1], group["eps"],
-                     group["weight_decay"], self._step, self.ema_decay)
+                     group["weight_decay"], max(1, self._step), self.ema_decay, hyper_dev=hyper_dev)
         for p, k in zip(frozen, kept):
             p.detach().copy_(k)
+
+    def _after_step(self):
         self.module.weights_changed()
         self.module.mark_grads_stale()      # consumed: a following backward starts a fresh gradient
         self._backward_seen = self.module._backward_count
         if self.ema_module is not None:
             self.ema_module.weights_changed()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        assert closure is None
+        self._state_buffers()
+        self.module.flat_grad()
+        if self.module._backward_count == self._backward_seen:
+            raise RuntimeError("FusedAdam.step(): no backward pass has run since the last zero_grad()/step(); the gradient "
+                               "buffer holds the previous step's (consumed) gradient")
+        self.module.adopt_foreign_grads()     # a foreign reducer may have replaced .grad (DDP bucket views)
+        self._step += 1
+        self._launch()
+        self._after_step()
 
     def state_dict(self):
         sd = super().state_dict()

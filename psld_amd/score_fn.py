@@ -204,7 +204,14 @@ class _Exec:
         sf = net.sf
         self.s = ops.INV_SQRT2 if sf.skip_rescale else 1.0
         self.drop_p = float(sf.dropout) if net.training else 0.0  # nn.Dropout: active in train mode
-        self.seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if self.drop_p > 0 else 0
+        # Dropout masks are derived in the kernels from (seed, element index).  The per-pass part of the seed stays in
+        # DEVICE memory (one int64 drawn on the device: no host synchronisation per forward, and a hipGraph-captured
+        # training step - which supplies its own static seed word, refreshed before every replay - draws fresh masks);
+        # the per-block part is a host constant.
+        self.seed_dev = None
+        if self.drop_p > 0:
+            self.seed_dev = net._dropout_seed_dev if net._dropout_seed_dev is not None else \
+                torch.randint(0, 2 ** 62, (1,), device=net._params()[0].device, dtype=torch.int64)
         self.n_drop = 0
         fk = tuple(sf.fir_kernel) if sf.fir else (1, 1)
         self.k_down = _fir_kernel(fk)
@@ -551,12 +558,13 @@ class _Exec:
         self.conv3(a0r, mod.Conv_0, h1, ops.epilogue(bias=mod.Conv_0.bias, rowbias=tp, rows_per_img=ho * wo,
                                                      ld_rowbias=tp_ld, gn_part=h1p, gn_hw=ho * wo), x2=a0b)
         st1 = self.node_stats(_Node(h1, h1p), gn1.weight, gn1.bias)
-        drop_p, seed = 0.0, 0
+        drop_p, seed, seed_dev = 0.0, 0, None
         if self.drop_p > 0:
             drop_p = self.drop_p
             self.n_drop += 1
-            seed = (self.seed + self.n_drop * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF
-        a1 = (ops.gn_apply_limb if lp1 else ops.gn_apply)(h1, st1, True, drop_p=drop_p, seed=seed)
+            seed = (self.n_drop * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF
+            seed_dev = self.seed_dev
+        a1 = (ops.gn_apply_limb if lp1 else ops.gn_apply)(h1, st1, True, drop_p=drop_p, seed=seed, seed_dev=seed_dev)
         out = torch.empty((b, ho, wo, cout), device=x.v.device, dtype=torch.float32)
         if mod.has_shortcut:
             c2 = mod.Conv_2
@@ -597,7 +605,7 @@ class _Exec:
             self.dgrad(dout, mod.Conv_1, 3, 1, 1, ho, wo, da1, alpha=s)
             dh1 = torch.empty_like(h1)
             ops.gn_bwd(da1, h1, st1, gn1.weight, gn1.bias, True, dh1, self.g(gn1.weight), self.g(gn1.bias),
-                       drop_p=drop_p, seed=seed)
+                       drop_p=drop_p, seed=seed, seed_dev=seed_dev)
             del da1
 
             # Conv_0 + time-embedding bias
@@ -1268,6 +1276,7 @@ class NCSNpp(nn.Module):
         self._gviews = None
         self._pending = 0
         self._backward_count = 0    # finished backward passes (FusedAdam.step refuses to re-apply a consumed gradient)
+        self._dropout_seed_dev = None   # static int64 device word supplied by a captured training step (wrapper.py)
         self._accumulating = False
         self._grad_stale = False
         self._scratch_grad = None
@@ -1683,7 +1692,7 @@ class NCSNpp(nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         skip = {"_flat", "_flat_grad", "_pack_cache", "_frag_table", "_temb_plan_cache", "_anchor", "_reducer", "_offsets", "_module_offs", "_posfreq",
-                "_side", "_plist", "_tlist", "_gviews", "_graphs", "_conv_by_weight", "_scratch_grad", "_sviews"}
+                "_side", "_plist", "_tlist", "_gviews", "_dropout_seed_dev", "_graphs", "_conv_by_weight", "_scratch_grad", "_sviews"}
         for k, v in self.__dict__.items():
             if k in skip:
                 continue
@@ -1695,6 +1704,7 @@ class NCSNpp(nn.Module):
         new._conv_by_weight = {}
         new._pending = 0
         new._backward_count = 0
+        new._dropout_seed_dev = None
         new._scratch_grad = new._sviews = None
         new._accumulating = new._grad_stale = False
         new._pack_cache = {}

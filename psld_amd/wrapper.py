@@ -3,13 +3,14 @@
 Same constructor signature, same ``training_step`` / ``predict_step`` / ``configure_optimizers``
 semantics.  With pytorch_lightning installed it IS a ``pl.LightningModule`` (train_sde.py:57-60,
 eval/sample.py:62-69 work unchanged); on boxes without Lightning (this image) a minimal base class
-supplies ``optimizers()/lr_schedulers()/manual_backward()/log()`` and ``psld_amd.trainer`` drives it.
+supplies ``optimizers()/lr_schedulers()/manual_backward()/log()`` and ``psld_amd.cli`` drives it.
 """
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
 
+from . import ops
 from .optim import FusedAdam
 from .registry import register_module
 
@@ -84,7 +85,93 @@ class SDEWrapper(_Base):
     def forward(self):
         pass
 
+    # ---- hipGraph-captured training step (launch-bound regime: small per-GPU batches) ---------------------------------
+    def enable_graphs(self, flag: bool = True, warmup_steps: int = 2):
+        """Capture the whole training step - perturb, forward, loss, backward tape, norm + clip + Adam - into a HIP
+        graph per batch shape and replay it: one graph launch instead of ~1700 kernel launches issued from Python
+        (43.6 -> ~30 ms per step at the reference's per-GPU batch of 16, scripts_psld/.../train_uncond_psld.sh:25-30).
+        Everything the reference draws per step (t, the discarded momentum draw, eps) and the dropout seed is drawn
+        OUTSIDE the graph into static device buffers, in the reference's order, so a seeded run consumes the RNG stream
+        exactly like the eager step; the step-dependent Adam scalars and the LR-schedule value travel through a 2-float
+        device buffer written before each replay.  The first ``warmup_steps`` steps of a shape run eagerly (they size
+        workspaces and weight caches).  Not captured: the NaN check of the perturbation coefficients (a host read),
+        gradient exchange (``set_reducer``), foreign optimizers."""
+        self._graphs_on = bool(flag)
+        self._graph_warmup = int(warmup_steps)
+        if not flag:
+            self._graph_steps = {}
+            self.score_fn._dropout_seed_dev = None
+
+    def _graph_ok(self, batch) -> bool:
+        optim = self.optimizers()
+        return (getattr(self, "_graphs_on", False) and torch.is_tensor(batch) and batch.is_cuda
+                and isinstance(optim, FusedAdam) and getattr(self.score_fn, "_reducer", None) is None
+                and not self.score_fn._params_visible() and optim.ema_module is None
+                and optim.param_groups[0]["weight_decay"] == 0)
+
+    def _graphed_step(self, batch):
+        net, optim, sde = self.score_fn, self.optimizers(), self.sde
+        if not hasattr(self, "_graph_steps"):
+            self._graph_steps = {}
+        key = (tuple(batch.shape), batch.device.index, bool(net.training))
+        ent = self._graph_steps.get(key)
+        if ent is None:
+            ent = self._graph_steps[key] = {"seen": 0}
+        if ent["seen"] < self._graph_warmup:
+            ent["seen"] += 1
+            return None                                   # eager warm-up step
+        dev = batch.device
+        b, c, h, w = batch.shape
+        if "graph" not in ent:
+            ent["x0"] = torch.empty_like(batch)
+            ent["t_"] = torch.empty(b, device=dev, dtype=torch.float64)
+            ent["m_draw"] = torch.empty_like(batch)
+            ent["eps"] = torch.empty((b, 2 * c, h, w), device=dev, dtype=torch.float32)
+            ent["seed"] = torch.zeros(1, device=dev, dtype=torch.int64)
+            ent["hyper"] = torch.zeros(2, device=dev, dtype=torch.float32)
+            ent["hyper_host"] = torch.zeros(2, dtype=torch.float32).pin_memory()
+        # the step's random draws, in the eager step's order (wrapper.py:72, losses.py:96,108, then the dropout seed)
+        torch.rand(b, dtype=torch.float64, device=dev, out=ent["t_"])
+        torch.randn(batch.shape, device=dev, out=ent["m_draw"])
+        torch.randn(ent["eps"].shape, device=dev, out=ent["eps"])
+        if net.training and float(net.sf.dropout) > 0:
+            ent["seed"].random_(0, 2 ** 62)
+        ent["x0"].copy_(batch)
+        optim._step += 1
+        group = optim.param_groups[0]
+        ops.adam_step_scalars(group["lr"], group["betas"][0], group["betas"][1], optim._step, ent["hyper_host"])
+        ent["hyper"].copy_(ent["hyper_host"], non_blocking=True)
+        if "graph" not in ent:
+            optim._state_buffers()
+            net.flat_grad()
+            net._dropout_seed_dev = ent["seed"]
+            check_nan, sde.check_nan = getattr(sde, "check_nan", False), False
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(graph):
+                    t = ent["t_"] * (sde.T - self.train_eps) + self.train_eps
+                    loss = self.criterion(ent["x0"], t, net, eps=ent["eps"], m_draw=ent["m_draw"])
+                    net.mark_grads_stale()
+                    loss.backward()
+                    with torch.no_grad():
+                        optim._launch(hyper_dev=ent["hyper"])
+            finally:
+                sde.check_nan = check_nan
+            ent["graph"], ent["loss"] = graph, loss.detach()
+        else:
+            net._dropout_seed_dev = ent["seed"]
+        ent["graph"].replay()
+        optim._after_step()
+        optim._opt_called = True          # what LambdaLR's step-order check looks at (optimizer.step() ran)
+        self.lr_schedulers().step()
+        return ent["loss"]
+
     def training_step(self, batch, batch_idx):
+        if self._graph_ok(batch):
+            loss = self._graphed_step(batch)
+            if loss is not None:
+                self.log("loss", loss, prog_bar=True)
+                return loss
         optim = self.optimizers()
         lr_sched = self.lr_schedulers()
         x_0 = batch

@@ -485,6 +485,8 @@ def test_dropout_mask_statistics_and_gradient_consistency():
     gamma, beta = torch.ones(c, device=DEV), torch.full((c,), 3.0, device=DEV)
     st = ops.gn_stats(x, gamma, beta)
     y = ops.gn_apply(x, st, True, drop_p=p, seed=1234)
+    # the per-step part of the seed may live in device memory (captured training step): seed + *seed_dev
+    assert torch.equal(ops.gn_apply(x, st, True, drop_p=p, seed=1000, seed_dev=torch.tensor([234], device=DEV)), y)
     y0 = ops.gn_apply(x, st, True)
     keep = (y != 0)
     rate = keep.float().mean().item()
@@ -1049,6 +1051,57 @@ def test_vpsde_score_loss_weightings_match_reference(golden, tag):
     with pytest.raises(ValueError, match="l_type can only be"):
         cfg.training.loss.weighting, cfg.training.loss.l_type = "nll", "l1"
         get_module("losses", "score_loss")(cfg, sde)
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.15])
+def test_graph_captured_training_step_is_bitwise_the_eager_step(dropout):
+    """SDEWrapper.enable_graphs: the hipGraph-captured training step (perturb + forward + loss + backward tape + norm +
+    clip + Adam, replayed as one launch) against the eager step on a twin network: same seeds -> the same random draws
+    in the same order (they are made outside the graph) -> bitwise equal losses, parameters, Adam state and EMA after
+    6 steps (2 eager warm-up steps, the capture, 3 replays), LR warm-up schedule included; then an eager eval forward
+    of both networks agrees bitwise (weight caches follow the replayed optimizer steps)."""
+    import psld_amd
+    psld_amd.import_modules_into_registry()
+    from psld_amd.optim import EMAWeightUpdate
+    from psld_amd.registry import get_module
+    cfg = C.tiny(nf=128, ch_mult=(1, 1), attn_resolutions=(16,))
+    cfg.model.score_fn.dropout = dropout
+    cfg.training.optimizer.warmup = 4                  # LR changes on every one of the first steps
+    torch.manual_seed(3)
+    net_a = get_module("score_fn", "ncsnpp")(cfg).to(DEV).train()
+    net_b = copy.deepcopy(net_a)
+    sde = get_module("sde", "psld")(cfg)
+    runs = []
+    data = [torch.rand(4, 3, 16, 16, device=DEV, generator=torch.Generator(device=DEV).manual_seed(i)) * 2 - 1 for i in range(6)]
+    for net, graphs in ((net_a, False), (net_b, True)):
+        ema = copy.deepcopy(net)
+        for p in ema.parameters():
+            p.requires_grad = False
+        crit = get_module("losses", "psld_score_loss")(cfg, sde)
+        wr = get_module("pl_modules", "sde_wrapper")(cfg, sde, net, ema_score_fn=ema, criterion=crit)
+        if graphs:
+            wr.enable_graphs(True, warmup_steps=2)
+        cb = EMAWeightUpdate(cfg.training.ema_decay)
+        torch.manual_seed(11)
+        losses = []
+        for i in range(6):
+            losses.append(wr.training_step(data[i], i).item())
+            cb.on_train_batch_end(None, wr)
+        opt = wr.optimizers()
+        runs.append((losses, net.flatten_parameters().clone(), opt._m.clone(), opt._v.clone(), ema.flatten_parameters().clone(),
+                     opt._step, opt.param_groups[0]["lr"]))
+        if graphs:
+            assert "graph" in next(iter(wr._graph_steps.values()))           # the captured path really ran
+    (la, pa, ma, va, ea, sa, lra), (lb, pb, mb, vb, eb, sb, lrb) = runs
+    print("eager  losses", la)
+    print("graph  losses", lb)
+    assert la == lb and sa == sb == 6 and lra == lrb
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb) and torch.equal(ea, eb)
+    net_a.eval(); net_b.eval()
+    x = torch.randn(2, 6, 16, 16, device=DEV)
+    tt = torch.rand(2, device=DEV) * 0.9 + 0.05
+    with torch.no_grad():
+        assert torch.equal(net_a(x, tt), net_b(x, tt))
 
 
 def test_gradient_accumulation_semantics():
