@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 
-#define PSLD_ABI_VERSION 6 /* 2: limb-MFMA convolutions, math mode, bias-gradient / batched-copy entry points; 3: pointwise weight gradient and batched activation GEMM on limb kernels; 4: GroupNorm statistics from the limb kernels' epilogue; 5: per-sample-time reverse SDE, ScoreLoss nll / l1; 6: limb-plane activations */
+#define PSLD_ABI_VERSION 7 /* 2: limb-MFMA convolutions, math mode, bias-gradient / batched-copy entry points; 3: pointwise weight gradient and batched activation GEMM on limb kernels; 4: GroupNorm statistics from the limb kernels' epilogue; 5: per-sample-time reverse SDE, ScoreLoss nll / l1; 6: limb-plane activations; 7: device-resident dropout seed / Adam scalars (captured training step), GroupNorm-backward sums from the producing epilogue */
 #define PSLD_COEFF_STRIDE 12
 
 int psld_version(void);
@@ -69,6 +69,25 @@ typedef struct psld_epilogue {
      * psld_gn_stats_from_partials_f32 turns them into the statistics of any group size that is a multiple of 8. */
     double* gn_part;
     int gn_hw;
+    /* Optional (same kernels, same no-split rule): pass 1 of a GroupNorm BACKWARD as a by-product.  The call's OUTPUT is
+     * the gradient dy w.r.t. y = dropout(act(GroupNorm(gnb_x))) - e.g. the data gradient of the convolution that
+     * consumed y - and must be a contiguous [rows][N] tensor (ldy == N); the kernel also accumulates, per image, 64-row
+     * run and channel, s1 = sum dz and s2 = sum dz * xhat with dz = dy * (dropout mask / keep) * act'(gamma*xhat + beta),
+     * xhat = (gnb_x - mean) * rstd, into gnb_part[((img*chunks + chunk)*2 + {0,1})*N + n] (chunks = gnb_hw / 64): what
+     * psld_gn_bwd_nhwc_f32 takes as part_in instead of reading dy and x a first time.  gnb_mean / gnb_rstd: [img][groups]
+     * of the forward statistics; N / gnb_groups a multiple of 4; dropout seed as in psld_gn_apply_nhwc_f32. */
+    const float* gnb_x;
+    const float* gnb_mean;
+    const float* gnb_rstd;
+    const float* gnb_gamma;
+    const float* gnb_beta;
+    float* gnb_part;
+    const unsigned long long* gnb_seed_dev;
+    unsigned long long gnb_seed;
+    float gnb_drop_p;
+    int gnb_groups;
+    int gnb_act;
+    int gnb_hw;
 } psld_epilogue_t;
 
 /* C[b] = epilogue(op(A[b]) * op(B[b])), fp32 MFMA (v_mfma_f32_32x32x2_f32), batched.
@@ -242,12 +261,15 @@ int psld_gn_apply_limb_nhwc(const float* x, const float* scale, const float* shi
                             const unsigned long long* seed_dev, hipStream_t stream);
 /* Backward of y = act(GN(x)): dgamma[C], dbeta[C] (written, not accumulated) and
  * dx = d/dx (+ add_scale * add when add != NULL: the gradient of an identity branch parallel to the normalisation,
- * e.g. the residual `(x + h) / sqrt(2)` of layerspp.py:271-274) (+ the previous dx when accumulate_dx). */
+ * e.g. the residual `(x + h) / sqrt(2)` of layerspp.py:271-274) (+ the previous dx when accumulate_dx).
+ * part_in (may be NULL): the pass-1 sums [batch][part_chunks][2][c] left by the producer of dy (psld_epilogue_t.gnb_part);
+ * then dy and x are read once (the apply pass) instead of twice. */
 int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float* mean, const float* rstd,
                          const float* gamma, const float* beta, int batch, int hw, int c, int groups,
                          int act, float drop_p, unsigned long long seed, const unsigned long long* seed_dev,
                          float* dx, float* dgamma, float* dbeta, int accumulate_dx,
-                         const float* add, float add_scale, void* workspace, hipStream_t stream);
+                         const float* add, float add_scale, const float* part_in, int part_chunks,
+                         void* workspace, hipStream_t stream);
 
 /* ---- FIR resampling: the replacement of the pybind op upfirdn2d_op.upfirdn2d
  *      (op/upfirdn2d.cpp:12-22, op/upfirdn2d_kernel.cu:209-369).  Same semantics: zero-insert

@@ -35,6 +35,10 @@ class Epilogue(C.Structure):
         ("accumulate", C.c_int),
         ("gn_part", C.c_void_p),
         ("gn_hw", C.c_int),
+        ("gnb_x", C.c_void_p), ("gnb_mean", C.c_void_p), ("gnb_rstd", C.c_void_p), ("gnb_gamma", C.c_void_p),
+        ("gnb_beta", C.c_void_p), ("gnb_part", C.c_void_p), ("gnb_seed_dev", C.c_void_p),
+        ("gnb_seed", C.c_ulonglong), ("gnb_drop_p", C.c_float), ("gnb_groups", C.c_int), ("gnb_act", C.c_int),
+        ("gnb_hw", C.c_int),
     ]
 
 
@@ -64,7 +68,7 @@ class SscsCoeffs(C.Structure):
 I, F, D, LL, P = C.c_int, C.c_float, C.c_double, C.c_longlong, C.c_void_p
 EP = C.POINTER(Epilogue)
 
-ABI_VERSION = 6    # PSLD_ABI_VERSION of include/psld_hip.h these signatures were written against
+ABI_VERSION = 7    # PSLD_ABI_VERSION of include/psld_hip.h these signatures were written against
 
 # name -> (restype, argtypes): every symbol include/psld_hip.h declares
 SIGNATURES = {
@@ -108,7 +112,7 @@ SIGNATURES = {
     "psld_gn_stats_nhwc_f32": (I, [P, I, I, I, I, F, P, P, P, P, P, P, P, P]),
     "psld_gn_stats_from_partials_f32": (I, [P, I, I, I, I, F, P, P, P, P, P, P, P]),
     "psld_gn_apply_nhwc_f32": (I, [P, P, P, P, I, I, I, I, F, C.c_ulonglong, P, P]),
-    "psld_gn_bwd_nhwc_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, F, C.c_ulonglong, P, P, P, P, I, P, F, P, P]),
+    "psld_gn_bwd_nhwc_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, F, C.c_ulonglong, P, P, P, P, I, P, F, P, I, P, P]),
     "psld_upfirdn2d_f32": (I, [P, P, I, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "psld_fused_bias_act_f32": (I, [P, P, P, LL, I, I, I, F, F, P]),
     "psld_axpby_f32": (I, [P, F, P, F, P, LL, I, P]),

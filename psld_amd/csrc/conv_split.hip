@@ -179,6 +179,29 @@ __device__ __forceinline__ void dconv_epilogue(const DConvArgs& a, f32x4v (&acc)
     float gs[4], gss[4];                 // GroupNorm by-product: sums of this lane's 4 channels x 4 pixels per block column
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) gs[nb] = gss[nb] = 0.f;
+    // GroupNorm-BACKWARD by-product (e.gnb_part): the output is dy of y = dropout(act(GN(gnb_x))); per channel
+    // s1 = sum dz, s2 = sum dz*xhat over this wave's 64 pixels (norm_act.hip: gn_bwd_partial_kernel, same arithmetic)
+    const bool gnb = e.gnb_part != nullptr;
+    f32x4v b1[4], b2[4], bga[4], bbe[4];
+    float bmu[4], brs[4];
+    const float keep_scale = e.gnb_drop_p > 0.f ? 1.0f / (1.0f - e.gnb_drop_p) : 1.0f;
+    unsigned long long bseed = e.gnb_seed;
+    if (gnb) {
+        if (e.gnb_seed_dev) bseed += e.gnb_seed_dev[0];
+        const int img = (m0 + wr * 64) / e.gnb_hw;          // one image per wave (gnb_hw % 64 == 0)
+        const int cpg = a.N / e.gnb_groups;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const int gn = cn0 + nb * 16;
+            b1[nb] = b2[nb] = zero4;
+            bga[nb] = *reinterpret_cast<const f32x4v*>(e.gnb_gamma + gn);
+            bbe[nb] = *reinterpret_cast<const f32x4v*>(e.gnb_beta + gn);
+            const int grp = gn / cpg;                        // the lane's 4 channels share a group (cpg % 4 == 0)
+            const int ii = min(img, (a.M - 1) / e.gnb_hw);
+            bmu[nb] = e.gnb_mean[ii * e.gnb_groups + grp];
+            brs[nb] = e.gnb_rstd[ii * e.gnb_groups + grp];
+        }
+    }
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
         const int row_base = m0 + wr * 64 + mb * 16;
@@ -212,6 +235,45 @@ __device__ __forceinline__ void dconv_epilogue(const DConvArgs& a, f32x4v (&acc)
                 for (int v = 0; v < 4; ++v) {
                     gs[nb] += o[v];
                     gss[nb] += o[v] * o[v];
+                }
+                if (gnb) {
+                    const f32x4v xv = *reinterpret_cast<const f32x4v*>(e.gnb_x + (long long)gm * a.N + gn);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const float xh = (xv[v] - bmu[nb]) * brs[nb];
+                        float dz = o[v];
+                        if (e.gnb_drop_p > 0.f)
+                            dz = psld_dropout_keep(bseed, (unsigned long long)((long long)gm * a.N + gn + v), e.gnb_drop_p)
+                                     ? dz * keep_scale : 0.f;
+                        if (e.gnb_act) dz *= dsilu_f(xh * bga[nb][v] + bbe[nb][v]);
+                        b1[nb][v] += dz;
+                        b2[nb][v] += dz * xh;
+                    }
+                }
+            }
+        }
+    }
+    if (gnb) {
+        const int row0 = m0 + wr * 64;
+        if (row0 < a.M) {
+            const int img = row0 / e.gnb_hw, chunk = (row0 - img * e.gnb_hw) >> 6, chunks = e.gnb_hw >> 6;
+            float* pp = e.gnb_part + ((long long)img * chunks + chunk) * 2 * a.N;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    float s1 = b1[nb][v], s2 = b2[nb][v];
+#pragma unroll
+                    for (int sft = 1; sft <= 8; sft <<= 1) {      // the 16 pixels of a block row sit in lanes r16
+                        s1 += __shfl_xor(s1, sft, 64);
+                        s2 += __shfl_xor(s2, sft, 64);
+                    }
+                    b1[nb][v] = s1;
+                    b2[nb][v] = s2;
+                }
+                if (r16 == 0) {                                   // one writer per (wave, channel quad)
+                    *reinterpret_cast<f32x4v*>(pp + cn0 + nb * 16) = b1[nb];
+                    *reinterpret_cast<f32x4v*>(pp + a.N + cn0 + nb * 16) = b2[nb];
                 }
             }
         }
@@ -1188,7 +1250,7 @@ int launch_dconv_lp(const DConvArgs& a, int nsplit, hipStream_t stream, const ch
 int plan_split(DConvArgs& a, const PsldEpilogue& e, float* y, int ldy, void* workspace, long long ws_bytes) {
     const long long tiles = (long long)cdiv(a.M, 128) * (a.N / 128);
     int ns = 1;
-    if (workspace && tiles < 384 && !e.gn_part && ldy % 4 == 0 && aligned16(y) && (!e.bias || aligned16(e.bias)) &&
+    if (workspace && tiles < 384 && !e.gn_part && !e.gnb_part && ldy % 4 == 0 && aligned16(y) && (!e.bias || aligned16(e.bias)) &&
         (!e.rowbias || (aligned16(e.rowbias) && e.ld_rowbias % 4 == 0)) && (!e.res || (aligned16(e.res) && e.ldres % 4 == 0))) {
         ns = (int)(512 / tiles);
         if (ns > 8) ns = 8;
@@ -1293,6 +1355,12 @@ extern "C" int psld_conv3x3_split_f32(const float* x1, int c1, const float* x2, 
                    "psld_conv3x3_split_f32: gn_part needs gn_hw = h*w, a multiple of 64, and no accumulation");
     const int ns = plan_split(a, e, y, ldy, workspace, ws_bytes);
     PSLD_CHECK_ARG(a.v4, "limb kernels: y, residual, bias and rowbias need 16-byte aligned rows (pointer and row stride)");
+    PSLD_CHECK_ARG(!e.gnb_part || (e.gnb_x && e.gnb_mean && e.gnb_rstd && e.gnb_gamma && e.gnb_beta && e.gnb_hw > 0 &&
+                                   e.gnb_hw % 64 == 0 && a.M % e.gnb_hw == 0 && ldy == a.N && e.gnb_groups > 0 &&
+                                   a.N % e.gnb_groups == 0 && (a.N / e.gnb_groups) % 4 == 0 && !e.accumulate &&
+                                   aligned16(e.gnb_x) && aligned16(e.gnb_gamma) && aligned16(e.gnb_beta) && aligned16(e.gnb_part)),
+                   "limb kernels: gnb_part needs a contiguous output (ldy == n), gnb_hw a multiple of 64 dividing the rows, "
+                   "groups of a multiple of 4 channels, 16-byte aligned operands and no accumulation");
     const int nh = cdiv((long long)halo_px * 8, 256);
     const char* name = "psld_conv3x3_split_f32";
     int st;
@@ -1346,6 +1414,12 @@ extern "C" int psld_conv3x3_limb_f32(const void* x1, int c1, const void* x2, int
                    "psld_conv3x3_limb_f32: gn_part needs gn_hw = h*w, a multiple of 64, and no accumulation");
     const int ns = plan_split(a, e, y, ldy, workspace, ws_bytes);
     PSLD_CHECK_ARG(a.v4, "limb kernels: y, residual, bias and rowbias need 16-byte aligned rows (pointer and row stride)");
+    PSLD_CHECK_ARG(!e.gnb_part || (e.gnb_x && e.gnb_mean && e.gnb_rstd && e.gnb_gamma && e.gnb_beta && e.gnb_hw > 0 &&
+                                   e.gnb_hw % 64 == 0 && a.M % e.gnb_hw == 0 && ldy == a.N && e.gnb_groups > 0 &&
+                                   a.N % e.gnb_groups == 0 && (a.N / e.gnb_groups) % 4 == 0 && !e.accumulate &&
+                                   aligned16(e.gnb_x) && aligned16(e.gnb_gamma) && aligned16(e.gnb_beta) && aligned16(e.gnb_part)),
+                   "limb kernels: gnb_part needs a contiguous output (ldy == n), gnb_hw a multiple of 64 dividing the rows, "
+                   "groups of a multiple of 4 channels, 16-byte aligned operands and no accumulation");
     const int rg = cdiv(halo_px, 16);
     const char* name = "psld_conv3x3_limb_f32";
     static const int single = [] { const char* v = getenv("PSLD_LP_SINGLE_BUFFER"); return v ? atoi(v) : 0; }();
@@ -1495,6 +1569,12 @@ extern "C" int psld_gemm_split_f32(const float* a1, int k1, const float* a2, int
                    "psld_gemm_split_f32: gn_part needs gn_hw (rows per image) a multiple of 64 dividing m, and no accumulation");
     const int ns = plan_split(a, e, y, ldy, workspace, ws_bytes);
     PSLD_CHECK_ARG(a.v4, "limb kernels: y, residual, bias and rowbias need 16-byte aligned rows (pointer and row stride)");
+    PSLD_CHECK_ARG(!e.gnb_part || (e.gnb_x && e.gnb_mean && e.gnb_rstd && e.gnb_gamma && e.gnb_beta && e.gnb_hw > 0 &&
+                                   e.gnb_hw % 64 == 0 && a.M % e.gnb_hw == 0 && ldy == a.N && e.gnb_groups > 0 &&
+                                   a.N % e.gnb_groups == 0 && (a.N / e.gnb_groups) % 4 == 0 && !e.accumulate &&
+                                   aligned16(e.gnb_x) && aligned16(e.gnb_gamma) && aligned16(e.gnb_beta) && aligned16(e.gnb_part)),
+                   "limb kernels: gnb_part needs a contiguous output (ldy == n), gnb_hw a multiple of 64 dividing the rows, "
+                   "groups of a multiple of 4 channels, 16-byte aligned operands and no accumulation");
     const int st = launch_dconv<8, 2, true>(a, ns, stream, "psld_gemm_split_f32");
     if (st != PSLD_OK) return st;
     if (ns >= 2) return psld_detail_conv_reduce_epilogue(a.C, ns, m, n, y, ldy, e, stream);

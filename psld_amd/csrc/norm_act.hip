@@ -466,7 +466,7 @@ extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float
                                     int act, float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* dx,
                                     float* dgamma,
                                     float* dbeta, int accumulate_dx, const float* add, float add_scale,
-                                    void* workspace, hipStream_t stream) {
+                                    const float* part_in, int part_chunks, void* workspace, hipStream_t stream) {
     PSLD_CHECK_ARG(dy && x && mean && rstd && gamma && beta && dx && dgamma && dbeta && workspace,
                    "psld_gn_bwd: null pointer");
     PSLD_CHECK_ARG(c % 4 == 0 && c / 4 <= MAXT && groups <= MAXG && c % groups == 0,
@@ -478,11 +478,18 @@ extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float
     ws += align256((size_t)batch * 2 * c * sizeof(float));      // (formerly the per-image sums; the size query is unchanged)
     float* coef = reinterpret_cast<float*>(ws);
     const size_t lds = (size_t)m.pl * m.cq * 8 * sizeof(float);
-    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(m.chunks, batch), dim3(m.threads), lds, stream, dy, x, mean, rstd,
-                       gamma, beta, hw, c, groups, m.cq, m.pl, m.chunk_px, m.chunks, act, drop_p, seed, seed_dev, part);
-    PSLD_CHECK_LAUNCH("gn_bwd_partial_kernel");
+    int chunks = m.chunks;
+    if (part_in) {        // pass 1 came with dy (the producing kernel's epilogue, psld_epilogue_t.gnb_part)
+        PSLD_CHECK_ARG(part_chunks >= 1, "psld_gn_bwd: part_chunks must be >= 1 with part_in");
+        part = const_cast<float*>(part_in);
+        chunks = part_chunks;
+    } else {
+        hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(m.chunks, batch), dim3(m.threads), lds, stream, dy, x, mean, rstd,
+                           gamma, beta, hw, c, groups, m.cq, m.pl, m.chunk_px, m.chunks, act, drop_p, seed, seed_dev, part);
+        PSLD_CHECK_LAUNCH("gn_bwd_partial_kernel");
+    }
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(batch + 2 * cdiv(c, 64)), dim3(1024), 0, stream, part, rstd, gamma,
-                       batch, hw, c, groups, m.chunks, coef, dgamma, dbeta);
+                       batch, hw, c, groups, chunks, coef, dgamma, dbeta);
     PSLD_CHECK_LAUNCH("gn_bwd_finalize_kernel");
     const Map ma = make_map(batch, hw, c, true);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ma.chunks, batch), dim3(ma.threads), 0, stream, dy, x, mean, rstd,

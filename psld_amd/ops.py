@@ -61,8 +61,9 @@ def _chk(t: Tensor, dtype=torch.float32):
 def epilogue(alpha: float = 1.0, bias: Optional[Tensor] = None, rowbias: Optional[Tensor] = None,
              rows_per_img: int = 1, residual: Optional[Tensor] = None, ld_residual: int = 0,
              residual_stride_batch: int = 0, out_scale: float = 1.0, accumulate: bool = False,
-             ld_rowbias: int = 0, gn_part: Optional[Tensor] = None, gn_hw: int = 0) -> Epilogue:
-    """``gn_part`` (limb kernels only; see gn_part_buffer): GroupNorm partial sums of the output as a by-product."""
+             ld_rowbias: int = 0, gn_part: Optional[Tensor] = None, gn_hw: int = 0, gnb=None) -> Epilogue:
+    """``gn_part`` (limb kernels only; see gn_part_buffer): GroupNorm partial sums of the output as a by-product.
+    ``gnb`` (limb kernels only; see gn_bwd_part): pass 1 of a GroupNorm backward whose dy IS the output."""
     e = Epilogue()
     e.alpha = alpha
     e.bias = _p(bias)
@@ -76,8 +77,31 @@ def epilogue(alpha: float = 1.0, bias: Optional[Tensor] = None, rowbias: Optiona
     e.accumulate = 1 if accumulate else 0
     e.gn_part = _p(gn_part)
     e.gn_hw = gn_hw if gn_part is not None else 0
-    e._keep = (bias, rowbias, residual, gn_part)  # the struct holds raw pointers: keep the tensors alive
+    e._keep = (bias, rowbias, residual, gn_part, gnb)  # the struct holds raw pointers: keep the tensors alive
+    if gnb is not None:
+        e.gnb_x, e.gnb_mean, e.gnb_rstd = gnb["x"].data_ptr(), gnb["st"].mean.data_ptr(), gnb["st"].rstd.data_ptr()
+        e.gnb_gamma, e.gnb_beta, e.gnb_part = gnb["gamma"].data_ptr(), gnb["beta"].data_ptr(), gnb["part"].data_ptr()
+        e.gnb_seed_dev = _p(gnb.get("seed_dev"))
+        e.gnb_seed, e.gnb_drop_p = int(gnb.get("seed", 0)), float(gnb.get("drop_p", 0.0))
+        e.gnb_groups, e.gnb_act, e.gnb_hw = int(gnb["groups"]), 1 if gnb["act"] else 0, int(gnb["hw"])
     return e
+
+
+def gn_bwd_part_supported(b: int, hw: int, c: int, groups: Optional[int] = None) -> bool:
+    """Can a limb kernel's epilogue produce pass 1 of the GroupNorm backward of its [b, hw, c] output?  (Whole 64-row runs
+    per image, a lane's four channels inside one group, and a grid large enough that the kernel does not split K.)"""
+    g = groups if groups is not None else gn_groups(c)
+    return hw % 64 == 0 and c % 128 == 0 and (c // g) % 4 == 0 and ((b * hw + 127) // 128) * (c // 128) >= 384
+
+
+def gn_bwd_part(x: Tensor, st: "GNStats", gamma: Tensor, beta: Tensor, act: bool, drop_p: float = 0.0, seed: int = 0,
+                seed_dev: Optional[Tensor] = None, groups: Optional[int] = None) -> dict:
+    """Descriptor for ``epilogue(gnb=...)``: x = the GroupNorm's input, st its forward statistics; the kernel fills
+    ``part`` [b][hw/64][2][c], which ``gn_bwd(..., part=...)`` consumes instead of its first pass over (dy, x)."""
+    b, h, w, c = x.shape
+    return {"x": x, "st": st, "gamma": gamma, "beta": beta, "act": act, "drop_p": drop_p, "seed": seed, "seed_dev": seed_dev,
+            "groups": groups if groups is not None else gn_groups(c), "hw": h * w,
+            "part": torch.empty((b, (h * w) // 64, 2, c), device=x.device, dtype=torch.float32)}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -411,7 +435,8 @@ def gn_apply_limb(x: Tensor, st: GNStats, act: bool, drop_p: float = 0.0, seed: 
 
 def gn_bwd(dy: Tensor, x: Tensor, st: GNStats, gamma: Tensor, beta: Tensor, act: bool, dx: Tensor, dgamma: Tensor,
            dbeta: Tensor, accumulate_dx: bool = False, drop_p: float = 0.0, seed: int = 0, groups: Optional[int] = None,
-           add: Optional[Tensor] = None, add_scale: float = 1.0, seed_dev: Optional[Tensor] = None):
+           add: Optional[Tensor] = None, add_scale: float = 1.0, seed_dev: Optional[Tensor] = None,
+           part: Optional[Tensor] = None):
     """``add`` (same shape as x): dx additionally receives add_scale * add (gradient of a parallel identity branch)."""
     b, h, w, c = x.shape
     g = groups if groups is not None else gn_groups(c)
@@ -420,7 +445,8 @@ def gn_bwd(dy: Tensor, x: Tensor, st: GNStats, gamma: Tensor, beta: Tensor, act:
                                      gamma.data_ptr(), beta.data_ptr(), b, h * w, c, g, 1 if act else 0,
                                      drop_p, seed, _p(seed_dev), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                      1 if accumulate_dx else 0,
-                                     _p(add), add_scale, ws.data_ptr(), _stream()), "psld_gn_bwd_nhwc_f32")
+                                     _p(add), add_scale, _p(part), part.shape[1] if part is not None else 0,
+                                     ws.data_ptr(), _stream()), "psld_gn_bwd_nhwc_f32")
 
 
 # ------------------------------------------------------------------------------------------------

@@ -228,6 +228,8 @@ class _Exec:
         self.split = ops.math_mode() == "bf16x6"   # 3x3 convs on the bf16 limb kernels (csrc/conv_split.hip)
         import os as _os
         self.limb_planes = _os.environ.get("PSLD_LIMB_PLANES", "1") != "0"    # A/B switch for tools/bench_sample.py
+        # pass 1 of GroupNorm's backward from the epilogue of the kernel that produces its dy (A/B switch)
+        self.fuse_gn_bwd = _os.environ.get("PSLD_FUSE_GN_BWD", "1") != "0"
         self.dx_nchw = None
 
     # -- helpers ------------------------------------------------------------------------------
@@ -415,14 +417,27 @@ class _Exec:
             self.bias_grad(dy, self.g(conv.bias))
         self.on_side(side, dy, a, cols)
 
+    def gnb_for(self, x: Tensor, st, gn: _Affine, act: bool, drop_p: float = 0.0, seed: int = 0, seed_dev=None,
+                gamma: Optional[Tensor] = None, beta: Optional[Tensor] = None, groups: Optional[int] = None):
+        """Descriptor that lets the limb kernel producing dy of GroupNorm ``gn`` (input ``x``, statistics ``st``) also
+        produce pass 1 of its backward (ops.gn_bwd_part), or None when the shape does not qualify."""
+        b, h, w, c = x.shape
+        if not (self.split and self.fuse_gn_bwd and ops.gn_bwd_part_supported(b, h * w, c, groups)):
+            return None
+        return ops.gn_bwd_part(x, st, gamma if gamma is not None else gn.weight.detach(),
+                               beta if beta is not None else gn.bias.detach(), act, drop_p, seed, seed_dev, groups)
+
     def dgrad(self, dy: Tensor, conv: _Affine, k: int, stride: int, pad: int, ih: int, iw: int, out: Tensor,
-              alpha: float = 1.0, accumulate: bool = False):
+              alpha: float = 1.0, accumulate: bool = False, gnb=None):
+        """``gnb``: see gnb_for - only honoured on the limb path (the caller checks ``limb_dgrad_ok`` first)."""
         cin = conv.weight.shape[1]
-        epi = ops.epilogue(alpha=alpha, accumulate=accumulate) if (alpha != 1.0 or accumulate) else None
+        epi = ops.epilogue(alpha=alpha, accumulate=accumulate, gnb=gnb) if (alpha != 1.0 or accumulate or gnb is not None) \
+            else None
         if self.split and k == 3 and stride == 1 and pad == 1 and \
                 ops.conv3x3_split_supported(dy.shape[-1], 0, dy.shape[0], ih, iw, cin):
             ops.conv3x3_split(dy, None, self.net._frag(conv, True), cin, out, epi)
             return
+        assert gnb is None, "GroupNorm-backward by-product needs the limb data-gradient kernel"
         wd = self.net._packed(conv, dgrad=True)
         ops.conv2d_nhwc(dy, None, wd, cin, k, k, 1, k - 1 - pad, stride, ih, iw, out, epi)
 
@@ -602,10 +617,12 @@ class _Exec:
 
             self.on_side(side1, dout, a1, xr_saved, xb_v)
             da1 = torch.empty_like(a1)
-            self.dgrad(dout, mod.Conv_1, 3, 1, 1, ho, wo, da1, alpha=s)
+            limb1 = self.split and ops.conv3x3_split_supported(cout, 0, b, ho, wo, cout)
+            gnb1 = self.gnb_for(h1, st1, gn1, True, drop_p, seed, seed_dev) if limb1 else None
+            self.dgrad(dout, mod.Conv_1, 3, 1, 1, ho, wo, da1, alpha=s, gnb=gnb1)
             dh1 = torch.empty_like(h1)
             ops.gn_bwd(da1, h1, st1, gn1.weight, gn1.bias, True, dh1, self.g(gn1.weight), self.g(gn1.bias),
-                       drop_p=drop_p, seed=seed, seed_dev=seed_dev)
+                       drop_p=drop_p, seed=seed, seed_dev=seed_dev, part=gnb1["part"] if gnb1 is not None else None)
             del da1
 
             # Conv_0 + time-embedding bias
@@ -641,7 +658,9 @@ class _Exec:
                 self._resblock_cat_bwd(mod, x, xb, dout, dh1, st0, st0b, g1, g2)
                 return
             da0r = torch.empty_like(a0r)
-            self.dgrad(dh1, mod.Conv_0, 3, 1, 1, ho, wo, da0r)
+            limb0 = self.split and not (up or down) and ops.conv3x3_split_supported(cout, 0, b, ho, wo, cin)
+            gnb0 = self.gnb_for(x.v, st0, gn0, True) if limb0 else None
+            self.dgrad(dh1, mod.Conv_0, 3, 1, 1, ho, wo, da0r, gnb=gnb0)
             del dh1
             xg, acc = _gbuf(x)
             identity = False
@@ -670,7 +689,8 @@ class _Exec:
             else:
                 da0 = da0r
             ops.gn_bwd(da0, x.v, st0, gn0.weight, gn0.bias, True, xg, self.g(gn0.weight), self.g(gn0.bias),
-                       accumulate_dx=not identity or acc, add=dout if identity else None, add_scale=s)
+                       accumulate_dx=not identity or acc, add=dout if identity else None, add_scale=s,
+                       part=gnb0["part"] if gnb0 is not None else None)
 
         self.push(bwd, mod)
         return on
@@ -697,9 +717,10 @@ class _Exec:
             xg, acc = _gbuf(node)
             ops.gemm_split(dout, None, m, fr1, c, xg, ops.epilogue(alpha=s, accumulate=acc))
             da0 = torch.empty_like(node.v)
-            ops.conv3x3_split(dh1, None, fr3, c, da0)
+            gnb = self.gnb_for(node.v, st, gn0, True, gamma=gam[lo:hi], beta=bet[lo:hi], groups=g)
+            ops.conv3x3_split(dh1, None, fr3, c, da0, ops.epilogue(gnb=gnb) if gnb is not None else None)
             ops.gn_bwd(da0, node.v, st, gam[lo:hi], bet[lo:hi], True, xg, dgam[lo:hi], dbet[lo:hi], accumulate_dx=True,
-                       groups=g)
+                       groups=g, part=gnb["part"] if gnb is not None else None)
 
     # -- AttnBlockpp.forward (layerspp.py:75-91) -----------------------------------------------------
     def attn(self, x: _Node, mod: AttnBlockpp) -> _Node:
@@ -793,8 +814,9 @@ class _Exec:
             dhn = torch.empty_like(hn)
             for nin, d in ((n0, dq), (n1, dk), (n2, dv)):
                 self.on_side(lambda nin=nin, d=d: nin_wgrad(hn, d, nin, 1.0, ld), hn, d)
+            gnb_a = self.gnb_for(x.v, st, gn, False) if fused else None
             if fused:
-                ops.gemm_split(dqkv, None, m, f_qkv_d, c, dhn)
+                ops.gemm_split(dqkv, None, m, f_qkv_d, c, dhn, ops.epilogue(gnb=gnb_a) if gnb_a is not None else None)
             else:
                 first = True
                 for nin, d in ((n0, dq), (n1, dk), (n2, dv)):
@@ -803,7 +825,7 @@ class _Exec:
                     first = False
             xg, acc = _gbuf(x)
             ops.gn_bwd(dhn, x.v, st, gn.weight, gn.bias, False, xg, self.g(gn.weight), self.g(gn.bias),
-                       accumulate_dx=acc, add=dout, add_scale=s)
+                       accumulate_dx=acc, add=dout, add_scale=s, part=gnb_a["part"] if gnb_a is not None else None)
 
         self.push(bwd, mod)
         return on

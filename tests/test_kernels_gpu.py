@@ -292,6 +292,55 @@ def test_conv3x3_split_dgrad_and_wgrad(ops, cfg):
     assert torch.count_nonzero(slabs[:, :, :, :col0]) == 0
 
 
+@pytest.mark.parametrize("act,drop_p", [(True, 0.0), (True, 0.15), (False, 0.0)])
+def test_gn_backward_pass1_from_the_conv_epilogue(ops, act, drop_p):
+    """psld_epilogue_t.gnb_part: the data-gradient kernel whose output is dy of a GroupNorm(+SiLU, dropout) also emits
+    pass 1 of that GroupNorm's backward (per image / 64-row run / channel: sum dz, sum dz*xhat); psld_gn_bwd_nhwc_f32
+    fed with it (part_in) must reproduce the two-pass result: dx, dgamma, dbeta.  48 images of 32x32: 384 tiles, the
+    smallest grid the by-product is offered on (smaller grids split K and finish in another kernel)."""
+    b, s_, c = 48, 32, 128
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(b, s_, s_, c, generator=g).to(DEV)                    # the GroupNorm's input
+    gy = torch.randn(b, s_, s_, c, generator=g).to(DEV)                   # upstream gradient fed to the data-gradient conv
+    w = (torch.randn(c, c, 3, 3, generator=g) * 0.05).to(DEV)
+    gamma = (1 + 0.2 * torch.randn(c, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(c, generator=g)).to(DEV)
+    st = ops.gn_stats(x, gamma, beta)
+    assert ops.gn_bwd_part_supported(b, s_ * s_, c)
+    frag = ops.conv3x3_frag(w, True)
+    seed_dev = torch.tensor([77], device=DEV)
+    # two-pass reference
+    dy0 = torch.empty_like(x)
+    ops.conv3x3_split(gy, None, frag, c, dy0, ops.epilogue(alpha=0.7))
+    dx0, dg0, db0 = torch.empty_like(x), torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    ops.gn_bwd(dy0, x, st, gamma, beta, act, dx0, dg0, db0, drop_p=drop_p, seed=5, seed_dev=seed_dev)
+    # by-product
+    gnb = ops.gn_bwd_part(x, st, gamma, beta, act, drop_p, 5, seed_dev)
+    gnb["part"].fill_(float("nan"))
+    dy1 = torch.empty_like(x)
+    ops.conv3x3_split(gy, None, frag, c, dy1, ops.epilogue(alpha=0.7, gnb=gnb))
+    assert torch.equal(dy1, dy0) and bool(torch.isfinite(gnb["part"]).all())
+    dx1, dg1, db1 = torch.empty_like(x), torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    ops.gn_bwd(dy1, x, st, gamma, beta, act, dx1, dg1, db1, drop_p=drop_p, seed=5, seed_dev=seed_dev, part=gnb["part"])
+    e = (rel_l2(dx1, dx0), rel_l2(dg1, dg0), rel_l2(db1, db0))
+    print("gn_bwd from the epilogue's pass 1 vs two passes: dx %.2e dgamma %.2e dbeta %.2e" % e)
+    assert max(e) < 2e-6
+    # the sums themselves against fp64
+    xd, dyd = x.double().cpu(), dy0.double().cpu()
+    mean = xd.view(b, s_ * s_, 32, c // 32).mean(dim=(1, 3))
+    var = xd.view(b, s_ * s_, 32, c // 32).var(dim=(1, 3), unbiased=False)
+    xh = (xd.view(b, s_ * s_, 32, c // 32) - mean[:, None, :, None]) / torch.sqrt(var[:, None, :, None] + 1e-6)
+    xh = xh.reshape(b, s_ * s_, c)
+    if drop_p == 0.0:
+        z = xh * gamma.double().cpu() + beta.double().cpu()
+        sg = torch.sigmoid(z)
+        dz = dyd.view(b, s_ * s_, c) * (sg * (1 + z * (1 - sg)) if act else 1.0)
+        s1 = dz.view(b, 16, 64, c).sum(2)
+        s2 = (dz * xh).view(b, 16, 64, c).sum(2)
+        part = gnb["part"].double().cpu()
+        assert rel_l2(part[:, :, 0], s1) < 2e-6 and rel_l2(part[:, :, 1], s2) < 2e-6
+
+
 def test_gn_apply_limb_planes_match_the_fp32_pass(ops):
     """psld_gn_apply_limb_nhwc writes exactly the limb decomposition of what psld_gn_apply_nhwc_f32 writes (same
     affine, SiLU and dropout mask)."""

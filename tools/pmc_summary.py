@@ -1,0 +1,45 @@
+"""Per-kernel averages of a rocprofv3 --pmc pass (csv): effective clock (GRBM_GUI_ACTIVE / 8 XCDs / duration),
+MFMA-busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES per the guide's units), VALU instructions, LDS
+conflicts.   python tools/pmc_summary.py <dir>"""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def main():
+    d = sys.argv[1]
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    acc = defaultdict(lambda: defaultdict(list))
+    dur = defaultdict(list)
+    for f in files:
+        with open(f, newline="") as fh:
+            for row in csv.DictReader(fh):
+                name = row["Kernel_Name"].split("(")[0][-60:]
+                acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                if row.get("Start_Timestamp") and row.get("End_Timestamp"):
+                    dur[(name, row.get("Dispatch_Id"))] = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+    dsum = defaultdict(list)
+    for (name, _), v in dur.items():
+        dsum[name].append(v)
+    print("| kernel | launches | avg us | eff. clock GHz | MFMA busy | VALU insts/launch | LDS conflict share |")
+    print("|---|---|---|---|---|---|---|")
+    for name, c in sorted(acc.items(), key=lambda kv: -sum(dsum.get(kv[0], [0]))):
+        n = len(next(iter(c.values())))
+        avg = lambda k: (sum(c[k]) / len(c[k])) if k in c and c[k] else float("nan")
+        us = (sum(dsum[name]) / len(dsum[name]) / 1e3) if dsum.get(name) else float("nan")
+        if not (us > 20):
+            continue
+        clock = avg("GRBM_GUI_ACTIVE") / 8 / (us * 1e3) if us == us else float("nan")
+        busy = avg("SQ_VALU_MFMA_BUSY_CYCLES") / (avg("SQ_BUSY_CYCLES") * 4) if avg("SQ_BUSY_CYCLES") else float("nan")
+        ldsc = avg("SQ_LDS_BANK_CONFLICT") / avg("SQ_LDS_IDX_ACTIVE") if avg("SQ_LDS_IDX_ACTIVE") else float("nan")
+        print(f"| {name} | {n} | {us:.1f} | {clock:.2f} | {busy:.3f} | {avg('SQ_INSTS_VALU'):.3g} | {ldsc:.3f} |")
+    print("\nraw per-kernel averages (all counters):")
+    for name, c in acc.items():
+        if dsum.get(name) and sum(dsum[name]) / len(dsum[name]) > 20e3:
+            print(name, {k: round(sum(v) / len(v), 1) for k, v in c.items()})
+
+
+if __name__ == "__main__":
+    main()
