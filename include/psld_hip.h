@@ -190,6 +190,11 @@ int psld_conv3x3_wgrad_split_cout_tile(int cout);
 int psld_conv3x3_wgrad_split_f32(const float* dy, int lddy, int cout, const float* x, int cin,
                                  const float* x2, int cin2, int batch, int h, int w, float* slabs,
                                  int cin_total, int col0, int nsplit, hipStream_t stream);
+/* The same weight gradient with x (and x2) given as limb planes (psld_gn_apply_limb_nhwc / psld_f32_to_limb): the x
+ * operand is staged without a split; dy stays fp32.  Bitwise the result of psld_conv3x3_wgrad_split_f32. */
+int psld_conv3x3_wgrad_xlimb_f32(const float* dy, int lddy, int cout, const void* x_limb, int cin,
+                                 const void* x2_limb, int cin2, int batch, int h, int w, float* slabs,
+                                 int cin_total, int col0, int nsplit, hipStream_t stream);
 /* Pointwise weight gradient on the limb kernels: slabs[s][i][j] (row stride ldc) = sum over the s-th range of
  * ceil(k/32 / nsplit) 32-row tiles of a[p][i] * b[p][j]  (a: [k][m] rows of lda floats, b: [k][n] rows of ldb floats;
  * b2 / ldb2 / n2 (null / 0 / 0 for none): further columns [n, n + n2) of B from a second tensor (concatenation);

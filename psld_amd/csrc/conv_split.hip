@@ -733,7 +733,10 @@ __device__ __forceinline__ u32x2 lds_tr16(const unsigned char* p) {
 
 // CB = 16-channel dy blocks per wave: 2 -> 64-co tile, three workgroups per CU; 4 -> 128-co tile, two per CU (every
 // staged x value and every B fragment then feeds twice the MFMAs).
-template <int CB>
+// XLP: x (and x2) are bf16 limb planes [pixel][c/32][3][32] (written by GroupNorm's apply pass): the x items are staged
+// as plain 16-byte copies (4.5 per thread, one limb each) - no split3 for that operand, which is re-staged by
+// cout_tiles * 3 workgroups (the split is 43 % of this kernel's VALU work, and VALU issue is what bounds it).
+template <int CB, bool XLP>
 __global__ void __launch_bounds__(256, CB == 2 ? 3 : 2) dwgrad_kernel(const DWgradArgs a) {
     constexpr int CO_T = 32 * CB;                // output channels per workgroup
     constexpr int RSA = CO_T * 2 + 32;           // dy row stride: 160 / 288 B, both conflict-free for the transposed reads
@@ -783,21 +786,33 @@ __global__ void __launch_bounds__(256, CB == 2 ? 3 : 2) dwgrad_kernel(const DWgr
     // variant with one barrier per K tile at two workgroups per CU (181-188 vs 200-209 TFLOP/s): the kernel runs
     // best as three single-buffered workgroups per CU overlapping each other's staging phases.  s_setprio(1) around
     // the MFMA phase: neutral.  Upper bound of removing the limb split altogether (operands pre-split in HBM): +9 %.
-    unsigned xoff[WG_NB];   // byte offset from pixel (img, oy0 + ky - 1, ox0 - 1), channel ci0
-    int xrow[WG_NB];        // staged row of the item (>= 8: never valid)
-    int xcol[WG_NB];        // bit 0: column valid when the K tile starts at ox0 = 0, bit 1: at ox0 = 32 (W = 64)
+    constexpr int NXI = XLP ? 5 : WG_NB;        // limb planes: 48 rows x 3 limbs x 8 sixteen-byte slots = 1152 items
+    unsigned xoff[NXI];     // byte offset from pixel (img, oy0 + ky - 1, ox0 - 1), channel ci0
+    int xmeta[NXI];         // bits 0-4: staged row of the item (31: never valid); bit 5: column valid when the K tile
+                            // starts at ox0 = 0, bit 6: at ox0 = 32 (W = 64)
+    int xdst[NXI];          // limb planes: LDS byte offset of the item inside Bs
 #pragma unroll
-    for (int i = 0; i < WG_NB; ++i) {
-        const int px = ra + 16 * i;
-        const int hr = px / a.hw_w, hc = px - hr * a.hw_w;
-        xoff[i] = (unsigned)(((hr * a.W + hc) * xc + qa * 4) * 4);
-        xrow[i] = hr < a.hrows ? hr : 31;
-        xcol[i] = ((hc >= 1 && hc <= a.W) ? 1 : 0) | ((hc + 31 < a.W) ? 2 : 0);
+    for (int i = 0; i < NXI; ++i) {
+        if constexpr (XLP) {
+            const int id = tid + 256 * i;                    // item: limb l, staged row px, 16-byte slot t (8 channels)
+            const int l = id / 384, rem = id - l * 384;
+            const int px = rem >> 3, t = rem & 7;
+            const int hr = px / a.hw_w, hc = px - hr * a.hw_w;
+            xoff[i] = (unsigned)((hr * a.W + hc) * xc * 6 + ((t >> 2) * 3 + l) * 64 + (t & 3) * 16);
+            xmeta[i] = ((id < 1152 && hr < a.hrows) ? hr : 31) | ((hc >= 1 && hc <= a.W) ? 32 : 0) | ((hc + 31 < a.W) ? 64 : 0);
+            xdst[i] = l * WG_BLIMB + px * WG_RS + t * 16;
+        } else {
+            const int px = ra + 16 * i;
+            const int hr = px / a.hw_w, hc = px - hr * a.hw_w;
+            xoff[i] = (unsigned)(((hr * a.W + hc) * xc + qa * 4) * 4);
+            xmeta[i] = (hr < a.hrows ? hr : 31) | ((hc >= 1 && hc <= a.W) ? 32 : 0) | ((hc + 31 < a.W) ? 64 : 0);
+            xdst[i] = 0;
+        }
     }
     unsigned aoff[CB];      // dy items: pixel ra + 16*(i & 1), channel quad qa + 16*(i >> 1)
 #pragma unroll
     for (int i = 0; i < CB; ++i) aoff[i] = (unsigned)(((ra + 16 * (i & 1)) * a.lddy + (qa + 16 * (i >> 1)) * 4) * 4);
-    f32x4 va[CB], vb[WG_NB];
+    f32x4 va[CB], vb[NXI];
     auto load_tile = [&](int kt) {
         const int p0 = kt * 32;
         const int img = p0 / HW;
@@ -806,17 +821,20 @@ __global__ void __launch_bounds__(256, CB == 2 ? 3 : 2) dwgrad_kernel(const DWgr
         const int iy0 = oy0 + ky - 1;
         unsigned rowmask = 0;                       // bit r: staged row r lies inside the image
         for (int rr = 0; rr < a.hrows; ++rr) rowmask |= (iy0 + rr >= 0 && iy0 + rr < a.H) ? 1u << rr : 0u;
-        const int colsel = ox0 >> 5;
-        const float* xb = xsrc + ((long long)((img * a.H + iy0) * a.W + ox0 - 1) * xc + ci0);
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, 0x7fffffff, 0x00020000);
+        const int colsel = 5 + (ox0 >> 5);
+        // limb planes: 6 bytes per element, the tile's first 32-channel chunk at (ci0 / 32) * 192 bytes into the pixel
+        const unsigned char* xb8 = reinterpret_cast<const unsigned char*>(xsrc) +
+                                   (XLP ? ((long long)((img * a.H + iy0) * a.W + ox0 - 1) * xc * 6 + (ci0 >> 5) * 192)
+                                        : ((long long)((img * a.H + iy0) * a.W + ox0 - 1) * xc + ci0) * 4);
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(xb8), 0, 0x7fffffff, 0x00020000);
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(a.dy + ((long long)p0 * a.lddy + co0)), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int i = 0; i < CB; ++i)
             va[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, aoff[i], 0, 0));
 #pragma unroll
-        for (int i = 0; i < WG_NB; ++i) {
-            const bool ok = ((rowmask >> xrow[i]) & (unsigned)(xcol[i] >> colsel) & 1u) != 0;
+        for (int i = 0; i < NXI; ++i) {
+            const bool ok = ((rowmask >> (xmeta[i] & 31)) & (unsigned)(xmeta[i] >> colsel) & 1u) != 0;
             vb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xoff[i] : 0xffffffffu, 0, 0));
         }
     };
@@ -846,7 +864,13 @@ __global__ void __launch_bounds__(256, CB == 2 ? 3 : 2) dwgrad_kernel(const DWgr
 #pragma unroll
         for (int i = 0; i < CB; ++i) store_rows(As + (ra + 16 * (i & 1)) * RSA + (qa + 16 * (i >> 1)) * 8, ALIMB, va[i]);
 #pragma unroll
-        for (int i = 0; i < WG_NB; ++i) store_rows(Bs + (ra + 16 * i) * WG_RS + qa * 8, WG_BLIMB, vb[i]);
+        for (int i = 0; i < NXI; ++i) {
+            if constexpr (XLP) {
+                if (tid + 256 * i < 1152) *reinterpret_cast<f32x4*>(Bs + xdst[i]) = vb[i];
+            } else {
+                store_rows(Bs + (ra + 16 * i) * WG_RS + qa * 8, WG_BLIMB, vb[i]);
+            }
+        }
         __syncthreads();
         if (kt + 1 < kt_end) load_tile(kt + 1);
         u32x4 fa[CB][3];
@@ -1188,12 +1212,12 @@ int launch_bgemm(const BGemmArgs& a, int batch, hipStream_t stream) {
     return PSLD_OK;
 }
 
-template <int CB>
+template <int CB, bool XLP>
 int launch_dwgrad(const DWgradArgs& a, int nsplit, hipStream_t stream) {
     constexpr size_t LDS = (size_t)3 * (WG_AROWS * (64 * CB + 32) + WG_BLIMB);
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dwgrad_kernel<CB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dwgrad_kernel<CB, XLP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         if (e != hipSuccess) {
             psld_set_error("psld_conv3x3_wgrad_split_f32: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -1201,7 +1225,7 @@ int launch_dwgrad(const DWgradArgs& a, int nsplit, hipStream_t stream) {
         }
         configured = true;
     }
-    hipLaunchKernelGGL(dwgrad_kernel<CB>, dim3((unsigned)(a.cout_tiles * a.cin_tiles * 3 * nsplit)), dim3(256), LDS,
+    hipLaunchKernelGGL((dwgrad_kernel<CB, XLP>), dim3((unsigned)(a.cout_tiles * a.cin_tiles * 3 * nsplit)), dim3(256), LDS,
                        stream, a);
     PSLD_CHECK_LAUNCH("psld_conv3x3_wgrad_split_f32");
     return PSLD_OK;
@@ -1469,7 +1493,33 @@ extern "C" int psld_conv3x3_wgrad_split_f32(const float* dy, int lddy, int cout,
     a.slab_stride = (long long)cout * 9 * cin_total;
     a.hw_w = (w < 32 ? w : 32) + 2;
     a.hrows = w >= 32 ? 1 : 32 / w;
-    return co_tile == 128 ? launch_dwgrad<4>(a, nsplit, stream) : launch_dwgrad<2>(a, nsplit, stream);
+    return co_tile == 128 ? launch_dwgrad<4, false>(a, nsplit, stream) : launch_dwgrad<2, false>(a, nsplit, stream);
+}
+
+extern "C" int psld_conv3x3_wgrad_xlimb_f32(const float* dy, int lddy, int cout, const void* x_limb, int cin,
+                                            const void* x2_limb, int cin2, int batch, int h, int w, float* slabs,
+                                            int cin_total, int col0, int nsplit, hipStream_t stream) {
+    PSLD_CHECK_ARG(dy && x_limb && slabs && nsplit >= 1 && cin2 >= 0 && (cin2 == 0 || x2_limb), "psld_conv3x3_wgrad_xlimb_f32: bad args");
+    PSLD_CHECK_ARG(psld_conv3x3_wgrad_split_supported(cout, cin, batch, h, w) &&
+                       (cin2 == 0 || psld_conv3x3_wgrad_split_supported(cout, cin2, batch, h, w)),
+                   "psld_conv3x3_wgrad_xlimb_f32: unsupported shape cout=%d cin=%d+%d %dx%d", cout, cin, cin2, h, w);
+    PSLD_CHECK_ARG(aligned16(dy) && aligned16(x_limb) && (cin2 == 0 || aligned16(x2_limb)) && lddy % 4 == 0,
+                   "psld_conv3x3_wgrad_xlimb_f32: unaligned operand");
+    DWgradArgs a{};
+    a.dy = dy; a.lddy = lddy; a.x = reinterpret_cast<const float*>(x_limb); a.cin = cin;
+    a.x2 = reinterpret_cast<const float*>(x2_limb); a.cin2 = cin2;
+    a.B = batch; a.H = h; a.W = w;
+    const int co_tile = psld_conv3x3_wgrad_split_cout_tile(cout);
+    a.cout_tiles = cout / co_tile; a.cin_tiles = (cin + cin2) / 64;
+    a.ktiles = batch * h * w / 32;
+    a.ktiles_per_split = cdiv(a.ktiles, nsplit);
+    PSLD_CHECK_ARG(cdiv(a.ktiles, a.ktiles_per_split) == nsplit, "psld_conv3x3_wgrad_xlimb_f32: nsplit %d leaves empty slabs", nsplit);
+    a.slabs = slabs + col0;
+    a.ld_tap = cin_total;
+    a.slab_stride = (long long)cout * 9 * cin_total;
+    a.hw_w = (w < 32 ? w : 32) + 2;
+    a.hrows = w >= 32 ? 1 : 32 / w;
+    return co_tile == 128 ? launch_dwgrad<4, true>(a, nsplit, stream) : launch_dwgrad<2, true>(a, nsplit, stream);
 }
 
 // ---- pointwise weight gradient ------------------------------------------------------------------------------

@@ -299,6 +299,13 @@ def conv3x3_wgrad_split(dy: Tensor, cout: int, x: Tensor, slabs: Tensor, cin_tot
                         x2: Optional[Tensor] = None):
     b, h, w, cin = x.shape
     cin2 = x2.shape[-1] if x2 is not None else 0
+    if isinstance(x, LimbPlanes):         # x pre-split (GroupNorm's apply pass wrote limb planes): no split for it
+        assert x2 is None or isinstance(x2, LimbPlanes)
+        check(lib().psld_conv3x3_wgrad_xlimb_f32(dy.data_ptr(), cout, cout, x.data_ptr(), cin,
+                                                 x2.data_ptr() if x2 is not None else None, cin2, b, h, w,
+                                                 slabs.data_ptr(), cin_total, col0, nsplit, _stream()),
+              "psld_conv3x3_wgrad_xlimb_f32")
+        return
     check(lib().psld_conv3x3_wgrad_split_f32(dy.data_ptr(), cout, cout, x.data_ptr(), cin, _p(x2), cin2, b, h, w,
                                              slabs.data_ptr(), cin_total, col0, nsplit, _stream()),
           "psld_conv3x3_wgrad_split_f32")

@@ -229,7 +229,7 @@ class _Exec:
         import os as _os
         self.limb_planes = _os.environ.get("PSLD_LIMB_PLANES", "1") != "0"    # A/B switch for tools/bench_sample.py
         # pass 1 of GroupNorm's backward from the epilogue of the kernel that produces its dy (A/B switch)
-        self.fuse_gn_bwd = _os.environ.get("PSLD_FUSE_GN_BWD", "1") != "0"
+        self.fuse_gn_bwd = _os.environ.get("PSLD_FUSE_GN_BWD", "0") == "1"    # measured: -0.8 % on the step
         self.dx_nchw = None
 
     # -- helpers ------------------------------------------------------------------------------
@@ -540,14 +540,18 @@ class _Exec:
             gam, bet = gn0.weight.detach(), gn0.bias.detach()
             st0 = self.node_stats(x, gam[:c1], bet[:c1], groups=g1)
             st0b = self.node_stats(xb, gam[c1:], bet[c1:], groups=g2)
-        # Forward-only passes (sampling) hand the activations to the 3x3 convolutions as bf16 limb planes: GroupNorm's
-        # apply pass writes them already split (6 B per element instead of 4) and the convolution stages its halo tile
-        # by LDS-DMA with no split in the MFMA kernel (ops.conv3x3_split on LimbPlanes; bitwise the same result).  The
-        # training tape keeps fp32: the weight-gradient kernels read these tensors as fp32 x operands.
-        lp0 = (not self.record) and self.split and self.limb_planes and not (up or down) and \
-            ops.conv3x3_split_supported(c1, cin - c1, b, h, w, cout)
-        lp1 = (not self.record) and self.split and self.limb_planes and ops.conv3x3_split_supported(cout, 0, b, h // 2 if down else (h * 2 if up else h),
-                                                                               w // 2 if down else (w * 2 if up else w), cout)
+        # The activations go to the 3x3 convolutions as bf16 LIMB PLANES: GroupNorm's apply pass writes them already
+        # split (6 B per element instead of 4), the forward convolution stages its halo tile by LDS-DMA with no split in
+        # the MFMA kernel and the weight gradient stages its x operand without one (ops.conv3x3_split /
+        # conv3x3_wgrad_split on LimbPlanes; both bitwise the fp32-input result).  Blocks that resample between the
+        # normalisation and the convolution (up / down) keep fp32.
+        ho_, wo_ = (h // 2, w // 2) if down else ((h * 2, w * 2) if up else (h, w))
+        c2_ = cin - c1
+        lp0 = self.split and self.limb_planes and not (up or down) and ops.conv3x3_split_supported(c1, c2_, b, h, w, cout) and \
+            (not self.record or (ops.conv3x3_wgrad_split_supported(cout, c1, b, h, w) and
+                                 (c2_ == 0 or ops.conv3x3_wgrad_split_supported(cout, c2_, b, h, w))))
+        lp1 = self.split and self.limb_planes and ops.conv3x3_split_supported(cout, 0, b, ho_, wo_, cout) and \
+            (not self.record or ops.conv3x3_wgrad_split_supported(cout, cout, b, ho_, wo_))
         apply0 = ops.gn_apply_limb if lp0 else ops.gn_apply
         if xb is not None:
             a0b = apply0(xb.v, st0b, True)

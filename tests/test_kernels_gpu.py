@@ -341,6 +341,45 @@ def test_gn_backward_pass1_from_the_conv_epilogue(ops, act, drop_p):
         assert rel_l2(part[:, :, 0], s1) < 2e-6 and rel_l2(part[:, :, 1], s2) < 2e-6
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(b=2, ci=128, co=64, h=8, w=8),
+    dict(b=3, ci=128, co=128, h=16, w=16),
+    dict(b=1, ci=256, co=64, h=32, w=32),
+    dict(b=1, ci=128, co=64, h=64, w=64),
+    dict(b=2, ci=128, co=256, h=32, w=32),
+])
+def test_conv3x3_wgrad_with_x_as_limb_planes(ops, cfg):
+    """psld_conv3x3_wgrad_xlimb_f32: the x operand staged from limb planes without a split - bitwise the result of the
+    kernel that splits fp32 x itself (same products, same order), on short last K ranges and column offsets."""
+    b, ci, co, h, w_ = (cfg[n] for n in ("b", "ci", "co", "h", "w"))
+    x = _nhwc(gen(b, ci, h, w_, seed=60)).to(DEV)
+    gy = _nhwc(gen(b, co, h, w_, seed=62)).to(DEV)
+    ktiles = b * h * w_ // 32
+    nsplit = min(3, ktiles)
+    per = -(-ktiles // nsplit)
+    nsplit = -(-ktiles // per)
+    cin_total, col0 = ci + 64, 64
+    ref = torch.zeros((nsplit, co, 9, cin_total), device=DEV)
+    ops.conv3x3_wgrad_split(gy, co, x, ref, cin_total, col0, nsplit)
+    xl = ops.f32_to_limb(x)
+    for rep in range(2):
+        got = torch.zeros_like(ref)
+        ops.conv3x3_wgrad_split(gy, co, xl, got, cin_total, col0, nsplit)
+        assert torch.equal(got, ref), (cfg, rep, rel_l2(got, ref))
+
+
+def test_conv3x3_wgrad_limb_x_two_sources(ops):
+    b, c1, c2, co, s_ = 2, 128, 256, 128, 16
+    x = gen(b, c1 + c2, s_, s_, seed=70)
+    gyd = _nhwc(gen(b, co, s_, s_, seed=71)).to(DEV)
+    x1, x2 = _nhwc(x[:, :c1]).to(DEV), _nhwc(x[:, c1:]).to(DEV)
+    ref = torch.zeros((2, co, 9, c1 + c2), device=DEV)
+    ops.conv3x3_wgrad_split(gyd, co, x1, ref, c1 + c2, 0, 2, x2)
+    got = torch.zeros_like(ref)
+    ops.conv3x3_wgrad_split(gyd, co, ops.f32_to_limb(x1), got, c1 + c2, 0, 2, ops.f32_to_limb(x2))
+    assert torch.equal(got, ref)
+
+
 def test_gn_apply_limb_planes_match_the_fp32_pass(ops):
     """psld_gn_apply_limb_nhwc writes exactly the limb decomposition of what psld_gn_apply_nhwc_f32 writes (same
     affine, SiLU and dropout mask)."""

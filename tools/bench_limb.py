@@ -55,5 +55,39 @@ def main():
               f"limb-in {fl / m1 / 1e12:6.1f} TF (best {fl / min(t1s) / 1e12:6.1f})   x{m0 / m1:.3f}   bitwise {same}")
 
 
+def wgrad():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--wgrad", action="store_true")
+    args = ap.parse_args()
+    B = args.batch
+    ops.lib()
+    for (cin, cout, s) in [(256, 256, 32), (512, 256, 32), (256, 256, 16), (512, 256, 16), (256, 256, 8), (512, 256, 8)]:
+        x = torch.randn(B, s, s, cin, device=DEV)
+        dy = torch.randn(B, s, s, cout, device=DEV)
+        fl = 2.0 * B * s * s * cout * 9 * cin
+        kt = B * s * s // 32
+        tiles = (cout // 128) * (cin // 64)
+        ns = max(1, min(512 // (3 * tiles), kt // 4))
+        per = -(-kt // ns)
+        ns = -(-kt // per)
+        s0, s1 = torch.empty(ns, cout, 9, cin, device=DEV), torch.empty(ns, cout, 9, cin, device=DEV)
+        xl = ops.f32_to_limb(x)
+        f0 = lambda: ops.conv3x3_wgrad_split(dy, cout, x, s0, cin, 0, ns)
+        f1 = lambda: ops.conv3x3_wgrad_split(dy, cout, xl, s1, cin, 0, ns)
+        ts = [[], []]
+        for _ in range(args.rounds):
+            for i, f in enumerate((f0, f1)):
+                ts[i].append(timeit(f, args.iters))
+        m = [sorted(t)[len(t) // 2] for t in ts]
+        print(f"wgrad {cin}->{cout} @{s} B={B} (split {ns}): x fp32 {fl / m[0] / 1e12:6.1f} TF   x limb planes {fl / m[1] / 1e12:6.1f} TF "
+              f"x{m[0] / m[1]:.3f}   bitwise {bool(torch.equal(s0, s1))}")
+
+
 if __name__ == "__main__":
+    if "--wgrad" in sys.argv:
+        wgrad()
+        sys.exit(0)
     main()
