@@ -620,7 +620,7 @@ class _Exec:
                     ops.axpby(self.g(mod.Conv_1.bias), 1.0, None, 0.0, self.g(mod.Conv_2.bias))
 
             self.on_side(side1, dout, a1, xr_saved, xb_v)
-            da1 = torch.empty_like(a1)
+            da1 = torch.empty_like(h1)
             limb1 = self.split and ops.conv3x3_split_supported(cout, 0, b, ho, wo, cout)
             gnb1 = self.gnb_for(h1, st1, gn1, True, drop_p, seed, seed_dev) if limb1 else None
             self.dgrad(dout, mod.Conv_1, 3, 1, 1, ho, wo, da1, alpha=s, gnb=gnb1)
@@ -661,7 +661,7 @@ class _Exec:
             if xb is not None:
                 self._resblock_cat_bwd(mod, x, xb, dout, dh1, st0, st0b, g1, g2)
                 return
-            da0r = torch.empty_like(a0r)
+            da0r = torch.empty((b, ho, wo, cin), device=dout.device, dtype=torch.float32)
             limb0 = self.split and not (up or down) and ops.conv3x3_split_supported(cout, 0, b, ho, wo, cin)
             gnb0 = self.gnb_for(x.v, st0, gn0, True) if limb0 else None
             self.dgrad(dh1, mod.Conv_0, 3, 1, 1, ho, wo, da0r, gnb=gnb0)
