@@ -119,6 +119,24 @@ def physical_cores():
             keep.append(c)
     if len(keep) * 4 < len(allowed):      # fewer than a quarter survive: the topology is not believable
         keep = allowed
+    # a container's CPU quota (cgroup v2 cpu.max / v1 cfs_quota) bounds what threads can actually run: more threads than
+    # that only spin against the throttle (a 256-CPU box with a 16-CPU quota ran 128 threads 20x slower than 16)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = fh.read().split()[:2]
+            if q != "max":
+                quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, per = int(fq.read()), int(fp.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota >= 1:
+        keep = keep[:max(1, int(quota))]
     return keep
 
 
@@ -130,6 +148,7 @@ def cpu_baseline(cfg, batch=16, timed=3, budget_s=150.0):
     from tests.synth import synth_inputs
     cores = physical_cores()
     os.sched_setaffinity(0, cores)
+    os.environ["OMP_NUM_THREADS"] = str(len(cores))
     torch.set_num_threads(len(cores))
     torch.manual_seed(0)
     net = NCSNpp(cfg)
@@ -168,6 +187,7 @@ def cpu_baseline(cfg, batch=16, timed=3, budget_s=150.0):
         t0 = time.perf_counter()
         O.train_step(sde, sd, cfg, x0, t, eps, opt_state, i + 1, ema_sd=ema_sd, dropout_masks=masks)
         times.append(time.perf_counter() - t0)
+        print(f"cpu_baseline: step {i} {times[-1]:.1f} s on {len(cores)} threads", file=sys.stderr, flush=True)
         if i >= 1 and time.perf_counter() - t_begin > budget_s:      # bounded sample: at least one timed step
             break
     steps = sorted(times[1:])

@@ -165,6 +165,21 @@ class PSLDOracle:
         sm = -bcast(c21, ex).type(f32) * ex - bcast(c22, em).type(f32) * em
         return torch.cat([sx, sm], dim=1)
 
+    # psld.py:289-328 (one time for the whole batch: the reference builds a 2x2 tensor from b_t)
+    def predict_x_from_eps(self, z_t, eps, t):
+        l11, l12, l21, l22 = self.coeff(self.cov(0.0, self.mm_0, t))
+        eps_x, eps_m = torch.chunk(eps, 2, dim=1)
+        z_x, z_m = torch.chunk(z_t, 2, dim=1)
+        mu_x = z_x - (l11 * eps_x + l12 * eps_m)
+        mu_m = z_m - (l21 * eps_x + l22 * eps_m)
+        b_t = self.b_t(t)
+        sf = torch.exp((self.nu + self.gamma) / 4 * b_t)
+        a1, a2 = (self.nu - self.gamma) / 4, (self.gamma - self.nu) ** 2 / 8
+        c1, c2 = -0.5, (self.gamma - self.nu) / 4
+        cm = torch.tensor([[a1 * b_t + 1, a2 * b_t], [c1 * b_t, c2 * b_t + 1]])
+        ci = torch.linalg.inv(cm) * sf
+        return ci[0, 0] * mu_x + ci[0, 1] * mu_m, ci[1, 0] * mu_x + ci[1, 1] * mu_m
+
     # psld.py:330-343
     def sde(self, u, t):
         x, m = torch.chunk(u, 2, dim=1)

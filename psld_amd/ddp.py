@@ -30,7 +30,14 @@ def init_distributed(backend: Optional[str] = None, force: bool = False) -> Tupl
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            if world == 1:          # single-rank rehearsal: any free port (a fixed one may still be held by a previous run)
+                import socket
+                with socket.socket() as s:
+                    s.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+            else:
+                os.environ["MASTER_PORT"] = "29500"
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
         if backend == "nccl":

@@ -797,6 +797,9 @@ def guide(x: Tensor, grad: Tensor, coef_x: float, coef_m: float, x_f32: Optional
 def softmax_xent(logits: Tensor, labels: Tensor, loss_scale: float, grad_scale: float, want_grad: bool = True):
     """(loss 0-d f32, dlogits or None, correct 0-d f32): cross entropy of [rows][n] logits vs int64 labels."""
     rows, n = logits.shape
+    # a label outside [0, n) would index past the logits row in the kernel; torch's cross entropy raises for it - this
+    # is the device-side equivalent (no host synchronisation: the assert fires when the stream reaches it)
+    torch._assert_async(((labels >= 0) & (labels < n)).all(), f"softmax_xent: label outside [0, {n})")
     loss = torch.empty((), device=logits.device, dtype=torch.float32)
     correct = torch.empty((), device=logits.device, dtype=torch.float32)
     grad = torch.empty_like(logits) if want_grad else None

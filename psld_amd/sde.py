@@ -190,6 +190,27 @@ class PSLD:
             return u, mu, var, z
         return u, mu, var
 
+    def predict_x_from_eps(self, z_t, eps, t):
+        """psld.py:289-328: the (x_0, m_0) pair implied by a noisy state and an epsilon.  Like the reference this takes
+        ONE time for the whole batch (it builds a 2x2 matrix from ``b_t``); ``t`` may be a float or a one-element
+        tensor.  Off the training / sampling path (nothing in the reference calls it): composed from the coefficient
+        kernel and a handful of elementwise torch ops on the device tensors."""
+        tt = float(t) if not torch.is_tensor(t) else float(t.reshape(-1)[0])
+        tv = torch.full((1,), tt, dtype=torch.float64, device=z_t.device)
+        var = self._cov(0.0, self.mm_0, tv)
+        l11, l12, l21, l22 = (c.reshape(()) for c in self.get_coeff(var))
+        eps_x, eps_m = torch.chunk(eps, 2, dim=1)
+        z_x, z_m = torch.chunk(z_t, 2, dim=1)
+        mu_x = z_x - (l11 * eps_x + l12 * eps_m)
+        mu_m = z_m - (l21 * eps_x + l22 * eps_m)
+        b = self.b_t(tt)
+        sf = math.exp((self.nu + self.gamma) / 4 * b)
+        a1, a2 = (self.nu - self.gamma) / 4, (self.gamma - self.nu) ** 2 / 8
+        c1, c2 = -0.5, (self.gamma - self.nu) / 4
+        cm = torch.tensor([[a1 * b + 1, a2 * b], [c1 * b, c2 * b + 1]], device=z_t.device, dtype=torch.float64)  # t is f64 there
+        ci = torch.linalg.inv(cm) * sf
+        return ci[0, 0] * mu_x + ci[0, 1] * mu_m, ci[1, 0] * mu_x + ci[1, 1] * mu_m
+
     def perturb_f32(self, x_0, m_0, xx_0, mm_0, t, eps) -> Tensor:
         """Training fast path: only the f32 state that feeds the network."""
         tb = self._coeff_table(t, xx_0, mm_0)

@@ -476,6 +476,16 @@ def test_sde_interface_matches_oracle(golden):
         bad.reverse_sde(uu, torch.full((4,), 1.0, dtype=torch.float64, device=DEV), fake)   # T - t = 0: xx = -1
 
 
+def test_predict_x_from_eps_matches_reference(golden):
+    from psld_amd.registry import get_module
+    g = golden("predict_x.npz")
+    sde = get_module("sde", "psld")(C.c10_sota())
+    for i, tv in enumerate(g["t"]):
+        x, m = sde.predict_x_from_eps(T(g["z"]).to(DEV), T(g["eps"]).to(DEV), torch.tensor(tv, dtype=torch.float64))
+        assert x.dtype == torch.float32
+        assert rel_l2(x, T(g[f"x_{i}"])) < 1e-6 and rel_l2(m, T(g[f"m_{i}"])) < 1e-6
+
+
 def test_dropout_mask_statistics_and_gradient_consistency():
     """In-kernel counter-based dropout: keep rate ~ 1-p, and forward/backward use the same mask
     (checked against the oracle fed with the mask extracted from the kernel)."""

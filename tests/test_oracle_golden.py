@@ -451,3 +451,13 @@ def test_vpsde_score_loss_weightings(golden, tag):
     for k in g.files:
         if k.startswith(f"g_{tag}:"):
             assert rel_l2(p[k.split(":", 1)[1]].grad, T(g[k])) < 2e-5, k
+
+
+def test_predict_x_from_eps(golden):
+    """psld.py:289-328 against the reference (three times, f32 state)."""
+    g = golden("predict_x.npz")
+    sde = make_sde()
+    for i, tv in enumerate(g["t"]):
+        x, m = sde.predict_x_from_eps(T(g["z"]), T(g["eps"]), torch.tensor(tv, dtype=torch.float64))
+        assert x.dtype == torch.float32
+        assert torch.equal(x, T(g[f"x_{i}"])) and torch.equal(m, T(g[f"m_{i}"]))

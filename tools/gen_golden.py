@@ -239,11 +239,25 @@ def vp_loss_section(get, C):
     save("vploss_tiny.npz", **out)
 
 
+def predict_x_section(get, C):
+    """PSLD.predict_x_from_eps (psld.py:289-328): API surface off the hot path, one time per call."""
+    print("predict_x_from_eps")
+    sde = get("sde", "psld")(C.c10_sota())
+    g = torch.Generator().manual_seed(77)
+    z = torch.randn(2, 6, 8, 8, generator=g)
+    eps = torch.randn(2, 6, 8, 8, generator=g)
+    out = {"z": z, "eps": eps, "t": np.array([0.05, 0.37, 0.9])}
+    for i, tv in enumerate(out["t"]):
+        x, m = sde.predict_x_from_eps(z, eps, torch.tensor(tv, dtype=torch.float64))
+        out[f"x_{i}"], out[f"m_{i}"] = x, m
+    save("predict_x.npz", **out)
+
+
 def main():
     util = import_reference()
     if "--only" in sys.argv:
         which = sys.argv[sys.argv.index("--only") + 1]
-        {"inpaint": inpaint_section, "clf": clf_section, "em_c10": em_c10_section, "vp_loss": vp_loss_section}[which](util.get_module, C)
+        {"inpaint": inpaint_section, "clf": clf_section, "em_c10": em_c10_section, "vp_loss": vp_loss_section, "predict_x": predict_x_section}[which](util.get_module, C)
         return
     get = util.get_module
     PSLD = get("sde", "psld")
@@ -612,6 +626,7 @@ def main():
     clf_section(get, C)
     em_c10_section(get, C)
     vp_loss_section(get, C)
+    predict_x_section(get, C)
     print("done")
 
 

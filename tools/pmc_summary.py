@@ -1,6 +1,7 @@
-"""Per-kernel averages of a rocprofv3 --pmc pass (csv): effective clock (GRBM_GUI_ACTIVE / 8 XCDs / duration),
-MFMA-busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES per the guide's units), VALU instructions, LDS
-conflicts.   python tools/pmc_summary.py <dir>"""
+"""Per-kernel averages of a rocprofv3 --pmc pass (csv), as profiles/r01/pmc_tile_kernels.md reads them: effective clock =
+GRBM_GUI_ACTIVE / 8 XCDs / duration; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (duration x clock x 1024 SIMDs); VALU
+instructions; LDS conflict cycles / LDS active cycles.   python tools/pmc_summary.py <dir>"""
+import re
 import csv
 import glob
 import os
@@ -16,7 +17,8 @@ def main():
     for f in files:
         with open(f, newline="") as fh:
             for row in csv.DictReader(fh):
-                name = row["Kernel_Name"].split("(")[0][-60:]
+                m = re.search(r"(\w+(?:<[^>]*>)?)\(", row["Kernel_Name"].replace("(anonymous namespace)::", ""))
+                name = m.group(1) if m else row["Kernel_Name"][:60]
                 acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
                 if row.get("Start_Timestamp") and row.get("End_Timestamp"):
                     dur[(name, row.get("Dispatch_Id"))] = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
@@ -32,7 +34,7 @@ def main():
         if not (us > 20):
             continue
         clock = avg("GRBM_GUI_ACTIVE") / 8 / (us * 1e3) if us == us else float("nan")
-        busy = avg("SQ_VALU_MFMA_BUSY_CYCLES") / (avg("SQ_BUSY_CYCLES") * 4) if avg("SQ_BUSY_CYCLES") else float("nan")
+        busy = avg("SQ_VALU_MFMA_BUSY_CYCLES") / (us * 1e3 * clock * 1024) if clock == clock and clock > 0 else float("nan")
         ldsc = avg("SQ_LDS_BANK_CONFLICT") / avg("SQ_LDS_IDX_ACTIVE") if avg("SQ_LDS_IDX_ACTIVE") else float("nan")
         print(f"| {name} | {n} | {us:.1f} | {clock:.2f} | {busy:.3f} | {avg('SQ_INSTS_VALU'):.3g} | {ldsc:.3f} |")
     print("\nraw per-kernel averages (all counters):")
