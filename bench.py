@@ -367,6 +367,10 @@ def main():
         one = torch.ones(1, device=torch.device("cuda", local) if on_dev else "cpu")
         dist.all_reduce(one)
         ones_ok = float(one.item()) == float(world)
+        # RCCL writes its version banner through C stdio when the first communicator comes up; push it out NOW so that the
+        # JSON line below stays the last line of stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
         if not ones_ok:
             print(f"bench.py: all-reduce of ones gave {one.item()} on a world of {world}", file=sys.stderr)
             return 3
@@ -534,6 +538,9 @@ def main():
         if world == 1 and args.sample_batch > 0 and args.config == "c10_sota":
             out["sampling"] = sampling_run(cfg, ema, sde, dev, args.sample_batch, max(3, args.sample_steps))
         out["cpu_baseline"] = cpu_base
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
         print(json.dumps(out), flush=True)
     if dist_on:
         barrier()

@@ -766,6 +766,11 @@ def test_pointwise_and_reductions(ops):
         assert rel_l2(dx, refdx) < 1e-5
 
 
+# measured on MI355X (round 2): max abs 4.8e-4, rel-L2 9.4e-5 (1 ulp of logf at ~1e4 rad moves sin/cos by ~1e-3);
+# asserted at 2x that
+TIME_EMBED_ABS, TIME_EMBED_REL = 1e-3, 2e-4
+
+
 def test_time_embedding(ops, golden):
     g = golden("layers.npz")
     t = torch.from_numpy(g["gfp.t"])
@@ -774,8 +779,9 @@ def test_time_embedding(ops, golden):
     y = ops.time_embed(t.to(DEV), W.to(DEV), True)
     ref = torch.from_numpy(g["gfp.y"])
     # arguments reach ~1e4 rad: 1 ulp of logf moves sin/cos by ~1e-3 there; typical error is far lower
-    assert (y.cpu() - ref).abs().max().item() < 2e-3
-    assert rel_l2(y, ref) < 2e-4
+    e_abs, e_rel = (y.cpu() - ref).abs().max().item(), rel_l2(y, ref)
+    print(f"time embedding vs reference: max abs {e_abs:.3e}, rel-L2 {e_rel:.3e}")
+    assert e_abs < TIME_EMBED_ABS and e_rel < TIME_EMBED_REL
     tt = torch.tensor([3.0, 999.0])
     freq = torch.exp(torch.arange(16, dtype=torch.float32) * -(math.log(10000) / 15))
     y = ops.time_embed(tt.to(DEV), freq.to(DEV), False)
