@@ -221,7 +221,7 @@ def test_hsm_loss_and_gradients(golden):
     assert abs(ld.item() - float(g["loss_dsm"])) < 2e-5 * abs(float(g["loss_dsm"]))
 
 
-PARAM_DELTA_REL = 2e-2     # re-measured below; tightened to ~2x the measured worst case
+PARAM_DELTA_REL = 5e-5     # measured on MI355X (round 2): 1.5e-5 worst over parameters whose delta exceeds 1e-6
 
 
 def test_three_training_steps(golden):
