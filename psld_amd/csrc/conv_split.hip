@@ -305,20 +305,104 @@ __device__ __forceinline__ void dconv_epilogue(const DConvArgs& a, f32x4v (&acc)
     }
 }
 
+// The same epilogue for a 128 (pixels) x 32 (channels) wave tile: 8 x 2 accumulator blocks at (m0, n0 + wave*32) - the
+// wave decomposition of dconv_lp_kernel<.., N32 = true>, where the four waves of a workgroup split the 128 output
+// channels instead of sharing them two by two (each weight fragment is then loaded by ONE wave: half the L2 -> CU
+// fragment stream).  GroupNorm partial sums per 64-row run (block rows 0-3 / 4-7).  No gnb by-product here.
+__device__ __forceinline__ void dconv_epilogue_n32(const DConvArgs& a, f32x4v (&acc)[8][2], int m0, int nw0, int lane,
+                                                   int split) {
+    const int r16 = lane & 15, kq = lane >> 4;
+    float* Cb = a.C + (long long)split * a.c_stride_split;
+    const PsldEpilogue& e = a.e;
+    const bool rb_uniform = e.rowbias && (e.rows_per_img % 16 == 0);
+    const int cn0 = nw0 + 4 * kq;
+    const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4v bias4[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+        bias4[nb] = e.bias ? *reinterpret_cast<const f32x4v*>(e.bias + cn0 + nb * 16) : zero4;
+    float gs[2][2], gss[2][2];           // [64-row run][block column]
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) gs[r][nb] = gss[r][nb] = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+        const int row_base = m0 + mb * 16;
+        if (row_base >= a.M) continue;                      // wave-uniform
+        const int gm = min(row_base + r16, a.M - 1);
+        const bool ok = row_base + r16 < a.M;
+        const long long coff = (long long)gm * a.ldc, roff = (long long)gm * e.ldres;
+        const long long toff = (long long)((rb_uniform ? row_base : gm) / e.rows_per_img) * e.ld_rowbias;
+        f32x4v rv[2], cv[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int gn = cn0 + nb * 16;
+            rv[nb] = e.res ? *reinterpret_cast<const f32x4v*>(e.res + roff + gn) : zero4;
+            cv[nb] = e.accumulate ? *reinterpret_cast<const f32x4v*>(Cb + coff + gn) : zero4;
+            const f32x4v tb = e.rowbias ? *reinterpret_cast<const f32x4v*>(e.rowbias + toff + gn) : zero4;
+            acc[mb][nb] = acc[mb][nb] * e.alpha + (bias4[nb] + tb);
+        }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int gn = cn0 + nb * 16;
+            f32x4v o = acc[mb][nb];
+            if (e.res) o += rv[nb];
+            o *= e.out_scale;
+            if (e.accumulate) o += cv[nb];
+            if (ok) {
+                *reinterpret_cast<f32x4v*>(Cb + coff + gn) = o;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    gs[mb >> 2][nb] += o[v];
+                    gss[mb >> 2][nb] += o[v] * o[v];
+                }
+            }
+        }
+    }
+    if (e.gn_part) {
+        const int fine = a.N >> 3, chunks = e.gn_hw >> 6;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int row0 = m0 + r * 64;
+            if (row0 >= a.M) continue;
+            const int img = row0 / e.gn_hw, chunk = (row0 - img * e.gn_hw) >> 6;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                float s1 = gs[r][nb], s2 = gss[r][nb];
+#pragma unroll
+                for (int sft = 1; sft <= 16; sft <<= 1) {
+                    s1 += __shfl_xor(s1, sft, 64);
+                    s2 += __shfl_xor(s2, sft, 64);
+                }
+                if ((lane & 0x1f) == 0) {
+                    const int f = ((nw0 + nb * 16) >> 3) + (lane >> 5);
+                    double* pp = e.gn_part + (((long long)img * chunks + chunk) * fine + f) * 2;
+                    pp[0] = (double)s1;
+                    pp[1] = (double)s2;
+                }
+            }
+        }
+    }
+}
+
 // NH = float4 staging items per thread and stage: the LDS image has NH*32 pixel rows per limb.
 // TAPS = K steps (of 32 channels) served by one staged image: the 9 filter taps of a 3x3 convolution (PW = false:
 // the image is the halo tile of ONE 32-channel chunk, >= nseg*(rps+2)*(W+2) rows), or, for the pointwise kernel
 // (PW = true: plain NT GEMM / 1x1 convolution, the image is the tile's 128 rows), TAPS consecutive 32-channel chunks
 // stored one after the other (NH = 4*TAPS).
-template <int NH, int TAPS, bool PW>
+// N32: the four waves of a workgroup split the 128 output channels (wave tile 128 x 32: each weight fragment is loaded by
+// one wave) instead of a 2 x 2 arrangement of 64 x 64 tiles (every fragment loaded by two waves).
+template <int NH, int TAPS, bool PW, bool N32>
 __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
+    constexpr int MBK = N32 ? 8 : 4, NBK = N32 ? 2 : 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LIMB = NH * 32 * ROWB;
     static_assert(!PW || NH == 4 * TAPS, "pointwise staging: 128 rows x 8 quads per 32-channel chunk");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = N32 ? 0 : wave >> 1, wc = N32 ? wave >> 1 : wave & 1;
     const int c4 = tid & 7;
 
     const int tiles_n = a.N >> 7;
@@ -386,9 +470,9 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
     // TFLOP/s on 256->256 @32x32): the 64x64 wave tile is 4x4 blocks, one 32-deep K step per tap and chunk.
     // Lane l holds A[row = l & 15][k = 8*(l >> 4) + j]: LDS pixel row of its rows at tap (0, 0)
     const int r16 = lane & 15, kq = lane >> 4;
-    int abase[4];
+    int abase[MBK];
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
+    for (int mb = 0; mb < MBK; ++mb) {
         const int ml = wr * 64 + mb * 16 + r16;
         if constexpr (PW) {
             abase[mb] = ml;
@@ -401,22 +485,23 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
     }
 
     // B fragments of K step sigma = stage*TAPS + tap for this wave's 64 columns
-    const u32x4* wp = a.wfrag + ((long long)(tile_n * 2 + wc) * a.chunks * TAPS) * TAP_U4 + lane;
+    const u32x4* wp = a.wfrag + ((long long)(tile_n * 2 + wc) * a.chunks * TAPS) * TAP_U4 + lane +
+                      (N32 ? (wave & 1) * 2 * 3 * 64 : 0);      // a 32-column wave: blocks 2*(wave & 1), +1 of its half
     const int sig_beg = c_beg * TAPS, sig_end = c_end * TAPS;
-    u32x4 bq[2][4][3];
-    auto load_b = [&](int sigma, u32x4 (&dst)[4][3]) {
+    u32x4 bq[2][NBK][3];
+    auto load_b = [&](int sigma, u32x4 (&dst)[NBK][3]) {
         const u32x4* p = wp + (long long)min(sigma, sig_end - 1) * TAP_U4;
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
+        for (int nb = 0; nb < NBK; ++nb)
 #pragma unroll
             for (int l = 0; l < 3; ++l) dst[nb][l] = p[(nb * 3 + l) * 64];
     };
 
-    f32x4v acc[4][4];
+    f32x4v acc[MBK][NBK];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MBK; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NBK; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
     load_halo(c_beg);
     load_b(sig_beg, bq[0]);
@@ -431,9 +516,9 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
         const bool more = (c + 1) < c_end;
         if (tap == PREFETCH_TAP && more) load_halo(c + 1);
         load_b(sigma + 1, bq[pp ^ 1]);
-        u32x4 fa[4][3];
+        u32x4 fa[MBK][3];
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
+        for (int mb = 0; mb < MBK; ++mb) {
             const int prow = abase[mb] + tap_off;
             const unsigned char* q = smem + prow * ROWB + ((kq ^ lds_swz(prow)) << 4);
 #pragma unroll
@@ -444,9 +529,9 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
 #pragma unroll
         for (int t = 0; t < 6; ++t)
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
+            for (int mb = 0; mb < MBK; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb)
+                for (int nb = 0; nb < NBK; ++nb)
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(       // weights first: D^T (see dconv_epilogue)
                         __builtin_bit_cast(bf16x8, bq[pp][nb][PB[t]]), __builtin_bit_cast(bf16x8, fa[mb][PA[t]]),
                         acc[mb][nb], 0, 0, 0);
@@ -469,7 +554,8 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
         if (sigma + 1 < sig_end) step(sigma + 1, std::integral_constant<int, 1>{});
     }
 
-    dconv_epilogue(a, acc, m0, n0, wr, wc, lane, split);
+    if constexpr (N32) dconv_epilogue_n32(a, acc, m0, n0 + wave * 32, lane, split);
+    else dconv_epilogue(a, acc, m0, n0, wr, wc, lane, split);
 }
 
 // ---- forward / data-gradient on pre-split activations ("limb planes") ----------------------------------------------
@@ -482,8 +568,9 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
 // RG = 16-row groups per image (>= halo pixels / 16); wave w moves row groups w, w + 4, ...
 constexpr int LP_PIX_BYTES_PER_CH = 6;     // bytes per element of a limb-plane tensor
 
-template <int RG, bool DB>
+template <int RG, bool DB, bool N32>
 __global__ void __launch_bounds__(256, 2) dconv_lp_kernel(const DConvArgs a) {
+    constexpr int MBK = N32 ? 8 : 4, NBK = N32 ? 2 : 4;    // accumulator blocks per wave: 64 x 64 (2 x 2 waves) or 128 x 32 (1 x 4)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LIMB = RG * 16 * ROWB;
     constexpr int BUF = 3 * LIMB;
@@ -492,7 +579,7 @@ __global__ void __launch_bounds__(256, 2) dconv_lp_kernel(const DConvArgs a) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: uniform branches below
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = N32 ? 0 : wave >> 1, wc = N32 ? wave >> 1 : wave & 1;
 
     const int tiles_n = a.N >> 7;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -552,9 +639,9 @@ __global__ void __launch_bounds__(256, 2) dconv_lp_kernel(const DConvArgs a) {
     };
 
     const int r16 = lane & 15, kq = lane >> 4;
-    int abase[4];
+    int abase[MBK];
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
+    for (int mb = 0; mb < MBK; ++mb) {
         const int ml = wr * 64 + mb * 16 + r16;
         const int seg = ml / (a.rps * a.W);
         const int rem = ml - seg * (a.rps * a.W);
@@ -563,22 +650,25 @@ __global__ void __launch_bounds__(256, 2) dconv_lp_kernel(const DConvArgs a) {
     }
 
     const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
-    const u32x4* wp = a.wfrag + ((long long)(tile_n * 2 + wc) * a.chunks * TAPS) * TAP_U4 + lane;
+    // fragment buffer: [n tile][64-column half wc][chunk][tap][16-column block nb 4][limb 3][lane]; a 32-column wave takes
+    // blocks 2*(wave & 1) and 2*(wave & 1) + 1 of its half
+    const u32x4* wp = a.wfrag + ((long long)(tile_n * 2 + wc) * a.chunks * TAPS) * TAP_U4 + lane +
+                      (N32 ? (wave & 1) * 2 * 3 * 64 : 0);
     const int sig_beg = c_beg * TAPS, sig_end = c_end * TAPS;
-    u32x4 bq[2][4][3];
-    auto load_b = [&](int sigma, u32x4 (&dst)[4][3]) {
+    u32x4 bq[2][NBK][3];
+    auto load_b = [&](int sigma, u32x4 (&dst)[NBK][3]) {
         const u32x4* p = wp + (long long)min(sigma, sig_end - 1) * TAP_U4;
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
+        for (int nb = 0; nb < NBK; ++nb)
 #pragma unroll
             for (int l = 0; l < 3; ++l) dst[nb][l] = p[(nb * 3 + l) * 64];
     };
 
-    f32x4v acc[4][4];
+    f32x4v acc[MBK][NBK];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MBK; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NBK; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
     for (int i = 0; i < NRG; ++i) issue_dma(c_beg, 0, i);
@@ -604,33 +694,33 @@ __global__ void __launch_bounds__(256, 2) dconv_lp_kernel(const DConvArgs a) {
         // A fragments by inline-asm ds_read_b128: to hipcc an LDS read it can see may alias the image an in-flight DMA is
         // filling (same array), and it would wait vmcnt(0) in front of every one of them.  Issue order = use order
         // (limb lo, hi, mid: the six products are lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi), counted lgkmcnt waits.
-        u32x4 fa[4][3];
-        unsigned addr[4];
+        u32x4 fa[MBK][3];
+        unsigned addr[MBK];
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
+        for (int mb = 0; mb < MBK; ++mb) {
             const int prow = abase[mb] + tap_off;
             addr[mb] = lds_base + buf * BUF + prow * ROWB + ((kq ^ lds_swz(prow)) << 4);
         }
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
+        for (int mb = 0; mb < MBK; ++mb)
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[mb][2]) : "v"(addr[mb]), "n"(2 * LIMB) : "memory");
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
+        for (int mb = 0; mb < MBK; ++mb)
             asm volatile("ds_read_b128 %0, %1" : "=v"(fa[mb][0]) : "v"(addr[mb]) : "memory");
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
+        for (int mb = 0; mb < MBK; ++mb)
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[mb][1]) : "v"(addr[mb]), "n"(LIMB) : "memory");
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
-            if (t == 0) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-            if (t == 1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            if (t == 0) { if constexpr (N32) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); }
+            if (t == 1) { if constexpr (N32) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); }
             if (t == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (t <= 2) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
+            for (int mb = 0; mb < MBK; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb)
+                for (int nb = 0; nb < NBK; ++nb)
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(       // weights first: D^T (see dconv_epilogue)
                         __builtin_bit_cast(bf16x8, bq[pp][nb][PB[t]]), __builtin_bit_cast(bf16x8, fa[mb][PA[t]]),
                         acc[mb][nb], 0, 0, 0);
@@ -661,7 +751,8 @@ __global__ void __launch_bounds__(256, 2) dconv_lp_kernel(const DConvArgs a) {
         if (sigma + 1 < sig_end) step(sigma + 1, std::integral_constant<int, 1>{});
     }
 
-    dconv_epilogue(a, acc, m0, n0, wr, wc, lane, split);
+    if constexpr (N32) dconv_epilogue_n32(a, acc, m0, n0 + wave * 32, lane, split);
+    else dconv_epilogue(a, acc, m0, n0, wr, wc, lane, split);
 }
 
 // fp32 NHWC [rows][c] -> limb planes [rows][c/32][3][32] (tests, and producers without a fused writer)
@@ -1231,12 +1322,12 @@ int launch_dwgrad(const DWgradArgs& a, int nsplit, hipStream_t stream) {
     return PSLD_OK;
 }
 
-template <int NH, int TAPS, bool PW>
-int launch_dconv(const DConvArgs& a, int nsplit, hipStream_t stream, const char* name) {
+template <int NH, int TAPS, bool PW, bool N32>
+int launch_dconv_impl(const DConvArgs& a, int nsplit, hipStream_t stream, const char* name) {
     constexpr size_t LDS = (size_t)3 * NH * 32 * ROWB;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv_kernel<NH, TAPS, PW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv_kernel<NH, TAPS, PW, N32>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         if (e != hipSuccess) {
             psld_set_error("%s: hipFuncSetAttribute failed: %s", name, hipGetErrorString(e));
@@ -1245,17 +1336,28 @@ int launch_dconv(const DConvArgs& a, int nsplit, hipStream_t stream, const char*
         configured = true;
     }
     dim3 grid((unsigned)(cdiv(a.M, 128) * (a.N / 128)), (unsigned)nsplit);
-    hipLaunchKernelGGL((dconv_kernel<NH, TAPS, PW>), grid, dim3(256), LDS, stream, a);
+    hipLaunchKernelGGL((dconv_kernel<NH, TAPS, PW, N32>), grid, dim3(256), LDS, stream, a);
     PSLD_CHECK_LAUNCH(name);
     return PSLD_OK;
 }
 
-template <int RG, bool DB>
+inline bool dconv_n32(const DConvArgs& a) {
+    static const int n32env = [] { const char* v = getenv("PSLD_DCONV_N32"); return v ? atoi(v) : 1; }();
+    return n32env && !a.e.gnb_part;        // the GroupNorm-backward by-product exists in the 2 x 2 layout only
+}
+
+template <int NH, int TAPS, bool PW>
+int launch_dconv(const DConvArgs& a, int nsplit, hipStream_t stream, const char* name) {
+    return dconv_n32(a) ? launch_dconv_impl<NH, TAPS, PW, true>(a, nsplit, stream, name)
+                        : launch_dconv_impl<NH, TAPS, PW, false>(a, nsplit, stream, name);
+}
+
+template <int RG, bool DB, bool N32>
 int launch_dconv_lp(const DConvArgs& a, int nsplit, hipStream_t stream, const char* name) {
     constexpr size_t LDS = (size_t)(DB ? 2 : 1) * 3 * RG * 16 * ROWB;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv_lp_kernel<RG, DB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv_lp_kernel<RG, DB, N32>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         if (e != hipSuccess) {
             psld_set_error("%s: hipFuncSetAttribute failed: %s", name, hipGetErrorString(e));
@@ -1264,7 +1366,7 @@ int launch_dconv_lp(const DConvArgs& a, int nsplit, hipStream_t stream, const ch
         configured = true;
     }
     dim3 grid((unsigned)(cdiv(a.M, 128) * (a.N / 128)), (unsigned)nsplit);
-    hipLaunchKernelGGL((dconv_lp_kernel<RG, DB>), grid, dim3(256), LDS, stream, a);
+    hipLaunchKernelGGL((dconv_lp_kernel<RG, DB, N32>), grid, dim3(256), LDS, stream, a);
     PSLD_CHECK_LAUNCH(name);
     return PSLD_OK;
 }
@@ -1449,9 +1551,15 @@ extern "C" int psld_conv3x3_limb_f32(const void* x1, int c1, const void* x2, int
     static const int single = [] { const char* v = getenv("PSLD_LP_SINGLE_BUFFER"); return v ? atoi(v) : 0; }();
     int st;
     // two images of RG <= 13 row groups (79,872 B) leave room for two workgroups per CU (163,840 B of LDS)
-    if (rg <= 12) st = single ? launch_dconv_lp<12, false>(a, ns, stream, name) : launch_dconv_lp<12, true>(a, ns, stream, name);
-    else if (rg <= 13) st = single ? launch_dconv_lp<13, false>(a, ns, stream, name) : launch_dconv_lp<13, true>(a, ns, stream, name);
-    else st = launch_dconv_lp<18, false>(a, ns, stream, name);
+    // wave decomposition: 1 x 4 waves of 128 x 32 (each weight fragment loaded once per workgroup) unless the epilogue has
+    // to produce the GroupNorm-backward by-product (2 x 2 layout only) or PSLD_DCONV_N32=0 asks for the old layout
+    static const int n32env = [] { const char* v = getenv("PSLD_DCONV_N32"); return v ? atoi(v) : 1; }();
+    const bool n32 = n32env && !e.gnb_part;
+    if (rg <= 12) st = single ? launch_dconv_lp<12, false, false>(a, ns, stream, name)
+                   : (n32 ? launch_dconv_lp<12, true, true>(a, ns, stream, name) : launch_dconv_lp<12, true, false>(a, ns, stream, name));
+    else if (rg <= 13) st = single ? launch_dconv_lp<13, false, false>(a, ns, stream, name)
+                        : (n32 ? launch_dconv_lp<13, true, true>(a, ns, stream, name) : launch_dconv_lp<13, true, false>(a, ns, stream, name));
+    else st = n32 ? launch_dconv_lp<18, false, true>(a, ns, stream, name) : launch_dconv_lp<18, false, false>(a, ns, stream, name);
     if (st != PSLD_OK) return st;
     if (ns >= 2) return psld_detail_conv_reduce_epilogue(a.C, ns, a.M, cout, y, ldy, e, stream);
     return PSLD_OK;
