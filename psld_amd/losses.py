@@ -43,6 +43,10 @@ class PSLDScoreLoss(nn.Module):
         self.decomp_mode = config.model.sde.decomp_mode
         self.reduce_strategy = "mean" if config.training.loss.reduce_mean else "sum"
 
+    def prefetch(self, t):
+        """The perturbation coefficients ``forward`` will ask for (SDEWrapper computes and checks them early)."""
+        self.sde.prefetch_coeffs(t, 0, self.sde.mm_0 if self.mode == "hsm" else 0.0)
+
     def forward(self, x_0, t, score_fn, eps=None, m_draw=None):
         """``eps`` / ``m_draw``: the two normal draws of losses.py:96,108 when the caller has made them already (tests;
         the captured training step, which keeps every RNG call outside its hipGraph)."""

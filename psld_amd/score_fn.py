@@ -162,6 +162,9 @@ class _CatNode:
         self.b = b
 
 
+_OVERLAP_MAX_PIXELS = 65536     # batch x H x W at the input resolution up to which weight gradients go to a side stream
+
+
 def _gbuf(node: _Node):
     """Gradient buffer of a node and whether it already holds a partial sum."""
     if node.g is None:
@@ -223,7 +226,10 @@ class _Exec:
         self.watermark = None  # callable(flat_offset) for the DDP reducer
         # weight / bias gradients are off the dependency chain of backward: they run on a side HIP stream so
         # that their MFMA-bound kernels overlap the HBM-bound kernels of the chain (GN backward, reductions)
-        self.side = net._side_stream() if (record and net.overlap_wgrad) else None
+        # (decided in _run, once the batch is known: net.overlap_wgrad None = automatic)
+        self.side = None
+        self.side_queue = []        # (fn, tensors) waiting for the next fork
+        self.side_group = net.side_group
         self.want_dx = False        # gradient w.r.t. the network input requested (x.requires_grad)
         self.split = ops.math_mode() == "bf16x6"   # 3x3 convs on the bf16 limb kernels (csrc/conv_split.hip)
         import os as _os
@@ -242,21 +248,35 @@ class _Exec:
 
     def on_side(self, fn, *tensors):
         """Run ``fn`` (kernel launches only) on the side stream, ordered after everything queued so far
-        on the compute stream.  ``tensors`` are inputs that the compute stream may free afterwards."""
+        on the compute stream.  ``tensors`` are inputs that the compute stream may free afterwards.
+        The work is forked in groups of ``side_group`` calls: one event + one stream wait per group instead of per call
+        (a cross-stream edge costs ~3.5 us inside a captured graph and ~10 us of host time outside; measured with
+        tools/scratch/graph_cross.py).  Until its group is launched a call keeps its inputs alive by reference."""
         if self.side is None:
             fn()
             return
+        self.side_queue.append((fn, tensors))
+        if len(self.side_queue) >= self.side_group:
+            self.flush_side()
+
+    def flush_side(self):
+        if not self.side_queue:
+            return
+        queue, self.side_queue = self.side_queue, []
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         self.side.wait_event(ev)
         with torch.cuda.stream(self.side), ops.stream_scope():
-            fn()
-        for t in tensors:
-            if t is not None:
-                t.record_stream(self.side)
+            for fn, _ in queue:
+                fn()
+        for _, tensors in queue:
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(self.side)
 
     def join_side(self):
         if self.side is not None:
+            self.flush_side()
             torch.cuda.current_stream().wait_stream(self.side)
 
     def wgrad(self, dy: Tensor, x: Tensor, conv: _Affine, k: int, stride: int, pad: int, alpha: float = 1.0,
@@ -665,7 +685,7 @@ class _Exec:
             limb0 = self.split and not (up or down) and ops.conv3x3_split_supported(cout, 0, b, ho, wo, cin)
             gnb0 = self.gnb_for(x.v, st0, gn0, True) if limb0 else None
             self.dgrad(dh1, mod.Conv_0, 3, 1, 1, ho, wo, da0r, gnb=gnb0)
-            del dh1
+            # (no `del dh1`: side0 above may still be waiting for its fork and looks the name up when it runs)
             xg, acc = _gbuf(x)
             identity = False
             if mod.has_shortcut:
@@ -968,6 +988,12 @@ class _Exec:
         stem = mods[mi]
         mi += 1
         b, hh, ww, _ = x_nhwc.shape
+        if self.record:
+            # Parameter-gradient kernels on a side stream.  Automatic rule: on while the kernels of the backward chain
+            # cannot fill the chip by themselves (32x32 images: B = 16 +9 %, B = 32 +5 %, B = 64 +1.3 %, B = 128 +0.3 % images/s - and per-kernel HIP
+            # event timings would be inflated by the concurrent MFMA kernel: off there)
+            use = net.overlap_wgrad if net.overlap_wgrad is not None else (b * hh * ww <= _OVERLAP_MAX_PIXELS)
+            self.side = net._side_stream() if use else None
         h0 = torch.empty((b, hh, ww, stem.weight.shape[0]), device=x.device, dtype=torch.float32)
         stem_small = x_nhwc.shape[-1] * 9 <= 64 and stem.weight.shape[0] % 4 == 0
         stem_cols = None
@@ -1105,6 +1131,7 @@ class _Exec:
         for fn, module in reversed(self.tape):
             fn()
             if module is not None and self.watermark is not None:
+                self.flush_side()       # the reducer may launch a bucket now: its gradients must at least be enqueued
                 self.watermark(net._module_offset(module))
         self.join_side()
         self.tape = None
@@ -1288,10 +1315,12 @@ class NCSNpp(nn.Module):
         self._reducer = None
         self._posfreq = None
         self._module_offs = None
-        # opt-in: parameter-gradient kernels on a side stream (+1.7 % measured at B=128; off by default so that
-        # per-kernel HIP-event timings are not inflated by a concurrent MFMA kernel)
+        # parameter-gradient kernels on a side stream: None = automatic (small batches, see _Exec._run); True / False or
+        # PSLD_OVERLAP_WGRAD=1 / 0 force it.  side_group: calls per fork (PSLD_SIDE_GROUP)
         import os as _os
-        self.overlap_wgrad = _os.environ.get("PSLD_OVERLAP_WGRAD", "0") == "1"
+        _ow = _os.environ.get("PSLD_OVERLAP_WGRAD")
+        self.overlap_wgrad = None if _ow is None else _ow == "1"
+        self.side_group = max(1, int(_os.environ.get("PSLD_SIDE_GROUP", "8")))
         # None (auto): parameters become inputs of the autograd node (gradients delivered through AccumulateGrad, so
         # torch DDP / Lightning's ddp strategy can reduce them) when a multi-rank process group exists and no
         # BucketReducer is attached; True / False (or PSLD_AUTOGRAD_PARAMS=1 / 0) force it.
@@ -1582,7 +1611,7 @@ class NCSNpp(nn.Module):
             target = self._scratch_grad
         if self._reducer is not None:
             self._reducer.begin(target)
-            self._reducer.producer_streams = [self._side] if (self.overlap_wgrad and self._side is not None) else []
+            self._reducer.producer_streams = [self._side] if self._side is not None else []
 
     def _watermark_hook(self, offset: int):
         if self._reducer is not None:

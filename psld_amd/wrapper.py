@@ -94,13 +94,35 @@ class SDEWrapper(_Base):
         OUTSIDE the graph into static device buffers, in the reference's order, so a seeded run consumes the RNG stream
         exactly like the eager step; the step-dependent Adam scalars and the LR-schedule value travel through a 2-float
         device buffer written before each replay.  The first ``warmup_steps`` steps of a shape run eagerly (they size
-        workspaces and weight caches).  Not captured: the NaN check of the perturbation coefficients (a host read),
-        gradient exchange (``set_reducer``), foreign optimizers."""
+        workspaces and weight caches).  The NaN check of the perturbation coefficients (a host read) stays outside the
+        graph, on the early stream of ``_draw_times``.  Not captured: gradient exchange (``set_reducer``), foreign
+        optimizers."""
         self._graphs_on = bool(flag)
         self._graph_warmup = int(warmup_steps)
         if not flag:
             self._graph_steps = {}
             self.score_fn._dropout_seed_dev = None
+
+    def _draw_times(self, b: int, dev):
+        """``t_ ~ U[0, 1)`` and ``t`` (wrapper.py:72-73) plus the NaN check of the perturbation coefficients
+        (psld.py:166-171, a host read) on a stream of their own that does NOT wait for the compute stream: none of it
+        depends on the previous step, and on the compute stream the flag read would make the host wait for the whole
+        queue of the previous step at every step boundary (4.4 ms of a 37 ms step at batch 16).  The random draw is
+        the first of the step on the host, so the device RNG stream is consumed in the reference's order."""
+        main = torch.cuda.current_stream(dev)
+        early = getattr(self, "_early", None)
+        if early is None or early.device != dev:
+            early = self._early = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(early):
+            t_ = torch.rand(b, device=dev, dtype=torch.float64)
+            t = t_ * (self.sde.T - self.train_eps) + self.train_eps
+            prefetch = getattr(self.criterion, "prefetch", None)
+            if prefetch is not None and getattr(self.sde, "check_nan", False):
+                prefetch(t)
+        main.wait_stream(early)
+        t_.record_stream(main)
+        t.record_stream(main)
+        return t_, t
 
     def _graph_ok(self, batch) -> bool:
         optim = self.optimizers()
@@ -131,7 +153,8 @@ class SDEWrapper(_Base):
             ent["hyper"] = torch.zeros(2, device=dev, dtype=torch.float32)
             ent["hyper_host"] = torch.zeros(2, dtype=torch.float32).pin_memory()
         # the step's random draws, in the eager step's order (wrapper.py:72, losses.py:96,108, then the dropout seed)
-        torch.rand(b, dtype=torch.float64, device=dev, out=ent["t_"])
+        t_new, _ = self._draw_times(b, dev)       # includes the NaN check the captured step cannot make
+        ent["t_"].copy_(t_new)
         torch.randn(batch.shape, device=dev, out=ent["m_draw"])
         torch.randn(ent["eps"].shape, device=dev, out=ent["eps"])
         if net.training and float(net.sf.dropout) > 0:
@@ -175,8 +198,11 @@ class SDEWrapper(_Base):
         optim = self.optimizers()
         lr_sched = self.lr_schedulers()
         x_0 = batch
-        t_ = torch.rand(x_0.shape[0], device=x_0.device, dtype=torch.float64)   # wrapper.py:72-73
-        t = t_ * (self.sde.T - self.train_eps) + self.train_eps
+        if x_0.is_cuda:
+            _, t = self._draw_times(x_0.shape[0], x_0.device)                   # wrapper.py:72-73
+        else:
+            t_ = torch.rand(x_0.shape[0], device=x_0.device, dtype=torch.float64)
+            t = t_ * (self.sde.T - self.train_eps) + self.train_eps
         loss = self.criterion(x_0, t, self.score_fn)
         optim.zero_grad()
         self.manual_backward(loss)
