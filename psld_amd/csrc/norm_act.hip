@@ -100,16 +100,32 @@ __global__ void gn_finalize_kernel(const double* __restrict__ part, int hw, int 
                                    float* __restrict__ mean, float* __restrict__ rstd,
                                    float* __restrict__ scale, float* __restrict__ shift) {
     __shared__ float smean[MAXG], srstd[MAXG];
+    __shared__ double ps[8][MAXG][2];
     const int n = blockIdx.x, tid = threadIdx.x;
     const int cpg = c / groups;
+    // chunk lane kl adds chunks kl, kl + 8, ... of group g (independent loads in flight: a single thread walking all
+    // chunks pays one memory latency per chunk, 9 us per launch); the 8 lanes are then combined in lane order
+    {
+        const int g = tid & 31, kl = tid >> 5;
+        double s = 0, ss = 0;
+        if (g < groups)
+            for (int k = kl; k < chunks; k += 8) {
+                const double* pp = part + (((long long)n * chunks + k) * groups + g) * fine * 2;
+                for (int f = 0; f < fine; ++f) {
+                    s += pp[2 * f];
+                    ss += pp[2 * f + 1];
+                }
+            }
+        ps[kl][g][0] = s;
+        ps[kl][g][1] = ss;
+    }
+    __syncthreads();
     if (tid < groups) {
         double s = 0, ss = 0;
-        for (int k = 0; k < chunks; ++k) {
-            const double* pp = part + (((long long)n * chunks + k) * groups + tid) * fine * 2;
-            for (int f = 0; f < fine; ++f) {
-                s += pp[2 * f];
-                ss += pp[2 * f + 1];
-            }
+#pragma unroll
+        for (int kl = 0; kl < 8; ++kl) {
+            s += ps[kl][tid][0];
+            ss += ps[kl][tid][1];
         }
         const double cnt = (double)cpg * hw;
         const double mu = s / cnt;
@@ -311,9 +327,22 @@ __global__ void __launch_bounds__(1024) gn_bwd_finalize_kernel(const float* __re
     const int cpg = c / groups;
     for (int ch = tid; ch < c; ch += blockDim.x) {
         double a = 0, b = 0;
-        for (int k = 0; k < chunks; ++k) {
-            a += (double)part[(((long long)n * chunks + k) * 2 + 0) * c + ch];
-            b += (double)part[(((long long)n * chunks + k) * 2 + 1) * c + ch];
+        // eight chunks' loads in flight at a time, added in chunk order (a load-add-load-add loop pays one memory
+        // latency per chunk)
+        for (int k0 = 0; k0 < chunks; k0 += 8) {
+            float va[8], vb[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = min(k0 + j, chunks - 1);
+                va[j] = part[(((long long)n * chunks + k) * 2 + 0) * c + ch];
+                vb[j] = part[(((long long)n * chunks + k) * 2 + 1) * c + ch];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (k0 + j < chunks) {
+                    a += (double)va[j];
+                    b += (double)vb[j];
+                }
         }
         sh[ch] = a * (double)gamma[ch];
         sh[MAXT * 4 + ch] = b * (double)gamma[ch];
