@@ -1320,7 +1320,7 @@ class NCSNpp(nn.Module):
         import os as _os
         _ow = _os.environ.get("PSLD_OVERLAP_WGRAD")
         self.overlap_wgrad = None if _ow is None else _ow == "1"
-        self.side_group = max(1, int(_os.environ.get("PSLD_SIDE_GROUP", "8")))
+        self.side_group = max(1, int(_os.environ.get("PSLD_SIDE_GROUP", "32")))
         # None (auto): parameters become inputs of the autograd node (gradients delivered through AccumulateGrad, so
         # torch DDP / Lightning's ddp strategy can reduce them) when a multi-rank process group exists and no
         # BucketReducer is attached; True / False (or PSLD_AUTOGRAD_PARAMS=1 / 0) force it.
