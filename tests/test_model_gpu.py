@@ -1180,3 +1180,64 @@ def test_input_gradient_matches_oracle():
     xd2 = x.to(DEV).requires_grad_(True)
     net(xd2, t.to(DEV)).backward(gy.to(DEV))
     assert rel_l2(xd2.grad, xr.grad) < 2e-5
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_ablation"])
+def test_side_stream_weight_gradients_are_bitwise_the_single_stream_ones(name):
+    """Parameter-gradient kernels on the side stream (the default below 64k pixels per batch), forked one call at a
+    time, in groups, or all at the end: every kernel is deterministic, so the flat gradient must not change by a bit;
+    a stale or early read on the side stream would."""
+    net, cfg, _ = _build(name, train=True)
+    size = cfg.data.image_size
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(3, 6, size, size, generator=g).to(DEV)
+    t = (torch.rand(3, generator=g) * 0.9 + 0.05).to(DEV)
+    gy = torch.randn(3, 6, size, size, generator=g)
+    grads = {}
+    for tag, overlap, group in (("off", False, 1), ("each", True, 1), ("grouped", True, 4), ("at the end", True, 10 ** 6)):
+        net.overlap_wgrad, net.side_group = overlap, group
+        for p in net.parameters():
+            p.grad = None
+        y = net(x, t)
+        y.backward(gy[:, :y.shape[1]].to(DEV))
+        torch.cuda.synchronize()
+        grads[tag] = net.flat_grad().clone()
+        assert bool(torch.isfinite(grads[tag]).all())
+    for tag in ("each", "grouped", "at the end"):
+        assert torch.equal(grads[tag], grads["off"]), tag
+    net.overlap_wgrad = None
+
+
+def test_nan_check_runs_early_and_still_raises():
+    """SDEWrapper draws t and checks the perturbation coefficients on a stream that does not wait for the compute stream
+    (no host wait for the previous step).  The coefficient table computed there must be the one the loss consumes, the
+    step must equal the plain criterion call on the same draws, and the reference's ValueError (psld.py:166-171) must
+    still be raised."""
+    from psld_amd import config as C
+    from psld_amd.registry import get_module
+    import psld_amd
+    psld_amd.import_modules_into_registry()
+    cfg = C.tiny()
+    torch.manual_seed(3)
+    net = get_module("score_fn", "ncsnpp")(cfg).to(DEV).eval()         # eval: no dropout, the loss is a pure function
+    sde = get_module("sde", "psld")(cfg)
+    crit = get_module("losses", "psld_score_loss")(cfg, sde)
+    w = get_module("pl_modules", "sde_wrapper")(cfg, sde, net, ema_score_fn=None, criterion=crit)
+    x = torch.rand(4, 3, cfg.data.image_size, cfg.data.image_size, device=DEV) * 2 - 1
+    torch.manual_seed(11)
+    _, t = w._draw_times(4, x.device)
+    assert sde._prefetched is not None and sde._prefetched[0] is t
+    l_early = float(crit(x, t, net))
+    assert sde._prefetched is None                                       # consumed by the loss
+    torch.manual_seed(11)
+    t_plain = torch.rand(4, device=DEV, dtype=torch.float64) * (sde.T - w.train_eps) + w.train_eps
+    assert torch.equal(t_plain, t)                                       # same first draw of the step
+    l_plain = float(crit(x, t_plain, net))                               # no prefetch: table computed in place
+    assert l_early == l_plain
+    # coefficients that are NaN for every t: the early check raises like the reference
+    bad = get_module("sde", "psld")(cfg)
+    bad._params.numerical_eps = -10.0
+    w_bad = get_module("pl_modules", "sde_wrapper")(cfg, bad, net, ema_score_fn=None,
+                                                      criterion=get_module("losses", "psld_score_loss")(cfg, bad))
+    with pytest.raises(ValueError, match="Numerical precision error"):
+        w_bad._draw_times(4, x.device)
