@@ -309,8 +309,10 @@ __device__ __forceinline__ void dconv_epilogue(const DConvArgs& a, f32x4v (&acc)
 // wave decomposition of dconv_lp_kernel<.., N32 = true>, where the four waves of a workgroup split the 128 output
 // channels instead of sharing them two by two (each weight fragment is then loaded by ONE wave: half the L2 -> CU
 // fragment stream).  GroupNorm partial sums per 64-row run (block rows 0-3 / 4-7).  No gnb by-product here.
-__device__ __forceinline__ void dconv_epilogue_n32(const DConvArgs& a, f32x4v (&acc)[8][2], int m0, int nw0, int lane,
+template <int MBK>      // 8: 128-row tile, 4: 64-row tile (small grids)
+__device__ __forceinline__ void dconv_epilogue_n32(const DConvArgs& a, f32x4v (&acc)[MBK][2], int m0, int nw0, int lane,
                                                    int split) {
+    constexpr int RUNS = MBK / 4;       // 64-row runs of the tile
     const int r16 = lane & 15, kq = lane >> 4;
     float* Cb = a.C + (long long)split * a.c_stride_split;
     const PsldEpilogue& e = a.e;
@@ -321,13 +323,13 @@ __device__ __forceinline__ void dconv_epilogue_n32(const DConvArgs& a, f32x4v (&
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
         bias4[nb] = e.bias ? *reinterpret_cast<const f32x4v*>(e.bias + cn0 + nb * 16) : zero4;
-    float gs[2][2], gss[2][2];           // [64-row run][block column]
+    float gs[RUNS][2], gss[RUNS][2];     // [64-row run][block column]
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < RUNS; ++r)
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) gs[r][nb] = gss[r][nb] = 0.f;
 #pragma unroll
-    for (int mb = 0; mb < 8; ++mb) {
+    for (int mb = 0; mb < MBK; ++mb) {
         const int row_base = m0 + mb * 16;
         if (row_base >= a.M) continue;                      // wave-uniform
         const int gm = min(row_base + r16, a.M - 1);
@@ -363,7 +365,7 @@ __device__ __forceinline__ void dconv_epilogue_n32(const DConvArgs& a, f32x4v (&
     if (e.gn_part) {
         const int fine = a.N >> 3, chunks = e.gn_hw >> 6;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < RUNS; ++r) {
             const int row0 = m0 + r * 64;
             if (row0 >= a.M) continue;
             const int img = row0 / e.gn_hw, chunk = (row0 - img * e.gn_hw) >> 6;
@@ -393,9 +395,12 @@ __device__ __forceinline__ void dconv_epilogue_n32(const DConvArgs& a, f32x4v (&
 // stored one after the other (NH = 4*TAPS).
 // N32: the four waves of a workgroup split the 128 output channels (wave tile 128 x 32: each weight fragment is loaded by
 // one wave) instead of a 2 x 2 arrangement of 64 x 64 tiles (every fragment loaded by two waves).
-template <int NH, int TAPS, bool PW, bool N32>
+// MT: pixel rows per workgroup tile, 128 or - with N32, 3x3 only - 64 (wave tile 64 x 32): twice the workgroups for output
+// grids too small to fill the chip, instead of (or with a shallower) split of the K range.
+template <int NH, int TAPS, bool PW, bool N32, int MT = 128>
 __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
-    constexpr int MBK = N32 ? 8 : 4, NBK = N32 ? 2 : 4;
+    static_assert(MT == 128 || (MT == 64 && N32 && !PW), "64-row tiles exist for the 1 x 4 wave layout of the 3x3 kernels");
+    constexpr int MBK = N32 ? MT / 16 : 4, NBK = N32 ? 2 : 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LIMB = NH * 32 * ROWB;
     static_assert(!PW || NH == 4 * TAPS, "pointwise staging: 128 rows x 8 quads per 32-channel chunk");
@@ -408,7 +413,7 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
     const int tiles_n = a.N >> 7;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
-    const int m0 = tile_m * 128, n0 = tile_n * 128;
+    const int m0 = tile_m * MT, n0 = tile_n * 128;
     const int split = blockIdx.y;
     const int c_beg = split * a.chunks_per_split;               // stages: chunks (conv) or groups of TAPS chunks (PW)
     const int c_end = min(a.chunks, c_beg + a.chunks_per_split);
@@ -554,7 +559,7 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
         if (sigma + 1 < sig_end) step(sigma + 1, std::integral_constant<int, 1>{});
     }
 
-    if constexpr (N32) dconv_epilogue_n32(a, acc, m0, n0 + wave * 32, lane, split);
+    if constexpr (N32) dconv_epilogue_n32<MBK>(a, acc, m0, n0 + wave * 32, lane, split);
     else dconv_epilogue(a, acc, m0, n0, wr, wc, lane, split);
 }
 
@@ -568,9 +573,11 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
 // RG = 16-row groups per image (>= halo pixels / 16); wave w moves row groups w, w + 4, ...
 constexpr int LP_PIX_BYTES_PER_CH = 6;     // bytes per element of a limb-plane tensor
 
-template <int RG, bool DB, bool N32>
+template <int RG, bool DB, bool N32, int MT = 128>
 __global__ void __launch_bounds__(256, 2) dconv_lp_kernel(const DConvArgs a) {
-    constexpr int MBK = N32 ? 8 : 4, NBK = N32 ? 2 : 4;    // accumulator blocks per wave: 64 x 64 (2 x 2 waves) or 128 x 32 (1 x 4)
+    static_assert(MT == 128 || (MT == 64 && N32), "64-row tiles exist for the 1 x 4 wave layout");
+    // accumulator blocks per wave: 64 x 64 (2 x 2 waves), 128 x 32 (1 x 4) or, on 64-row tiles, 64 x 32
+    constexpr int MBK = N32 ? MT / 16 : 4, NBK = N32 ? 2 : 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LIMB = RG * 16 * ROWB;
     constexpr int BUF = 3 * LIMB;
@@ -584,7 +591,7 @@ __global__ void __launch_bounds__(256, 2) dconv_lp_kernel(const DConvArgs a) {
     const int tiles_n = a.N >> 7;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
-    const int m0 = tile_m * 128, n0 = tile_n * 128;
+    const int m0 = tile_m * MT, n0 = tile_n * 128;
     const int split = blockIdx.y;
     const int c_beg = split * a.chunks_per_split;
     const int c_end = min(a.chunks, c_beg + a.chunks_per_split);
@@ -713,8 +720,8 @@ __global__ void __launch_bounds__(256, 2) dconv_lp_kernel(const DConvArgs a) {
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
-            if (t == 0) { if constexpr (N32) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); }
-            if (t == 1) { if constexpr (N32) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); }
+            if (t == 0) { if constexpr (MBK == 8) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); }
+            if (t == 1) { if constexpr (MBK == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); }
             if (t == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (t <= 2) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -751,7 +758,7 @@ __global__ void __launch_bounds__(256, 2) dconv_lp_kernel(const DConvArgs a) {
         if (sigma + 1 < sig_end) step(sigma + 1, std::integral_constant<int, 1>{});
     }
 
-    if constexpr (N32) dconv_epilogue_n32(a, acc, m0, n0 + wave * 32, lane, split);
+    if constexpr (N32) dconv_epilogue_n32<MBK>(a, acc, m0, n0 + wave * 32, lane, split);
     else dconv_epilogue(a, acc, m0, n0, wr, wc, lane, split);
 }
 
@@ -1322,12 +1329,12 @@ int launch_dwgrad(const DWgradArgs& a, int nsplit, hipStream_t stream) {
     return PSLD_OK;
 }
 
-template <int NH, int TAPS, bool PW, bool N32>
+template <int NH, int TAPS, bool PW, bool N32, int MT = 128>
 int launch_dconv_impl(const DConvArgs& a, int nsplit, hipStream_t stream, const char* name) {
     constexpr size_t LDS = (size_t)3 * NH * 32 * ROWB;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv_kernel<NH, TAPS, PW, N32>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv_kernel<NH, TAPS, PW, N32, MT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         if (e != hipSuccess) {
             psld_set_error("%s: hipFuncSetAttribute failed: %s", name, hipGetErrorString(e));
@@ -1335,8 +1342,8 @@ int launch_dconv_impl(const DConvArgs& a, int nsplit, hipStream_t stream, const 
         }
         configured = true;
     }
-    dim3 grid((unsigned)(cdiv(a.M, 128) * (a.N / 128)), (unsigned)nsplit);
-    hipLaunchKernelGGL((dconv_kernel<NH, TAPS, PW, N32>), grid, dim3(256), LDS, stream, a);
+    dim3 grid((unsigned)(cdiv(a.M, MT) * (a.N / 128)), (unsigned)nsplit);
+    hipLaunchKernelGGL((dconv_kernel<NH, TAPS, PW, N32, MT>), grid, dim3(256), LDS, stream, a);
     PSLD_CHECK_LAUNCH(name);
     return PSLD_OK;
 }
@@ -1352,12 +1359,12 @@ int launch_dconv(const DConvArgs& a, int nsplit, hipStream_t stream, const char*
                         : launch_dconv_impl<NH, TAPS, PW, false>(a, nsplit, stream, name);
 }
 
-template <int RG, bool DB, bool N32>
+template <int RG, bool DB, bool N32, int MT = 128>
 int launch_dconv_lp(const DConvArgs& a, int nsplit, hipStream_t stream, const char* name) {
     constexpr size_t LDS = (size_t)(DB ? 2 : 1) * 3 * RG * 16 * ROWB;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv_lp_kernel<RG, DB, N32>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv_lp_kernel<RG, DB, N32, MT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         if (e != hipSuccess) {
             psld_set_error("%s: hipFuncSetAttribute failed: %s", name, hipGetErrorString(e));
@@ -1365,16 +1372,16 @@ int launch_dconv_lp(const DConvArgs& a, int nsplit, hipStream_t stream, const ch
         }
         configured = true;
     }
-    dim3 grid((unsigned)(cdiv(a.M, 128) * (a.N / 128)), (unsigned)nsplit);
-    hipLaunchKernelGGL((dconv_lp_kernel<RG, DB, N32>), grid, dim3(256), LDS, stream, a);
+    dim3 grid((unsigned)(cdiv(a.M, MT) * (a.N / 128)), (unsigned)nsplit);
+    hipLaunchKernelGGL((dconv_lp_kernel<RG, DB, N32, MT>), grid, dim3(256), LDS, stream, a);
     PSLD_CHECK_LAUNCH(name);
     return PSLD_OK;
 }
 
 // split the K stages over extra workgroups when the output grid cannot fill 256 CUs x 2 slots; returns the number
 // of slabs (1 = write the output directly) and fills the slab fields of `a`
-int plan_split(DConvArgs& a, const PsldEpilogue& e, float* y, int ldy, void* workspace, long long ws_bytes) {
-    const long long tiles = (long long)cdiv(a.M, 128) * (a.N / 128);
+int plan_split(DConvArgs& a, const PsldEpilogue& e, float* y, int ldy, void* workspace, long long ws_bytes, int mt = 128) {
+    const long long tiles = (long long)cdiv(a.M, mt) * (a.N / 128);
     int ns = 1;
     if (workspace && tiles < 384 && !e.gn_part && !e.gnb_part && ldy % 4 == 0 && aligned16(y) && (!e.bias || aligned16(e.bias)) &&
         (!e.rowbias || (aligned16(e.rowbias) && e.ld_rowbias % 4 == 0)) && (!e.res || (aligned16(e.res) && e.ldres % 4 == 0))) {
@@ -1406,20 +1413,31 @@ int plan_split(DConvArgs& a, const PsldEpilogue& e, float* y, int ldy, void* wor
     return ns;
 }
 
-bool dconv_geometry(int h, int w, int* nseg, int* rps, int* halo_px) {
+bool dconv_geometry(int h, int w, int* nseg, int* rps, int* halo_px, int mt = 128) {
     if (w != 8 && w != 16 && w != 32 && w != 64) return false;
     const int hw = h * w;
-    if (hw >= 128) {
-        if (hw % 128) return false;
+    if (hw >= mt) {
+        if (hw % mt || mt % w) return false;
         *nseg = 1;
-        *rps = 128 / w;
+        *rps = mt / w;
     } else {
-        if (128 % hw) return false;
-        *nseg = 128 / hw;
+        if (mt % hw) return false;
+        *nseg = mt / hw;
         *rps = h;
     }
     *halo_px = *nseg * (*rps + 2) * (w + 2);
     return *halo_px <= 9 * 32;
+}
+
+// Tile height of a 3x3 limb convolution: 64-row tiles (1 x 4 wave layout only) when 128-row tiles leave the grid short of
+// 384 workgroups - the same bound under which plan_split starts cutting the K range - and the geometry allows them.
+// PSLD_DCONV_MT64=0 switches them off.
+int dconv_tile_rows(const DConvArgs& a, bool n32, int h, int w) {
+    static const int on = [] { const char* v = getenv("PSLD_DCONV_MT64"); return v ? atoi(v) : 1; }();
+    int nseg, rps, halo;
+    const long long tiles128 = (long long)cdiv(a.M, 128) * (a.N / 128);
+    // halo of a 64-row tile <= 144 pixel rows: the images the 64-row instances are built with (9 row groups / 5 items)
+    return (on && n32 && tiles128 < 384 && a.M % 64 == 0 && dconv_geometry(h, w, &nseg, &rps, &halo, 64) && halo <= 144) ? 64 : 128;
 }
 
 }  // namespace
@@ -1476,13 +1494,15 @@ extern "C" int psld_conv3x3_split_f32(const float* x1, int c1, const float* x2, 
     a.N = cout; a.M = batch * h * w;
     a.chunks = (c1 + c2) / 32;
     int halo_px = 0;
-    dconv_geometry(h, w, &a.nseg, &a.rps, &halo_px);
+    const PsldEpilogue e = make_epilogue(epi);
+    a.e = e;
+    const int mt = dconv_tile_rows(a, dconv_n32(a), h, w);
+    dconv_geometry(h, w, &a.nseg, &a.rps, &halo_px, mt);
     a.zero = psld_detail_zero_page("psld_conv3x3_split_f32");
     if (!a.zero) return PSLD_ERR_LAUNCH;
-    const PsldEpilogue e = make_epilogue(epi);
     PSLD_CHECK_ARG(!e.gn_part || (e.gn_hw == h * w && e.gn_hw % 64 == 0 && !e.accumulate),
                    "psld_conv3x3_split_f32: gn_part needs gn_hw = h*w, a multiple of 64, and no accumulation");
-    const int ns = plan_split(a, e, y, ldy, workspace, ws_bytes);
+    const int ns = plan_split(a, e, y, ldy, workspace, ws_bytes, mt);
     PSLD_CHECK_ARG(a.v4, "limb kernels: y, residual, bias and rowbias need 16-byte aligned rows (pointer and row stride)");
     PSLD_CHECK_ARG(!e.gnb_part || (e.gnb_x && e.gnb_mean && e.gnb_rstd && e.gnb_gamma && e.gnb_beta && e.gnb_hw > 0 &&
                                    e.gnb_hw % 64 == 0 && a.M % e.gnb_hw == 0 && ldy == a.N && e.gnb_groups > 0 &&
@@ -1493,7 +1513,9 @@ extern "C" int psld_conv3x3_split_f32(const float* x1, int c1, const float* x2, 
     const int nh = cdiv((long long)halo_px * 8, 256);
     const char* name = "psld_conv3x3_split_f32";
     int st;
-    if (nh <= 6) st = launch_dconv<6, 9, false>(a, ns, stream, name);
+    if (mt == 64) st = nh <= 4 ? launch_dconv_impl<4, 9, false, true, 64>(a, ns, stream, name)
+                               : launch_dconv_impl<5, 9, false, true, 64>(a, ns, stream, name);
+    else if (nh <= 6) st = launch_dconv<6, 9, false>(a, ns, stream, name);
     else if (nh <= 7) st = launch_dconv<7, 9, false>(a, ns, stream, name);
     else st = launch_dconv<9, 9, false>(a, ns, stream, name);
     if (st != PSLD_OK) return st;
@@ -1535,13 +1557,19 @@ extern "C" int psld_conv3x3_limb_f32(const void* x1, int c1, const void* x2, int
     a.N = cout; a.M = batch * h * w;
     a.chunks = (c1 + c2) / 32;
     int halo_px = 0;
-    dconv_geometry(h, w, &a.nseg, &a.rps, &halo_px);
+    const PsldEpilogue e = make_epilogue(epi);
+    static const int n32env = [] { const char* v = getenv("PSLD_DCONV_N32"); return v ? atoi(v) : 1; }();
+    static const int single = [] { const char* v = getenv("PSLD_LP_SINGLE_BUFFER"); return v ? atoi(v) : 0; }();
+    // wave decomposition: 1 x 4 waves of 128 x 32 (each weight fragment loaded once per workgroup) unless the epilogue has
+    // to produce the GroupNorm-backward by-product (2 x 2 layout only) or PSLD_DCONV_N32=0 asks for the old layout
+    const bool n32 = n32env && !e.gnb_part;
+    const int mt = dconv_tile_rows(a, n32 && !single, h, w);
+    dconv_geometry(h, w, &a.nseg, &a.rps, &halo_px, mt);
     a.zero = psld_detail_zero_page("psld_conv3x3_limb_f32");
     if (!a.zero) return PSLD_ERR_LAUNCH;
-    const PsldEpilogue e = make_epilogue(epi);
     PSLD_CHECK_ARG(!e.gn_part || (e.gn_hw == h * w && e.gn_hw % 64 == 0 && !e.accumulate),
                    "psld_conv3x3_limb_f32: gn_part needs gn_hw = h*w, a multiple of 64, and no accumulation");
-    const int ns = plan_split(a, e, y, ldy, workspace, ws_bytes);
+    const int ns = plan_split(a, e, y, ldy, workspace, ws_bytes, mt);
     PSLD_CHECK_ARG(a.v4, "limb kernels: y, residual, bias and rowbias need 16-byte aligned rows (pointer and row stride)");
     PSLD_CHECK_ARG(!e.gnb_part || (e.gnb_x && e.gnb_mean && e.gnb_rstd && e.gnb_gamma && e.gnb_beta && e.gnb_hw > 0 &&
                                    e.gnb_hw % 64 == 0 && a.M % e.gnb_hw == 0 && ldy == a.N && e.gnb_groups > 0 &&
@@ -1551,14 +1579,11 @@ extern "C" int psld_conv3x3_limb_f32(const void* x1, int c1, const void* x2, int
                    "groups of a multiple of 4 channels, 16-byte aligned operands and no accumulation");
     const int rg = cdiv(halo_px, 16);
     const char* name = "psld_conv3x3_limb_f32";
-    static const int single = [] { const char* v = getenv("PSLD_LP_SINGLE_BUFFER"); return v ? atoi(v) : 0; }();
     int st;
     // two images of RG <= 13 row groups (79,872 B) leave room for two workgroups per CU (163,840 B of LDS)
-    // wave decomposition: 1 x 4 waves of 128 x 32 (each weight fragment loaded once per workgroup) unless the epilogue has
-    // to produce the GroupNorm-backward by-product (2 x 2 layout only) or PSLD_DCONV_N32=0 asks for the old layout
-    static const int n32env = [] { const char* v = getenv("PSLD_DCONV_N32"); return v ? atoi(v) : 1; }();
-    const bool n32 = n32env && !e.gnb_part;
-    if (rg <= 12) st = single ? launch_dconv_lp<12, false, false>(a, ns, stream, name)
+    if (mt == 64) st = rg <= 7 ? launch_dconv_lp<7, true, true, 64>(a, ns, stream, name)
+                               : launch_dconv_lp<9, true, true, 64>(a, ns, stream, name);
+    else if (rg <= 12) st = single ? launch_dconv_lp<12, false, false>(a, ns, stream, name)
                    : (n32 ? launch_dconv_lp<12, true, true>(a, ns, stream, name) : launch_dconv_lp<12, true, false>(a, ns, stream, name));
     else if (rg <= 13) st = single ? launch_dconv_lp<13, false, false>(a, ns, stream, name)
                         : (n32 ? launch_dconv_lp<13, true, true>(a, ns, stream, name) : launch_dconv_lp<13, true, false>(a, ns, stream, name));
