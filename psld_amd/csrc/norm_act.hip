@@ -297,12 +297,14 @@ __global__ void gn_bwd_partial_kernel(const float* __restrict__ dy, const float*
 __global__ void __launch_bounds__(1024) gn_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, int batch, int hw, int c,
                                                                int groups, int chunks, float* __restrict__ coef,
-                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               int first_block) {
     __shared__ double sh[2 * MAXT * 4];          // image role: s1*gamma, s2*gamma per channel; param role: [16][64]
     __shared__ double g1[MAXG], g2[MAXG];
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x >= batch) {
-        const int r = blockIdx.x - batch;
+    const int bid = (int)blockIdx.x + first_block;      // first_block = batch: parameter-gradient blocks only
+    if (bid >= batch) {
+        const int r = bid - batch;
         const int which = r & 1;
         const int col = (r >> 1) * 64 + (tid & 63);
         const int lane = tid >> 6;
@@ -323,7 +325,7 @@ __global__ void __launch_bounds__(1024) gn_bwd_finalize_kernel(const float* __re
         }
         return;
     }
-    const int n = blockIdx.x;
+    const int n = bid;
     const int cpg = c / groups;
     for (int ch = tid; ch < c; ch += blockDim.x) {
         double a = 0, b = 0;
@@ -424,6 +426,134 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
     }
 }
 
+// ---- backward in ONE pass over (dy, x) ----------------------------------------------------------------------------
+// A block owns image n and a slab of `gb` whole groups (cw = gb * cpg <= 32 channels); its threads keep the slab's dy and
+// x values in REGISTERS (ITEMS float4 of each per thread): pass 1 turns them into dz and xhat in place and reduces the
+// per-channel sums (fp32 per thread, fp64 across the pixel lanes through LDS, like the three-kernel path), the group
+// terms follow from those, pass 2 writes dx straight from the registers.  dy and x are read once instead of twice (20 ->
+// 12 bytes per element) and two of the three launches go away; the per-image channel sums land in part[n][2][c], from
+// which the parameter-gradient blocks of gn_bwd_finalize_kernel form dgamma / dbeta as before.
+// Thread -> (channel quad q = tid % cq, pixel lane l = tid / cq), pixels l, l + pl, ...
+template <int ITEMS>
+__global__ void __launch_bounds__(512) gn_bwd_fused_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           int hw, int c, int groups, int gb, int pl, int act, float drop_p,
+                                                           unsigned long long seed,
+                                                           const unsigned long long* __restrict__ seed_dev, int accumulate,
+                                                           const float* __restrict__ add, float add_scale,
+                                                           float* __restrict__ dx, float* __restrict__ part) {
+    extern __shared__ float red[];               // [pl][cq][8] thread sums, then (as doubles) [cw][2] channel sums + [gb][2]
+    const int n = blockIdx.y, slab = blockIdx.x;
+    if (seed_dev) seed += seed_dev[0];
+    const int tid = threadIdx.x;
+    const int cpg = c / groups;
+    const int cw = gb * cpg, cq = cw >> 2;
+    const int q = tid % cq, l = tid / cq;
+    const int c0 = slab * cw;
+    const int ch0 = c0 + q * 4;
+    const int g = ch0 / cpg;                     // cpg % 4 == 0: a quad lies in one group
+    const float mu = mean[n * groups + g], rs = rstd[n * groups + g];
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + ch0), be = *reinterpret_cast<const f32x4*>(beta + ch0);
+    const long long off = ((long long)n * hw) * c + ch0;
+    const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    f32x4 xv[ITEMS], gv[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int p = l + i * pl;
+        if (p < hw) {
+            xv[i] = *reinterpret_cast<const f32x4*>(x + off + (long long)p * c);
+            gv[i] = *reinterpret_cast<const f32x4*>(dy + off + (long long)p * c);
+        }
+    }
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int p = l + i * pl;
+        if (p < hw) {
+            const long long idx = off + (long long)p * c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (xv[i][e] - mu) * rs;
+                float dz = gv[i][e];
+                if (drop_p > 0.f) dz = psld_dropout_keep(seed, (unsigned long long)(idx + e), drop_p) ? dz * keep_scale : 0.f;
+                if (act) dz *= dsilu_f(xh * ga[e] + be[e]);
+                s1[e] += dz;
+                s2[e] += dz * xh;
+                xv[i][e] = xh;
+                gv[i][e] = dz;
+            }
+        }
+    }
+    float* my = red + ((long long)l * cq + q) * 8;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        my[e] = s1[e];
+        my[4 + e] = s2[e];
+    }
+    __syncthreads();
+    double* chs = reinterpret_cast<double*>(red + (long long)pl * cq * 8);      // [cw][2]: gamma-weighted channel sums
+    double* grp = chs + cw * 2;                                                  // [gb][2]
+    for (int i = tid; i < cq * 8; i += blockDim.x) {
+        double acc = 0;
+        for (int ll = 0; ll < pl; ++ll) acc += (double)red[(long long)ll * cq * 8 + i];
+        const int qq = i >> 3, k = i & 7;
+        const int chl = qq * 4 + (k & 3);
+        const float rounded = (float)acc;                                          // what the three-kernel path stores
+        part[(((long long)n * 2 + (k >> 2))) * c + c0 + chl] = rounded;
+        chs[chl * 2 + (k >> 2)] = (double)rounded * (double)gamma[c0 + chl];
+    }
+    __syncthreads();
+    if (tid < gb * 2) {
+        const int gg = tid >> 1, w = tid & 1;
+        double t = 0;
+        for (int i = 0; i < cpg; ++i) t += chs[(gg * cpg + i) * 2 + w];
+        grp[gg * 2 + w] = t;
+    }
+    __syncthreads();
+    const int gl = (q * 4) / cpg;
+    const double cnt = (double)cpg * hw;
+    const float k1 = (float)((double)rs * grp[gl * 2 + 0] / cnt), k2 = (float)((double)rs * grp[gl * 2 + 1] / cnt);
+    f32x4 k0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) k0[e] = rs * ga[e];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int p = l + i * pl;
+        if (p < hw) {
+            const long long idx = off + (long long)p * c;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = k0[e] * gv[i][e] - k1 - xv[i][e] * k2;
+            if (add) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(add + idx);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += add_scale * av[e];
+            }
+            if (accumulate) o += *reinterpret_cast<const f32x4*>(dx + idx);
+            *reinterpret_cast<f32x4*>(dx + idx) = o;
+        }
+    }
+}
+
+// groups per block / pixel lanes / items per thread of the fused backward, or false when the slab does not fit registers
+inline bool gn_bwd_fused_plan(int hw, int c, int groups, int* gb, int* pl, int* items) {
+    static const int on = [] { const char* v = getenv("PSLD_GN_BWD_FUSED"); return v ? atoi(v) : 1; }();
+    const int cpg = c / groups;
+    if (!on || cpg % 4 || cpg > 32) return false;
+    int g = 32 / cpg;                              // as many whole groups as fit 32 channels (whole 128-byte lines; 16-channel
+                                                   // slabs measured 136 vs 112 us on 128x32x32x256) ...
+    while (g > 1 && groups % g) --g;               // ... dividing the group count
+    const int cq = g * cpg / 4;
+    const int lanes = 512 / cq;
+    const int it = cdiv(hw, lanes);
+    if (it > 16) return false;
+    *gb = g;
+    *pl = lanes;
+    *items = it <= 1 ? 1 : it <= 2 ? 2 : it <= 4 ? 4 : it <= 8 ? 8 : 16;
+    return true;
+}
+
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
@@ -508,6 +638,29 @@ extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float
     float* coef = reinterpret_cast<float*>(ws);
     const size_t lds = (size_t)m.pl * m.cq * 8 * sizeof(float);
     int chunks = m.chunks;
+    int gb = 0, fpl = 0, items = 0;
+    if (!part_in && gn_bwd_fused_plan(hw, c, groups, &gb, &fpl, &items)) {
+        const int cpg = c / groups, cw = gb * cpg, cq = cw / 4;
+        const dim3 grid(groups / gb, batch), block(cq * fpl);
+        const size_t flds = (size_t)fpl * cq * 8 * sizeof(float) + (size_t)(cw + gb) * 2 * sizeof(double);
+#define PSLD_GN_FUSED(IT)                                                                                              \
+    hipLaunchKernelGGL((gn_bwd_fused_kernel<IT>), grid, block, flds, stream, dy, x, mean, rstd, gamma, beta, hw, c, groups, \
+                       gb, fpl, act, drop_p, seed, seed_dev, accumulate_dx, add, add_scale, dx, part)
+        switch (items) {
+            case 1: PSLD_GN_FUSED(1); break;
+            case 2: PSLD_GN_FUSED(2); break;
+            case 4: PSLD_GN_FUSED(4); break;
+            case 8: PSLD_GN_FUSED(8); break;
+            default: PSLD_GN_FUSED(16); break;
+        }
+#undef PSLD_GN_FUSED
+        PSLD_CHECK_LAUNCH("gn_bwd_fused_kernel");
+        // dgamma / dbeta: the parameter blocks of the finalize kernel over the per-image sums (chunks = 1)
+        hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(2 * cdiv(c, 64)), dim3(1024), 0, stream, part, rstd, gamma, batch, hw,
+                           c, groups, 1, coef, dgamma, dbeta, batch);
+        PSLD_CHECK_LAUNCH("gn_bwd_finalize_kernel");
+        return PSLD_OK;
+    }
     if (part_in) {        // pass 1 came with dy (the producing kernel's epilogue, psld_epilogue_t.gnb_part)
         PSLD_CHECK_ARG(part_chunks >= 1, "psld_gn_bwd: part_chunks must be >= 1 with part_in");
         part = const_cast<float*>(part_in);
@@ -518,7 +671,7 @@ extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float
         PSLD_CHECK_LAUNCH("gn_bwd_partial_kernel");
     }
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(batch + 2 * cdiv(c, 64)), dim3(1024), 0, stream, part, rstd, gamma,
-                       batch, hw, c, groups, chunks, coef, dgamma, dbeta);
+                       batch, hw, c, groups, chunks, coef, dgamma, dbeta, 0);
     PSLD_CHECK_LAUNCH("gn_bwd_finalize_kernel");
     const Map ma = make_map(batch, hw, c, true);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ma.chunks, batch), dim3(ma.threads), 0, stream, dy, x, mean, rstd,

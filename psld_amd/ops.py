@@ -5,6 +5,7 @@ libpsld_hip.so.  All tensors must be contiguous CUDA(ROCm) tensors.
 from __future__ import annotations
 
 import ctypes as C
+import functools
 from typing import Optional, Sequence, Tuple
 
 import numpy as np
@@ -154,6 +155,7 @@ def math_mode() -> str:
     return ("f32", "bf16x6")[lib().psld_get_math_mode()]
 
 
+@functools.lru_cache(maxsize=None)
 def conv3x3_split_supported(c1: int, c2: int, b: int, h: int, w: int, cout: int) -> bool:
     return bool(lib().psld_conv3x3_split_supported(c1, c2, b, h, w, cout))
 
@@ -237,6 +239,7 @@ def limb_to_f32(x: LimbPlanes) -> Tensor:
     return out
 
 
+@functools.lru_cache(maxsize=None)
 def gemm_split_supported(k1: int, k2: int, m: int, n: int) -> bool:
     return bool(lib().psld_gemm_split_supported(k1, k2, m, n))
 
@@ -264,10 +267,12 @@ def gemm_split(a1: Tensor, a2: Optional[Tensor], m: int, bfrag: Tensor, n: int, 
                                     ws, wsb, _stream()), "psld_gemm_split_f32")
 
 
+@functools.lru_cache(maxsize=None)
 def conv3x3_wgrad_split_supported(cout: int, cin: int, b: int, h: int, w: int) -> bool:
     return bool(lib().psld_conv3x3_wgrad_split_supported(cout, cin, b, h, w))
 
 
+@functools.lru_cache(maxsize=None)
 def gemm_tn_split_supported(m: int, n: int, k: int) -> bool:
     return bool(lib().psld_gemm_tn_split_supported(m, n, k))
 
@@ -280,6 +285,7 @@ def gemm_tn_split(M: int, N: int, K: int, A: Tensor, lda: int, B: Tensor, ldb: i
                                        ldc, nsplit, _stream()), "psld_gemm_tn_split_f32")
 
 
+@functools.lru_cache(maxsize=None)
 def bgemm_split_supported(ta: int, tb: int, m: int, n: int, k: int) -> bool:
     return bool(lib().psld_bgemm_split_supported(ta, tb, m, n, k))
 
@@ -291,6 +297,7 @@ def bgemm_split(ta: int, tb: int, M: int, N: int, K: int, A: Tensor, lda: int, s
                                      batch, alpha, _stream()), "psld_bgemm_split_f32")
 
 
+@functools.lru_cache(maxsize=None)
 def conv3x3_wgrad_split_cout_tile(cout: int) -> int:
     return lib().psld_conv3x3_wgrad_split_cout_tile(cout)
 
@@ -377,6 +384,7 @@ class GNStats:
         self.shift = torch.empty((b, c), device=device, dtype=torch.float32)
 
 
+@functools.lru_cache(maxsize=None)
 def gn_groups(c: int) -> int:
     return min(c // 4, 32)
 
@@ -393,6 +401,7 @@ def gn_stats(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-6, groups: 
     return st
 
 
+@functools.lru_cache(maxsize=None)
 def gn_part_supported(b: int, hw: int, c: int) -> bool:
     """Can a limb kernel's epilogue produce the GroupNorm partial sums of its [b, hw, c] output?  (Whole 64-row
     runs per image, groups made of 8-channel fine groups, and a grid large enough that the kernel does not split

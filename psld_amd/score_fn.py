@@ -21,6 +21,7 @@ Supported config branches = the ones the north-star configs take
 """
 from __future__ import annotations
 
+import functools
 import math
 from typing import List, Optional
 
@@ -176,6 +177,7 @@ def _gbuf(node: _Node):
 _RESIDENT_BLOCKS = 512  # 256 CUs x 2 workgroups (64-72 KB LDS each) of the tile kernels
 
 
+@functools.lru_cache(maxsize=None)
 def _pick_nsplit(tiles: int, k: int, min_k: int = 256, resident: int = _RESIDENT_BLOCKS) -> int:
     """Split-K factor of a weight-gradient GEMM: fill whole rounds of resident workgroups (a 1.5-round
     grid wastes a quarter of the machine) while keeping >= ``min_k`` K per split."""

@@ -39,6 +39,18 @@ def main():
         wrapper.training_step(x, i)
         cb.on_train_batch_end(None, wrapper)
     torch.cuda.synchronize()
+    # the backward tape runs on the autograd engine's thread: give it a profiler of its own
+    from psld_amd import score_fn as SF
+    pr_b = cProfile.Profile()
+    orig = SF._Exec._backward
+
+    def profiled_backward(self, g):
+        pr_b.enable()
+        try:
+            return orig(self, g)
+        finally:
+            pr_b.disable()
+    SF._Exec._backward = profiled_backward
     pr = cProfile.Profile()
     pr.enable()
     for i in range(args.steps):
@@ -46,7 +58,9 @@ def main():
         cb.on_train_batch_end(None, wrapper)
     pr.disable()
     torch.cuda.synchronize()
+    SF._Exec._backward = orig
     st = pstats.Stats(pr)
+    st.add(pr_b)
     st.sort_stats("tottime")
     total = sum(v[2] for v in st.stats.values())
     print(f"host time under the profiler: {total / args.steps * 1e3:.1f} ms/step")
