@@ -32,6 +32,9 @@ xs = torch.randn(B, 16, 16, C, device=DEV); up = torch.empty(B, 32, 32, C, devic
 rec("FIR up x2 (16->32)", A / 4 + A, lambda: ops.upfirdn2d_raw(xs, k * 4, 2, 1, (2, 1), 1, out=up))
 dn = torch.empty(B, 16, 16, C, device=DEV)
 rec("FIR down x2 (32->16)", A + A / 4, lambda: ops.upfirdn2d_raw(x, k, 1, 2, (1, 1), 1, out=dn))
+# context for the two resamplers: a write-dominated stream (up: 1 byte read per 4 written) and a read-dominated one
+rec("  (ceiling) fill: write-only, same bytes as FIR up's output", A, lambda: up.fill_(1.0))
+rec("  (ceiling) sum: read-only, same bytes as FIR down's input", A, lambda: torch.sum(x))
 cat = torch.empty(B, S, S, 2 * C, device=DEV)
 rec("concat copy2d (one half)", 2 * A, lambda: ops.copy2d(x, C, cat, 2 * C, B * S * S, C))
 rec("axpby accumulate", 3 * A, lambda: ops.axpby(x, 0.7, None, 0.0, y, accumulate=True))
