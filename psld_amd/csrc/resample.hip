@@ -98,6 +98,59 @@ __global__ void upfirdn4_nhwc_kernel(const float* __restrict__ x, float* __restr
     *reinterpret_cast<f32x4*>(op) = acc;
 }
 
+// ---- 2 x 2 outputs per thread --------------------------------------------------------------------------------------
+// x2 UP with a 4x4 FIR: output row 2i + r reads the two input rows i + m_r, i + m_r + 1 with the two taps ky = ((pad - r) &
+// 1) + 2a, where m_r = (r + ((pad - r) & 1) - pad) / 2 - so the row pair (2i, 2i + 1) needs input rows i + m_0 .. and,
+// when pad is even, one more (m_1 = m_0 + 1): a 3 x 3 (even pads) or 2 x 2 (odd pads) neighbourhood feeds four outputs:
+// 9/4 loads per output instead of 4, and 4 stores per thread keep the write stream busy.  PY / PX = pad parity.
+template <int PY, int PX>
+__global__ void upfirdn4_up2_quad_kernel(const float* __restrict__ x, float* __restrict__ y, const Fir f, int c, int in_h,
+                                         int in_w, int out_h, int out_w, int accumulate) {
+    constexpr int NR = PY ? 2 : 3, NC = PX ? 2 : 3;
+    const int cq = c >> 2;
+    const int pairs_x = (out_w + 1) >> 1, pairs_y = (out_h + 1) >> 1;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= pairs_x * cq) return;
+    const int j = t / cq, q = t - j * cq;
+    const int n = blockIdx.y / pairs_y, i = blockIdx.y - n * pairs_y;
+    // m_0 for rows / columns (floor division: the numerators are even)
+    const int my = (((f.pad_y0) & 1) - f.pad_y0) >> 1, mx = (((f.pad_x0) & 1) - f.pad_x0) >> 1;
+    const float* xin = x + (long long)n * in_h * in_w * c + q * 4;
+    f32x4 v[NR][NC];
+#pragma unroll
+    for (int a = 0; a < NR; ++a) {
+        const int iy = i + my + a;
+#pragma unroll
+        for (int b = 0; b < NC; ++b) {
+            const int ix = j + mx + b;
+            const bool ok = iy >= 0 && iy < in_h && ix >= 0 && ix < in_w;
+            v[a][b] = ok ? *reinterpret_cast<const f32x4*>(xin + ((long long)iy * in_w + ix) * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int oy = 2 * i + r;
+        if (oy >= out_h) continue;
+        const int ky0 = (f.pad_y0 - r) & 1;
+        const int ry = PY ? 0 : r;                       // first source row of output row r inside v
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+            const int ox = 2 * j + sx;
+            if (ox >= out_w) continue;
+            const int kx0 = (f.pad_x0 - sx) & 1;
+            const int rx = PX ? 0 : sx;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc += v[ry + a][rx + b] * f.w[(ky0 + 2 * a) * 4 + kx0 + 2 * b];
+            float* op = y + (((long long)n * out_h + oy) * out_w + ox) * c + q * 4;
+            if (accumulate) acc += *reinterpret_cast<const f32x4*>(op);
+            *reinterpret_cast<f32x4*>(op) = acc;
+        }
+    }
+}
+
 __global__ void upfirdn_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, const Fir f, int planes,
                                     int in_h, int in_w, int out_h, int out_w, int accumulate) {
     const long long total = (long long)planes * out_h * out_w;
@@ -159,6 +212,25 @@ extern "C" int psld_upfirdn2d_f32(const float* x, float* y, int batch, int c, in
     if (layout == 1) {
         PSLD_CHECK_ARG(c % 4 == 0, "psld_upfirdn2d_f32: NHWC needs C%%4==0 (C=%d)", c);
         const bool k4 = kh == 4 && kw == 4 && up_x == up_y && down_x == down_y && (long long)batch * out_h < 65536;
+        static const int quad = [] { const char* v = getenv("PSLD_FIR_QUAD"); return v ? atoi(v) : 1; }();
+        if (quad && k4 && up_x == 2 && down_x == 1) {
+            // x2 up, 2 x 2 outputs per thread: 42.9 -> 34.8 us on 128x16x16x256 (a pure fill of the output: 20.6 us).  The
+            // same form for x2 down (6 x 6 inputs -> 2 x 2 outputs, 9 loads per output instead of 16) measured SLOWER
+            // (56.5 vs 47.4 us), and so did a branch-free one-output form with all sixteen loads issued up front (48.9 us): the
+            // generic one-output kernel stays for x2 down.
+            const dim3 grid((unsigned)cdiv((long long)((out_w + 1) / 2) * (c / 4), 256), (unsigned)(batch * ((out_h + 1) / 2)));
+#define PSLD_FIR_UP(PY, PX)                                                                                              \
+    hipLaunchKernelGGL((upfirdn4_up2_quad_kernel<PY, PX>), grid, dim3(256), 0, stream, x, y, f, c, in_h, in_w, out_h, out_w, \
+                       accumulate)
+            const int py = pad_y0 & 1, px = pad_x0 & 1;
+            if (py && px) PSLD_FIR_UP(1, 1);
+            else if (py) PSLD_FIR_UP(1, 0);
+            else if (px) PSLD_FIR_UP(0, 1);
+            else PSLD_FIR_UP(0, 0);
+#undef PSLD_FIR_UP
+            PSLD_CHECK_LAUNCH("psld_upfirdn2d_f32");
+            return PSLD_OK;
+        }
         if (k4 && ((up_x == 2 && down_x == 1) || (up_x == 1 && down_x == 2))) {
             const dim3 grid((unsigned)cdiv((long long)out_w * (c / 4), 256), (unsigned)(batch * out_h));
             if (up_x == 2)
