@@ -170,6 +170,7 @@ def test_limb_fragments_exact(ops):
     dict(b=1, c1=32, c2=0, co=128, h=64, w=64),      # CelebA-64 resolution (2-row tiles)
     dict(b=1, c1=256, c2=256, co=256, h=8, w=8),     # north-star K = 4608, split over the channel chunks
     dict(b=2, c1=32, c2=0, co=128, h=4, w=8),        # h*w = 32: four images per tile
+    dict(b=12, c1=64, c2=0, co=256, h=32, w=32),     # 192 tiles of 128 rows -> 384 tiles of 64 rows, no K split
 ])
 def test_conv3x3_split_forward(ops, cfg):
     b, c1, c2, co, h, w_ = (cfg[n] for n in ("b", "c1", "c2", "co", "h", "w"))
@@ -220,6 +221,7 @@ def test_limb_planes_roundtrip_is_exact(ops):
     dict(b=1, c1=32, c2=0, co=128, h=64, w=64),      # CelebA-64 resolution: single-image (non double-buffered) variant
     dict(b=1, c1=256, c2=256, co=256, h=8, w=8),     # split over the channel chunks
     dict(b=2, c1=32, c2=0, co=128, h=4, w=8),
+    dict(b=12, c1=64, c2=0, co=256, h=32, w=32),     # 64-row tiles without a K split (9 row groups per image)
 ])
 def test_conv3x3_limb_input_is_bitwise_the_split_kernel(ops, cfg):
     """psld_conv3x3_limb_f32 (input as bf16 limb planes, halo tile staged by LDS-DMA into two images) computes the
