@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 
-#define PSLD_ABI_VERSION 7 /* 2: limb-MFMA convolutions, math mode, bias-gradient / batched-copy entry points; 3: pointwise weight gradient and batched activation GEMM on limb kernels; 4: GroupNorm statistics from the limb kernels' epilogue; 5: per-sample-time reverse SDE, ScoreLoss nll / l1; 6: limb-plane activations; 7: device-resident dropout seed / Adam scalars (captured training step), GroupNorm-backward sums from the producing epilogue */
+#define PSLD_ABI_VERSION 8 /* 2: limb-MFMA convolutions, math mode, bias-gradient / batched-copy entry points; 3: pointwise weight gradient and batched activation GEMM on limb kernels; 4: GroupNorm statistics from the limb kernels' epilogue; 5: per-sample-time reverse SDE, ScoreLoss nll / l1; 6: limb-plane activations; 7: device-resident dropout seed / Adam scalars (captured training step), GroupNorm-backward sums from the producing epilogue; 8: Winograd F(2x2,3x3) limb convolution */
 #define PSLD_COEFF_STRIDE 12
 
 int psld_version(void);
@@ -150,6 +150,21 @@ int psld_pack_frag_batch(const long long* table_dev, int entries, long long tota
 int psld_conv3x3_split_f32(const float* x1, int c1, const float* x2, int c2, int batch, int h, int w,
                            const void* wfrag, int cout, float* y, int ldy, const psld_epilogue_t* epi,
                            void* workspace, long long ws_bytes, hipStream_t stream);
+
+/* Winograd F(2x2, 3x3) form of psld_conv3x3_split_f32 (forward and, with dgrad fragments, data gradient): the same
+ * convolution, contract and fused epilogue (no gnb_* by-product, no split-K workspace) with 2.25x fewer matrix
+ * instructions.  Y = A^T[(G g G^T) (.) (B^T d B)]A per 2x2 output tile; the transformed operands are formed in fp32 and
+ * carried as three exact bf16 limbs each, six limb products per product, fp32 accumulation: fp32-equivalent arithmetic
+ * re-associated (what cuDNN may pick for the reference's nn.Conv2d 3x3, song_sde/layers.py:103-109), within ~2x of
+ * the direct kernel's rounding error against fp64.  Weights come pre-transformed and pre-split in MFMA operand order
+ * (psld_pack_conv3x3_wino, once per optimizer step; psld_conv3x3_wino_frag_bytes = 16/9 of the direct fragments).
+ * Shapes: c1, c2 multiples of 32, cout a multiple of 128, h even, w in {8,16,32,64}, h*w dividing or divisible by 128. */
+long long psld_conv3x3_wino_frag_bytes(int cout, int cin);
+int psld_conv3x3_wino_supported(int c1, int c2, int batch, int h, int w, int cout);
+int psld_pack_conv3x3_wino(const float* w_oihw, void* ufrag, int cout, int cin, int dgrad, hipStream_t stream);
+int psld_conv3x3_wino_f32(const float* x1, int c1, const float* x2, int c2, int batch, int h, int w,
+                          const void* ufrag, int cout, float* y, int ldy, const psld_epilogue_t* epi,
+                          hipStream_t stream);
 
 /* "Limb planes": an NHWC activation [rows][c] (c a multiple of 32) stored already decomposed, as bf16
  * [rows][c/32 chunks][3 limbs hi|mid|lo][32 channels] (6 bytes per element; hi + mid + lo == x bit for bit).  The

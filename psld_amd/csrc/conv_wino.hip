@@ -1,0 +1,446 @@
+// Winograd F(2x2, 3x3) form of the 3x3 stride-1 pad-1 convolutions (forward and data gradient) on the bf16 limb MFMA
+// path of conv_split.hip: 2.25x fewer matrix instructions for the same fp32-equivalent result.
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A        d: 4x4 input tile, g: 3x3 filter, Y: 2x2 output tile (Lavin & Gray)
+//
+// It is a re-association of the same fp32 arithmetic, not a narrower one: the transformed operands V = B^T d B and
+// U = G g G^T are formed in fp32, each is decomposed EXACTLY into three bf16 limbs (limb.h: split3) and every product
+// is accumulated in fp32 from the six limb products of weight >= 2^-16, as in the direct kernels.  What the reference's
+// GPU path may run for exactly these layers (nn.Conv2d 3x3 fp32 -> cuDNN Winograd; song_sde/layers.py:103-109).
+//
+// Shape of the kernel (one 512-thread workgroup per CU, two waves per SIMD):
+//   * a workgroup owns 32 tiles (= 128 consecutive output pixels, the direct kernel's tile) x 128 output channels for
+//     ALL 16 transform positions; wave w owns the 16 channels n0 + 16w.. for the 32 tiles: 16 positions x 2 tile blocks
+//     of v_mfma_f32_16x16x32_bf16 accumulators = 128 VGPRs, so the output transform A^T m A is register arithmetic in
+//     the lane that holds (tile, 4 channels) - no exchange between waves;
+//   * per 32-channel chunk the raw fp32 halo tile ((rows+2) x (W+2) pixels, <= 36 KB) goes global -> registers (loaded
+//     a whole MFMA phase ahead) -> LDS; every thread then transforms (tile, 4 channels, 8 of the 16 positions):
+//     2 adds per V element, split3, and writes the limb image V[pos][limb][tile][32 ch] (96 KB) - the split is paid
+//     once per V element and workgroup;
+//   * U comes pre-transformed and pre-split in MFMA operand order (psld_pack_conv3x3_wino, once per optimizer step,
+//     16/9 the bytes of the direct fragments) straight from L2, each fragment loaded by exactly one wave;
+//   * per chunk and wave: 16 positions x (6 ds_read_b128 + 3 global loads + 12 MFMAs).
+// Epilogue = the direct kernels' (bias / time-embedding row bias / residual / scale / accumulate / GroupNorm partial
+// sums of the output), applied to the four output pixels of a tile.
+#include <cstdlib>
+#include <cstring>
+
+#include "common.h"
+#include "psld_hip.h"
+#include "tile_shared.h"
+#include "limb.h"
+
+namespace {
+
+constexpr int WT = 32;                    // tiles per workgroup
+constexpr int VPLANE = WT * ROWB;         // bytes of one (position, limb) plane of the V image: 32 tiles x 64 B
+constexpr int VBYTES = 16 * 3 * VPLANE;   // 98,304
+constexpr int WINO_THREADS = 512;
+
+struct WinoArgs {
+    const float* x1;
+    const float* x2;
+    int C1, C2;
+    int B, H, W;
+    const u32x4* ufrag;     // [N/128][8 waves][chunk][16 pos][3 limbs][64 lanes]
+    int N, M;               // cout (multiple of 128), B*H*W
+    int chunks;             // (C1 + C2) / 32
+    float* C;
+    int ldc;
+    int nseg, rps;          // image segments per 128-pixel tile and output rows per segment (dconv_geometry, mt = 128)
+    PsldEpilogue e;
+    const float* zero;
+};
+
+// raw halo image: pixel hp, 16-byte slot q (4 channels) -> byte offset.  Pixels sit pairwise in 256-byte rows and the
+// half of the row a pixel takes alternates with the pair index: the transform phase reads pixels 2 apart (tiles are two
+// pixels wide), which a linear [pixel][128 B] image would put on half of the banks (2-way conflict on ds_read_b128).
+__device__ __forceinline__ int raw_off(int hp, int q) {
+    return (hp >> 1) * 256 + (((((hp & 1) ^ ((hp >> 1) & 1)) << 3) + q) << 4);
+}
+
+// ---- weights -> transformed limb fragments -----------------------------------------------------------------
+// One work item = lane slot (nt, wave, chunk, lane): n = nt*128 + wave*16 + (lane & 15), k = chunk*32 + (lane >> 4)*8 + j.
+// dgrad = 0: g = w[co = n][ci = k][:, :]; dgrad = 1: g = w[co = k][ci = n] rotated by 180 degrees (conv_split.hip).
+__global__ void wino_pack_kernel(const float* __restrict__ w, u32x4* __restrict__ out, int n_out, int k_in,
+                                 long long sn, long long sk, int flip) {
+    const int chunks = k_in / 32;
+    const long long items = (long long)(n_out / 16) * chunks * 64;
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long long)gridDim.x * blockDim.x) {
+        long long t = it;
+        const int lane = (int)(t & 63); t >>= 6;
+        const int chunk = (int)(t % chunks); t /= chunks;
+        const int nblk = (int)t;                            // nt*8 + wave
+        const int n = nblk * 16 + (lane & 15);
+        const int k0 = chunk * 32 + (lane >> 4) * 8;
+        float U[8][16];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float* p = w + n * sn + (k0 + j) * sk;
+            float g[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) g[a][b] = flip ? p[8 - (a * 3 + b)] : p[a * 3 + b];
+            float t4[4][3];                                 // G g
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                t4[0][b] = g[0][b];
+                t4[1][b] = 0.5f * ((g[0][b] + g[2][b]) + g[1][b]);
+                t4[2][b] = 0.5f * ((g[0][b] + g[2][b]) - g[1][b]);
+                t4[3][b] = g[2][b];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {                   // (G g) G^T
+                U[j][a * 4 + 0] = t4[a][0];
+                U[j][a * 4 + 1] = 0.5f * ((t4[a][0] + t4[a][2]) + t4[a][1]);
+                U[j][a * 4 + 2] = 0.5f * ((t4[a][0] + t4[a][2]) - t4[a][1]);
+                U[j][a * 4 + 3] = t4[a][2];
+            }
+        }
+        u32x4* o = out + ((long long)nblk * chunks + chunk) * (16 * 3 * 64) + lane;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split3(U[2 * j][p], U[2 * j + 1][p], hi[j], mid[j], lo[j]);
+            o[(p * 3 + 0) * 64] = u32x4{hi[0], hi[1], hi[2], hi[3]};
+            o[(p * 3 + 1) * 64] = u32x4{mid[0], mid[1], mid[2], mid[3]};
+            o[(p * 3 + 2) * 64] = u32x4{lo[0], lo[1], lo[2], lo[3]};
+        }
+    }
+}
+
+// ---- forward / data gradient ----------------------------------------------------------------------------------
+// NI = float4 staging items per thread and chunk: the raw image has NI*64 halo pixels.
+template <int NI>
+__global__ void __launch_bounds__(WINO_THREADS) wino_conv_kernel(const WinoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Vs = smem;
+    unsigned char* Rs = smem + VBYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = a.N >> 7;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    const int m0 = tile_m * 128, n0 = tile_n * 128;
+
+    const int W2 = a.W + 2, HW = a.H * a.W;
+    const int tiles_x = a.W >> 1;
+    const int tps = (a.rps >> 1) * tiles_x;          // tiles per segment
+    const int img0 = m0 / HW;
+    const int oy0 = (m0 - img0 * HW) / a.W;          // 0 when a tile holds whole images
+    const float* zp = a.zero;
+
+    // ---- raw staging items: halo pixel (tid + 512 i) >> 3, channel quad tid & 7 -------------------------------
+    const int c4 = tid & 7;
+    int hoff[NI], rdst[NI];
+    {
+        const int seg_px = (a.rps + 2) * W2;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int px = (tid + WINO_THREADS * i) >> 3;
+            const int seg = px / seg_px;
+            const int rem = px - seg * seg_px;
+            const int hr = rem / W2, hx = rem - hr * W2;
+            const int img = img0 + seg, iy = oy0 + hr - 1, ix = hx - 1;
+            const bool ok = seg < a.nseg && img < a.B && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            hoff[i] = ok ? (img * a.H + iy) * a.W + ix : -1;
+            rdst[i] = raw_off(px, c4);
+        }
+    }
+    f32x4 hv[NI];
+    auto load_raw = [&](int c) {
+        const int c0 = c * 32;
+        const bool second = c0 >= a.C1;
+        const float* src = second ? a.x2 : a.x1;
+        const int cs = second ? a.C2 : a.C1;
+        const int cc = (second ? c0 - a.C1 : c0) + c4 * 4;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) hv[i] = ld4(hoff[i] >= 0 ? src + ((long long)hoff[i] * cs + cc) : zp);
+    };
+    auto store_raw = [&]() {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) *reinterpret_cast<f32x4*>(Rs + rdst[i]) = hv[i];
+    };
+
+    // ---- transform role: (half of the positions, tile, channel quad) ----------------------------------------------
+    // waves 0-3 produce V rows 0,1 (positions 0-7) from d rows 0,1,2; waves 4-7 rows 2,3 (positions 8-15) from d rows 1,2,3
+    const int th = wave >> 2;
+    const int t_tile = (tid & 255) >> 3, t_q = tid & 7;
+    int t_src;      // halo pixel of d[th][0]
+    {
+        const int seg = t_tile / tps, rem = t_tile - seg * tps;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        t_src = (seg * (a.rps + 2) + 2 * ty + th) * W2 + 2 * tx;
+    }
+    const int t_dst = t_tile * ROWB + (((t_q >> 1) ^ lds_swz(t_tile)) << 4) + (t_q & 1) * 8;
+    auto transform = [&]() {
+        f32x4 e[3][4];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) e[r][c] = *reinterpret_cast<const f32x4*>(Rs + raw_off(t_src + r * W2 + c, t_q));
+        // row stage of B^T d: V rows (0: d0 - d2, 1: d1 + d2) or (2: d2 - d1, 3: d1 - d3)
+        f32x4 ra[4], rb[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            ra[c] = e[0][c] - e[2][c];                      // V row 0 (th = 0) / V row 3 (th = 1)
+            rb[c] = th ? e[1][c] - e[0][c] : e[1][c] + e[2][c];     // V row 1 / V row 2
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const f32x4* r = half ? rb : ra;
+            const int vrow = th ? (half ? 2 : 3) : (half ? 1 : 0);
+            f32x4 v[4];
+            v[0] = r[0] - r[2];
+            v[1] = r[1] + r[2];
+            v[2] = r[2] - r[1];
+            v[3] = r[1] - r[3];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned h0, m0_, l0, h1, m1, l1;
+                split3(v[j][0], v[j][1], h0, m0_, l0);
+                split3(v[j][2], v[j][3], h1, m1, l1);
+                unsigned char* q = Vs + (vrow * 4 + j) * 3 * VPLANE + t_dst;
+                *reinterpret_cast<u32x2*>(q) = u32x2{h0, h1};
+                *reinterpret_cast<u32x2*>(q + VPLANE) = u32x2{m0_, m1};
+                *reinterpret_cast<u32x2*>(q + 2 * VPLANE) = u32x2{l0, l1};
+            }
+        }
+    };
+
+    // ---- MFMA role: 32 tiles x 16 channels x 16 positions ------------------------------------------------------------
+    const int r16 = lane & 15, kq = lane >> 4;
+    int aoff[2];
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+        const int row = tb * 16 + r16;
+        aoff[tb] = row * ROWB + ((kq ^ lds_swz(row)) << 4);
+    }
+    const u32x4* up = a.ufrag + ((long long)(tile_n * 8 + wave) * a.chunks) * (16 * 3 * 64) + lane;
+    const int sig_end = a.chunks * 16;
+    u32x4 bq[2][3];
+    auto load_b = [&](int sigma, u32x4 (&dst)[3]) {
+        const u32x4* p = up + (long long)min(sigma, sig_end - 1) * (3 * 64);
+#pragma unroll
+        for (int l = 0; l < 3; ++l) dst[l] = p[l * 64];
+    };
+
+    f32x4v acc[16][2];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) acc[p][tb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    load_raw(0);
+    load_b(0, bq[0]);
+    store_raw();
+    __syncthreads();
+    transform();
+    __syncthreads();
+
+    for (int c = 0; c < a.chunks; ++c) {
+        const bool more = c + 1 < a.chunks;
+        if (more) load_raw(c + 1);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            load_b(c * 16 + p + 1, bq[(p & 1) ^ 1]);
+            u32x4 fa[2][3];
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                for (int l = 0; l < 3; ++l)
+                    fa[tb][l] = *reinterpret_cast<const u32x4*>(Vs + (p * 3 + l) * VPLANE + aoff[tb]);
+            // limb products, smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)   [activation, weight]
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb)
+                    acc[p][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(      // weights first: D^T[channel][tile]
+                        __builtin_bit_cast(bf16x8, bq[p & 1][PB[t]]), __builtin_bit_cast(bf16x8, fa[tb][PA[t]]),
+                        acc[p][tb], 0, 0, 0);
+        }
+        if (more) {
+            store_raw();            // the raw image was last read by transform() of this chunk, two barriers ago
+            __syncthreads();        // every wave is done with V(c); raw(c + 1) is visible
+            transform();
+            __syncthreads();
+        }
+    }
+
+    // ---- output transform + fused epilogue ----------------------------------------------------------------------------
+    // lane: tile tb*16 + r16, channels cn .. cn+3
+    const PsldEpilogue& e = a.e;
+    const int cn = n0 + wave * 16 + 4 * kq;
+    const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4v bias4 = e.bias ? *reinterpret_cast<const f32x4v*>(e.bias + cn) : zero4;
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+        const int tile = tb * 16 + r16;
+        const int seg = tile / tps, rem = tile - seg * tps;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        const int gm00 = m0 + seg * (a.rps * a.W) + (2 * ty) * a.W + 2 * tx;
+        const bool ok = gm00 < a.M;                         // whole images only: a tile is in range or not
+        f32x4v s[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s[i][0] = (acc[4 * i][tb] + acc[4 * i + 1][tb]) + acc[4 * i + 2][tb];
+            s[i][1] = (acc[4 * i + 1][tb] - acc[4 * i + 2][tb]) - acc[4 * i + 3][tb];
+        }
+        f32x4v y[2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            y[0][b] = (s[0][b] + s[1][b]) + s[2][b];
+            y[1][b] = (s[1][b] - s[2][b]) - s[3][b];
+        }
+        float gs = 0.f, gss = 0.f;
+        const int gmc = ok ? gm00 : 0;                       // clamped: loads stay in range
+        f32x4v rv[2][2], cv[2][2], tbv[2][2];
+#pragma unroll
+        for (int ya = 0; ya < 2; ++ya)
+#pragma unroll
+            for (int xb = 0; xb < 2; ++xb) {
+                const int gm = gmc + ya * a.W + xb;
+                rv[ya][xb] = e.res ? *reinterpret_cast<const f32x4v*>(e.res + (long long)gm * e.ldres + cn) : zero4;
+                cv[ya][xb] = e.accumulate ? *reinterpret_cast<const f32x4v*>(a.C + (long long)gm * a.ldc + cn) : zero4;
+                tbv[ya][xb] = e.rowbias ? *reinterpret_cast<const f32x4v*>(e.rowbias + (long long)(gm / e.rows_per_img) * e.ld_rowbias + cn)
+                                        : zero4;
+            }
+#pragma unroll
+        for (int ya = 0; ya < 2; ++ya)
+#pragma unroll
+            for (int xb = 0; xb < 2; ++xb) {
+                const int gm = gmc + ya * a.W + xb;
+                // x = ((acc*alpha + bias + rowbias) + res) * out_scale + prev: the direct kernels' order
+                f32x4v o = y[ya][xb] * e.alpha + (bias4 + tbv[ya][xb]);
+                if (e.res) o += rv[ya][xb];
+                o *= e.out_scale;
+                if (e.accumulate) o += cv[ya][xb];
+                if (ok) {
+                    *reinterpret_cast<f32x4v*>(a.C + (long long)gm * a.ldc + cn) = o;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        gs += o[v];
+                        gss += o[v] * o[v];
+                    }
+                }
+            }
+        if (e.gn_part) {
+            // tile block tb = 64 pixels of one image = one "run" of the partial-sum table (any fixed partition of the image
+            // into hw/64 runs serves: the consumer sums all of them).  Fine group = 8 channels = lane pairs kq (0,1) / (2,3).
+            float s1 = gs, s2 = gss;
+#pragma unroll
+            for (int sft = 1; sft <= 16; sft <<= 1) {
+                s1 += __shfl_xor(s1, sft, 64);
+                s2 += __shfl_xor(s2, sft, 64);
+            }
+            const int row0 = m0 + tb * 64;
+            if ((lane & 0x1f) == 0 && row0 < a.M) {
+                const int img = row0 / e.gn_hw, chunk = (row0 - img * e.gn_hw) >> 6, chunks = e.gn_hw >> 6;
+                const int f = ((n0 + wave * 16) >> 3) + (lane >> 5);
+                double* pp = e.gn_part + (((long long)img * chunks + chunk) * (a.N >> 3) + f) * 2;
+                pp[0] = (double)s1;
+                pp[1] = (double)s2;
+            }
+        }
+    }
+}
+
+template <int NI>
+int launch_wino(const WinoArgs& a, hipStream_t stream, const char* name) {
+    constexpr size_t LDS = (size_t)VBYTES + (size_t)NI * 64 * 128;
+    static_assert(LDS <= 163840, "LDS budget");
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel<NI>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        if (e != hipSuccess) {
+            psld_set_error("%s: hipFuncSetAttribute failed: %s", name, hipGetErrorString(e));
+            return PSLD_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    dim3 grid((unsigned)(cdiv(a.M, 128) * (a.N / 128)));
+    hipLaunchKernelGGL((wino_conv_kernel<NI>), grid, dim3(WINO_THREADS), LDS, stream, a);
+    PSLD_CHECK_LAUNCH(name);
+    return PSLD_OK;
+}
+
+bool wino_geometry(int h, int w, int* nseg, int* rps, int* halo_px) {
+    if (w != 8 && w != 16 && w != 32 && w != 64) return false;
+    if (h % 2) return false;
+    const int hw = h * w;
+    if (hw >= 128) {
+        if (hw % 128) return false;
+        *nseg = 1;
+        *rps = 128 / w;
+    } else {
+        if (128 % hw) return false;
+        *nseg = 128 / hw;
+        *rps = h;
+    }
+    if (*rps % 2) return false;
+    *halo_px = *nseg * (*rps + 2) * (w + 2);
+    return *halo_px <= 5 * 64;
+}
+
+}  // namespace
+
+extern "C" long long psld_conv3x3_wino_frag_bytes(int cout, int cin) { return (long long)cout * cin * 16 * 6; }
+
+extern "C" int psld_conv3x3_wino_supported(int c1, int c2, int batch, int h, int w, int cout) {
+    int nseg, rps, halo;
+    return c1 > 0 && c2 >= 0 && c1 % 32 == 0 && c2 % 32 == 0 && cout > 0 && cout % 128 == 0 && batch > 0 &&
+           wino_geometry(h, w, &nseg, &rps, &halo);
+}
+
+extern "C" int psld_pack_conv3x3_wino(const float* w_oihw, void* ufrag, int cout, int cin, int dgrad, hipStream_t stream) {
+    PSLD_CHECK_ARG(w_oihw && ufrag && aligned16(ufrag), "psld_pack_conv3x3_wino: null / unaligned pointer");
+    const int n_out = dgrad ? cin : cout, k_in = dgrad ? cout : cin;
+    PSLD_CHECK_ARG(n_out > 0 && k_in > 0 && n_out % 128 == 0 && k_in % 32 == 0,
+                   "psld_pack_conv3x3_wino: needs out channels %%128 and in channels %%32 (got %d, %d)", n_out, k_in);
+    const long long items = (long long)(n_out / 16) * (k_in / 32) * 64;
+    const int blocks = (int)((items + 63) / 64 < 16384 ? (items + 63) / 64 : 16384);
+    if (dgrad) hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(64), 0, stream, w_oihw, reinterpret_cast<u32x4*>(ufrag),
+                                  n_out, k_in, 9LL, (long long)cin * 9, 1);
+    else hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(64), 0, stream, w_oihw, reinterpret_cast<u32x4*>(ufrag),
+                            n_out, k_in, (long long)cin * 9, 9LL, 0);
+    PSLD_CHECK_LAUNCH("psld_pack_conv3x3_wino");
+    return PSLD_OK;
+}
+
+extern "C" int psld_conv3x3_wino_f32(const float* x1, int c1, const float* x2, int c2, int batch, int h, int w,
+                                     const void* ufrag, int cout, float* y, int ldy, const psld_epilogue_t* epi,
+                                     hipStream_t stream) {
+    PSLD_CHECK_ARG(x1 && ufrag && y && (c2 == 0 || x2), "psld_conv3x3_wino_f32: null pointer");
+    PSLD_CHECK_ARG(psld_conv3x3_wino_supported(c1, c2, batch, h, w, cout),
+                   "psld_conv3x3_wino_f32: unsupported shape c1=%d c2=%d %dx%d cout=%d", c1, c2, h, w, cout);
+    PSLD_CHECK_ARG(aligned16(x1) && (!x2 || aligned16(x2)) && aligned16(ufrag), "psld_conv3x3_wino_f32: unaligned pointer");
+    WinoArgs a{};
+    a.x1 = x1; a.x2 = x2; a.C1 = c1; a.C2 = c2;
+    a.B = batch; a.H = h; a.W = w;
+    a.ufrag = reinterpret_cast<const u32x4*>(ufrag);
+    a.N = cout; a.M = batch * h * w;
+    a.chunks = (c1 + c2) / 32;
+    a.C = y; a.ldc = ldy;
+    int halo_px = 0;
+    wino_geometry(h, w, &a.nseg, &a.rps, &halo_px);
+    a.e = make_epilogue(epi);
+    const PsldEpilogue& e = a.e;
+    PSLD_CHECK_ARG(!e.gnb_part, "psld_conv3x3_wino_f32: no GroupNorm-backward by-product in this kernel");
+    PSLD_CHECK_ARG(!e.gn_part || (e.gn_hw == h * w && e.gn_hw % 64 == 0 && !e.accumulate),
+                   "psld_conv3x3_wino_f32: gn_part needs gn_hw = h*w, a multiple of 64, and no accumulation");
+    PSLD_CHECK_ARG(ldy % 4 == 0 && aligned16(y) && (!e.res || (e.ldres % 4 == 0 && aligned16(e.res))) &&
+                       (!e.bias || aligned16(e.bias)) && (!e.rowbias || (e.ld_rowbias % 4 == 0 && aligned16(e.rowbias))),
+                   "limb kernels: y, residual, bias and rowbias need 16-byte aligned rows (pointer and row stride)");
+    a.zero = psld_detail_zero_page("psld_conv3x3_wino_f32");
+    if (!a.zero) return PSLD_ERR_LAUNCH;
+    const int ni = cdiv((long long)halo_px * 8, WINO_THREADS);
+    const char* name = "psld_conv3x3_wino_f32";
+    if (ni <= 3) return launch_wino<3>(a, stream, name);
+    if (ni <= 4) return launch_wino<4>(a, stream, name);
+    return launch_wino<5>(a, stream, name);
+}

@@ -203,6 +203,31 @@ def conv3x3_split(x1: Tensor, x2: Optional[Tensor], wfrag: Tensor, cout: int, y:
                                        ws, wsb, _stream()), "psld_conv3x3_split_f32")
 
 
+@functools.lru_cache(maxsize=None)
+def conv3x3_wino_supported(c1: int, c2: int, b: int, h: int, w: int, cout: int) -> bool:
+    return bool(lib().psld_conv3x3_wino_supported(c1, c2, b, h, w, cout))
+
+
+def conv3x3_wino_frag(w_oihw: Tensor, dgrad: bool, out: Optional[Tensor] = None) -> Tensor:
+    """3x3 weights -> Winograd-transformed (G g G^T) bf16 limb fragments (uint8 buffer of psld_conv3x3_wino_frag_bytes)."""
+    co, ci = w_oihw.shape[0], w_oihw.shape[1]
+    if out is None:
+        out = torch.empty(lib().psld_conv3x3_wino_frag_bytes(co, ci), dtype=torch.uint8, device=w_oihw.device)
+    check(lib().psld_pack_conv3x3_wino(w_oihw.data_ptr(), out.data_ptr(), co, ci, int(dgrad), _stream()),
+          "psld_pack_conv3x3_wino")
+    return out
+
+
+def conv3x3_wino(x1: Tensor, x2: Optional[Tensor], ufrag: Tensor, cout: int, y: Tensor,
+                 epi: Optional[Epilogue] = None, ldy: Optional[int] = None):
+    """conv3x3_split in Winograd F(2x2, 3x3) form (fp32 NHWC input(s), fragments of conv3x3_wino_frag)."""
+    b, h, w, c1 = x1.shape
+    c2 = x2.shape[-1] if x2 is not None else 0
+    check(lib().psld_conv3x3_wino_f32(x1.data_ptr(), c1, _p(x2), c2, b, h, w, ufrag.data_ptr(), cout, y.data_ptr(),
+                                      ldy if ldy is not None else cout, C.byref(epi) if epi is not None else None,
+                                      _stream()), "psld_conv3x3_wino_f32")
+
+
 class LimbPlanes:
     """An NHWC activation stored as bf16 limb planes [rows][c/32][3][32] (include/psld_hip.h): ``t`` is the raw int16
     storage, ``shape`` the logical (b, h, w, c)."""
