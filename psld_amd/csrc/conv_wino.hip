@@ -50,6 +50,7 @@ struct WinoArgs {
     int nseg, rps;          // image segments per 128-pixel tile and output rows per segment (dconv_geometry, mt = 128)
     PsldEpilogue e;
     const float* zero;
+    int nmajor;
 };
 
 // raw halo image: pixel hp, 16-byte slot q (4 channels) -> byte offset.  Pixels sit pairwise in 256-byte rows and the
@@ -113,7 +114,9 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, u32x4* __restrict_
 
 // ---- forward / data gradient ----------------------------------------------------------------------------------
 // NI = float4 staging items per thread and chunk: the raw image has NI*64 halo pixels.
-template <int NI>
+// ABL: timing-only ablations (results wrong): 1 = transform only for the first chunk, 2 = weight fragments loaded once,
+// 4 = raw halo loaded once
+template <int NI, int ABL = 0>
 __global__ void __launch_bounds__(WINO_THREADS) wino_conv_kernel(const WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Vs = smem;
@@ -123,7 +126,11 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv_kernel(const WinoArgs 
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_n = a.N >> 7;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    const int tiles_m = gridDim.x / tiles_n;
+    // n-major: an XCD's contiguous run of logical tiles then streams ONE 128-channel slice of U (3.1 MB at 256 input
+    // channels: it stays in the XCD's 4 MB L2) instead of alternating between all of them
+    const int tile_n = a.nmajor ? bid / tiles_m : bid % tiles_n;
+    const int tile_m = a.nmajor ? bid - tile_n * tiles_m : bid / tiles_n;
     const int m0 = tile_m * 128, n0 = tile_n * 128;
 
     const int W2 = a.W + 2, HW = a.H * a.W;
@@ -221,7 +228,7 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv_kernel(const WinoArgs 
     }
     const u32x4* up = a.ufrag + ((long long)(tile_n * 8 + wave) * a.chunks) * (16 * 3 * 64) + lane;
     const int sig_end = a.chunks * 16;
-    u32x4 bq[2][3];
+    u32x4 bq[4][3];
     auto load_b = [&](int sigma, u32x4 (&dst)[3]) {
         const u32x4* p = up + (long long)min(sigma, sig_end - 1) * (3 * 64);
 #pragma unroll
@@ -236,37 +243,58 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv_kernel(const WinoArgs 
 
     load_raw(0);
     load_b(0, bq[0]);
+    load_b(1, bq[1]);
     store_raw();
     __syncthreads();
     transform();
     __syncthreads();
 
+    // One position = 12 MFMAs in three groups by ACTIVATION limb - (lo,hi) | (mid,mid) (mid,hi) | (hi,lo) (hi,mid) (hi,hi)
+    // [activation, weight]; lowest weight first within what that allows - so that a limb's fragment registers are dead after
+    // its group and are refilled IN PLACE with the next position's fragments while the remaining groups run: every
+    // ds_read_b128 has 6-10 MFMAs (plus the partner wave's) to land and no second fragment set is needed.  Weight fragments
+    // are loaded two positions ahead into a ring of four sets.  sched_barrier(0) keeps hipcc from sinking the reads to
+    // their first use (what it does on its own at 254 VGPRs: three exposed LDS latencies per position).
+    u32x4 fa[3][2];          // [limb hi | mid | lo][tile block]
+    auto read_a = [&](int p, int l) {
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) fa[l][tb] = *reinterpret_cast<const u32x4*>(Vs + (p * 3 + l) * VPLANE + aoff[tb]);
+    };
+    auto mm = [&](int p, int la, int lb) {
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+            acc[p][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(      // weights first: D^T[channel][tile]
+                __builtin_bit_cast(bf16x8, bq[p & 3][lb]), __builtin_bit_cast(bf16x8, fa[la][tb]), acc[p][tb], 0, 0, 0);
+    };
     for (int c = 0; c < a.chunks; ++c) {
         const bool more = c + 1 < a.chunks;
-        if (more) load_raw(c + 1);
+        read_a(0, 2);
+        read_a(0, 1);
+        read_a(0, 0);
+        if (more && !(ABL & 4)) load_raw(c + 1);
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
-            load_b(c * 16 + p + 1, bq[(p & 1) ^ 1]);
-            u32x4 fa[2][3];
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-                for (int l = 0; l < 3; ++l)
-                    fa[tb][l] = *reinterpret_cast<const u32x4*>(Vs + (p * 3 + l) * VPLANE + aoff[tb]);
-            // limb products, smallest first: (lo,hi) (hi,lo) (mid,mid) (mid,hi) (hi,mid) (hi,hi)   [activation, weight]
-            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
-#pragma unroll
-                for (int tb = 0; tb < 2; ++tb)
-                    acc[p][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(      // weights first: D^T[channel][tile]
-                        __builtin_bit_cast(bf16x8, bq[p & 1][PB[t]]), __builtin_bit_cast(bf16x8, fa[tb][PA[t]]),
-                        acc[p][tb], 0, 0, 0);
+            if (!(ABL & 2)) load_b(c * 16 + p + 2, bq[(p + 2) & 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(p, 2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (p < 15) read_a(p + 1, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(p, 1, 1);
+            mm(p, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (p < 15) read_a(p + 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(p, 0, 2);
+            mm(p, 0, 1);
+            mm(p, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (p < 15) read_a(p + 1, 0);
         }
         if (more) {
-            store_raw();            // the raw image was last read by transform() of this chunk, two barriers ago
-            __syncthreads();        // every wave is done with V(c); raw(c + 1) is visible
-            transform();
+            if (!(ABL & 1)) store_raw();    // the raw image was last read by transform() of this chunk, two barriers ago
+            __syncthreads();                // every wave is done with V(c); raw(c + 1) is visible
+            if (!(ABL & 1)) transform();
             __syncthreads();
         }
     }
@@ -349,13 +377,13 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv_kernel(const WinoArgs 
     }
 }
 
-template <int NI>
+template <int NI, int ABL = 0>
 int launch_wino(const WinoArgs& a, hipStream_t stream, const char* name) {
     constexpr size_t LDS = (size_t)VBYTES + (size_t)NI * 64 * 128;
     static_assert(LDS <= 163840, "LDS budget");
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel<NI>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel<NI, ABL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         if (e != hipSuccess) {
             psld_set_error("%s: hipFuncSetAttribute failed: %s", name, hipGetErrorString(e));
@@ -364,7 +392,7 @@ int launch_wino(const WinoArgs& a, hipStream_t stream, const char* name) {
         configured = true;
     }
     dim3 grid((unsigned)(cdiv(a.M, 128) * (a.N / 128)));
-    hipLaunchKernelGGL((wino_conv_kernel<NI>), grid, dim3(WINO_THREADS), LDS, stream, a);
+    hipLaunchKernelGGL((wino_conv_kernel<NI, ABL>), grid, dim3(WINO_THREADS), LDS, stream, a);
     PSLD_CHECK_LAUNCH(name);
     return PSLD_OK;
 }
@@ -438,8 +466,20 @@ extern "C" int psld_conv3x3_wino_f32(const float* x1, int c1, const float* x2, i
                    "limb kernels: y, residual, bias and rowbias need 16-byte aligned rows (pointer and row stride)");
     a.zero = psld_detail_zero_page("psld_conv3x3_wino_f32");
     if (!a.zero) return PSLD_ERR_LAUNCH;
+    static const int nmaj = [] { const char* v = getenv("PSLD_WINO_NMAJOR"); return v ? atoi(v) : 1; }();
+    a.nmajor = nmaj;
     const int ni = cdiv((long long)halo_px * 8, WINO_THREADS);
     const char* name = "psld_conv3x3_wino_f32";
+    static const int abl = [] { const char* v = getenv("PSLD_WINO_ABL"); return v ? atoi(v) : 0; }();
+    if (abl && ni <= 4) {
+        switch (abl) {
+            case 1: return launch_wino<4, 1>(a, stream, name);
+            case 2: return launch_wino<4, 2>(a, stream, name);
+            case 3: return launch_wino<4, 3>(a, stream, name);
+            case 6: return launch_wino<4, 6>(a, stream, name);
+            case 7: return launch_wino<4, 7>(a, stream, name);
+        }
+    }
     if (ni <= 3) return launch_wino<3>(a, stream, name);
     if (ni <= 4) return launch_wino<4>(a, stream, name);
     return launch_wino<5>(a, stream, name);
