@@ -19,15 +19,19 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 
 // Exact three-limb decomposition of two fp32 values into packed bf16 pairs (x0 in the low half):
 // hi = rne_bf16(x), mid = rne_bf16(x - hi), lo = x - hi - mid (at most 8 significant bits left: exact).
+// v_cvt_pk_bf16_f32 as an opaque (pure) instruction: written with bf16 vector casts, hipcc may re-derive "hi << 16" from a
+// second, single-value conversion (5 conversions per pair instead of 3 - seen under -fno-slp-vectorize).
+__device__ __forceinline__ unsigned cvt_pk_bf16(float x0, float x1) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(x0), "v"(x1));
+    return r;
+}
 __device__ __forceinline__ void split3(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
-    const bf16x2 ph = {(__bf16)x0, (__bf16)x1};
-    hi = __builtin_bit_cast(unsigned, ph);
+    hi = cvt_pk_bf16(x0, x1);
     const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
-    const bf16x2 pm = {(__bf16)r0, (__bf16)r1};
-    mid = __builtin_bit_cast(unsigned, pm);
+    mid = cvt_pk_bf16(r0, r1);
     const float s0 = r0 - __uint_as_float(mid << 16), s1 = r1 - __uint_as_float(mid & 0xffff0000u);
-    const bf16x2 pl = {(__bf16)s0, (__bf16)s1};
-    lo = __builtin_bit_cast(unsigned, pl);
+    lo = cvt_pk_bf16(s0, s1);
 }
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));

@@ -1,1 +1,1 @@
-for nm in 0 1; do for a in 0 2; do echo "NMAJOR=$nm ABL=$a"; PSLD_WINO_NMAJOR=$nm PSLD_WINO_ABL=$a python tools/bench_wino.py --rounds 3 --shapes "256,256,32;512,256,32;256,256,16" 2>&1 | grep "conv fwd"; done; done
+for a in 0 1 2 3; do echo "W4 ABL=$a"; PSLD_WINO_ABL=$a python tools/bench_wino.py --rounds 3 --shapes "256,256,32;512,256,16" 2>&1 | grep "conv fwd"; done
