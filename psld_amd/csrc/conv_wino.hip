@@ -690,6 +690,292 @@ __global__ void __launch_bounds__(256, 1) wino_conv4_kernel(const WinoArgs a) {
     }
 }
 
+// ---- eight waves, staggered roles: the transform of one SIMD partner runs under the MFMAs of the other ----------------
+// Same tile, same wave tile as wino_conv_kernel (wave w: 32 tiles x 16 channels x 16 positions, 128 accumulator VGPRs,
+// two waves per SIMD) and the half-image schedule of wino_conv4_kernel (HP0(c): MFMAs on V rows 0,1 of chunk c, V rows 2,3
+// of chunk c being produced; HP1(c): MFMAs on rows 2,3, rows 0,1 of chunk c + 1 being produced; one barrier after each).
+// Inside a half-phase every wave has two blocks of work - its share of the transform (one V row of one (tile, channel
+// quad) item: 8 ds_read_b128, 32 adds, 8 split3 pairs, 12 ds_write_b64) and 8 positions x 12 MFMAs - and the two waves
+// that share a SIMD (w and w + 4) run them in OPPOSITE order: while one issues vector ALU work the other owns the matrix
+// pipe, with no instruction-level interleaving to get right (the hardware arbitrates between the two waves) and the
+// partner's MFMAs covering each wave's memory latencies, which one wave per SIMD has to cover by itself.
+template <int ABL = 0>
+__global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NI = 4;                     // raw image: 256 halo pixels
+    constexpr int RAWB = NI * 64 * 128;
+    unsigned char* Vs = smem;
+    unsigned char* Rs = smem + VBYTES;        // two raw images
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = a.N >> 7;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles_m = gridDim.x / tiles_n;
+    const int tile_n = a.nmajor ? bid / tiles_m : bid % tiles_n;
+    const int tile_m = a.nmajor ? bid - tile_n * tiles_m : bid / tiles_n;
+    const int m0 = tile_m * 128, n0 = tile_n * 128;
+
+    const int W2 = a.W + 2, HW = a.H * a.W;
+    const int tiles_x = a.W >> 1;
+    const int tps = (a.rps >> 1) * tiles_x;
+    const int img0 = m0 / HW;
+    const int oy0 = (m0 - img0 * HW) / a.W;
+    const float* zp = a.zero;
+
+    const int c4 = tid & 7;
+    int hoff[NI], rdst[NI];
+    {
+        const int seg_px = (a.rps + 2) * W2;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int px = (tid + WINO_THREADS * i) >> 3;
+            const int seg = px / seg_px;
+            const int rem = px - seg * seg_px;
+            const int hr = rem / W2, hx = rem - hr * W2;
+            const int img = img0 + seg, iy = oy0 + hr - 1, ix = hx - 1;
+            const bool ok = seg < a.nseg && img < a.B && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            hoff[i] = ok ? (img * a.H + iy) * a.W + ix : -1;
+            rdst[i] = raw_off(px, c4);
+        }
+    }
+    f32x4 hv[NI];
+    auto load_raw = [&](int c) {
+        const int c0 = c * 32;
+        const bool second = c0 >= a.C1;
+        const float* src = second ? a.x2 : a.x1;
+        const int cs = second ? a.C2 : a.C1;
+        const int cc = (second ? c0 - a.C1 : c0) + c4 * 4;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) hv[i] = ld4(hoff[i] >= 0 ? src + ((long long)hoff[i] * cs + cc) : zp);
+    };
+    auto store_raw = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) *reinterpret_cast<f32x4*>(Rs + buf * RAWB + rdst[i]) = hv[i];
+    };
+
+    // ---- transform share of this thread: item (tile, channel quad) = tid & 255, V row vr = wave >> 2 of the half -------------
+    const int vr = wave >> 2;
+    const int t_tile = (tid & 255) >> 3, t_q = tid & 7;
+    int t_src;      // halo pixel of d[0][0]
+    {
+        const int seg = t_tile / tps, rem = t_tile - seg * tps;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        t_src = (seg * (a.rps + 2) + 2 * ty) * W2 + 2 * tx;
+    }
+    const int t_dst = t_tile * ROWB + (((t_q >> 1) ^ lds_swz(t_tile)) << 4) + (t_q & 1) * 8;
+    // V row 2 th + vr from two d rows: th = 0: (0: d0 - d2) (1: d1 + d2); th = 1: (2: d2 - d1) (3: d1 - d3)
+    auto transform = [&](auto TH, auto VR, int rbuf) {
+        constexpr int th = decltype(TH)::value, v_r = decltype(VR)::value;
+        constexpr int ra_ = th == 0 ? (v_r == 0 ? 0 : 1) : (v_r == 0 ? 2 : 1);
+        constexpr int rb_ = th == 0 ? 2 : (v_r == 0 ? 1 : 3);
+        constexpr bool plus = th == 0 && v_r == 1;
+        constexpr int vrow = 2 * th + v_r;
+        const unsigned char* Rb = Rs + rbuf * RAWB;
+        f32x4 ea[4], eb[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            ea[c] = *reinterpret_cast<const f32x4*>(Rb + raw_off(t_src + ra_ * W2 + c, t_q));
+            eb[c] = *reinterpret_cast<const f32x4*>(Rb + raw_off(t_src + rb_ * W2 + c, t_q));
+        }
+        f32x4 r[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) r[c] = plus ? ea[c] + eb[c] : ea[c] - eb[c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 v = j == 0 ? r[0] - r[2] : j == 1 ? r[1] + r[2] : j == 2 ? r[2] - r[1] : r[1] - r[3];
+            unsigned h0, m0_, l0, h1, m1, l1;
+            split3(v[0], v[1], h0, m0_, l0);
+            split3(v[2], v[3], h1, m1, l1);
+            unsigned char* q = Vs + (vrow * 4 + j) * 3 * VPLANE + t_dst;
+            *reinterpret_cast<u32x2*>(q) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(q + VPLANE) = u32x2{m0_, m1};
+            *reinterpret_cast<u32x2*>(q + 2 * VPLANE) = u32x2{l0, l1};
+        }
+    };
+
+    // ---- MFMA role: 32 tiles x 16 channels x 16 positions ------------------------------------------------------------
+    const int r16 = lane & 15, kq = lane >> 4;
+    int aoff[2];
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+        const int row = tb * 16 + r16;
+        aoff[tb] = row * ROWB + ((kq ^ lds_swz(row)) << 4);
+    }
+    const u32x4* ub = a.ufrag + ((long long)(tile_n * 8 + wave) * a.chunks) * (16 * 3 * 64);      // wave-uniform
+    u32x4 bq[4][3];
+    auto load_b = [&](int sigma, u32x4 (&dst)[3]) {
+        const u32x4* p = ub + (long long)sigma * (3 * 64);
+#pragma unroll
+        for (int l = 0; l < 3; ++l) dst[l] = p[l * 64 + lane];
+    };
+    f32x4v acc[16][2];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) acc[p][tb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    u32x4 fa[3][2];          // [limb hi | mid | lo][tile block]
+    auto read_a = [&](int p, int l) {
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) fa[l][tb] = *reinterpret_cast<const u32x4*>(Vs + (p * 3 + l) * VPLANE + aoff[tb]);
+    };
+    auto mm = [&](int p, int la, int lb) {
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+            acc[p][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(      // weights first: D^T[channel][tile]
+                __builtin_bit_cast(bf16x8, bq[p & 3][lb]), __builtin_bit_cast(bf16x8, fa[la][tb]), acc[p][tb], 0, 0, 0);
+    };
+    // the eight positions of half h of chunk c (see wino_conv_kernel for the group order and the in-place A prefetch)
+    auto mfma_half = [&](auto HH, int c) {
+        constexpr int h = decltype(HH)::value;
+        read_a(8 * h, 2);
+        read_a(8 * h, 1);
+        read_a(8 * h, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int p = 8 * h + i;
+            if (!(ABL & 2)) load_b(c * 16 + p + 2, bq[(p + 2) & 3]);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(p, 2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i < 7) read_a(p + 1, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(p, 1, 1);
+            mm(p, 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i < 7) read_a(p + 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(p, 0, 2);
+            mm(p, 0, 1);
+            mm(p, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i < 7) read_a(p + 1, 0);
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    load_raw(0);
+    load_b(0, bq[0]);
+    load_b(1, bq[1]);
+    store_raw(0);
+    __syncthreads();
+    if (vr == 0) transform(I0{}, I0{}, 0); else transform(I0{}, I1{}, 0);      // V rows 0,1 of chunk 0
+    __syncthreads();
+
+    for (int c = 0; c < a.chunks; ++c) {
+        // HP0: MFMAs on V rows 0,1 of chunk c || V rows 2,3 of chunk c (raw image c & 1)
+        load_raw(min(c + 1, a.chunks - 1));
+        if (vr == 0 && !(ABL & 1)) transform(I1{}, I0{}, c & 1);             // waves 0-3: transform, then MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(I0{}, c);
+        __builtin_amdgcn_sched_barrier(0);
+        if (vr != 0 && !(ABL & 1)) transform(I1{}, I1{}, c & 1);             // waves 4-7: MFMAs, then transform
+        store_raw((c + 1) & 1);
+        __syncthreads();
+        // HP1: MFMAs on V rows 2,3 of chunk c || V rows 0,1 of chunk c + 1 (raw image (c + 1) & 1; stale for the last chunk)
+        if (vr == 0 && !(ABL & 1)) transform(I0{}, I0{}, (c + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(I1{}, c);
+        __builtin_amdgcn_sched_barrier(0);
+        if (vr != 0 && !(ABL & 1)) transform(I0{}, I1{}, (c + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- output transform + fused epilogue (as wino_conv_kernel) -----------------------------------------------------
+    const PsldEpilogue& e = a.e;
+    const int cn = n0 + wave * 16 + 4 * kq;
+    const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4v bias4 = e.bias ? *reinterpret_cast<const f32x4v*>(e.bias + cn) : zero4;
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+        const int tile = tb * 16 + r16;
+        const int seg = tile / tps, rem = tile - seg * tps;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        const int gm00 = m0 + seg * (a.rps * a.W) + (2 * ty) * a.W + 2 * tx;
+        const bool ok = gm00 < a.M;
+        f32x4v s[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s[i][0] = (acc[4 * i][tb] + acc[4 * i + 1][tb]) + acc[4 * i + 2][tb];
+            s[i][1] = (acc[4 * i + 1][tb] - acc[4 * i + 2][tb]) - acc[4 * i + 3][tb];
+        }
+        f32x4v y[2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            y[0][b] = (s[0][b] + s[1][b]) + s[2][b];
+            y[1][b] = (s[1][b] - s[2][b]) - s[3][b];
+        }
+        float gs = 0.f, gss = 0.f;
+        const int gmc = ok ? gm00 : 0;
+        f32x4v rv[2][2], cv[2][2], tbv[2][2];
+#pragma unroll
+        for (int ya = 0; ya < 2; ++ya)
+#pragma unroll
+            for (int xb = 0; xb < 2; ++xb) {
+                const int gm = gmc + ya * a.W + xb;
+                rv[ya][xb] = e.res ? *reinterpret_cast<const f32x4v*>(e.res + (long long)gm * e.ldres + cn) : zero4;
+                cv[ya][xb] = e.accumulate ? *reinterpret_cast<const f32x4v*>(a.C + (long long)gm * a.ldc + cn) : zero4;
+                tbv[ya][xb] = e.rowbias ? *reinterpret_cast<const f32x4v*>(e.rowbias + (long long)(gm / e.rows_per_img) * e.ld_rowbias + cn)
+                                        : zero4;
+            }
+#pragma unroll
+        for (int ya = 0; ya < 2; ++ya)
+#pragma unroll
+            for (int xb = 0; xb < 2; ++xb) {
+                const int gm = gmc + ya * a.W + xb;
+                f32x4v o = y[ya][xb] * e.alpha + (bias4 + tbv[ya][xb]);
+                if (e.res) o += rv[ya][xb];
+                o *= e.out_scale;
+                if (e.accumulate) o += cv[ya][xb];
+                if (ok) {
+                    *reinterpret_cast<f32x4v*>(a.C + (long long)gm * a.ldc + cn) = o;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        gs += o[v];
+                        gss += o[v] * o[v];
+                    }
+                }
+            }
+        if (e.gn_part) {
+            float s1 = gs, s2 = gss;
+#pragma unroll
+            for (int sft = 1; sft <= 16; sft <<= 1) {
+                s1 += __shfl_xor(s1, sft, 64);
+                s2 += __shfl_xor(s2, sft, 64);
+            }
+            const int row0 = m0 + tb * 64;
+            if ((lane & 0x1f) == 0 && row0 < a.M) {
+                const int img = row0 / e.gn_hw, chunk = (row0 - img * e.gn_hw) >> 6, chunks = e.gn_hw >> 6;
+                const int f = ((n0 + wave * 16) >> 3) + (lane >> 5);
+                double* pp = e.gn_part + (((long long)img * chunks + chunk) * (a.N >> 3) + f) * 2;
+                pp[0] = (double)s1;
+                pp[1] = (double)s2;
+            }
+        }
+    }
+}
+
+template <int ABL = 0>
+int launch_wino8s(const WinoArgs& a, hipStream_t stream, const char* name) {
+    constexpr size_t LDS = (size_t)VBYTES + 2 * (size_t)4 * 64 * 128;
+    static_assert(LDS <= 163840, "LDS budget");
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv8s_kernel<ABL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        if (e != hipSuccess) {
+            psld_set_error("%s: hipFuncSetAttribute failed: %s", name, hipGetErrorString(e));
+            return PSLD_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    dim3 grid((unsigned)(cdiv(a.M, 128) * (a.N / 128)));
+    hipLaunchKernelGGL((wino_conv8s_kernel<ABL>), grid, dim3(WINO_THREADS), LDS, stream, a);
+    PSLD_CHECK_LAUNCH(name);
+    return PSLD_OK;
+}
+
 template <int NI, int ABL = 0>
 int launch_wino4(const WinoArgs& a, hipStream_t stream, const char* name) {
     constexpr size_t LDS = (size_t)VBYTES + 2 * (size_t)NI * 32 * 128;
@@ -804,8 +1090,15 @@ extern "C" int psld_conv3x3_wino_f32(const float* x1, int c1, const float* x2, i
     a.nmajor = nmaj;
     const int ni = cdiv((long long)halo_px * 8, WINO_THREADS);
     const char* name = "psld_conv3x3_wino_f32";
-    static const int w4 = [] { const char* v = getenv("PSLD_WINO_W4"); return v ? atoi(v) : 1; }();
-    if (w4) {
+    static const int w4 = [] { const char* v = getenv("PSLD_WINO_W4"); return v ? atoi(v) : 2; }();
+    if (w4 == 2 && halo_px <= 256) {
+        static const int abl8 = [] { const char* v = getenv("PSLD_WINO_ABL"); return v ? atoi(v) : 0; }();
+        if (abl8 == 1) return launch_wino8s<1>(a, stream, name);
+        if (abl8 == 2) return launch_wino8s<2>(a, stream, name);
+        if (abl8 == 3) return launch_wino8s<3>(a, stream, name);
+        return launch_wino8s<0>(a, stream, name);
+    }
+    if (w4 == 1) {
         const int ni4 = cdiv((long long)halo_px * 8, 256);
         static const int abl4 = [] { const char* v = getenv("PSLD_WINO_ABL"); return v ? atoi(v) : 0; }();
         if (abl4 == 1 && ni4 <= 7) return launch_wino4<7, 1>(a, stream, name);
