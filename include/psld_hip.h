@@ -162,6 +162,11 @@ int psld_conv3x3_split_f32(const float* x1, int c1, const float* x2, int c2, int
 long long psld_conv3x3_wino_frag_bytes(int cout, int cin);
 int psld_conv3x3_wino_supported(int c1, int c2, int batch, int h, int w, int cout);
 int psld_pack_conv3x3_wino(const float* w_oihw, void* ufrag, int cout, int cin, int dgrad, hipStream_t stream);
+/* All Winograd fragment sets of a network in ONE launch.  table_dev: `entries` x 8 int64 {src pointer (OIHW weights),
+ * dst pointer, n_out, k_in, flip, stride_n, stride_k, first work item}: forward fragments of a [cout][cin][3][3] weight
+ * are {w, dst, cout, cin, 0, cin*9, 9, first}, data-gradient fragments {w, dst, cin, cout, 1, 9, cin*9, first}; an entry
+ * has n_out*k_in/8 work items and produces exactly what psld_pack_conv3x3_wino would. */
+int psld_pack_wino_batch(const long long* table_dev, int entries, long long total_items, hipStream_t stream);
 int psld_conv3x3_wino_f32(const float* x1, int c1, const float* x2, int c2, int batch, int h, int w,
                           const void* ufrag, int cout, float* y, int ldy, const psld_epilogue_t* epi,
                           hipStream_t stream);

@@ -90,6 +90,7 @@ SIGNATURES = {
     "psld_conv3x3_wino_frag_bytes": (LL, [I, I]),
     "psld_conv3x3_wino_supported": (I, [I, I, I, I, I, I]),
     "psld_pack_conv3x3_wino": (I, [P, P, I, I, I, P]),
+    "psld_pack_wino_batch": (I, [P, I, LL, P]),
     "psld_conv3x3_wino_f32": (I, [P, I, P, I, I, I, I, P, I, P, I, EP, P]),
     "psld_gn_apply_limb_nhwc": (I, [P, P, P, P, I, I, I, I, F, C.c_ulonglong, P, P]),
     "psld_limb_bytes": (LL, [LL, I]),

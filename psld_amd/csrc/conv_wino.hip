@@ -64,52 +64,72 @@ __device__ __forceinline__ int raw_off(int hp, int q) {
 // ---- weights -> transformed limb fragments -----------------------------------------------------------------
 // One work item = lane slot (nt, wave, chunk, lane): n = nt*128 + wave*16 + (lane & 15), k = chunk*32 + (lane >> 4)*8 + j.
 // dgrad = 0: g = w[co = n][ci = k][:, :]; dgrad = 1: g = w[co = k][ci = n] rotated by 180 degrees (conv_split.hip).
+__device__ __forceinline__ void wino_pack_item(const float* __restrict__ w, u32x4* __restrict__ out, long long it, int k_in,
+                                               long long sn, long long sk, int flip) {
+    const int chunks = k_in / 32;
+    long long t = it;
+    const int lane = (int)(t & 63); t >>= 6;
+    const int chunk = (int)(t % chunks); t /= chunks;
+    const int nblk = (int)t;                            // nt*8 + wave
+    const int n = nblk * 16 + (lane & 15);
+    const int k0 = chunk * 32 + (lane >> 4) * 8;
+    float U[8][16];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float* p = w + n * sn + (k0 + j) * sk;
+        float g[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = flip ? p[8 - (a * 3 + b)] : p[a * 3 + b];
+        float t4[4][3];                                 // G g
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            t4[0][b] = g[0][b];
+            t4[1][b] = 0.5f * ((g[0][b] + g[2][b]) + g[1][b]);
+            t4[2][b] = 0.5f * ((g[0][b] + g[2][b]) - g[1][b]);
+            t4[3][b] = g[2][b];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {                   // (G g) G^T
+            U[j][a * 4 + 0] = t4[a][0];
+            U[j][a * 4 + 1] = 0.5f * ((t4[a][0] + t4[a][2]) + t4[a][1]);
+            U[j][a * 4 + 2] = 0.5f * ((t4[a][0] + t4[a][2]) - t4[a][1]);
+            U[j][a * 4 + 3] = t4[a][2];
+        }
+    }
+    u32x4* o = out + ((long long)nblk * chunks + chunk) * (16 * 3 * 64) + lane;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split3(U[2 * j][p], U[2 * j + 1][p], hi[j], mid[j], lo[j]);
+        o[(p * 3 + 0) * 64] = u32x4{hi[0], hi[1], hi[2], hi[3]};
+        o[(p * 3 + 1) * 64] = u32x4{mid[0], mid[1], mid[2], mid[3]};
+        o[(p * 3 + 2) * 64] = u32x4{lo[0], lo[1], lo[2], lo[3]};
+    }
+}
+
 __global__ void wino_pack_kernel(const float* __restrict__ w, u32x4* __restrict__ out, int n_out, int k_in,
                                  long long sn, long long sk, int flip) {
-    const int chunks = k_in / 32;
-    const long long items = (long long)(n_out / 16) * chunks * 64;
-    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long long)gridDim.x * blockDim.x) {
-        long long t = it;
-        const int lane = (int)(t & 63); t >>= 6;
-        const int chunk = (int)(t % chunks); t /= chunks;
-        const int nblk = (int)t;                            // nt*8 + wave
-        const int n = nblk * 16 + (lane & 15);
-        const int k0 = chunk * 32 + (lane >> 4) * 8;
-        float U[8][16];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float* p = w + n * sn + (k0 + j) * sk;
-            float g[3][3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int b = 0; b < 3; ++b) g[a][b] = flip ? p[8 - (a * 3 + b)] : p[a * 3 + b];
-            float t4[4][3];                                 // G g
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                t4[0][b] = g[0][b];
-                t4[1][b] = 0.5f * ((g[0][b] + g[2][b]) + g[1][b]);
-                t4[2][b] = 0.5f * ((g[0][b] + g[2][b]) - g[1][b]);
-                t4[3][b] = g[2][b];
-            }
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {                   // (G g) G^T
-                U[j][a * 4 + 0] = t4[a][0];
-                U[j][a * 4 + 1] = 0.5f * ((t4[a][0] + t4[a][2]) + t4[a][1]);
-                U[j][a * 4 + 2] = 0.5f * ((t4[a][0] + t4[a][2]) - t4[a][1]);
-                U[j][a * 4 + 3] = t4[a][2];
-            }
+    const long long items = (long long)(n_out / 16) * (k_in / 32) * 64;
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += (long long)gridDim.x * blockDim.x)
+        wino_pack_item(w, out, it, k_in, sn, sk, flip);
+}
+
+// Many weight tensors in one launch (as pack_frag_batch_kernel of conv_split.hip).  tab[8*i ..]: src pointer, dst
+// pointer, n_out, k_in, flip, sn, sk, first work item of tensor i (a tensor has n_out * k_in / 8 items).
+__global__ void wino_pack_batch_kernel(const long long* __restrict__ tab, int ntab, long long total) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = ntab - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (tab[8 * mid + 7] <= idx) lo = mid; else hi = mid - 1;
         }
-        u32x4* o = out + ((long long)nblk * chunks + chunk) * (16 * 3 * 64) + lane;
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            unsigned hi[4], mid[4], lo[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) split3(U[2 * j][p], U[2 * j + 1][p], hi[j], mid[j], lo[j]);
-            o[(p * 3 + 0) * 64] = u32x4{hi[0], hi[1], hi[2], hi[3]};
-            o[(p * 3 + 1) * 64] = u32x4{mid[0], mid[1], mid[2], mid[3]};
-            o[(p * 3 + 2) * 64] = u32x4{lo[0], lo[1], lo[2], lo[3]};
-        }
+        const long long* d = tab + 8 * lo;
+        wino_pack_item(reinterpret_cast<const float*>(d[0]), reinterpret_cast<u32x4*>(d[1]), idx - d[7], (int)d[3], d[5], d[6],
+                       (int)d[4]);
     }
 }
 
@@ -1057,6 +1077,15 @@ extern "C" int psld_pack_conv3x3_wino(const float* w_oihw, void* ufrag, int cout
     else hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(64), 0, stream, w_oihw, reinterpret_cast<u32x4*>(ufrag),
                             n_out, k_in, (long long)cin * 9, 9LL, 0);
     PSLD_CHECK_LAUNCH("psld_pack_conv3x3_wino");
+    return PSLD_OK;
+}
+
+extern "C" int psld_pack_wino_batch(const long long* table_dev, int entries, long long total_items, hipStream_t stream) {
+    PSLD_CHECK_ARG(table_dev && entries > 0 && total_items > 0, "psld_pack_wino_batch: bad args");
+    const long long want = (total_items + 63) / 64;
+    hipLaunchKernelGGL(wino_pack_batch_kernel, dim3((unsigned)(want < 32768 ? want : 32768)), dim3(64), 0, stream,
+                       table_dev, entries, total_items);
+    PSLD_CHECK_LAUNCH("psld_pack_wino_batch");
     return PSLD_OK;
 }
 

@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import ctypes as C
 import functools
+import os
 from typing import Optional, Sequence, Tuple
 
 import numpy as np
@@ -216,6 +217,42 @@ def conv3x3_wino_frag(w_oihw: Tensor, dgrad: bool, out: Optional[Tensor] = None)
     check(lib().psld_pack_conv3x3_wino(w_oihw.data_ptr(), out.data_ptr(), co, ci, int(dgrad), _stream()),
           "psld_pack_conv3x3_wino")
     return out
+
+
+def conv3x3_wino_frag_entry(w_oihw: Tensor, dgrad: bool, out: Tensor):
+    """Table entry (without the running index) of ``pack_wino_batch`` equivalent to conv3x3_wino_frag(w, dgrad, out)."""
+    co, ci = w_oihw.shape[0], w_oihw.shape[1]
+    if dgrad:
+        return [w_oihw.data_ptr(), out.data_ptr(), ci, co, 1, 9, ci * 9]
+    return [w_oihw.data_ptr(), out.data_ptr(), co, ci, 0, ci * 9, 9]
+
+
+def pack_wino_batch(table: Tensor, entries: int, total_items: int):
+    """table rows: conv3x3_wino_frag_entry(...) + [first work item]; a tensor has cout*cin/8 work items."""
+    check(lib().psld_pack_wino_batch(table.data_ptr(), entries, total_items, _stream()), "psld_pack_wino_batch")
+
+
+_WINO_MODE = None     # 0: never, 1: where it pays (default), 2: wherever the kernel takes the shape (tests)
+
+
+def set_winograd(mode: Optional[int]):
+    """Override ``PSLD_WINOGRAD`` for this process (None: back to the environment); see conv3x3_wino_wanted."""
+    global _WINO_MODE
+    _WINO_MODE = mode
+    conv3x3_wino_wanted.cache_clear()
+
+
+@functools.lru_cache(maxsize=None)
+def conv3x3_wino_wanted(c1: int, c2: int, b: int, h: int, w: int, cout: int) -> bool:
+    """Policy (limb-MFMA math mode only - the caller checks that): does a 3x3 stride-1 convolution of this shape run in
+    Winograd F(2x2, 3x3) form?  By default (``PSLD_WINOGRAD=1``) when the kernel takes the shape, the map is at least
+    16x16 (the 8x8 level's small grids run faster on the direct kernel, which can split its K range) and the grid gives
+    every CU a workgroup; ``PSLD_WINOGRAD=0`` restores the direct limb kernels everywhere, ``=2`` takes every supported
+    shape (parity tests at small batches).  The environment is read once; set_winograd() overrides it."""
+    mode = _WINO_MODE if _WINO_MODE is not None else int(os.environ.get("PSLD_WINOGRAD", "1"))
+    if mode == 0 or not conv3x3_wino_supported(c1, c2, b, h, w, cout):
+        return False
+    return mode == 2 or (h * w >= 256 and (b * h * w // 128) * (cout // 128) >= 256)
 
 
 def conv3x3_wino(x1: Tensor, x2: Optional[Tensor], ufrag: Tensor, cout: int, y: Tensor,

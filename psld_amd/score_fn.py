@@ -378,7 +378,9 @@ class _Exec:
         b, h, w, c = x.shape
         c2 = x2.shape[-1] if x2 is not None else 0
         cout = conv.weight.shape[0]
-        if self.split and ops.conv3x3_split_supported(c, c2, b, h, w, cout):
+        if self.split and not isinstance(x, ops.LimbPlanes) and ops.conv3x3_wino_wanted(c, c2, b, h, w, cout):
+            ops.conv3x3_wino(x, x2, self.net._wfrag(conv, False), cout, out, epi)       # Winograd F(2x2, 3x3)
+        elif self.split and ops.conv3x3_split_supported(c, c2, b, h, w, cout):
             ops.conv3x3_split(x, x2, self.net._frag(conv, False), cout, out, epi)
         else:
             ops.conv2d_nhwc(x, x2, self.net._packed(conv), cout, 3, 3, 1, 1, 1, h, w, out, epi)
@@ -455,6 +457,10 @@ class _Exec:
         cin = conv.weight.shape[1]
         epi = ops.epilogue(alpha=alpha, accumulate=accumulate, gnb=gnb) if (alpha != 1.0 or accumulate or gnb is not None) \
             else None
+        if self.split and k == 3 and stride == 1 and pad == 1 and gnb is None and \
+                ops.conv3x3_wino_wanted(dy.shape[-1], 0, dy.shape[0], ih, iw, cin):
+            ops.conv3x3_wino(dy, None, self.net._wfrag(conv, True), cin, out, epi)      # Winograd F(2x2, 3x3)
+            return
         if self.split and k == 3 and stride == 1 and pad == 1 and \
                 ops.conv3x3_split_supported(dy.shape[-1], 0, dy.shape[0], ih, iw, cin):
             ops.conv3x3_split(dy, None, self.net._frag(conv, True), cin, out, epi)
@@ -569,10 +575,13 @@ class _Exec:
         # normalisation and the convolution (up / down) keep fp32.
         ho_, wo_ = (h // 2, w // 2) if down else ((h * 2, w * 2) if up else (h, w))
         c2_ = cin - c1
-        lp0 = self.split and self.limb_planes and not (up or down) and ops.conv3x3_split_supported(c1, c2_, b, h, w, cout) and \
+        # (a convolution that runs in Winograd form transforms fp32 input itself: its producer writes plain fp32)
+        lp0 = self.split and self.limb_planes and not (up or down) and not ops.conv3x3_wino_wanted(c1, c2_, b, h, w, cout) and \
+            ops.conv3x3_split_supported(c1, c2_, b, h, w, cout) and \
             (not self.record or (ops.conv3x3_wgrad_split_supported(cout, c1, b, h, w) and
                                  (c2_ == 0 or ops.conv3x3_wgrad_split_supported(cout, c2_, b, h, w))))
-        lp1 = self.split and self.limb_planes and ops.conv3x3_split_supported(cout, 0, b, ho_, wo_, cout) and \
+        lp1 = self.split and self.limb_planes and not ops.conv3x3_wino_wanted(cout, 0, b, ho_, wo_, cout) and \
+            ops.conv3x3_split_supported(cout, 0, b, ho_, wo_, cout) and \
             (not self.record or ops.conv3x3_wgrad_split_supported(cout, cout, b, ho_, wo_))
         apply0 = ops.gn_apply_limb if lp0 else ops.gn_apply
         if xb is not None:
@@ -732,9 +741,12 @@ class _Exec:
         m = b * h * w
         c1 = xa.v.shape[-1]
         cin = c1 + xb.v.shape[-1]
-        f3 = net._frag(mod.Conv_0, True)                        # [cin/128 tiles][...]: data gradient of the 3x3
+        wino = self.split and not self.fuse_gn_bwd and ops.conv3x3_wino_wanted(cout, 0, b, h, w, c1) and \
+            ops.conv3x3_wino_wanted(cout, 0, b, h, w, cin - c1)
+        # [cin/128 tiles][...]: data gradient of the 3x3 (Winograd fragments carry 16 KB of read-ahead padding at the end)
+        f3 = net._wfrag(mod.Conv_0, True) if wino else net._frag(mod.Conv_0, True)
         f1 = net._pfrag(c2.weight, "dgrad", cin, cout, 1, cin)  # same for the shortcut
-        cut3, cut1 = f3.numel() * c1 // cin, f1.numel() * c1 // cin
+        cut3, cut1 = (f3.numel() - (16384 if wino else 0)) * c1 // cin, f1.numel() * c1 // cin
         gam, bet = gn0.weight.detach(), gn0.bias.detach()
         dgam, dbet = self.g(gn0.weight), self.g(gn0.bias)
         for node, lo, hi, fr3, fr1, st, g in ((xa, 0, c1, f3[:cut3], f1[:cut1], sta, g1),
@@ -743,8 +755,11 @@ class _Exec:
             xg, acc = _gbuf(node)
             ops.gemm_split(dout, None, m, fr1, c, xg, ops.epilogue(alpha=s, accumulate=acc))
             da0 = torch.empty_like(node.v)
-            gnb = self.gnb_for(node.v, st, gn0, True, gamma=gam[lo:hi], beta=bet[lo:hi], groups=g)
-            ops.conv3x3_split(dh1, None, fr3, c, da0, ops.epilogue(gnb=gnb) if gnb is not None else None)
+            gnb = None if wino else self.gnb_for(node.v, st, gn0, True, gamma=gam[lo:hi], beta=bet[lo:hi], groups=g)
+            if wino:
+                ops.conv3x3_wino(dh1, None, fr3, c, da0)
+            else:
+                ops.conv3x3_split(dh1, None, fr3, c, da0, ops.epilogue(gnb=gnb) if gnb is not None else None)
             ops.gn_bwd(da0, node.v, st, gam[lo:hi], bet[lo:hi], True, xg, dgam[lo:hi], dbet[lo:hi], accumulate_dx=True,
                        groups=g, part=gnb["part"] if gnb is not None else None)
 
@@ -1310,6 +1325,7 @@ class NCSNpp(nn.Module):
         self._offsets = None
         self._pack_cache = {}
         self._frag_table = None     # (signature, device table, entries, total work items) of the batched fragment refresh
+        self._wfrag_table = None    # the same for the Winograd fragment sets
         self._temb_plan_cache = None
         self._pack_key = None
         self._epoch = 0
@@ -1466,6 +1482,48 @@ class NCSNpp(nn.Module):
         self._pack_cache[key] = (stamp, out)
         self._frag_table = None
         return out
+
+    def _wfrag(self, conv: _Affine, dgrad: bool) -> Tensor:
+        """Winograd-transformed bf16 limb fragments of a 3x3 weight (ops.conv3x3_wino_frag), cached and refreshed like
+        ``_frag`` (one batched launch for all of them after a weight update)."""
+        w = conv.weight
+        key = (id(w), dgrad, "wfrag")
+        self._conv_by_weight[id(w)] = conv
+        ent = self._pack_cache.get(key)
+        stamp = (self._epoch, w._version, w.data_ptr())
+        if ent is not None and ent[0] == stamp:
+            return ent[1]
+        if ent is not None and ent[1].device == w.device and self._refresh_wfrags():
+            ent = self._pack_cache[key]
+            if ent[0] == stamp:
+                return ent[1]
+        out = ops.conv3x3_wino_frag(w.detach(), dgrad, ent[1] if ent is not None and ent[1].device == w.device else None)
+        self._pack_cache[key] = (stamp, out)
+        self._wfrag_table = None
+        return out
+
+    def _refresh_wfrags(self) -> bool:
+        """Re-transform every registered Winograd fragment set into its existing buffer with ONE launch
+        (psld_pack_wino_batch).  False when there is nothing to batch."""
+        keys = [k for k in self._pack_cache if len(k) == 3 and k[2] == "wfrag"]
+        if len(keys) < 2:
+            return False
+        ws = [self._conv_by_weight[k[0]].weight for k in keys]
+        outs = [self._pack_cache[k][1] for k in keys]
+        if any(o.device != w.device for o, w in zip(outs, ws)):
+            return False
+        sig = tuple((k, w.data_ptr(), o.data_ptr()) for k, w, o in zip(keys, ws, outs))
+        if self._wfrag_table is None or self._wfrag_table[0] != sig:
+            rows, total = [], 0
+            for k, w, o in zip(keys, ws, outs):
+                rows.append(ops.conv3x3_wino_frag_entry(w.detach(), k[1], o) + [total])
+                total += w.shape[0] * w.shape[1] // 8
+            self._wfrag_table = (sig, torch.tensor(rows, dtype=torch.int64, device=ws[0].device), len(rows), total)
+        _, table, n, total = self._wfrag_table
+        ops.pack_wino_batch(table, n, total)
+        for k, w, o in zip(keys, ws, outs):
+            self._pack_cache[k] = ((self._epoch, w._version, w.data_ptr()),) + tuple(self._pack_cache[k][1:])
+        return True
 
     def _refresh_frags(self) -> bool:
         """Re-split every registered 3x3 / pointwise weight into its existing fragment buffer with ONE launch
@@ -1748,7 +1806,7 @@ class NCSNpp(nn.Module):
         cls = self.__class__
         new = cls.__new__(cls)
         memo[id(self)] = new
-        skip = {"_flat", "_flat_grad", "_pack_cache", "_frag_table", "_temb_plan_cache", "_anchor", "_reducer", "_offsets", "_module_offs", "_posfreq",
+        skip = {"_flat", "_flat_grad", "_pack_cache", "_frag_table", "_wfrag_table", "_temb_plan_cache", "_anchor", "_reducer", "_offsets", "_module_offs", "_posfreq",
                 "_side", "_plist", "_tlist", "_gviews", "_dropout_seed_dev", "_graphs", "_conv_by_weight", "_scratch_grad", "_sviews"}
         for k, v in self.__dict__.items():
             if k in skip:
@@ -1766,6 +1824,7 @@ class NCSNpp(nn.Module):
         new._accumulating = new._grad_stale = False
         new._pack_cache = {}
         new._frag_table = None
+        new._wfrag_table = None
         new._temb_plan_cache = None
         new._pack_key = None
         new._epoch = 0

@@ -261,6 +261,142 @@ def test_conv3x3_split_wide_dynamic_range(ops):
     assert rel_l2(y.permute(0, 3, 1, 2), ref) < 2.0 * max(rel_l2(ref32, ref), 2e-7)
 
 
+# ---------------------------------------------------------------------------------------------------
+# Winograd F(2x2, 3x3) limb convolution (conv_wino.hip): the same convolution, re-associated
+# ---------------------------------------------------------------------------------------------------
+WINO_FWD = [
+    dict(b=2, c1=64, c2=0, co=128, h=8, w=8),        # two images per workgroup tile
+    dict(b=3, c1=32, c2=0, co=128, h=8, w=8),        # odd batch: the last tile is half empty
+    dict(b=2, c1=64, c2=32, co=128, h=16, w=16),     # two sources, odd chunk count
+    dict(b=1, c1=32, c2=0, co=256, h=32, w=32),
+    dict(b=5, c1=96, c2=0, co=128, h=32, w=32),      # odd batch, odd chunk count
+    dict(b=1, c1=32, c2=0, co=128, h=64, w=64),      # CelebA-64 resolution: halo of 264 pixels -> the unstaggered kernel
+    dict(b=3, c1=256, c2=256, co=256, h=16, w=16),   # the up path's two-source 512 -> 256
+    dict(b=2, c1=32, c2=0, co=128, h=4, w=8),        # four images per tile
+    dict(b=7, c1=256, c2=0, co=256, h=32, w=32),     # north-star layer shape, odd batch
+]
+
+
+@pytest.mark.parametrize("variant", [2, 1, 0])       # staggered eight waves (default) | four waves x 512 registers | plain eight
+@pytest.mark.parametrize("cfg", WINO_FWD)
+def test_conv3x3_wino_forward(ops, cfg, variant, monkeypatch):
+    """psld_conv3x3_wino_f32 against fp64 torch with the full epilogue (bias, time-embedding row bias, residual, scale),
+    next to the direct limb kernel on the same inputs: within 3e-6 of fp64 and no worse than 2x the direct kernel's
+    error (the gate of VERDICT r02 was 1e-5).  Reference: nn.Conv2d 3x3, song_sde/layers.py:103-109."""
+    import subprocess, sys, os, json
+    b, c1, c2, co, h, w_ = (cfg[n] for n in ("b", "c1", "c2", "co", "h", "w"))
+    if variant != 2:
+        # the kernel variant is read once per process (PSLD_WINO_W4): run the odd variants in a child
+        if (b, c1, h) not in ((2, 64, 16), (5, 96, 32), (3, 256, 16)):
+            pytest.skip("odd kernel variants: three shapes")
+        code = ("import os, sys, json; sys.path.insert(0, %r); os.environ['PSLD_WINO_W4'] = %r;"
+                "import tests.test_kernels_gpu as t; from psld_amd import ops; ops.lib();"
+                "print(json.dumps(t._wino_forward_errors(ops, %r)))" % (os.path.dirname(os.path.dirname(__file__)), str(variant), cfg))
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        e, ed = json.loads(out.stdout.strip().splitlines()[-1])
+    else:
+        e, ed = _wino_forward_errors(ops, cfg)
+    print(f"winograd {e:.2e} direct {ed:.2e}")
+    assert e < 3e-6 and e < 2.0 * max(ed, 2e-7)
+
+
+def _wino_forward_errors(ops, cfg):
+    b, c1, c2, co, h, w_ = (cfg[n] for n in ("b", "c1", "c2", "co", "h", "w"))
+    assert ops.conv3x3_wino_supported(c1, c2, b, h, w_, co)
+    x = gen(b, c1 + c2, h, w_, seed=40)
+    w = gen(co, c1 + c2, 3, 3, seed=41, scale=0.1)
+    bias, res = gen(co, seed=42), gen(b, co, h, w_, seed=43)
+    temb = gen(b, co, seed=44)
+    ref = (F.conv2d(x.double(), w.double(), bias.double(), padding=1) + temb.double()[:, :, None, None]
+           + res.double()) * 0.7
+    x1 = _nhwc(x[:, :c1]).to(DEV)
+    x2 = _nhwc(x[:, c1:]).to(DEV) if c2 else None
+    epi = ops.epilogue(bias=bias.to(DEV), rowbias=temb.to(DEV), rows_per_img=h * w_, residual=_nhwc(res).to(DEV),
+                       ld_residual=co, out_scale=0.7)
+    y = torch.full((b, h, w_, co), float("nan"), device=DEV)
+    ops.conv3x3_wino(x1, x2, ops.conv3x3_wino_frag(w.to(DEV), False), co, y, epi)
+    yd = torch.empty_like(y)
+    ops.conv3x3_split(x1, x2, ops.conv3x3_frag(w.to(DEV), False), co, yd, epi)
+    return rel_l2(y.permute(0, 3, 1, 2), ref), rel_l2(yd.permute(0, 3, 1, 2), ref)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(b=2, ci=128, co=64, h=8, w=8),
+    dict(b=3, ci=128, co=128, h=16, w=16),
+    dict(b=1, ci=256, co=64, h=32, w=32),
+    dict(b=2, ci=128, co=256, h=32, w=32),
+    dict(b=3, ci=256, co=512, h=16, w=16),
+])
+def test_conv3x3_wino_dgrad(ops, cfg):
+    """Data gradient = the same kernel on the rotated, role-swapped filter (psld_pack_conv3x3_wino(dgrad = 1)), with the
+    alpha / accumulate epilogue the backward tape uses."""
+    b, ci, co, h, w_ = (cfg[n] for n in ("b", "ci", "co", "h", "w"))
+    x = gen(b, ci, h, w_, seed=60).requires_grad_(True)
+    w = gen(co, ci, 3, 3, seed=61, scale=0.1).requires_grad_(True)
+    y = F.conv2d(x.double(), w.double(), padding=1)
+    gy = gen(*y.shape, seed=62)
+    y.backward(gy.double())
+    gyd = _nhwc(gy).to(DEV)
+    assert ops.conv3x3_wino_supported(co, 0, b, h, w_, ci)
+    uf = ops.conv3x3_wino_frag(w.detach().to(DEV), True)
+    dx = torch.full((b, h, w_, ci), float("nan"), device=DEV)
+    ops.conv3x3_wino(gyd, None, uf, ci, dx)
+    assert rel_l2(dx.permute(0, 3, 1, 2), x.grad) < 3e-6
+    prev = gen(b, h, w_, ci, seed=63).to(DEV)
+    acc = prev.clone()
+    ops.conv3x3_wino(gyd, None, uf, ci, acc, ops.epilogue(alpha=0.5, accumulate=True))
+    assert rel_l2(acc.permute(0, 3, 1, 2), 0.5 * x.grad + prev.permute(0, 3, 1, 2).cpu().double()) < 3e-6
+
+
+def test_conv3x3_wino_wide_dynamic_range(ops):
+    """The transformed operands are sums of four values of possibly very different magnitude: fp32 adds, then the exact
+    three-limb split.  Within 4x of plain fp32 direct convolution on operands spanning many binades."""
+    b, c, co, s = 2, 64, 128, 8
+    g = torch.Generator().manual_seed(50)
+    x = gen(b, c, s, s, seed=51) * torch.exp(torch.randn(b, c, s, s, generator=g) * 6.0) * 1e-6
+    w = gen(co, c, 3, 3, seed=52) * torch.exp(torch.randn(co, c, 3, 3, generator=g) * 4.0)
+    ref = F.conv2d(x.double(), w.double(), padding=1)
+    y = torch.empty(b, s, s, co, device=DEV)
+    ops.conv3x3_wino(_nhwc(x).to(DEV), None, ops.conv3x3_wino_frag(w.to(DEV), False), co, y)
+    ref32 = F.conv2d(x, w, padding=1)
+    assert rel_l2(y.permute(0, 3, 1, 2), ref) < 4.0 * max(rel_l2(ref32, ref), 2e-7)
+
+
+@pytest.mark.parametrize("b,c,co,h", [(24, 128, 256, 32), (96, 128, 256, 16), (6, 32, 128, 64)])
+def test_gn_partials_from_wino_epilogue(ops, b, c, co, h):
+    """psld_epilogue_t.gn_part from the Winograd kernel's epilogue: GroupNorm statistics of its output, for every group
+    size that is a multiple of the 8-channel fine groups, against a statistics pass over the written tensor."""
+    x = gen(b, h, h, c, seed=70).to(DEV)
+    w = gen(co, c, 3, 3, seed=71, scale=0.05).to(DEV)
+    bias = gen(co, seed=72).to(DEV)
+    gamma, beta = (1 + 0.1 * gen(co, seed=73)).to(DEV), (0.1 * gen(co, seed=74)).to(DEV)
+    part = ops.gn_part_buffer(b, h * h, co, DEV)
+    part.fill_(float("nan"))
+    y = torch.empty(b, h, h, co, device=DEV)
+    ops.conv3x3_wino(x, None, ops.conv3x3_wino_frag(w, False), co, y, ops.epilogue(bias=bias, gn_part=part, gn_hw=h * h))
+    assert bool(torch.isfinite(part).all())
+    for groups in (co // 8, co // 16):
+        st = ops.gn_stats_from_part(part, y.shape, gamma, beta, groups=groups)
+        ref = ops.gn_stats(y, gamma, beta, groups=groups)
+        assert rel_l2(st.mean, ref.mean) < 1e-5 and rel_l2(st.rstd, ref.rstd) < 1e-5
+
+
+def test_wino_pack_batch_matches_single(ops):
+    ws = [gen(128, 64, 3, 3, seed=80).to(DEV), gen(256, 128, 3, 3, seed=81).to(DEV), gen(128, 256, 3, 3, seed=82).to(DEV)]
+    singles, outs, rows, total = [], [], [], 0
+    for i, w in enumerate(ws):
+        dgrad = bool(i & 1)
+        singles.append(ops.conv3x3_wino_frag(w, dgrad))
+        o = torch.zeros_like(singles[-1])
+        outs.append(o)
+        rows.append(ops.conv3x3_wino_frag_entry(w, dgrad, o) + [total])
+        total += w.shape[0] * w.shape[1] // 8
+    ops.pack_wino_batch(torch.tensor(rows, dtype=torch.int64, device=DEV), len(rows), total)
+    for a, bb in zip(singles, outs):
+        assert torch.equal(a[:-16384], bb[:-16384])       # (the tail is read-ahead padding, never written)
+
+
 @pytest.mark.parametrize("cfg", [
     dict(b=2, ci=128, co=64, h=8, w=8),
     dict(b=3, ci=128, co=128, h=16, w=16),

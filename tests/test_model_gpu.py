@@ -63,6 +63,28 @@ def test_network_forward_matches_reference(golden, name):
     assert err < 2e-5
 
 
+@pytest.mark.parametrize("name", ["c10_sota", "celeba64"])
+def test_network_forward_with_winograd_convolutions(golden, name):
+    """Every 3x3 stride-1 convolution the Winograd F(2x2, 3x3) kernel takes runs on it (PSLD_WINOGRAD=2; by default it
+    is used where the grid fills the chip, i.e. not at these golden batch sizes): same goldens, same gate; and the
+    direct limb kernels (PSLD_WINOGRAD=0) next to it."""
+    from psld_amd import ops
+    net, cfg, _ = _build(name)
+    g = golden(f"net_{name}.npz")
+    errs = {}
+    try:
+        for mode in (2, 0):
+            ops.set_winograd(mode)
+            with torch.no_grad():
+                y = net(T(g["x"]).to(DEV), T(g["t"]).to(DEV))
+            errs[mode] = rel_l2(y, T(g["y"]))
+    finally:
+        ops.set_winograd(None)
+    print(f"{name}: rel-L2 vs reference: winograd {errs[2]:.3e}, direct {errs[0]:.3e}")
+    assert errs[2] < 2e-5 and errs[0] < 2e-5
+    assert errs[2] != errs[0]          # the two paths really are different kernels
+
+
 def test_network_forward_in_f32_mfma_mode(golden):
     """PSLD_MATH=f32 (fp32 MFMA for every contraction) stays a supported, parity-green path, and agrees with the
     default bf16x6 limb arithmetic to fp32 rounding on the north-star network."""
@@ -851,10 +873,22 @@ def test_fused_adam_refuses_a_consumed_gradient():
         opt.step()
 
 
-@pytest.mark.parametrize("name", ["c10_sota", "celeba64"])
-def test_full_size_network_gradients_against_live_oracle(name):
+@pytest.mark.parametrize("name,winograd", [("c10_sota", 1), ("c10_sota", 2), ("celeba64", 2)])
+def test_full_size_network_gradients_against_live_oracle(name, winograd):
     """North-star scale backward: every parameter gradient of the 97.6 M (C10-SOTA) / 62.8 M (CelebA-64)
-    network vs torch autograd through the oracle on this box's CPU (same weights, inputs, t, eps)."""
+    network vs torch autograd through the oracle on this box's CPU (same weights, inputs, t, eps).  ``winograd`` = 2:
+    forward and data-gradient convolutions in Winograd F(2x2, 3x3) form wherever the kernel takes the shape (at this
+    batch size the default policy, 1, keeps the direct kernels)."""
+    from psld_amd import ops
+    from psld_amd.registry import get_module
+    ops.set_winograd(winograd)
+    try:
+        _full_size_gradients(name)
+    finally:
+        ops.set_winograd(None)
+
+
+def _full_size_gradients(name):
     from psld_amd.registry import get_module
     net, cfg, sd = _build(name, train=True)
     cfg.model.score_fn.dropout = 0.0
