@@ -49,7 +49,8 @@ class ConvProbe:
         self.ops = ops
         self.orig_split = ops.conv3x3_split
         self.orig_tile = ops.conv2d_nhwc
-        self.records = {"split": [], "tile": []}
+        self.orig_wino = ops.conv3x3_wino
+        self.records = {"split": [], "tile": [], "wino": []}
         self.enabled = False
 
     def install(self):
@@ -69,6 +70,11 @@ class ConvProbe:
             flops = 2.0 * x1.shape[0] * x1.shape[1] * x1.shape[2] * cout * 9 * cin
             timed("split", flops, lambda: probe.orig_split(x1, x2, wfrag, cout, y, epi, ldy))
 
+        def wino(x1, x2, ufrag, cout, y, epi=None, ldy=None):
+            cin = x1.shape[-1] + (x2.shape[-1] if x2 is not None else 0)
+            flops = 2.0 * x1.shape[0] * x1.shape[1] * x1.shape[2] * cout * 9 * cin      # direct-convolution (algorithmic) count
+            timed("wino", flops, lambda: probe.orig_wino(x1, x2, ufrag, cout, y, epi, ldy))
+
         def tile(x1, x2, w, cout, kh, kw, stride, pad, tstride, oh, ow, y, epi=None, ldy=None):
             cin = x1.shape[-1] + (x2.shape[-1] if x2 is not None else 0)
             flops = 2.0 * x1.shape[0] * oh * ow * cout * kh * kw * cin
@@ -78,10 +84,11 @@ class ConvProbe:
                                                          epi, ldy))
 
         self.ops.conv3x3_split = split
+        self.ops.conv3x3_wino = wino
         self.ops.conv2d_nhwc = tile
 
     def summary(self, kind):
-        recs = self.records[kind]
+        recs = self.records[kind] if isinstance(kind, str) else [r for k in kind for r in self.records[k]]
         if not recs:
             return None
         ms = sum(s.elapsed_time(e) for s, e, _ in recs)
@@ -260,6 +267,45 @@ def sampling_run(cfg, ema_net, sde, dev, batch, n_discrete_steps):
                     "over 8 GPUs)"}
 
 
+def sampling_shard(rank: int, world: int, seed: int, n_samples: int = 50000, batch: int = 512):
+    """What rank ``rank`` of ``world`` samples in the 50 000-sample run (main/eval/sample.py:100-109: Trainer.predict
+    shards the latent dataset over the ranks; wrapper.py:93-99: RNG seed = evaluation.seed + global_rank): its
+    contiguous shard, the number of per-GPU batches it takes and its seed.  No collective on the data path."""
+    from psld_amd.ddp import shard_range
+    lo, hi = shard_range(n_samples, rank, world)
+    return {"rank": rank, "seed": seed + rank, "lo": lo, "hi": hi, "batches": -(-(hi - lo) // batch)}
+
+
+def reduce_sampling(res, rank: int, world: int, on_dev: bool, dev, shard):
+    """All ranks sampled one batch of their own concurrently; rank 0 reports the SLOWEST rank (max over ranks, like the
+    training timing) and the figure for the whole 50 000-sample run: batches-per-rank x that time."""
+    import torch.distributed as dist
+    where = dev if on_dev else "cpu"
+    mx = torch.tensor([res["measured_batch_s"], res["sampler_s"]], device=where, dtype=torch.float64)
+    mn = mx.clone()
+    ok = torch.tensor([1.0 if res["finite"] else 0.0], device=where, dtype=torch.float64)
+    seeds = torch.zeros(world, device=where, dtype=torch.float64)
+    seeds[rank] = shard["seed"]
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    dist.all_reduce(seeds, op=dist.ReduceOp.SUM)
+    out = dict(res)
+    scale = float(mx[0]) / res["measured_batch_s"]
+    out.update({"n_gpus": world, "measured_batch_s": float(mx[0]), "sampler_s": float(mx[1]),
+                "measured_batch_s_min_over_ranks": float(mn[0]), "finite": bool(ok.item() == 1.0),
+                "rank_seeds": [int(v) for v in seeds.tolist()], "batches_per_rank": shard["batches"],
+                "network_evals_per_s": world * res["network_evals_per_s"] / scale,
+                "fwd_tflops": res["fwd_tflops"] / scale})
+    steps_scale = 1000.0 / res["n_discrete_steps"]
+    out["wallclock_50k_samples_s"] = shard["batches"] * float(mx[0]) * steps_scale
+    out.pop("per_gpu_50k_samples_8gpu_s", None)
+    out["note"] = (f"every one of the {world} ranks sampled ONE batch of its own shard concurrently (seed + rank, no "
+                   "collective); measured_batch_s = max over ranks; wallclock_50k_samples_s = batches per rank "
+                   f"({shard['batches']}) x that, scaled to 1000 discretisation steps if the run was shortened")
+    return out
+
+
 def pmc_traffic_record():
     """HBM bytes per launch of the dominant convolution from the committed PMC passes (profiles/r02/pmc_traffic.json,
     written by tools/pmc_traffic.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs).  The record carries the hash of
@@ -376,9 +422,19 @@ def main():
             return 3
     if args.launch_check:
         barrier()
+        samp = None
+        if dist_on:     # the sampling half's rank rule, on fake timings: shard, seed + rank, max over ranks
+            sh = sampling_shard(rank, world, 0, batch=max(1, args.sample_batch))
+            fake = {"measured_batch_s": 1.0 + rank, "sampler_s": 0.5 + rank, "finite": True, "n_discrete_steps": 1000,
+                    "network_evals_per_s": 1.0, "fwd_tflops": 1.0}
+            samp = reduce_sampling(fake, rank, world, backend_name == "nccl", torch.device("cuda", local) if backend_name == "nccl" else None, sh)
+            lohi = torch.zeros(2 * world, dtype=torch.float64, device=torch.device("cuda", local) if backend_name == "nccl" else "cpu")
+            lohi[2 * rank], lohi[2 * rank + 1] = sh["lo"], sh["hi"]
+            dist.all_reduce(lohi)
+            samp["shards"] = [[int(lohi[2 * r]), int(lohi[2 * r + 1])] for r in range(world)]
         if rank == 0:
             print(json.dumps({"launch_check": True, "n_gpus": world, "backend": backend_name,
-                              "allreduce_ones_ok": ones_ok, "parallelism": f"dp{world}",
+                              "allreduce_ones_ok": ones_ok, "parallelism": f"dp{world}", "sampling_check": samp,
                               "self_launched": os.environ.get("TORCHELASTIC_RUN_ID") is not None}), flush=True)
         if dist_on:
             dist.destroy_process_group()
@@ -470,6 +526,17 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         in_sync = bool(lo.item() == hi.item())
 
+    sampling = None
+    if args.sample_batch > 0 and args.config == "c10_sota":
+        # second half of the metric: EVERY rank samples one batch of its own shard at the same time (eval/sample.py:100-109)
+        shard = sampling_shard(rank, world, int(cfg.evaluation.seed), batch=args.sample_batch)
+        if world > 1:
+            torch.manual_seed(shard["seed"])                  # wrapper.py:93-99: seed + global_rank
+        sampling = sampling_run(cfg, ema, sde, dev, args.sample_batch, max(3, args.sample_steps))
+        if world > 1:
+            sampling = reduce_sampling(sampling, rank, world, backend_name == "nccl", dev, shard)
+        fence()
+
     if rank == 0:
         total_imgs = world * args.batch * args.steps
         out = {
@@ -478,8 +545,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "math": ("f32 in / f32 accumulate; 3x3 convolutions, 1x1 / NIN projections, attention products and their gradients as exact "
-                     "3-limb bf16 splits, 6 bf16 MFMA products per fp32 product (dropped terms < 2^-23 of the product); "
-                     "everything else fp32 MFMA / fp32 VALU"
+                     "3-limb bf16 splits, 6 bf16 MFMA products per fp32 product (dropped terms < 2^-23 of the product); the 3x3 "
+                     "convolutions of the 32x32 / 16x16 levels (forward, data gradient) in Winograd F(2x2,3x3) form on the same "
+                     "limb arithmetic (fp32 transforms; PSLD_WINOGRAD=0: direct); everything else fp32 MFMA / fp32 VALU"
                      if ops.math_mode() == "bf16x6" else "f32 MFMA (v_mfma_f32_32x32x2_f32)"),
             "config": {"workload": "C10-SOTA NCSN++ (nf=128, ch_mult=[2,2,2], nres=8, attn@16, fir, fourier, "
                                    "dropout 0.15) full HSM train step: perturb+fwd+loss+bwd+clip+Adam+EMA",
@@ -497,22 +565,30 @@ def main():
                                   "gradient_bytes_per_step": int(net.flat_grad().numel()) * 4,
                                   "shared_gpu_rehearsal": share_gpu}
             out["overlap"] = st if st is not None else {"note": "no collective ran"}
-        ps = probe.summary("split")
+        ps = probe.summary(("split", "wino"))      # every 3x3 limb convolution, forward + data gradient
+        pw, pd = probe.summary("wino"), probe.summary("split")
         pt = probe.summary("tile")
         pmc, pmc_err = pmc_traffic_record()
         if ps is not None:
             peak = PEAK_BF16_MFMA_TFLOPS / LIMB_PRODUCTS
+            issued = ((pw["total_flop"] / 2.25 if pw else 0.0) + (pd["total_flop"] if pd else 0.0)) * LIMB_PRODUCTS / (ps["total_ms"] * 1e-3) / 1e12
             out["roofline"] = {
-                "bound": "mfma", "kernel": "dconv_kernel (3x3 conv forward + data gradient, bf16x6 limb MFMA)",
+                "bound": "mfma",
+                "kernel": "3x3 limb-MFMA convolutions, forward + data gradient: wino_conv8s_kernel (Winograd F(2x2,3x3), "
+                          "32x32 and 16x16 levels) + dconv_kernel / dconv_lp_kernel (direct, 8x8 level), bf16x6",
                 "achieved": ps["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": ps["tflops"] / peak,
-                "peak_note": "fp32-equivalent (algorithmic 2MNK) rate; peak = 2500 TFLOP/s dense bf16 MFMA / 6 limb "
-                             "products per fp32 product.  MFMA flops issued = 6 x achieved; the fp32 MFMA peak this "
-                             "replaces is 157.3 TFLOP/s.  Under this load the chip holds ~1.65-1.8 GHz (PMC, "
-                             "profiles/); a register-only loop with random operand data sustains 1.90 PFLOP/s "
-                             "(tools/mfma_peak.hip), i.e. 317 TFLOP/s fp32-equivalent is the practical ceiling.",
-                "mfma_issued_tflops": LIMB_PRODUCTS * ps["tflops"],
-                "frac_of_sustained_mfma": LIMB_PRODUCTS * ps["tflops"] / SUSTAINED_BF16_MFMA_TFLOPS,
+                "peak_note": "achieved = ALGORITHMIC (direct-convolution) 2*M*N*9*Cin of every launch / its HIP-event duration; "
+                             "peak = 2500 TFLOP/s dense bf16 MFMA / 6 limb products per fp32 product = the fp32-equivalent "
+                             "ceiling of a DIRECT limb convolution.  The Winograd launches issue 2.25x fewer MFMAs than "
+                             "that count (mfma_issued_tflops is what the matrix pipe really runs); a register-only loop "
+                             "with random operand data sustains 1.90 PFLOP/s (tools/mfma_peak.hip).",
+                "mfma_issued_tflops": issued,
+                "frac_of_sustained_mfma": issued / SUSTAINED_BF16_MFMA_TFLOPS,
                 "frac_of_f32_mfma_peak": ps["tflops"] / PEAK_F32_MFMA_TFLOPS,
+                "winograd": ({"tflops_direct_equivalent": pw["tflops"], "launches": pw["launches"], "avg_launch_us": pw["avg_us"],
+                              "share_of_step": pw["total_ms"] / (1e3 * dt)} if pw else None),
+                "direct": ({"tflops": pd["tflops"], "launches": pd["launches"], "avg_launch_us": pd["avg_us"],
+                            "share_of_step": pd["total_ms"] / (1e3 * dt)} if pd else None),
                 "traffic": pmc.get("traffic_bytes") if pmc else None,
                 "traffic_note": pmc.get("note") if pmc else pmc_err,
                 "launches": ps["launches"], "avg_launch_us": ps["avg_us"],
@@ -535,8 +611,8 @@ def main():
             out["metric"] = out["metric"].replace("CIFAR-10 PSLD (6ch 32x32)", f"{args.config} (6ch {size}x{size})")
             out["config"]["workload"] = f"{args.config} NCSN++ full HSM train step"
             out["config"]["image"] = f"6x{size}x{size}"
-        if world == 1 and args.sample_batch > 0 and args.config == "c10_sota":
-            out["sampling"] = sampling_run(cfg, ema, sde, dev, args.sample_batch, max(3, args.sample_steps))
+        if sampling is not None:
+            out["sampling"] = sampling
         out["cpu_baseline"] = cpu_base
         import ctypes
         ctypes.CDLL(None).fflush(None)

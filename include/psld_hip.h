@@ -501,6 +501,8 @@ int psld_adam_ema_f32(float* p, const float* g, float* m, float* v, float* ema, 
  * double like the launcher does: what a caller writes into hyper_dev[0..1] (device floats) before replaying a
  * captured training step (then lr / step of the captured call are ignored). */
 void psld_adam_step_scalars(double lr, double beta1, double beta2, int step, float* out2_host);
+/* The same two scalars written to a 2-float DEVICE buffer by a kernel that takes them by value (captured training step). */
+int psld_adam_step_scalars_dev(double lr, double beta1, double beta2, int step, float* out2_dev, hipStream_t stream);
 /* target = target*tau + src*(1-tau) (callbacks.py:62-64); hyper-parameters are doubles so that
  * (1 - tau), (1 - beta) are formed in double and rounded once, as torch does for python floats. */
 int psld_ema_f32(float* target, const float* src, long long n, double tau, hipStream_t stream);

@@ -162,6 +162,7 @@ SIGNATURES = {
     "psld_grad_norm_f32": (I, [P, LL, P, P, P]),
     "psld_adam_ema_f32": (I, [P, P, P, P, P, LL, P, D, D, D, D, D, D, I, D, I, P, P, P]),
     "psld_adam_step_scalars": (None, [D, D, D, I, P]),
+    "psld_adam_step_scalars_dev": (I, [D, D, D, I, P, P]),
     "psld_ema_f32": (I, [P, P, LL, D, P]),
 }
 

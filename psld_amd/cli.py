@@ -175,8 +175,9 @@ def epoch_indices(n_items: int, batch_size: int, seed: int, epoch: int, rank: in
     g = torch.Generator().manual_seed(seed + epoch)
     perm = torch.randperm(n_items, generator=g)
     total = -(-n_items // world) * world
-    if total > n_items:
-        perm = torch.cat([perm, perm[:total - n_items]])
+    if total > n_items:             # DistributedSampler: repeat the list as often as the padding needs (world > n_items)
+        pad = total - n_items
+        perm = torch.cat([perm, perm.repeat(-(-pad // n_items))[:pad]])
     mine = perm[rank:total:world]
     return mine[:mine.numel() // batch_size * batch_size]
 

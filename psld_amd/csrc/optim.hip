@@ -129,6 +129,21 @@ extern "C" void psld_adam_step_scalars(double lr, double beta1, double beta2, in
     out2_host[1] = (float)(1.0 / sqrt(bc2));
 }
 
+// The same two scalars written to DEVICE memory by a kernel that takes them by value: the captured training step reads
+// them from a 2-float buffer, and a pinned host staging buffer rewritten every step would race with its own asynchronous
+// copies once the host runs several replays ahead.
+__global__ void set2_kernel(float* __restrict__ dst, float a, float b) {
+    if (threadIdx.x == 0) { dst[0] = a; dst[1] = b; }
+}
+extern "C" int psld_adam_step_scalars_dev(double lr, double beta1, double beta2, int step, float* out2_dev, hipStream_t stream) {
+    PSLD_CHECK_ARG(out2_dev && step >= 1, "psld_adam_step_scalars_dev: bad args");
+    float h[2];
+    psld_adam_step_scalars(lr, beta1, beta2, step, h);
+    hipLaunchKernelGGL(set2_kernel, dim3(1), dim3(64), 0, stream, out2_dev, h[0], h[1]);
+    PSLD_CHECK_LAUNCH("set2_kernel");
+    return PSLD_OK;
+}
+
 extern "C" int psld_ema_f32(float* target, const float* src, long long n, double tau, hipStream_t stream) {
     PSLD_CHECK_ARG(target && src && n > 0, "psld_ema_f32: bad args");
     long long b = (n + 1023) / 1024;

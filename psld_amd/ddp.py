@@ -15,6 +15,8 @@ tested in this container (tests/test_ddp_cpu.py).
 """
 from __future__ import annotations
 
+import collections
+
 import os
 from typing import List, Optional, Tuple
 
@@ -48,14 +50,19 @@ def init_distributed(backend: Optional[str] = None, force: bool = False) -> Tupl
 
 class BucketReducer:
     def __init__(self, process_group=None, bucket_bytes: int = 64 << 20, average: bool = True,
-                 force_collective: bool = False, profile: bool = False):
+                 force_collective: bool = False, profile: bool = False, first_bucket_bytes: Optional[int] = None):
         self.pg = process_group
         # profile: bracket every collective with HIP events on the side stream and the join in finish() with events
         # on the compute stream -> stats(): how much of the exchange ran hidden under backward (bench.py "overlap")
         self.profile = profile
-        self._prof = []          # per finished backward: ([(start, end) per bucket], (join0, join1)) or host seconds
+        self._prof = collections.deque(maxlen=4096)   # (bounded: stats() drains it) per finished backward: ([(start, end) per bucket], (join0, join1)) or host seconds
         self._cur = None
         self.bucket_elems = max(1, bucket_bytes // 4)
+        # Geometric sizes from the FRONT of the flat buffer: gradients are produced from its end towards its front, so the
+        # front bucket (stem-side parameters) is launched last and is the one collective nothing can hide - keep it small
+        # (default 1/8 of bucket_bytes: 8 MiB) and double up to bucket_bytes towards the end, where the collectives run
+        # under the rest of backward.
+        self.first_elems = max(1, (first_bucket_bytes if first_bucket_bytes is not None else bucket_bytes // 8) // 4)
         self.average = average
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # force_collective: issue the collectives even for a single-rank group (exercises the RCCL +
@@ -73,13 +80,26 @@ class BucketReducer:
         self._flat = flat_grad
         n = flat_grad.numel()
         if not self._bounds or self._bounds[-1][1] != n:
-            self._bounds = [(lo, min(n, lo + self.bucket_elems)) for lo in range(0, n, self.bucket_elems)]
+            self._bounds = self.make_bounds(n, self.first_elems, self.bucket_elems)
         self._next = len(self._bounds) - 1
         self._works = []
         self.launched = []
         self._cur = [] if self.profile else None
         if flat_grad.is_cuda and self._side is None:
             self._side = torch.cuda.Stream(device=flat_grad.device)
+
+    @staticmethod
+    def make_bounds(n: int, first: int, full: int) -> List[Tuple[int, int]]:
+        """[lo, hi) of the buckets, front to back: sizes first, 2 first, 4 first, ... capped at ``full``; a remainder
+        shorter than half a bucket joins its neighbour."""
+        bounds, lo, size = [], 0, min(first, full)
+        while lo < n:
+            hi = min(n, lo + size)
+            if n - hi < size // 2:
+                hi = n
+            bounds.append((lo, hi))
+            lo, size = hi, min(full, size * 2)
+        return bounds
 
     def _launch(self, lo: int, hi: int):
         self.launched.append((lo, hi))
@@ -169,7 +189,7 @@ class BucketReducer:
                 comm += sum(a.elapsed_time(b) for a, b in evs)
                 exposed += join[0].elapsed_time(join[1])
         if reset:
-            self._prof = []
+            self._prof.clear()
         return {"steps": steps, "buckets_per_step": buckets / steps, "bucket_mb": self.bucket_elems * 4 / 2 ** 20,
                 "comm_ms_per_step": comm / steps, "exposed_ms_per_step": exposed / steps,
                 "hidden_ms_per_step": max(0.0, comm - exposed) / steps}

@@ -926,5 +926,14 @@ def adam_step_scalars(lr: float, beta1: float, beta2: float, step: int, out: Ten
     return out
 
 
+def adam_step_scalars_dev(lr: float, beta1: float, beta2: float, step: int, out: Tensor) -> Tensor:
+    """The same two scalars into the 2-element float32 DEVICE tensor ``out``, by a kernel that takes them by value
+    (stream-ordered: no host staging buffer to race with)."""
+    assert out.dtype == torch.float32 and out.numel() == 2 and out.is_cuda
+    check(lib().psld_adam_step_scalars_dev(float(lr), float(beta1), float(beta2), int(step), out.data_ptr(), _stream()),
+          "psld_adam_step_scalars_dev")
+    return out
+
+
 def ema(target: Tensor, src: Tensor, tau: float):
     check(lib().psld_ema_f32(target.data_ptr(), src.data_ptr(), target.numel(), tau, _stream()), "psld_ema_f32")

@@ -210,7 +210,12 @@ class PSLD:
         ONE time for the whole batch (it builds a 2x2 matrix from ``b_t``); ``t`` may be a float or a one-element
         tensor.  Off the training / sampling path (nothing in the reference calls it): composed from the coefficient
         kernel and a handful of elementwise torch ops on the device tensors."""
-        tt = float(t) if not torch.is_tensor(t) else float(t.reshape(-1)[0])
+        if torch.is_tensor(t):
+            tf = t.reshape(-1)
+            assert tf.numel() == 1 or bool((tf == tf[0]).all()), "predict_x_from_eps takes ONE time for the whole batch"
+            tt = float(tf[0])
+        else:
+            tt = float(t)
         tv = torch.full((1,), tt, dtype=torch.float64, device=z_t.device)
         var = self._cov(0.0, self.mm_0, tv)
         l11, l12, l21, l22 = (c.reshape(()) for c in self.get_coeff(var))
@@ -270,7 +275,10 @@ class PSLD:
         if torch.is_tensor(t):
             u64, tt = self._rows(u_t, t)
             flag = torch.zeros(1, dtype=torch.int32, device=u64.device)
-            return ops.reverse_sde_rows(u64, None, tt, self._params, 0.0, self.mm_0, self._score_mode(), False, flag)
+            out = ops.reverse_sde_rows(u64, None, tt, self._params, 0.0, self.mm_0, self._score_mode(), False, flag)
+            if self.check_nan and int(flag.item()) != 0:
+                raise ValueError("Numerical precision error.")
+            return out
         tt = float(t)
         k = self.em_coeffs(tt, 0.0)
         k.c11 = k.c12 = k.c21 = k.c22 = 0.0   # score := 0 -> f_bar = -f

@@ -88,8 +88,10 @@ class SDEWrapper(_Base):
     # ---- hipGraph-captured training step (launch-bound regime: small per-GPU batches) ---------------------------------
     def enable_graphs(self, flag: bool = True, warmup_steps: int = 2):
         """Capture the whole training step - perturb, forward, loss, backward tape, norm + clip + Adam - into a HIP
-        graph per batch shape and replay it: one graph launch instead of ~1700 kernel launches issued from Python
-        (43.6 -> ~30 ms per step at the reference's per-GPU batch of 16, scripts_psld/.../train_uncond_psld.sh:25-30).
+        graph per batch shape and replay it: one graph launch instead of ~2700 kernel launches issued from Python (the
+        reference's per-GPU batch of 16, scripts_psld/.../train_uncond_psld.sh:25-30; measured in profiles/: worth a few
+        percent on its own there - the eager step with the weight-gradient side stream is the faster mode at B = 16, the
+        graph pays below B ~ 8 where the host is the bound).
         Everything the reference draws per step (t, the discarded momentum draw, eps) and the dropout seed is drawn
         OUTSIDE the graph into static device buffers, in the reference's order, so a seeded run consumes the RNG stream
         exactly like the eager step; the step-dependent Adam scalars and the LR-schedule value travel through a 2-float
@@ -101,7 +103,6 @@ class SDEWrapper(_Base):
         self._graph_warmup = int(warmup_steps)
         if not flag:
             self._graph_steps = {}
-            self.score_fn._dropout_seed_dev = None
 
     def _draw_times(self, b: int, dev):
         """``t_ ~ U[0, 1)`` and ``t`` (wrapper.py:72-73) plus the NaN check of the perturbation coefficients
@@ -151,7 +152,6 @@ class SDEWrapper(_Base):
             ent["eps"] = torch.empty((b, 2 * c, h, w), device=dev, dtype=torch.float32)
             ent["seed"] = torch.zeros(1, device=dev, dtype=torch.int64)
             ent["hyper"] = torch.zeros(2, device=dev, dtype=torch.float32)
-            ent["hyper_host"] = torch.zeros(2, dtype=torch.float32).pin_memory()
         # the step's random draws, in the eager step's order (wrapper.py:72, losses.py:96,108, then the dropout seed)
         t_new, _ = self._draw_times(b, dev)       # includes the NaN check the captured step cannot make
         ent["t_"].copy_(t_new)
@@ -160,16 +160,19 @@ class SDEWrapper(_Base):
         if net.training and float(net.sf.dropout) > 0:
             ent["seed"].random_(0, 2 ** 62)
         ent["x0"].copy_(batch)
-        optim._step += 1
         group = optim.param_groups[0]
-        ops.adam_step_scalars(group["lr"], group["betas"][0], group["betas"][1], optim._step, ent["hyper_host"])
-        ent["hyper"].copy_(ent["hyper_host"], non_blocking=True)
+        # the two step-dependent Adam scalars: written by a kernel that takes them BY VALUE, in stream order (a pinned
+        # host buffer rewritten per step would be read by its asynchronous copies only when they execute - with graphs
+        # the host runs several steps ahead)
+        ops.adam_step_scalars_dev(group["lr"], group["betas"][0], group["betas"][1], optim._step + 1, ent["hyper"])
         if "graph" not in ent:
             optim._state_buffers()
             net.flat_grad()
-            net._dropout_seed_dev = ent["seed"]
             check_nan, sde.check_nan = getattr(sde, "check_nan", False), False
             graph = torch.cuda.CUDAGraph()
+            # the dropout seed word is baked into the graph as a pointer: the attribute is set for the capture only
+            # (an eager step that found it set would skip its own seed draw and repeat the static word's mask)
+            net._dropout_seed_dev = ent["seed"]
             try:
                 with torch.cuda.graph(graph):
                     t = ent["t_"] * (sde.T - self.train_eps) + self.train_eps
@@ -180,9 +183,9 @@ class SDEWrapper(_Base):
                         optim._launch(hyper_dev=ent["hyper"])
             finally:
                 sde.check_nan = check_nan
+                net._dropout_seed_dev = None
             ent["graph"], ent["loss"] = graph, loss.detach()
-        else:
-            net._dropout_seed_dev = ent["seed"]
+        optim._step += 1                    # after a successful capture: a failed one leaves the step count alone
         ent["graph"].replay()
         optim._after_step()
         optim._opt_called = True          # what LambdaLR's step-order check looks at (optimizer.step() ran)

@@ -31,7 +31,7 @@ def _worker_buckets(rank, world, port, q):
     _init(rank, world, port)
     n = 1000
     flat = torch.arange(n, dtype=torch.float32) * (rank + 1)
-    red = BucketReducer(bucket_bytes=4 * 256, profile=True)   # 256-element buckets -> 4 buckets
+    red = BucketReducer(bucket_bytes=4 * 256, profile=True)   # 32, 64, 128 then 256-element buckets from the front
     red.begin(flat)
     for off in (900, 600, 512, 300, 0):                # watermarks as the backward tape would report them
         red.ready_from(off)
@@ -40,9 +40,10 @@ def _worker_buckets(rank, world, port, q):
         assert all(lo >= off for lo, _ in launched_so_far), (off, launched_so_far)
     red.finish()
     expect = torch.arange(n, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
-    ok = torch.allclose(flat, expect) and red.launched == [(768, 1000), (512, 768), (256, 512), (0, 256)]
+    # launched from the end of the buffer (where backward finishes first): large buckets first, the small front one last
+    ok = torch.allclose(flat, expect) and red.launched == [(736, 1000), (480, 736), (224, 480), (96, 224), (32, 96), (0, 32)]
     st = red.stats()                                   # host-synchronous backend: all of the exchange is exposed
-    ok = ok and st["steps"] == 1 and st["buckets_per_step"] == 4 and st["hidden_ms_per_step"] == 0.0 and \
+    ok = ok and st["steps"] == 1 and st["buckets_per_step"] == 6 and st["hidden_ms_per_step"] == 0.0 and \
         st["comm_ms_per_step"] > 0 and red.stats() is None
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
@@ -86,6 +87,17 @@ def _worker_grads(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def test_bucket_sizes_are_geometric_from_the_front():
+    """C10-SOTA gradient buffer (97.6 M floats), 64 MiB buckets: the front (stem-side, launched last, cannot hide under
+    backward) bucket is 8 MiB, sizes double up to 64 MiB, every element is covered once."""
+    n = 97_627_910
+    b = BucketReducer.make_bounds(n, (8 << 20) // 4, (64 << 20) // 4)
+    assert b[0] == (0, (8 << 20) // 4) and b[-1][1] == n and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+    sizes = [hi - lo for lo, hi in b]
+    assert sizes[:4] == [(8 << 20) // 4, (16 << 20) // 4, (32 << 20) // 4, (64 << 20) // 4]
+    assert max(sizes) <= (64 << 20) // 4 * 3 // 2 and min(sizes) >= (8 << 20) // 4 and len(b) == 8
+
+
 @pytest.mark.parametrize("worker", [_worker_buckets, _worker_grads])
 def test_two_process_gloo(worker):
     world, port = 2, _free_port()
@@ -123,6 +135,11 @@ def test_bench_self_launches_its_ranks():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["allreduce_ones_ok"] is True and out["parallelism"] == "dp2"
     assert out["self_launched"] is True and out["backend"] == "gloo"
+    # the sampling half under N > 1: every rank its own shard and seed + rank, rank 0 reports the slowest
+    sc = out["sampling_check"]
+    assert sc["n_gpus"] == 2 and sc["rank_seeds"] == [0, 1] and sc["shards"] == [[0, 25000], [25000, 50000]]
+    assert sc["measured_batch_s"] == 2.0 and sc["measured_batch_s_min_over_ranks"] == 1.0      # fake timings 1 + rank
+    assert sc["batches_per_rank"] == 49 and sc["wallclock_50k_samples_s"] == 98.0               # ceil(25000 / 512) x max
 
 
 def test_bench_refuses_a_world_that_is_not_gpus():

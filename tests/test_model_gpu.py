@@ -1155,6 +1155,42 @@ def test_graph_captured_training_step_is_bitwise_the_eager_step(dropout):
         assert torch.equal(net_a(x, tt), net_b(x, tt))
 
 
+def test_graph_replays_without_host_syncs_track_the_lr_schedule():
+    """with no host read per step the host runs many replays ahead of the GPU; the step-dependent Adam
+    scalars (LR warm-up, bias corrections) must still be the ones of THEIR step.  14 steps (2 eager, 12 captured), the
+    losses read back only at the end, LR changing on every step, an eager step after the replays (its dropout masks
+    must be fresh ones: the captured seed word does not leak into eager forwards): bitwise the all-eager twin."""
+    import psld_amd
+    psld_amd.import_modules_into_registry()
+    from psld_amd.registry import get_module
+    cfg = C.tiny(nf=128, ch_mult=(1, 1), attn_resolutions=(16,))
+    cfg.model.score_fn.dropout = 0.15
+    cfg.training.optimizer.warmup = 20
+    torch.manual_seed(5)
+    net_a = get_module("score_fn", "ncsnpp")(cfg).to(DEV).train()
+    net_b = copy.deepcopy(net_a)
+    sde = get_module("sde", "psld")(cfg)
+    data = [torch.rand(4, 3, 16, 16, device=DEV, generator=torch.Generator(device=DEV).manual_seed(i)) * 2 - 1 for i in range(15)]
+    runs = []
+    for net, graphs in ((net_a, False), (net_b, True)):
+        crit = get_module("losses", "psld_score_loss")(cfg, sde)
+        wr = get_module("pl_modules", "sde_wrapper")(cfg, sde, net, criterion=crit)
+        if graphs:
+            wr.enable_graphs(True, warmup_steps=2)
+        torch.manual_seed(13)
+        losses = [wr.training_step(data[i], i).clone() for i in range(14)]        # no .item(): nothing syncs per step
+        if graphs:
+            assert net._dropout_seed_dev is None
+            wr.enable_graphs(False)
+        losses.append(wr.training_step(data[14], 14).clone())                     # one eager step after the replays
+        torch.cuda.synchronize()
+        opt = wr.optimizers()
+        runs.append(([float(l) for l in losses], net.flatten_parameters().clone(), opt._m.clone(), opt._v.clone(), opt._step))
+    (la, pa, ma, va, sa), (lb, pb, mb, vb, sb) = runs
+    assert la == lb and sa == sb == 15
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+
+
 def test_gradient_accumulation_semantics():
     """torch semantics: a populated .grad is accumulated into.  Two micro-batches (and two simultaneously
     outstanding graphs) must give the sum of the individual gradients; zero_grad() of either flavour resets."""
