@@ -253,7 +253,7 @@ class _Exec:
         on the compute stream.  ``tensors`` are inputs that the compute stream may free afterwards.
         The work is forked in groups of ``side_group`` calls: one event + one stream wait per group instead of per call
         (a cross-stream edge costs ~3.5 us inside a captured graph and ~10 us of host time outside; measured with
-        tools/scratch/graph_cross.py).  Until its group is launched a call keeps its inputs alive by reference."""
+        tools/graph_cross.py).  Until its group is launched a call keeps its inputs alive by reference."""
         if self.side is None:
             fn()
             return

@@ -10,5 +10,5 @@ python3 tools/bench_limb.py --wgrad --rounds 5 --iters 5 > $OUT/wgrad_xlimb_ab.t
 python3 tools/bench_limb.py --batch 16 --rounds 3 > $OUT/limb_planes_b16.txt 2>&1
 python3 tools/bench_hbm.py > $OUT/hbm_kernels.txt 2>&1
 python3 tools/bench_sample.py > $OUT/sampling.txt 2>&1
-python3 tools/scratch/graph_midfork.py > $OUT/graph_fork_cost.txt 2>&1
-python3 tools/scratch/graph_cross.py >> $OUT/graph_fork_cost.txt 2>&1
+python3 tools/graph_midfork.py > $OUT/graph_fork_cost.txt 2>&1
+python3 tools/graph_cross.py >> $OUT/graph_fork_cost.txt 2>&1

@@ -1,6 +1,6 @@
 """Import the *reference* (mandt-lab/PSLD, /root/reference) on CPU inside the build container.
 
-Used ONLY by tools/gen_golden.py and tools/check_oracle_vs_ref.py to pin the oracle and to
+Used ONLY by tools/gen_golden.py to pin the oracle and to
 emit golden fixtures.  Nothing here (and nothing from /root/reference) ships to the GPU box;
 tests, smoke() and bench.py never import this module.
 
