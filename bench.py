@@ -307,16 +307,16 @@ def reduce_sampling(res, rank: int, world: int, on_dev: bool, dev, shard):
 
 
 def pmc_traffic_record():
-    """HBM bytes per launch of the dominant convolution from the committed PMC passes (profiles/r02/pmc_traffic.json,
+    """HBM bytes per launch of the dominant convolution from the committed PMC passes (profiles/r03/pmc_traffic.json,
     written by tools/pmc_traffic.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs).  The record carries the hash of
     the kernel sources it was measured on; a record measured on other sources is refused (traffic = null)."""
     import hashlib
-    path = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")
     try:
         with open(path) as fh:
             rec = json.load(fh)
     except Exception:  # noqa: BLE001
-        return None, "no PMC record (profiles/r02/pmc_traffic.json)"
+        return None, "no PMC record (profiles/r03/pmc_traffic.json)"
     h = hashlib.sha256()
     for f in rec.get("sources", []):
         try:
