@@ -127,6 +127,7 @@ struct DConvArgs {
     int ldc;
     long long c_stride_split;
     int nseg, rps;          // image segments per 128-pixel tile and output rows per segment
+    int pitch;              // pixel rows of the LDS halo image per image row: W + 2, or 16 for 8-wide maps on 64-row tiles (see dconv_pitch)
     PsldEpilogue e;
     const float* zero;
     int v4;                 // rows of C / residual / bias / row bias are 16-byte aligned: dwordx4 epilogue (set by plan_split)
@@ -392,7 +393,7 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
     const int c_beg = split * a.chunks_per_split;               // stages: chunks (conv) or groups of TAPS chunks (PW)
     const int c_end = min(a.chunks, c_beg + a.chunks_per_split);
 
-    const int W2 = a.W + 2;
+    const int W2 = a.pitch;          // >= W + 2 (columns beyond W + 1 are never read)
     const float* zp = a.zero;
 
     // source pixel of every item this thread stages (-1: zero padding / beyond the batch)
@@ -570,7 +571,7 @@ __global__ void __launch_bounds__(256, 2) dconv_lp_kernel(const DConvArgs a) {
     const int c_beg = split * a.chunks_per_split;
     const int c_end = min(a.chunks, c_beg + a.chunks_per_split);
 
-    const int W2 = a.W + 2;
+    const int W2 = a.pitch;          // >= W + 2 (columns beyond W + 1 are never read)
     const unsigned char* zp = reinterpret_cast<const unsigned char*>(a.zero);
     const unsigned char* p1 = reinterpret_cast<const unsigned char*>(a.x1);
     const unsigned char* p2 = reinterpret_cast<const unsigned char*>(a.x2);
@@ -1387,6 +1388,20 @@ int plan_split(DConvArgs& a, const PsldEpilogue& e, float* y, int ldy, void* wor
     return ns;
 }
 
+// Pixel rows the LDS halo image spends per image row.  W + 2, except 8-wide maps on 64-row tiles: there a 16-row MFMA block
+// spans two image rows, and with a pitch of 10 the rows b..b+7 | b+10..b+17 put two rows of the same 16-lane ds_read_b128
+// group on one 16-byte slot of the bank line for every XOR swizzle that is linear in the row index (enumerated; measured
+// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.47-0.50, profiles/r02/pmc_tile_kernels.md).  With a pitch of 16 the second
+// image row sits 16 rows further and lds_swz is conflict-free again: conflict share 0.474 / 0.500 -> 0.000, MFMA busy 0.503
+// -> 0.504 / 0.516 -> 0.541, 74.2 -> 73.1 / 71.3 -> 68.8 us under the counters (profiles/r03/pmc_lds_w8_pitch{0,1}.md) and
+// nothing in an interleaved A/B (profiles/r03/ab_w8.txt: 181.1 vs 181.6 TFLOP/s at B=128, 58.5 vs 60.0 at B=16): the
+// conflict cycles sat in the shadow of the MFMAs; what holds these launches at half the pipe is their grid (256
+// workgroups of 64 rows at B=128: one per CU).  PSLD_DCONV_W8_PITCH16=0 restores the pitch of 10.
+int dconv_pitch(int w, int mt) {
+    static const int on = [] { const char* v = getenv("PSLD_DCONV_W8_PITCH16"); return v ? atoi(v) : 1; }();
+    return (w == 8 && mt == 64 && on) ? 16 : w + 2;
+}
+
 bool dconv_geometry(int h, int w, int* nseg, int* rps, int* halo_px, int mt = 128) {
     if (w != 8 && w != 16 && w != 32 && w != 64) return false;
     const int hw = h * w;
@@ -1399,7 +1414,7 @@ bool dconv_geometry(int h, int w, int* nseg, int* rps, int* halo_px, int mt = 12
         *nseg = mt / hw;
         *rps = h;
     }
-    *halo_px = *nseg * (*rps + 2) * (w + 2);
+    *halo_px = *nseg * (*rps + 2) * dconv_pitch(w, mt);
     return *halo_px <= 9 * 32;
 }
 
@@ -1408,10 +1423,14 @@ bool dconv_geometry(int h, int w, int* nseg, int* rps, int* halo_px, int mt = 12
 // PSLD_DCONV_MT64=0 switches them off.
 int dconv_tile_rows(const DConvArgs& a, bool n32, int h, int w) {
     static const int on = [] { const char* v = getenv("PSLD_DCONV_MT64"); return v ? atoi(v) : 1; }();
+    // PSLD_DCONV_W8_MT64=1: 8-wide maps on 64-row tiles at every batch size (the 128-row tile has no room for the wider
+    // pitch of dconv_pitch).  Measured slower at large batches (B=512: 236-251 vs 244-267 TFLOP/s): off by default
+    static const int w8 = [] { const char* v = getenv("PSLD_DCONV_W8_MT64"); return v ? atoi(v) : 0; }();
     int nseg, rps, halo;
     const long long tiles128 = (long long)cdiv(a.M, 128) * (a.N / 128);
-    // halo of a 64-row tile <= 144 pixel rows: the images the 64-row instances are built with (9 row groups / 5 items)
-    return (on && n32 && tiles128 < 384 && a.M % 64 == 0 && dconv_geometry(h, w, &nseg, &rps, &halo, 64) && halo <= 144) ? 64 : 128;
+    // halo of a 64-row tile <= 160 pixel rows: the images the 64-row instances are built with (10 row groups / 5 items)
+    return (on && n32 && (tiles128 < 384 || (w == 8 && w8)) && a.M % 64 == 0 && dconv_geometry(h, w, &nseg, &rps, &halo, 64) &&
+            halo <= 160) ? 64 : 128;
 }
 
 }  // namespace
@@ -1472,6 +1491,7 @@ extern "C" int psld_conv3x3_split_f32(const float* x1, int c1, const float* x2, 
     a.e = e;
     const int mt = dconv_tile_rows(a, dconv_n32(a), h, w);
     dconv_geometry(h, w, &a.nseg, &a.rps, &halo_px, mt);
+    a.pitch = dconv_pitch(w, mt);
     a.zero = psld_detail_zero_page("psld_conv3x3_split_f32");
     if (!a.zero) return PSLD_ERR_LAUNCH;
     PSLD_CHECK_ARG(!e.gn_part || (e.gn_hw == h * w && e.gn_hw % 64 == 0 && !e.accumulate),
@@ -1539,6 +1559,7 @@ extern "C" int psld_conv3x3_limb_f32(const void* x1, int c1, const void* x2, int
     const bool n32 = n32env && !e.gnb_part;
     const int mt = dconv_tile_rows(a, n32 && !single, h, w);
     dconv_geometry(h, w, &a.nseg, &a.rps, &halo_px, mt);
+    a.pitch = dconv_pitch(w, mt);
     a.zero = psld_detail_zero_page("psld_conv3x3_limb_f32");
     if (!a.zero) return PSLD_ERR_LAUNCH;
     PSLD_CHECK_ARG(!e.gn_part || (e.gn_hw == h * w && e.gn_hw % 64 == 0 && !e.accumulate),
@@ -1556,7 +1577,8 @@ extern "C" int psld_conv3x3_limb_f32(const void* x1, int c1, const void* x2, int
     int st;
     // two images of RG <= 13 row groups (79,872 B) leave room for two workgroups per CU (163,840 B of LDS)
     if (mt == 64) st = rg <= 7 ? launch_dconv_lp<7, true, true, 64>(a, ns, stream, name)
-                               : launch_dconv_lp<9, true, true, 64>(a, ns, stream, name);
+                     : rg <= 9 ? launch_dconv_lp<9, true, true, 64>(a, ns, stream, name)
+                               : launch_dconv_lp<10, true, true, 64>(a, ns, stream, name);
     else if (rg <= 12) st = single ? launch_dconv_lp<12, false, false>(a, ns, stream, name)
                    : (n32 ? launch_dconv_lp<12, true, true>(a, ns, stream, name) : launch_dconv_lp<12, true, false>(a, ns, stream, name));
     else if (rg <= 13) st = single ? launch_dconv_lp<13, false, false>(a, ns, stream, name)
@@ -1721,7 +1743,7 @@ extern "C" int psld_gemm_split_f32(const float* a1, int k1, const float* a2, int
     a.wfrag = reinterpret_cast<const u32x4*>(bfrag);
     a.N = n; a.M = m;
     a.chunks = (k1 + k2) / 64;          // stages of two 32-channel chunks
-    a.nseg = 1; a.rps = 1;
+    a.nseg = 1; a.rps = 1; a.pitch = a.W + 2;
     a.zero = psld_detail_zero_page("psld_gemm_split_f32");
     if (!a.zero) return PSLD_ERR_LAUNCH;
     const PsldEpilogue e = make_epilogue(epi);
