@@ -809,7 +809,9 @@ __device__ __forceinline__ u32x2 lds_tr16(const unsigned char* p) {
 // XLP: x (and x2) are bf16 limb planes [pixel][c/32][3][32] (written by GroupNorm's apply pass): the x items are staged
 // as plain 16-byte copies (4.5 per thread, one limb each) - no split3 for that operand, which is re-staged by
 // cout_tiles * 3 workgroups (the split is 43 % of this kernel's VALU work, and VALU issue is what bounds it).
-template <int CB, bool XLP>
+// ABL: timing-only ablations (wrong results; PSLD_DWGRAD_ABL, tools/bench_limb.py --wgrad): 1 = no limb split (raw halves are
+// stored), 2 = one ds_read_b128 per fragment instead of two transposed reads, 4 = no staging stores at all
+template <int CB, bool XLP, int ABL = 0>
 __global__ void __launch_bounds__(256, CB == 2 ? 3 : 2) dwgrad_kernel(const DWgradArgs a) {
     constexpr int CO_T = 32 * CB;                // output channels per workgroup
     constexpr int RSA = CO_T * 2 + 32;           // dy row stride: 160 / 288 B, both conflict-free for the transposed reads
@@ -912,14 +914,21 @@ __global__ void __launch_bounds__(256, CB == 2 ? 3 : 2) dwgrad_kernel(const DWgr
         }
     };
     auto store_rows = [&](unsigned char* d, int limb_stride, const f32x4& v) {
+        if constexpr ((ABL & 4) != 0) return;
         unsigned h0, m0, l0, h1, m1, l1;
-        split3(v[0], v[1], h0, m0, l0);
-        split3(v[2], v[3], h1, m1, l1);
+        if constexpr ((ABL & 1) != 0) {
+            h0 = m0 = l0 = __float_as_uint(v[0]) ^ __float_as_uint(v[1]);
+            h1 = m1 = l1 = __float_as_uint(v[2]) ^ __float_as_uint(v[3]);
+        } else {
+            split3(v[0], v[1], h0, m0, l0);
+            split3(v[2], v[3], h1, m1, l1);
+        }
         *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
         *reinterpret_cast<u32x2*>(d + limb_stride) = u32x2{m0, m1};
         *reinterpret_cast<u32x2*>(d + 2 * limb_stride) = u32x2{l0, l1};
     };
     auto frag = [&](const unsigned char* img, const int (&base)[2], int off) -> u32x4 {
+        if constexpr ((ABL & 2) != 0) return *reinterpret_cast<const u32x4*>(img + ((base[0] + off) & ~15));
         const u32x2 lo = lds_tr16(img + base[0] + off), hi = lds_tr16(img + base[1] + off);
         return u32x4{lo[0], lo[1], hi[0], hi[1]};
     };
@@ -1285,12 +1294,12 @@ int launch_bgemm(const BGemmArgs& a, int batch, hipStream_t stream) {
     return PSLD_OK;
 }
 
-template <int CB, bool XLP>
+template <int CB, bool XLP, int ABL = 0>
 int launch_dwgrad(const DWgradArgs& a, int nsplit, hipStream_t stream) {
     constexpr size_t LDS = (size_t)3 * (WG_AROWS * (64 * CB + 32) + WG_BLIMB);
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dwgrad_kernel<CB, XLP>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dwgrad_kernel<CB, XLP, ABL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         if (e != hipSuccess) {
             psld_set_error("psld_conv3x3_wgrad_split_f32: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -1298,7 +1307,7 @@ int launch_dwgrad(const DWgradArgs& a, int nsplit, hipStream_t stream) {
         }
         configured = true;
     }
-    hipLaunchKernelGGL((dwgrad_kernel<CB, XLP>), dim3((unsigned)(a.cout_tiles * a.cin_tiles * 3 * nsplit)), dim3(256), LDS,
+    hipLaunchKernelGGL((dwgrad_kernel<CB, XLP, ABL>), dim3((unsigned)(a.cout_tiles * a.cin_tiles * 3 * nsplit)), dim3(256), LDS,
                        stream, a);
     PSLD_CHECK_LAUNCH("psld_conv3x3_wgrad_split_f32");
     return PSLD_OK;
@@ -1625,6 +1634,16 @@ extern "C" int psld_conv3x3_wgrad_split_f32(const float* dy, int lddy, int cout,
     a.slab_stride = (long long)cout * 9 * cin_total;
     a.hw_w = (w < 32 ? w : 32) + 2;
     a.hrows = w >= 32 ? 1 : 32 / w;
+    static const int abl = [] { const char* v = getenv("PSLD_DWGRAD_ABL"); return v ? atoi(v) : 0; }();
+    if (abl && co_tile == 128) {
+        switch (abl) {
+            case 1: return launch_dwgrad<4, false, 1>(a, nsplit, stream);
+            case 2: return launch_dwgrad<4, false, 2>(a, nsplit, stream);
+            case 3: return launch_dwgrad<4, false, 3>(a, nsplit, stream);
+            case 4: return launch_dwgrad<4, false, 4>(a, nsplit, stream);
+            case 6: return launch_dwgrad<4, false, 6>(a, nsplit, stream);
+        }
+    }
     return co_tile == 128 ? launch_dwgrad<4, false>(a, nsplit, stream) : launch_dwgrad<2, false>(a, nsplit, stream);
 }
 
