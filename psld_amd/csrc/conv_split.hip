@@ -810,7 +810,17 @@ __device__ __forceinline__ u32x2 lds_tr16(const unsigned char* p) {
 // as plain 16-byte copies (4.5 per thread, one limb each) - no split3 for that operand, which is re-staged by
 // cout_tiles * 3 workgroups (the split is 43 % of this kernel's VALU work, and VALU issue is what bounds it).
 // ABL: timing-only ablations (wrong results; PSLD_DWGRAD_ABL, tools/bench_limb.py --wgrad): 1 = no limb split (raw halves are
-// stored), 2 = one ds_read_b128 per fragment instead of two transposed reads, 4 = no staging stores at all
+// stored), 2 = one ds_read_b128 per fragment instead of two transposed reads, 4 = no staging at all (no split, no LDS
+// stores, and with them the global loads).  Round 3 (profiles/r03/ab_dwgrad.txt, 256->256 @32 B=128): 213 TFLOP/s as
+// shipped, 231 without the split, 223 with half the LDS read instructions, 233 with both, 275 with no staging at all.  An
+// eight-wave form built on that reading - 128 x 128 x 3-tap tiles (29 % fewer staged bytes per MFMA), two LDS images, one
+// barrier per K tile, SIMD partners staging and multiplying in opposite order as in wino_conv8s_kernel, the tile after
+// next held in registers - was bitwise this kernel and exactly as fast (222 / 230 / 232 / 238 vs 222 / 232 / 234 / 234
+// TFLOP/s on the four 32x32 / 16x16 shapes): per K tile a wave issues ~350 vector / LDS / memory instructions (staging
+// ~200 of them, tile addressing the rest) beside 144 MFMAs, and 2 waves x (350 x 4 + 144 x 8) issue cycles exceed the
+// 4608 cycles the SIMD's matrix pipe needs - the kernel is ISSUE-bound at ~0.65 pipe occupancy in both forms.  What
+// would move it is operands that arrive pre-split (no producer can write them for less than the split costs here: +6 B per
+// element on kernels that run at the HBM roofline).  Removed again.
 template <int CB, bool XLP, int ABL = 0>
 __global__ void __launch_bounds__(256, CB == 2 ? 3 : 2) dwgrad_kernel(const DWgradArgs a) {
     constexpr int CO_T = 32 * CB;                // output channels per workgroup
