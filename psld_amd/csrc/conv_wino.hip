@@ -49,6 +49,7 @@ struct WinoArgs {
     float* C;
     int ldc;
     int nseg, rps;          // image segments per 128-pixel tile and output rows per segment (dconv_geometry, mt = 128)
+    int cw;                 // wino_conv8s_kernel: width of a workgroup's pixel block (W, or 32 on 64-wide maps: rps = 4)
     PsldEpilogue e;
     const float* zero;
     int nmajor;
@@ -719,6 +720,10 @@ __global__ void __launch_bounds__(256, 1) wino_conv4_kernel(const WinoArgs a) {
 // that share a SIMD (w and w + 4) run them in OPPOSITE order: while one issues vector ALU work the other owns the matrix
 // pipe, with no instruction-level interleaving to get right (the hardware arbitrates between the two waves) and the
 // partner's MFMAs covering each wave's memory latencies, which one wave per SIMD has to cover by itself.
+// (Two persistent forms of this kernel were built and measured slower: workgroups walking (pixel tile, channel tile) work
+// lists, 480 vs 454 us on 256->256 @32x32 B=128, and one workgroup per pixel tile looping over the channel tiles with the
+// half-phase pipeline running across the passes, 522 vs 451 us - hipcc's code for the accumulators degrades once the
+// epilogue sits inside a loop.  One workgroup per (pixel tile, channel tile) it is.)
 template <int ABL = 0>
 __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -731,16 +736,22 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArg
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_n = a.N >> 7;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tiles_m = gridDim.x / tiles_n;
+    const int tiles_m = (int)gridDim.x / tiles_n;
     const int tile_n = a.nmajor ? bid / tiles_m : bid % tiles_n;
     const int tile_m = a.nmajor ? bid - tile_n * tiles_m : bid / tiles_n;
-    const int m0 = tile_m * 128, n0 = tile_n * 128;
+    const int n0 = tile_n * 128;
 
-    const int W2 = a.W + 2, HW = a.H * a.W;
-    const int tiles_x = a.W >> 1;
+    // Region of this workgroup: nseg images (maps smaller than 128 pixels) or one rps x cw block of an image - cw = W, or 32
+    // for 64-wide maps, whose full-width tile (2 rows x 64) would need a 264-pixel halo where the two raw images hold 256.
+    const int HW = a.H * a.W;
+    const int W2 = a.cw + 2;
+    const int tiles_x = a.cw >> 1;
     const int tps = (a.rps >> 1) * tiles_x;
-    const int img0 = m0 / HW;
-    const int oy0 = (m0 - img0 * HW) / a.W;
+    const int rpi = HW >= 128 ? HW >> 7 : 1;                    // regions per image
+    const int xblocks = a.W / a.cw;
+    const int reg = tile_m % rpi;
+    const int img0 = HW >= 128 ? tile_m / rpi : tile_m * a.nseg;
+    const int oy0 = (reg / xblocks) * a.rps, ox0 = (reg % xblocks) * a.cw;
     const float* zp = a.zero;
 
     const int c4 = tid & 7;
@@ -753,7 +764,7 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArg
             const int seg = px / seg_px;
             const int rem = px - seg * seg_px;
             const int hr = rem / W2, hx = rem - hr * W2;
-            const int img = img0 + seg, iy = oy0 + hr - 1, ix = hx - 1;
+            const int img = img0 + seg, iy = oy0 + hr - 1, ix = ox0 + hx - 1;
             const bool ok = seg < a.nseg && img < a.B && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
             hoff[i] = ok ? (img * a.H + iy) * a.W + ix : -1;
             rdst[i] = raw_off(px, c4);
@@ -912,8 +923,8 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArg
         const int tile = tb * 16 + r16;
         const int seg = tile / tps, rem = tile - seg * tps;
         const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
-        const int gm00 = m0 + seg * (a.rps * a.W) + (2 * ty) * a.W + 2 * tx;
-        const bool ok = gm00 < a.M;
+        const int gm00 = ((img0 + seg) * a.H + oy0 + 2 * ty) * a.W + ox0 + 2 * tx;
+        const bool ok = img0 + seg < a.B;                   // whole images only: a tile is in range or not
         f32x4v s[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -964,9 +975,10 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArg
                 s1 += __shfl_xor(s1, sft, 64);
                 s2 += __shfl_xor(s2, sft, 64);
             }
-            const int row0 = m0 + tb * 64;
-            if ((lane & 0x1f) == 0 && row0 < a.M) {
-                const int img = row0 / e.gn_hw, chunk = (row0 - img * e.gn_hw) >> 6, chunks = e.gn_hw >> 6;
+            // tile block tb = 64 pixels of one image = one run of the partial-sum table (any fixed partition of an image
+            // into hw/64 runs serves: the consumer sums all of them): run 2 reg + tb, or image img0 + tb of a two-image region
+            const int img = a.nseg == 1 ? img0 : img0 + tb, chunk = a.nseg == 1 ? 2 * reg + tb : 0, chunks = e.gn_hw >> 6;
+            if ((lane & 0x1f) == 0 && img < a.B) {
                 const int f = ((n0 + wave * 16) >> 3) + (lane >> 5);
                 double* pp = e.gn_part + (((long long)img * chunks + chunk) * (a.N >> 3) + f) * 2;
                 pp[0] = (double)s1;
@@ -1120,6 +1132,11 @@ extern "C" int psld_conv3x3_wino_f32(const float* x1, int c1, const float* x2, i
     const int ni = cdiv((long long)halo_px * 8, WINO_THREADS);
     const char* name = "psld_conv3x3_wino_f32";
     static const int w4 = [] { const char* v = getenv("PSLD_WINO_W4"); return v ? atoi(v) : 2; }();
+    a.cw = w;
+    if (w4 == 2 && w == 64 && h % 4 == 0) {     // 4 x 32 pixel blocks: the 32x32 level's halo (6 x 34 = 204 pixels)
+        a.cw = 32; a.rps = 4; a.nseg = 1;
+        halo_px = 6 * 34;
+    }
     if (w4 == 2 && halo_px <= 256) {
         static const int abl8 = [] { const char* v = getenv("PSLD_WINO_ABL"); return v ? atoi(v) : 0; }();
         if (abl8 == 1) return launch_wino8s<1>(a, stream, name);

@@ -245,9 +245,9 @@ def set_winograd(mode: Optional[int]):
 @functools.lru_cache(maxsize=None)
 def conv3x3_wino_wanted(c1: int, c2: int, b: int, h: int, w: int, cout: int) -> bool:
     """Policy (limb-MFMA math mode only - the caller checks that): does a 3x3 stride-1 convolution of this shape run in
-    Winograd F(2x2, 3x3) form?  By default (``PSLD_WINOGRAD=1``) when the kernel takes the shape, the map is at least
-    16x16 (the 8x8 level's small grids run faster on the direct kernel, which can split its K range) and the grid has at
-    least 384 workgroups; ``PSLD_WINOGRAD=0`` restores the direct limb kernels everywhere, ``=2`` takes every supported
+    Winograd F(2x2, 3x3) form?  By default (``PSLD_WINOGRAD=1``) when the kernel takes the shape and the grid has at least
+    384 workgroups (smaller grids - the 8x8 level at training batch sizes, everything at batch 16 - run faster on the
+    direct kernels, which can split their K range and leave room for a second resident workgroup); ``PSLD_WINOGRAD=0`` restores the direct limb kernels everywhere, ``=2`` takes every supported
     shape (parity tests at small batches).  The environment is read once; set_winograd() overrides it."""
     mode = _WINO_MODE if _WINO_MODE is not None else int(os.environ.get("PSLD_WINOGRAD", "1"))
     if mode == 0 or not conv3x3_wino_supported(c1, c2, b, h, w, cout):
@@ -255,7 +255,7 @@ def conv3x3_wino_wanted(c1: int, c2: int, b: int, h: int, w: int, cout: int) -> 
     # >= 384 workgroups (one per CU, 160 KB of LDS each: 1.5 rounds).  Measured (tools/ab_wino_batches.sh): at 256 workgroups
     # (32x32 level, batch 16) the step is 3 % SLOWER than with the direct kernels - a workgroup per CU leaves no room
     # for the weight-gradient kernels of the side stream that small batches overlap with - from 512 on it is 7-16 % faster
-    return mode == 2 or (h * w >= 256 and (b * h * w // 128) * (cout // 128) >= 384)
+    return mode == 2 or (b * h * w // 128) * (cout // 128) >= 384
 
 
 def conv3x3_wino(x1: Tensor, x2: Optional[Tensor], ufrag: Tensor, cout: int, y: Tensor,
