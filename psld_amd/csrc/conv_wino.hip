@@ -720,6 +720,9 @@ __global__ void __launch_bounds__(256, 1) wino_conv4_kernel(const WinoArgs a) {
 // that share a SIMD (w and w + 4) run them in OPPOSITE order: while one issues vector ALU work the other owns the matrix
 // pipe, with no instruction-level interleaving to get right (the hardware arbitrates between the two waves) and the
 // partner's MFMAs covering each wave's memory latencies, which one wave per SIMD has to cover by itself.
+// (Output tile through LDS so that every wave stores whole 512-byte pixel rows instead of 64-byte runs: built, correct,
+// 2.5 % slower - 454 vs 443 us - although skipping the stores altogether saves 8 %: the exposed part of the epilogue is the
+// drain of 64 KB per workgroup, not the segment size.)
 // (Two persistent forms of this kernel were built and measured slower: workgroups walking (pixel tile, channel tile) work
 // lists, 480 vs 454 us on 256->256 @32x32 B=128, and one workgroup per pixel tile looping over the channel tiles with the
 // half-phase pipeline running across the passes, 522 vs 451 us - hipcc's code for the accumulators degrades once the
