@@ -312,6 +312,11 @@ int psld_upfirdn2d_f32(const float* x, float* y, int batch, int c, int in_h, int
  * (op/fused_bias_act_kernel.cu:18-49, forward only). */
 int psld_fused_bias_act_f32(const float* x, const float* b, float* y, long long n, int size_b, int step_b,
                             int act, float alpha, float scale, hipStream_t stream);
+/* The op with all seven arguments of the reference's binding (op/fused_bias_act.cpp:11-20: input, bias, refer, act,
+ * grad, alpha, scale): grad = 1 is the first derivative - x is the incoming gradient, `refer` the forward output, as
+ * FusedLeakyReLUFunctionBackward calls it (op/fused_act.py:27-33) - grad = 2 the second (zero for both activations). */
+int psld_fused_bias_act_grad_f32(const float* x, const float* b, const float* refer, float* y, long long n, int size_b,
+                                 int step_b, int act, int grad, float alpha, float scale, hipStream_t stream);
 
 /* ---- pointwise / reductions ---------------------------------------------------------------*/
 /* y = (a*sa + b*sb) (b may be NULL); accumulate: y += ... */

@@ -121,6 +121,7 @@ SIGNATURES = {
     "psld_gn_bwd_nhwc_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, F, C.c_ulonglong, P, P, P, P, I, P, F, P, I, P, P]),
     "psld_upfirdn2d_f32": (I, [P, P, I, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "psld_fused_bias_act_f32": (I, [P, P, P, LL, I, I, I, F, F, P]),
+    "psld_fused_bias_act_grad_f32": (I, [P, P, P, P, LL, I, I, I, I, F, F, P]),
     "psld_axpby_f32": (I, [P, F, P, F, P, LL, I, P]),
     "psld_silu_f32": (I, [P, P, LL, P]),
     "psld_silu_bwd_f32": (I, [P, P, P, LL, P]),

@@ -180,14 +180,19 @@ __global__ void upfirdn_nchw_kernel(const float* __restrict__ x, float* __restri
     }
 }
 
-__global__ void fused_bias_act_kernel(const float* __restrict__ x, const float* __restrict__ b,
-                                      float* __restrict__ y, long long n, int size_b, int step_b, int act,
+// grad = 0: y = act(x + b) * scale; grad = 1 (first derivative: x is the incoming gradient, ref the forward OUTPUT):
+// y = (act == lrelu && ref <= 0 ? x * alpha : x) * scale; grad = 2 (second derivative): 0 - the switch of
+// op/fused_bias_act_kernel.cu:35-47, cases 10 11 12 / 30 31 32.
+__global__ void fused_bias_act_kernel(const float* __restrict__ x, const float* __restrict__ b, const float* __restrict__ ref,
+                                      float* __restrict__ y, long long n, int size_b, int step_b, int act, int grad,
                                       float alpha, float scale) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
         float v = x[i];
         if (b) v += b[(i / step_b) % size_b];
-        if (act == 3) v = v > 0.f ? v : v * alpha;
+        const float r = ref ? ref[i] : 0.f;
+        if (grad == 2) v = 0.f;
+        else if (act == 3) v = ((grad == 1 ? r : v) > 0.f) ? v : v * alpha;
         y[i] = v * scale;
     }
 }
@@ -256,14 +261,21 @@ extern "C" int psld_upfirdn2d_f32(const float* x, float* y, int batch, int c, in
     return PSLD_OK;
 }
 
-extern "C" int psld_fused_bias_act_f32(const float* x, const float* b, float* y, long long n, int size_b,
-                                       int step_b, int act, float alpha, float scale, hipStream_t stream) {
+extern "C" int psld_fused_bias_act_grad_f32(const float* x, const float* b, const float* refer, float* y, long long n,
+                                            int size_b, int step_b, int act, int grad, float alpha, float scale,
+                                            hipStream_t stream) {
     PSLD_CHECK_ARG(x && y && n >= 0 && (!b || (size_b > 0 && step_b > 0)), "psld_fused_bias_act_f32: bad args");
     PSLD_CHECK_ARG(act == 1 || act == 3, "psld_fused_bias_act_f32: act must be 1 (linear) or 3 (lrelu)");
+    PSLD_CHECK_ARG(grad >= 0 && grad <= 2, "psld_fused_bias_act_f32: grad must be 0, 1 or 2");
     if (n == 0) return PSLD_OK;
     const int blocks = (int)min((long long)cdiv(n, 256), 256LL * 32);
-    hipLaunchKernelGGL(fused_bias_act_kernel, dim3(blocks), dim3(256), 0, stream, x, b, y, n, size_b, step_b, act,
-                       alpha, scale);
+    hipLaunchKernelGGL(fused_bias_act_kernel, dim3(blocks), dim3(256), 0, stream, x, b, refer, y, n, size_b, step_b, act,
+                       grad, alpha, scale);
     PSLD_CHECK_LAUNCH("psld_fused_bias_act_f32");
     return PSLD_OK;
+}
+
+extern "C" int psld_fused_bias_act_f32(const float* x, const float* b, float* y, long long n, int size_b,
+                                       int step_b, int act, float alpha, float scale, hipStream_t stream) {
+    return psld_fused_bias_act_grad_f32(x, b, nullptr, y, n, size_b, step_b, act, 0, alpha, scale, stream);
 }

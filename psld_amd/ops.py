@@ -692,15 +692,18 @@ def time_embed(t: Tensor, W: Tensor, use_log: bool) -> Tensor:
     return out
 
 
-def fused_bias_act(x: Tensor, bias: Optional[Tensor], act: int = 3, alpha: float = 0.2, scale: float = 2 ** 0.5):
-    """Inventory parity with op/fused_act.py:86-97 (forward): bias indexed along dim 1."""
+def fused_bias_act(x: Tensor, bias: Optional[Tensor], act: int = 3, alpha: float = 0.2, scale: float = 2 ** 0.5,
+                   refer: Optional[Tensor] = None, grad: int = 0):
+    """The reference's second native op with its full argument list (op/fused_bias_act.cpp:11-20; Python wrappers
+    op/fused_act.py:20-97): bias indexed along dim 1; ``grad`` = 1 with ``refer`` = the forward output is the first
+    derivative applied to the incoming gradient ``x``, ``grad`` = 2 the (zero) second derivative."""
     y = torch.empty_like(x)
     step_b = 1
     for d in x.shape[2:]:
         step_b *= d
-    check(lib().psld_fused_bias_act_f32(_chk(x).data_ptr(), _p(bias), y.data_ptr(), x.numel(),
-                                        bias.numel() if bias is not None else 1, step_b, act, alpha, scale, _stream()),
-          "psld_fused_bias_act_f32")
+    check(lib().psld_fused_bias_act_grad_f32(_chk(x).data_ptr(), _p(bias), _p(refer), y.data_ptr(), x.numel(),
+                                             bias.numel() if bias is not None else 1, step_b, act, grad, alpha, scale,
+                                             _stream()), "psld_fused_bias_act_grad_f32")
     return y
 
 

@@ -862,6 +862,17 @@ def test_fused_bias_act(ops):
     ref = F.leaky_relu(x + b.view(1, -1, 1, 1), 0.2) * 2 ** 0.5   # op/fused_act.py:86-94
     y = ops.fused_bias_act(x.to(DEV), b.to(DEV))
     np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), rtol=1e-6, atol=1e-7)
+    # gradient modes (op/fused_bias_act_kernel.cu cases 31 / 32, 11 / 12) against autograd of the CPU path: grad = 1 takes the
+    # incoming gradient as input and the forward OUTPUT as refer (op/fused_act.py:27-33)
+    xr = x.clone().requires_grad_(True)
+    out = F.leaky_relu(xr + b.view(1, -1, 1, 1), 0.2) * 2 ** 0.5
+    gy = gen(*x.shape, seed=54)
+    out.backward(gy)
+    g1 = ops.fused_bias_act(gy.to(DEV), None, refer=out.detach().to(DEV), grad=1)
+    np.testing.assert_allclose(g1.cpu().numpy(), xr.grad.numpy(), rtol=1e-6, atol=1e-7)
+    assert float(ops.fused_bias_act(gy.to(DEV), None, refer=out.detach().to(DEV), grad=2).abs().max()) == 0.0
+    lin = ops.fused_bias_act(gy.to(DEV), None, act=1, refer=out.detach().to(DEV), grad=1, scale=0.5)
+    np.testing.assert_allclose(lin.cpu().numpy(), (gy * 0.5).numpy(), rtol=1e-6, atol=1e-7)
 
 
 # ---------------------------------------------------------------------------------------------------
