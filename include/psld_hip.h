@@ -197,6 +197,16 @@ int psld_gemm_split_f32(const float* a1, int k1, const float* a2, int k2, int m,
                         float* y, int ldy, const psld_epilogue_t* epi, void* workspace, long long ws_bytes,
                         hipStream_t stream);
 
+/* Fused single-head spatial self-attention, forward: o[b][i][:] = sum_j softmax_j(scale * q[b][i] . k[b][j]) v[b][j][:] in
+ * one kernel, the hw x hw score matrix never written (unless p != NULL: the probabilities [batch][hw][hw] fp32, what the
+ * backward pass reads).  q / k / v: [batch*hw][c] fp32 with a common row stride ld (the fused q|k|v buffer: ld = 3c); o:
+ * [batch*hw][c], row stride ldo.  Limb-MFMA arithmetic (three exact bf16 limbs, six products, fp32 accumulation), fp32 softmax.
+ * hw in {256, 64} (16x16 / 8x8 maps), c in {256, 128}.  Replaces einsum -> softmax -> einsum of AttnBlockpp.forward
+ * (song_sde/layerspp.py:82-86). */
+int psld_attn_fwd_split_supported(int hw, int c);
+int psld_attn_fwd_split_f32(const float* q, const float* k, const float* v, int ld, int batch, int hw, int c, float scale,
+                            float* o, int ldo, float* p, hipStream_t stream);
+
 /* Weight gradient of the same convolution, same slab contract as psld_conv2d_wgrad_nhwc_f32 (kh = kw = 3,
  * stride = pad = 1): slabs[s][cout][9][cin_total] restricted to columns [col0, col0 + cin), one slab per K range
  * of ceil(batch*h*w/32 / nsplit) 32-pixel tiles (every slab must be non-empty); the caller reduces

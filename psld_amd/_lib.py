@@ -87,6 +87,8 @@ SIGNATURES = {
     "psld_pack_conv3x3_frag": (I, [P, P, I, I, I, P]),
     "psld_pack_frag_batch": (I, [P, I, LL, P]),
     "psld_conv3x3_split_f32": (I, [P, I, P, I, I, I, I, P, I, P, I, EP, P, LL, P]),
+    "psld_attn_fwd_split_supported": (I, [I, I]),
+    "psld_attn_fwd_split_f32": (I, [P, P, P, I, I, I, I, F, P, I, P, P]),
     "psld_conv3x3_wino_frag_bytes": (LL, [I, I]),
     "psld_conv3x3_wino_supported": (I, [I, I, I, I, I, I]),
     "psld_pack_conv3x3_wino": (I, [P, P, I, I, I, P]),

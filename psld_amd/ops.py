@@ -363,6 +363,19 @@ def bgemm_split(ta: int, tb: int, M: int, N: int, K: int, A: Tensor, lda: int, s
 
 
 @functools.lru_cache(maxsize=None)
+@functools.lru_cache(maxsize=None)
+def attn_fwd_supported(hw: int, c: int) -> bool:
+    return bool(lib().psld_attn_fwd_split_supported(hw, c))
+
+
+def attn_fwd(q: Tensor, k: Tensor, v: Tensor, ld: int, batch: int, hw: int, c: int, scale: float, out: Tensor,
+             p: Optional[Tensor] = None):
+    """out[b][i] = sum_j softmax_j(scale q[b][i].k[b][j]) v[b][j] in one kernel (csrc/attention.hip); q / k / v may be
+    column slices of one buffer (common row stride ``ld``).  ``p`` ([batch, hw, hw]): also write the probabilities."""
+    check(lib().psld_attn_fwd_split_f32(q.data_ptr(), k.data_ptr(), v.data_ptr(), ld, batch, hw, c, float(scale),
+                                        out.data_ptr(), c, _p(p), _stream()), "psld_attn_fwd_split_f32")
+
+
 def conv3x3_wgrad_split_cout_tile(cout: int) -> int:
     return lib().psld_conv3x3_wgrad_split_cout_tile(cout)
 

@@ -238,6 +238,10 @@ class _Exec:
         self.limb_planes = _os.environ.get("PSLD_LIMB_PLANES", "1") != "0"    # A/B switch for tools/bench_sample.py
         # pass 1 of GroupNorm's backward from the epilogue of the kernel that produces its dy (A/B switch)
         self.fuse_gn_bwd = _os.environ.get("PSLD_FUSE_GN_BWD", "0") == "1"    # measured: -0.8 % on the step
+        # forward attention in one kernel (attention.hip): 1 = where it is faster (8x8 maps: 18.8 vs 54.1 us at B=128; on
+        # 16x16 maps every 64-query workgroup re-splits all 256 keys and values and the kernel is vector-issue-bound: 121 vs
+        # 71 us for the three-kernel path, tools/bench_attn.py), 2 = wherever the kernel takes the shape, 0 = never
+        self.fused_attn = int(_os.environ.get("PSLD_FUSED_ATTN", "1"))
         self.dx_nchw = None
 
     # -- helpers ------------------------------------------------------------------------------
@@ -799,11 +803,17 @@ class _Exec:
                 qkv.append(y)
             q, k, v = qkv
             ld = c
-        p = torch.empty((b, hw, hw), device=dev, dtype=torch.float32)
-        self.bmm(0, 1, hw, hw, c, q, ld, hw * ld, k, ld, hw * ld, p, hw, hw * hw, b, scale)
-        ops.softmax_rows(p, p, b * hw, hw)
         ho = torch.empty((b, hw, c), device=dev, dtype=torch.float32)
-        self.bmm(0, 0, hw, c, hw, p, hw, hw * hw, v, ld, hw * ld, ho, c, hw * c, b)
+        if self.split and (self.fused_attn == 2 or (self.fused_attn == 1 and hw <= 64)) and ops.attn_fwd_supported(hw, c):
+            # QK^T -> softmax -> PV in ONE kernel: the [B, HW, HW] scores never reach HBM; the probabilities are written
+            # only when a backward pass will read them
+            p = torch.empty((b, hw, hw), device=dev, dtype=torch.float32) if self.record else None
+            ops.attn_fwd(q, k, v, ld, b, hw, c, scale, ho, p)
+        else:
+            p = torch.empty((b, hw, hw), device=dev, dtype=torch.float32)
+            self.bmm(0, 1, hw, hw, c, q, ld, hw * ld, k, ld, hw * ld, p, hw, hw * hw, b, scale)
+            ops.softmax_rows(p, p, b * hw, hw)
+            self.bmm(0, 0, hw, c, hw, p, hw, hw * hw, v, ld, hw * ld, ho, c, hw * c, b)
         out = torch.empty_like(x.v)
         outp = self.part_for(b, hw, c, dev, fused)
         epi_out = ops.epilogue(bias=n3.b, residual=x.v, ld_residual=c, out_scale=s, gn_part=outp, gn_hw=hw)

@@ -669,6 +669,42 @@ def test_gemm_tn_split(ops, m, n, k, lda, ldb, ldc, nsplit):
     assert not ops.gemm_tn_split_supported(64, 128, 64) and not ops.gemm_tn_split_supported(128, 128, 48)
 
 
+@pytest.mark.parametrize("b,hw,c,fused_buf", [(3, 256, 256, True), (2, 64, 256, True), (5, 256, 128, False), (1, 64, 128, False)])
+def test_fused_attention_forward(ops, b, hw, c, fused_buf):
+    """psld_attn_fwd_split_f32: softmax(scale q k^T) v in one kernel against fp64 torch (einsum -> softmax -> einsum of
+    AttnBlockpp.forward, layerspp.py:82-86), with q | k | v as column slices of one buffer (row stride 3c) or as three
+    tensors, the probabilities written or not, and against the three-kernel path on the same inputs."""
+    assert ops.attn_fwd_supported(hw, c)
+    g = torch.Generator().manual_seed(90)
+    qkv = torch.randn(b, hw, 3 * c, generator=g) * 1.5
+    scale = float(c) ** -0.5
+    q64, k64, v64 = (t.double() for t in qkv.split(c, dim=-1))
+    pref = torch.softmax(torch.einsum("bic,bjc->bij", q64, k64) * scale, dim=-1)
+    oref = torch.einsum("bij,bjc->bic", pref, v64)
+    dev = qkv.to(DEV)
+    if fused_buf:
+        q, k, v, ld = dev[..., :c], dev[..., c:2 * c], dev[..., 2 * c:], 3 * c
+    else:
+        q, k, v = (t.contiguous() for t in dev.split(c, dim=-1))
+        ld = c
+    out = torch.full((b, hw, c), float("nan"), device=DEV)
+    p = torch.full((b, hw, hw), float("nan"), device=DEV)
+    ops.attn_fwd(q, k, v, ld, b, hw, c, scale, out, p)
+    assert rel_l2(out, oref) < 3e-6 and rel_l2(p, pref) < 3e-6
+    out2 = torch.full((b, hw, c), float("nan"), device=DEV)
+    ops.attn_fwd(q, k, v, ld, b, hw, c, scale, out2, None)
+    assert torch.equal(out, out2)
+    # the three-kernel path (batched limb GEMM, softmax rows, batched limb GEMM), where the limb GEMM takes the shape
+    if not ops.bgemm_split_supported(0, 1, hw, hw, c):
+        return
+    p3 = torch.empty((b, hw, hw), device=DEV)
+    ops.bgemm_split(0, 1, hw, hw, c, q, ld, hw * ld, k, ld, hw * ld, p3, hw, hw * hw, b, scale)
+    ops.softmax_rows(p3, p3, b * hw, hw)
+    o3 = torch.empty((b, hw, c), device=DEV)
+    ops.bgemm_split(0, 0, hw, c, hw, p3, hw, hw * hw, v, ld, hw * ld, o3, c, hw * c, b)
+    assert rel_l2(out, o3) < 3e-6 and rel_l2(p, p3) < 3e-6
+
+
 @pytest.mark.parametrize("m,n,k1,k2", [(256, 128, 64, 0), (1000, 256, 256, 0), (640, 128, 96, 32), (4096, 768, 256, 0),
                                        (130, 128, 512, 0)])
 def test_gemm_split(ops, m, n, k1, k2):
