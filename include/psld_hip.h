@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 
-#define PSLD_ABI_VERSION 8 /* 2: limb-MFMA convolutions, math mode, bias-gradient / batched-copy entry points; 3: pointwise weight gradient and batched activation GEMM on limb kernels; 4: GroupNorm statistics from the limb kernels' epilogue; 5: per-sample-time reverse SDE, ScoreLoss nll / l1; 6: limb-plane activations; 7: device-resident dropout seed / Adam scalars (captured training step), GroupNorm-backward sums from the producing epilogue; 8: Winograd F(2x2,3x3) limb convolution */
+#define PSLD_ABI_VERSION 9 /* 2: limb-MFMA convolutions, math mode, bias-gradient / batched-copy entry points; 3: pointwise weight gradient and batched activation GEMM on limb kernels; 4: GroupNorm statistics from the limb kernels' epilogue; 5: per-sample-time reverse SDE, ScoreLoss nll / l1; 6: limb-plane activations; 7: device-resident dropout seed / Adam scalars (captured training step), GroupNorm-backward sums from the producing epilogue; 8: Winograd F(2x2,3x3) limb convolution; 9: launch tape */
 #define PSLD_COEFF_STRIDE 12
 
 int psld_version(void);
@@ -521,6 +521,27 @@ int psld_adam_step_scalars_dev(double lr, double beta1, double beta2, int step, 
 /* target = target*tau + src*(1-tau) (callbacks.py:62-64); hyper-parameters are doubles so that
  * (1 - tau), (1 - beta) are formed in double and rounded once, as torch does for python floats. */
 int psld_ema_f32(float* target, const float* src, long long n, double tau, hipStream_t stream);
+
+/* ---- launch tape ------------------------------------------------------------------------------------------------
+ * Replays a recorded list of the launches above from C: the training step at the reference's per-GPU batch of 16
+ * (scripts_psld/.../train_uncond_psld.sh:25-30) issues ~2700 launches, and what bounds it is the host getting through
+ * them, not the GPU.  A caller records (function index, argument words) once - while the step runs under stream
+ * capture, which pins every buffer of the step at a fixed address - and then replays the list per step; the launches
+ * are ordinary stream launches on the recorded streams (unlike a hipGraph replay: no per-node edge cost, and the
+ * side stream really overlaps), joined by PSLD_TAPE_EDGE entries.
+ * Every status-returning entry point of this header whose last parameter is the stream can be taped. */
+#define PSLD_TAPE_MAX_ARGS 24
+#define PSLD_TAPE_EDGE (-1) /* a[0] = source stream, a[1] = destination stream, a[2] = event from psld_tape_event_create */
+typedef struct psld_tape_entry {
+    int fn;                                   /* psld_tape_fn_index(name), or PSLD_TAPE_EDGE */
+    int nargs;
+    unsigned long long a[PSLD_TAPE_MAX_ARGS]; /* integers and pointers as they are; float / double as their bit patterns */
+} psld_tape_entry;
+int psld_tape_fn_index(const char* name);     /* -1: not a launching entry point */
+void* psld_tape_event_create(void);           /* a hipEvent_t without timing; NULL on failure */
+int psld_tape_event_destroy(void* event);
+/* Issues entries[0..n) in order; stops at the first non-zero status, returns it and stores the entry's index. */
+int psld_tape_replay(const psld_tape_entry* entries, int n, int* failed_at);
 
 #ifdef __cplusplus
 }

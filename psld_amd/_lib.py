@@ -68,7 +68,7 @@ class SscsCoeffs(C.Structure):
 I, F, D, LL, P = C.c_int, C.c_float, C.c_double, C.c_longlong, C.c_void_p
 EP = C.POINTER(Epilogue)
 
-ABI_VERSION = 8    # PSLD_ABI_VERSION of include/psld_hip.h these signatures were written against
+ABI_VERSION = 9    # PSLD_ABI_VERSION of include/psld_hip.h these signatures were written against
 
 # name -> (restype, argtypes): every symbol include/psld_hip.h declares
 SIGNATURES = {
@@ -167,7 +167,21 @@ SIGNATURES = {
     "psld_adam_step_scalars": (None, [D, D, D, I, P]),
     "psld_adam_step_scalars_dev": (I, [D, D, D, I, P, P]),
     "psld_ema_f32": (I, [P, P, LL, D, P]),
+    "psld_tape_fn_index": (I, [C.c_char_p]),
+    "psld_tape_event_create": (P, []),
+    "psld_tape_event_destroy": (I, [P]),
+    "psld_tape_replay": (I, [P, I, C.POINTER(C.c_int)]),
 }
+
+TAPE_HOST_ONLY = ("psld_tape_event_destroy",)
+
+
+def is_launch(name: str) -> bool:
+    """Entry points that enqueue work on a stream (status-returning, ``hipStream_t stream`` last): the ones a launch
+    tape (psld_amd/tape.py) records.  Queries (``*_supported``, ``*_bytes``), the math-mode switch and the tape's own
+    entry points are host-only.  tests/test_abi_cpu.py checks this rule against the header's parameter names."""
+    res, args = SIGNATURES[name]
+    return res is I and bool(args) and args[-1] is P and name not in TAPE_HOST_ONLY
 
 PSLD_ERR_NUMERIC = 3
 
@@ -178,7 +192,31 @@ class PsldHipError(RuntimeError):
     pass
 
 
-def load() -> C.CDLL:
+_proxy = None     # psld_amd/tape.py: a recording stand-in for the library while a launch tape is being recorded
+
+
+def set_proxy(proxy):
+    global _proxy
+    _proxy = proxy
+
+
+def keep_host_memory(obj):
+    """A launch is about to be handed a pointer into ``obj``'s HOST memory (the FIR taps of psld_upfirdn2d_f32 are the
+    only such argument of the ABI; structures passed by reference are copied by the tape itself).  The launcher reads it
+    during the call, so eager and captured launches need nothing; a recording launch tape replays the call later and
+    keeps the object alive."""
+    if _proxy is not None:
+        _proxy._tape._keep.append(obj)
+
+
+def load():
+    """The loaded library (or, while a launch tape records, the proxy that notes every launch it forwards)."""
+    if _proxy is not None:
+        return _proxy
+    return _lib if _lib is not None else load_real()
+
+
+def load_real() -> C.CDLL:
     """Load libpsld_hip.so and bind every declared symbol.  Raises if anything is missing."""
     global _lib
     if _lib is not None:

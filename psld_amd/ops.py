@@ -573,6 +573,7 @@ def upfirdn2d_raw(x: Tensor, kernel: np.ndarray, up: int, down: int, pad, layout
     if out is None:
         shape = (b, c, oh, ow) if layout == 0 else (b, oh, ow, c)
         out = torch.empty(shape, device=x.device, dtype=torch.float32)
+    _lib.keep_host_memory(k)      # the one HOST pointer of the ABI: a recording launch tape must outlive a temporary k
     check(lib().psld_upfirdn2d_f32(_chk(x).data_ptr(), out.data_ptr(), b, c, h, w, k.ctypes.data, kh, kw, up, up,
                                    down, down, px0, px1, py0, py1, layout, 1 if accumulate else 0,
                                    _stream()), "psld_upfirdn2d_f32")

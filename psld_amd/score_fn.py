@@ -30,6 +30,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from . import tape as _tape
 from .registry import register_module
 
 Tensor = torch.Tensor
@@ -270,8 +271,10 @@ class _Exec:
             return
         queue, self.side_queue = self.side_queue, []
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
+        cur = torch.cuda.current_stream()
+        ev.record(cur)
         self.side.wait_event(ev)
+        _tape.note_edge(cur, self.side)
         with torch.cuda.stream(self.side), ops.stream_scope():
             for fn, _ in queue:
                 fn()
@@ -283,7 +286,9 @@ class _Exec:
     def join_side(self):
         if self.side is not None:
             self.flush_side()
-            torch.cuda.current_stream().wait_stream(self.side)
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(self.side)
+            _tape.note_edge(self.side, cur)
 
     def wgrad(self, dy: Tensor, x: Tensor, conv: _Affine, k: int, stride: int, pad: int, alpha: float = 1.0,
               x2: Optional[Tensor] = None):

@@ -20,6 +20,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--tape", action="store_true")
+    ap.add_argument("--graphs", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     psld_amd.import_modules_into_registry()
@@ -33,6 +35,8 @@ def main():
     crit = get_module("losses", "psld_score_loss")(cfg, sde)
     wrapper = get_module("pl_modules", "sde_wrapper")(cfg, sde, net, ema_score_fn=ema, criterion=crit)
     cb = EMAWeightUpdate(cfg.training.ema_decay)
+    if args.tape or args.graphs:
+        wrapper.enable_graphs(True, tape=args.tape)
     x = torch.rand(args.batch, 3, 32, 32, device=dev) * 2 - 1
     for i in range(5):
         wrapper.training_step(x, i)
@@ -45,7 +49,18 @@ def main():
     t_host = time.perf_counter() - t0
     torch.cuda.synchronize()
     t_all = time.perf_counter() - t0
-    print(f"batch {args.batch}: host enqueue {t_host / args.steps * 1e3:.2f} ms/step, finished {t_all / args.steps * 1e3:.2f} ms/step "
+    # the host's own cost of issuing ONE step (queue empty: no back-pressure from the launch queue, which holds fewer
+    # packets than 30 steps and makes the back-to-back figure above track the GPU time whenever the GPU is the bound)
+    t_one = 0.0
+    for i in range(10):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        wrapper.training_step(x, i)
+        cb.on_train_batch_end(None, wrapper)
+        t_one += time.perf_counter() - t1
+    torch.cuda.synchronize()
+    print(f"batch {args.batch}: host cost of one step issued into an empty queue {t_one / 10 * 1e3:.2f} ms")
+    print(f"batch {args.batch}{' tape' if args.tape else ' graph' if args.graphs else ''}: host enqueue {t_host / args.steps * 1e3:.2f} ms/step, finished {t_all / args.steps * 1e3:.2f} ms/step "
           f"-> {'host' if t_host > 0.9 * t_all else 'GPU'}-bound")
 
 
