@@ -166,3 +166,46 @@ def test_train_forward_backward_at_full_batch_equals_its_slices(golden, name, ba
     eg2 = ((gl - gsum).norm() / gsum.norm()).item()
     print(f"{name} B={batch}: HSM loss {lfull:.6f} vs mean of slices {lsum:.6f} ({el:.2e}); gradient {eg2:.3e}")
     assert np.isfinite(lfull) and el < 2e-6 and eg2 < 1e-5
+
+
+def test_taped_training_step_on_c10_sota_is_bitwise_the_eager_step():
+    """configs[1]'s network at the reference's per-GPU batch of 16 (train_uncond_psld.sh:25-30): the launch-tape step
+    (SDEWrapper.enable_graphs(tape=True): ~1700 launches + the side-stream edges replayed by psld_tape_replay) against
+    the eager step on a twin, dropout 0.15 and EMA on: same losses, parameters, Adam state and EMA bitwise after 5 steps
+    (2 eager, the capture + 2 replays)."""
+    import copy
+    import psld_amd
+    from psld_amd import config as C
+    from psld_amd.optim import EMAWeightUpdate
+    from psld_amd.registry import get_module
+    psld_amd.import_modules_into_registry()
+    cfg = C.c10_sota()
+    cfg.training.batch_size = 16
+    torch.manual_seed(7)
+    net_a = get_module("score_fn", "ncsnpp")(cfg).to(DEV).train()
+    net_b = copy.deepcopy(net_a)
+    sde = get_module("sde", "psld")(cfg)
+    data = [torch.rand(16, 3, 32, 32, device=DEV, generator=torch.Generator(device=DEV).manual_seed(i)) * 2 - 1 for i in range(5)]
+    runs = []
+    for net, tape in ((net_a, False), (net_b, True)):
+        ema = copy.deepcopy(net)
+        for p in ema.parameters():
+            p.requires_grad = False
+        crit = get_module("losses", "psld_score_loss")(cfg, sde)
+        wr = get_module("pl_modules", "sde_wrapper")(cfg, sde, net, ema_score_fn=ema, criterion=crit)
+        if tape:
+            wr.enable_graphs(True, warmup_steps=2, tape=True)
+        cb = EMAWeightUpdate(cfg.training.ema_decay)
+        torch.manual_seed(21)
+        losses = []
+        for i in range(5):
+            losses.append(wr.training_step(data[i], i).item())
+            cb.on_train_batch_end(None, wr)
+        opt = wr.optimizers()
+        runs.append((losses, net.flatten_parameters().clone(), opt._m.clone(), opt._v.clone(), ema.flatten_parameters().clone()))
+        if tape:
+            tp = next(iter(wr._graph_steps.values()))["tape"]
+            assert tp is not None and tp.n_launches > 1000 and tp.n_edges > 10
+    (la, pa, ma, va, ea), (lb, pb, mb, vb, eb) = runs
+    assert la == lb
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb) and torch.equal(ea, eb)
