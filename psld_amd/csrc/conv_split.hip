@@ -284,49 +284,85 @@ __device__ __forceinline__ void dconv_epilogue(const DConvArgs& a, f32x4v (&acc)
 // wave decomposition of dconv_lp_kernel<.., N32 = true>, where the four waves of a workgroup split the 128 output
 // channels instead of sharing them two by two (each weight fragment is then loaded by ONE wave: half the L2 -> CU
 // fragment stream).  GroupNorm partial sums per 64-row run (block rows 0-3 / 4-7).  No gnb by-product here.
+// Wave-uniform values pinned to scalar registers.  The epilogue parameters arrive in the by-value kernel argument; left to
+// itself hipcc keeps part of that structure in SCRATCH and reloads out_scale / accumulate in front of every store - and a
+// scratch load is a vector-memory load, so each reload waits (vmcnt(0)) for every store issued before it: the 16 stores
+// of a wave went out one memory round trip at a time (timing ablation of the pointwise kernel without its epilogue:
+// 243 -> 171 us; the loop of a 128 x 256 x 512 tile is only ~25 us long).
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uni(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+template <class T>
+__device__ __forceinline__ T* uni(T* p) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+    // back through a GLOBAL address-space pointer: a bare integer -> pointer cast is a generic pointer, and its accesses
+    // become flat_load / flat_store (which also tick the LDS counter and can only be waited for with vmcnt(0) lgkmcnt(0))
+    typedef __attribute__((address_space(1))) T G;
+    return (T*)(G*)(((unsigned long long)hi << 32) | lo);
+}
+
 template <int MBK>      // 8: 128-row tile, 4: 64-row tile (small grids)
 __device__ __forceinline__ void dconv_epilogue_n32(const DConvArgs& a, f32x4v (&acc)[MBK][2], int m0, int nw0, int lane,
                                                    int split) {
     constexpr int RUNS = MBK / 4;       // 64-row runs of the tile
     const int r16 = lane & 15, kq = lane >> 4;
-    float* Cb = a.C + (long long)split * a.c_stride_split;
+    const int M = uni(a.M), ldc = uni(a.ldc);
+    float* Cb = uni(a.C) + (long long)split * a.c_stride_split;
+    const float alpha = uni(a.e.alpha), out_scale = uni(a.e.out_scale);
+    const bool accumulate = uni(a.e.accumulate) != 0;
+    const float* e_bias = uni(a.e.bias);
+    const float* e_rowbias = uni(a.e.rowbias);
+    const float* e_res = uni(a.e.res);
+    const int ldres = uni(a.e.ldres), rows_per_img = uni(a.e.rows_per_img), ld_rowbias = uni(a.e.ld_rowbias);
     const PsldEpilogue& e = a.e;
-    const bool rb_uniform = e.rowbias && (e.rows_per_img % 16 == 0);
+    const bool rb_uniform = e_rowbias && (rows_per_img % 16 == 0);
     const int cn0 = nw0 + 4 * kq;
     const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4v bias4[2];
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
-        bias4[nb] = e.bias ? *reinterpret_cast<const f32x4v*>(e.bias + cn0 + nb * 16) : zero4;
+        bias4[nb] = e_bias ? *reinterpret_cast<const f32x4v*>(e_bias + cn0 + nb * 16) : zero4;
     float gs[RUNS][2], gss[RUNS][2];     // [64-row run][block column]
 #pragma unroll
     for (int r = 0; r < RUNS; ++r)
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) gs[r][nb] = gss[r][nb] = 0.f;
-#pragma unroll
-    for (int mb = 0; mb < MBK; ++mb) {
+    // STRAIGHT-LINE code, no branch around a memory instruction: loads and stores share one in-order counter on this chip,
+    // and behind a branch the compiler can only wait for "everything" (vmcnt(0)) - i.e. for the stores of the previous
+    // block row as well.  Absent operands (no residual / previous output / row bias) are read from the 16-byte zero
+    // page instead, rows beyond M are clamped for the loads and masked for the store, and the loads of block row mb + 1
+    // are issued BEFORE the stores of row mb, so waiting for them does not wait for those stores.
+    const float* zp = a.zero;
+    const bool any_load = e_res || accumulate || e_rowbias;
+    auto row_loads = [&](int mb, f32x4v (&rv)[2], f32x4v (&cv)[2], f32x4v (&tb)[2]) {
         const int row_base = m0 + mb * 16;
-        if (row_base >= a.M) continue;                      // wave-uniform
-        const int gm = min(row_base + r16, a.M - 1);
-        const bool ok = row_base + r16 < a.M;
-        const long long coff = (long long)gm * a.ldc, roff = (long long)gm * e.ldres;
-        const long long toff = (long long)((rb_uniform ? row_base : gm) / e.rows_per_img) * e.ld_rowbias;
-        f32x4v rv[2], cv[2];
+        const int gm = min(row_base + r16, M - 1);
+        const long long coff = (long long)gm * ldc, roff = (long long)gm * ldres;
+        const long long toff = (long long)((rb_uniform ? min(row_base, M - 1) : gm) / rows_per_img) * ld_rowbias;
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
             const int gn = cn0 + nb * 16;
-            rv[nb] = e.res ? *reinterpret_cast<const f32x4v*>(e.res + roff + gn) : zero4;
-            cv[nb] = e.accumulate ? *reinterpret_cast<const f32x4v*>(Cb + coff + gn) : zero4;
-            const f32x4v tb = e.rowbias ? *reinterpret_cast<const f32x4v*>(e.rowbias + toff + gn) : zero4;
-            acc[mb][nb] = acc[mb][nb] * e.alpha + (bias4[nb] + tb);
+            rv[nb] = *reinterpret_cast<const f32x4v*>(e_res ? e_res + roff + gn : zp);
+            cv[nb] = *reinterpret_cast<const f32x4v*>(accumulate ? Cb + coff + gn : zp);
+            tb[nb] = *reinterpret_cast<const f32x4v*>(e_rowbias ? e_rowbias + toff + gn : zp);
         }
+    };
+    auto row_store = [&](int mb, const f32x4v (&rv)[2], const f32x4v (&cv)[2], const f32x4v (&tb)[2]) {
+        const int row_base = m0 + mb * 16;
+        const int gm = min(row_base + r16, M - 1);
+        const bool ok = row_base + r16 < M;
+        const long long coff = (long long)gm * ldc;
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
             const int gn = cn0 + nb * 16;
-            f32x4v o = acc[mb][nb];
-            if (e.res) o += rv[nb];
-            o *= e.out_scale;
-            if (e.accumulate) o += cv[nb];
+            // x = ((acc*alpha + bias + rowbias) + res) * out_scale + prev: the additive terms in the scalar form's order
+            f32x4v o = acc[mb][nb] * alpha + (bias4[nb] + tb[nb]);
+            o += rv[nb];
+            o *= out_scale;
+            o += cv[nb];
             if (ok) {
                 *reinterpret_cast<f32x4v*>(Cb + coff + gn) = o;
 #pragma unroll
@@ -336,6 +372,19 @@ __device__ __forceinline__ void dconv_epilogue_n32(const DConvArgs& a, f32x4v (&
                 }
             }
         }
+    };
+    if (any_load) {
+        f32x4v rv[2][2], cv[2][2], tb[2][2];
+        row_loads(0, rv[0], cv[0], tb[0]);
+#pragma unroll
+        for (int mb = 0; mb < MBK; ++mb) {
+            if (mb + 1 < MBK) row_loads(mb + 1, rv[(mb + 1) & 1], cv[(mb + 1) & 1], tb[(mb + 1) & 1]);
+            row_store(mb, rv[mb & 1], cv[mb & 1], tb[mb & 1]);
+        }
+    } else {
+        const f32x4v z2[2] = {zero4, zero4};
+#pragma unroll
+        for (int mb = 0; mb < MBK; ++mb) row_store(mb, z2, z2, z2);
     }
     if (e.gn_part) {
         const int fine = a.N >> 3, chunks = e.gn_hw >> 6;
@@ -1304,6 +1353,185 @@ int launch_bgemm(const BGemmArgs& a, int batch, hipStream_t stream) {
     return PSLD_OK;
 }
 
+// ---- pointwise, eight waves ------------------------------------------------------------------------------------------
+// The pointwise GEMMs (ResBlock shortcuts 512 -> 256, attention projections) ran at 113-161 TFLOP/s on dconv_kernel<8, 2,
+// PW>: a 1x1 convolution has one K step per staged chunk where the 3x3 form has nine, so per MFMA it stages (loads, splits,
+// stores to LDS) nine times the activations, each 128-channel tile re-stages its rows, and its single LDS image puts every
+// stage's split3 + ds_write between two barriers.  Here one workgroup of EIGHT waves owns 128 rows x 256 channels (wave w:
+// all 128 rows x channels 32 w .. 32 w + 31, the 8 x 2 accumulator blocks and epilogue of the N32 layout): the rows are
+// staged once for twice the channels, by twice the threads (4 float4 per thread and 64-channel stage instead of 8), into
+// TWO images - stage s + 1 is split and stored while stage s multiplies, one barrier per stage - and the raw operands of
+// stage s + 2 are already in flight.  Weight fragments: the existing layout (per 64-channel half tile), wave w reads the
+// two 16-channel blocks of its 32 channels.
+constexpr int PW8_ROWS = 256;                       // LDS pixel rows per image: 128 rows x 2 chunks
+constexpr int PW8_LIMB = PW8_ROWS * ROWB;           // bytes per limb of one image
+constexpr int PW8_IMG = 3 * PW8_LIMB;
+template <int ABL = 0>      // timing-only ablations (PSLD_PW8_ABL): 1 no staging after the prologue, 2 weights loaded once, 4 no epilogue
+__global__ void __launch_bounds__(512) pw8_kernel(const DConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int c4 = tid & 7;
+    const int tiles_n = a.N >> 8;
+    const int total = ((a.M + 127) >> 7) * tiles_n;
+    const int S = a.chunks;                          // stages (of two 32-channel chunks) per tile
+    // PERSISTENT: the workgroup walks tiles blockIdx.x, + gridDim.x, ... as ONE stream of stages - the staging pipeline
+    // (raw rows two stages ahead, the split image one stage ahead, weights one K step ahead) runs across tile boundaries,
+    // and a tile's output stores drain while the next tile multiplies.  A 128 x 256 x 512 tile is only ~25 us of MFMAs:
+    // with one workgroup per CU retiring per tile, its prologue and the wait for its 128 KB of stores were 30-40 % of the
+    // launch (timing ablation without the epilogue: 243 -> 171 us on 512 -> 256 @32x32, B=128).
+    const int nseq = (total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int G = nseq * S;
+    const float* zp = a.zero;
+    auto tile_origin = [&](int seq, int& m0, int& tn) {
+        const int t = xcd_remap((int)blockIdx.x + seq * (int)gridDim.x, total);
+        const int tm = t / tiles_n;
+        tn = t - tm * tiles_n;
+        m0 = tm * 128;
+    };
+
+    f32x4 hv[4];
+    int lseq = 0, lst = 0, lm0, ltn;                 // cursor of the row loads
+    tile_origin(0, lm0, ltn);
+    auto load_rows = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gm = lm0 + (((tid >> 3) + 64 * i) & 127);
+            const int c0 = (lst * 2 + (i >> 1)) * 32;          // items 0, 1: first chunk of the stage, 2, 3: second
+            const bool second = c0 >= a.C1;
+            const float* src = second ? a.x2 : a.x1;
+            const int cs = second ? a.C2 : a.C1;
+            const int cc = (second ? c0 - a.C1 : c0) + c4 * 4;
+            hv[i] = ld4(gm < a.M ? src + ((long long)gm * cs + cc) : zp);
+        }
+        if (++lst == S) {
+            lst = 0;
+            if (++lseq < nseq) tile_origin(lseq, lm0, ltn);
+        }
+    };
+    auto store_rows = [&](int img) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned h0, m0_, l0, h1, m1, l1;
+            split3(hv[i][0], hv[i][1], h0, m0_, l0);
+            split3(hv[i][2], hv[i][3], h1, m1, l1);
+            const int prow = (tid >> 3) + 64 * i;
+            unsigned char* q = smem + img * PW8_IMG + prow * ROWB + (((c4 >> 1) ^ lds_swz(prow)) << 4) + (c4 & 1) * 8;
+            *reinterpret_cast<u32x2*>(q) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(q + PW8_LIMB) = u32x2{m0_, m1};
+            *reinterpret_cast<u32x2*>(q + 2 * PW8_LIMB) = u32x2{l0, l1};
+        }
+    };
+
+    const int r16 = lane & 15, kq = lane >> 4;
+    const long long tile_u4 = (long long)a.chunks * 2 * TAP_U4;                  // fragments of one 64-channel half tile
+    const u32x4* wbase = a.wfrag + (long long)(wave >> 1) * tile_u4 + lane + (wave & 1) * 2 * 3 * 64;
+    u32x4 bq[2][2][3];
+    auto load_b = [&](const u32x4* p, u32x4 (&dst)[2][3]) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) dst[nb][l] = p[(nb * 3 + l) * 64];
+    };
+    f32x4v acc[8][2];
+
+    // A stage = 2 K steps (chunks) x 4 quarters of the 128 rows (two 16-row blocks each): 24 MFMAs per quarter.  The A
+    // fragments of quarter j + 1 are read from LDS before the MFMAs of quarter j are issued (rolling two-deep buffer).
+    // Per accumulator the six limb products keep their order, smallest first.
+    u32x4 fa[2][2][3];
+    auto read_q = [&](int img, int j, u32x4 (&dst)[2][3]) {          // quarter j of the stage: chunk j >> 2, blocks 2 (j & 3), +1
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const int prow = (j >> 2) * 128 + ((j & 3) * 2 + mb) * 16 + r16;
+            const unsigned char* q = smem + img * PW8_IMG + prow * ROWB + ((kq ^ lds_swz(prow)) << 4);
+#pragma unroll
+            for (int l = 0; l < 3; ++l) dst[mb][l] = *reinterpret_cast<const u32x4*>(q + l * PW8_LIMB);
+        }
+    };
+    auto mfma_q = [&](auto J) {
+        constexpr int j = decltype(J)::value;
+        constexpr int pp = j >> 2, b0 = (j & 3) * 2;
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[b0 + mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, bq[pp][nb][PB[t]]), __builtin_bit_cast(bf16x8, fa[j & 1][mb][PA[t]]),
+                        acc[b0 + mb][nb], 0, 0, 0);
+    };
+
+    int m0, tn;
+    tile_origin(0, m0, tn);
+    const u32x4* wp = wbase + (long long)tn * 4 * tile_u4;
+    load_rows();
+    load_b(wp, bq[0]);
+    store_rows(0);
+    if (G > 1) load_rows();
+    __syncthreads();
+    int g = 0;
+    for (int seq = 0; seq < nseq; ++seq) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        int nm0 = m0, ntn = tn;
+        if (seq + 1 < nseq) tile_origin(seq + 1, nm0, ntn);
+        const u32x4* wp_next = wbase + (long long)ntn * 4 * tile_u4;
+        for (int st = 0; st < S; ++st, ++g) {
+            const int img = g & 1;
+            if (!(ABL & 2)) load_b(wp + (long long)(2 * st + 1) * TAP_U4, bq[1]);
+            read_q(img, 0, fa[0]);
+#define PW8_Q(J)                                                       \
+            if (J < 7) read_q(img, J + 1, fa[(J + 1) & 1]);            \
+            __builtin_amdgcn_sched_barrier(0);                         \
+            mfma_q(std::integral_constant<int, J>{});                  \
+            __builtin_amdgcn_sched_barrier(0);
+            PW8_Q(0) PW8_Q(1) PW8_Q(2) PW8_Q(3)
+            if (!(ABL & 1)) {
+                if (g + 1 < G) store_rows(img ^ 1);        // everyone left image img ^ 1 at the last barrier
+                if (g + 2 < G) load_rows();
+            }
+            // the first chunk's weights are done with: the next stage's first chunk (of the next tile after the last stage)
+            if (!(ABL & 2)) load_b(st + 1 < S ? wp + (long long)(2 * st + 2) * TAP_U4 : wp_next, bq[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            PW8_Q(4) PW8_Q(5) PW8_Q(6) PW8_Q(7)
+#undef PW8_Q
+            __syncthreads();
+        }
+        if (ABL & 4) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t += acc[i][0][0] + acc[i][1][1];
+            if (t == 1.2345f) a.C[tid] = t;
+        } else {
+            dconv_epilogue_n32<8>(a, acc, m0, tn * 256 + wave * 32, lane, 0);
+        }
+        m0 = nm0; tn = ntn; wp = wp_next;
+    }
+}
+
+template <int ABL = 0>
+int launch_pw8(const DConvArgs& a, hipStream_t stream, const char* name) {
+    constexpr size_t LDS = (size_t)2 * PW8_IMG;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw8_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)LDS);
+        if (e != hipSuccess) {
+            psld_set_error("%s: hipFuncSetAttribute failed: %s", name, hipGetErrorString(e));
+            return PSLD_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    const int total = cdiv(a.M, 128) * (a.N / 256);
+    hipLaunchKernelGGL(pw8_kernel<ABL>, dim3((unsigned)(total < 256 ? total : 256)), dim3(512), LDS, stream, a);
+    PSLD_CHECK_LAUNCH(name);
+    return PSLD_OK;
+}
+
 template <int CB, bool XLP, int ABL = 0>
 int launch_dwgrad(const DWgradArgs& a, int nsplit, hipStream_t stream) {
     constexpr size_t LDS = (size_t)3 * (WG_AROWS * (64 * CB + 32) + WG_BLIMB);
@@ -1778,7 +2006,10 @@ extern "C" int psld_gemm_split_f32(const float* a1, int k1, const float* a2, int
     const PsldEpilogue e = make_epilogue(epi);
     PSLD_CHECK_ARG(!e.gn_part || (e.gn_hw > 0 && e.gn_hw % 64 == 0 && m % e.gn_hw == 0 && !e.accumulate),
                    "psld_gemm_split_f32: gn_part needs gn_hw (rows per image) a multiple of 64 dividing m, and no accumulation");
-    const int ns = plan_split(a, e, y, ldy, workspace, ws_bytes);
+    // eight-wave 128 x 256 tiles when they fill the chip (PSLD_PW8=0: the four-wave 128 x 128 kernel everywhere)
+    static const int pw8 = [] { const char* v = getenv("PSLD_PW8"); return v ? atoi(v) : 1; }();
+    const bool wide = pw8 && n % 256 == 0 && !e.gnb_part && (long long)cdiv(m, 128) * (n / 256) >= 256;
+    const int ns = plan_split(a, e, y, ldy, wide ? nullptr : workspace, ws_bytes);
     PSLD_CHECK_ARG(a.v4, "limb kernels: y, residual, bias and rowbias need 16-byte aligned rows (pointer and row stride)");
     PSLD_CHECK_ARG(!e.gnb_part || (e.gnb_x && e.gnb_mean && e.gnb_rstd && e.gnb_gamma && e.gnb_beta && e.gnb_hw > 0 &&
                                    e.gnb_hw % 64 == 0 && a.M % e.gnb_hw == 0 && ldy == a.N && e.gnb_groups > 0 &&
@@ -1786,6 +2017,17 @@ extern "C" int psld_gemm_split_f32(const float* a1, int k1, const float* a2, int
                                    aligned16(e.gnb_x) && aligned16(e.gnb_gamma) && aligned16(e.gnb_beta) && aligned16(e.gnb_part)),
                    "limb kernels: gnb_part needs a contiguous output (ldy == n), gnb_hw a multiple of 64 dividing the rows, "
                    "groups of a multiple of 4 channels, 16-byte aligned operands and no accumulation");
+    if (wide) {
+        static const int abl = [] { const char* v = getenv("PSLD_PW8_ABL"); return v ? atoi(v) : 0; }();
+        switch (abl) {
+            case 1: return launch_pw8<1>(a, stream, "psld_gemm_split_f32");
+            case 2: return launch_pw8<2>(a, stream, "psld_gemm_split_f32");
+            case 3: return launch_pw8<3>(a, stream, "psld_gemm_split_f32");
+            case 4: return launch_pw8<4>(a, stream, "psld_gemm_split_f32");
+            case 7: return launch_pw8<7>(a, stream, "psld_gemm_split_f32");
+            default: return launch_pw8<0>(a, stream, "psld_gemm_split_f32");
+        }
+    }
     const int st = launch_dconv<8, 2, true>(a, ns, stream, "psld_gemm_split_f32");
     if (st != PSLD_OK) return st;
     if (ns >= 2) return psld_detail_conv_reduce_epilogue(a.C, ns, m, n, y, ldy, e, stream);

@@ -564,7 +564,7 @@ def test_conv3x3_fewout(ops, b, c, co, h, w_):
     assert not ops.conv3x3_fewout_supported(512, 6) and not ops.conv3x3_fewout_supported(256, 8)
 
 
-@pytest.mark.parametrize("b,c,co,h", [(24, 128, 256, 32), (96, 128, 256, 16)])
+@pytest.mark.parametrize("b,c,co,h", [(24, 128, 256, 32), (96, 128, 256, 16), (40, 128, 256, 32)])   # last: eight-wave pointwise kernel
 def test_gn_partials_from_conv_epilogue(ops, b, c, co, h):
     """GroupNorm statistics of a limb convolution's output as a by-product of its epilogue == gn_stats of the output,
     for the consumer's own group size and for the coarser groups of a concatenation source; same for the pointwise form."""
@@ -706,9 +706,13 @@ def test_fused_attention_forward(ops, b, hw, c, fused_buf):
 
 
 @pytest.mark.parametrize("m,n,k1,k2", [(256, 128, 64, 0), (1000, 256, 256, 0), (640, 128, 96, 32), (4096, 768, 256, 0),
-                                       (130, 128, 512, 0)])
+                                       (130, 128, 512, 0),
+                                       # grids of >= 256 tiles of 128 x 256: the eight-wave kernel (ragged last tile, two
+                                       # sources, one stage only, three channel tiles)
+                                       (32838, 256, 256, 256), (16500, 512, 256, 0), (11000, 768, 64, 0), (32768, 256, 160, 96)])
 def test_gemm_split(ops, m, n, k1, k2):
-    """Pointwise limb kernel: y = (concat(a1, a2) @ B^T + bias + residual) * scale, B from an [n][k] or a [k][n] matrix."""
+    """Pointwise limb kernels (four waves, 128 x 128 tiles; eight waves, 128 x 256 tiles when those fill the chip):
+    y = (concat(a1, a2) @ B^T + bias + residual) * scale, B from an [n][k] or a [k][n] matrix."""
     a = gen(m, k1 + k2, seed=70)
     bmat = gen(n, k1 + k2, seed=71, scale=0.1)
     bias, res = gen(n, seed=72), gen(m, n, seed=73)

@@ -1,0 +1,60 @@
+"""Pointwise limb GEMMs (1x1 convolutions: ResBlock shortcuts, attention projections) on the shapes of a B=128 step:
+    python tools/bench_pw.py [--batch 128]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from psld_amd import ops  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--rounds", type=int, default=1, help="ignored (pmc_wait.sh passes it)")
+    ap.add_argument("--only", type=int, default=-1, help="index of the one shape to run")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    b = args.batch
+    shapes = [("shortcut fwd  512->256 @32 (two sources)", b * 1024, 256, 256, 256, 9),
+              ("shortcut dgrad 256->512 @32", b * 1024, 256, 0, 512, 9),
+              ("shortcut fwd  512->256 @16 (two sources)", b * 256, 256, 256, 256, 9),
+              ("shortcut dgrad 256->512 @16", b * 256, 256, 0, 512, 9),
+              ("q|k|v fwd     256->768 @16", b * 256, 256, 0, 768, 17),
+              ("q|k|v dgrad   768->256 @16", b * 256, 768, 0, 256, 17),
+              ("out proj      256->256 @16", b * 256, 256, 0, 256, 34),
+              ("shortcut fwd  512->256 @8 (two sources)", b * 64, 256, 256, 256, 9),
+              ("shortcut dgrad 256->512 @8", b * 64, 256, 0, 512, 9)]
+    total = 0.0
+    if args.only >= 0:
+        shapes = shapes[args.only:args.only + 1]
+    for name, m, k1, k2, n, per_step in shapes:
+        a1 = torch.randn(m, k1, device=dev)
+        a2 = torch.randn(m, k2, device=dev) if k2 else None
+        w = torch.randn(n, k1 + k2, device=dev) * 0.05
+        frag = ops.gemm_frag(w, n, k1 + k2, k1 + k2, 1)
+        y = torch.empty(m, n, device=dev)
+        bias = torch.randn(n, device=dev)
+        epi = ops.epilogue(bias=bias)
+        for _ in range(3):
+            ops.gemm_split(a1, a2, m, frag, n, y, epi)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            ops.gemm_split(a1, a2, m, frag, n, y, epi)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / args.iters
+        flops = 2.0 * m * (k1 + k2) * n
+        mb = (m * (k1 + k2) + m * n) * 4 / 1e6
+        total += us * per_step
+        print(f"{name:44s} M={m:7d}  {us:8.1f} us  {flops / us / 1e6:6.1f} TF  {mb / us:6.0f} TB/s x1e-3  x{per_step}/step = {us * per_step / 1e3:.2f} ms")
+    print(f"sum over a step: {total / 1e3:.2f} ms")
+
+
+if __name__ == "__main__":
+    main()
