@@ -52,7 +52,7 @@ def main():
         flops = 2.0 * m * (k1 + k2) * n
         mb = (m * (k1 + k2) + m * n) * 4 / 1e6
         total += us * per_step
-        print(f"{name:44s} M={m:7d}  {us:8.1f} us  {flops / us / 1e6:6.1f} TF  {mb / us:6.0f} TB/s x1e-3  x{per_step}/step = {us * per_step / 1e3:.2f} ms")
+        print(f"{name:44s} M={m:7d}  {us:8.1f} us  {flops / us / 1e6:6.1f} TF  {mb / us:5.2f} TB/s  x{per_step}/step = {us * per_step / 1e3:.2f} ms")
     print(f"sum over a step: {total / 1e3:.2f} ms")
 
 

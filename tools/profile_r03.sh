@@ -19,6 +19,7 @@ cd $ROOT
 # 3. micro-benchmarks
 python3 tools/bench_wino.py --rounds 5 > $OUT/wino_kernels.txt 2>&1
 python3 tools/bench_tile.py > $OUT/tile_kernels.txt 2>&1
+(python3 tools/bench_pw.py; echo "PSLD_PW8=0 (four-wave kernel on every grid)"; PSLD_PW8=0 python3 tools/bench_pw.py) > $OUT/pw_kernels.txt 2>&1
 python3 tools/bench_limb.py --wgrad --rounds 5 --iters 5 > $OUT/wgrad_xlimb_ab.txt 2>&1
 python3 tools/bench_hbm.py > $OUT/hbm_kernels.txt 2>&1
 python3 tools/bench_sample.py > $OUT/sampling.txt 2>&1
@@ -32,5 +33,8 @@ python3 bench.py --batch 64 --steps 20 --warmup 5 --sample-batch 0 --no-cpu-base
 python3 bench.py --config celeba64_sota --steps 10 --warmup 3 --sample-batch 0 --no-cpu-baseline > $OUT/bench_celeba64.json 2>/dev/null
 PSLD_FORCE_PG=1 python3 bench.py --steps 10 --warmup 3 --sample-batch 0 --no-cpu-baseline > $OUT/bench_rccl_1rank.json 2>/dev/null
 PSLD_DIST_BACKEND=gloo PSLD_SHARE_GPU=1 python3 bench.py --gpus 2 --steps 3 --warmup 1 --batch 32 --sample-batch 64 --sample-steps 10 --no-cpu-baseline > $OUT/rehearsal_gloo_2rank.json 2>/dev/null
-(python3 tools/host_vs_gpu.py --batch 2; python3 tools/host_vs_gpu.py --batch 16) 2>/dev/null | grep batch > $OUT/host_vs_gpu.txt
+(python3 tools/host_vs_gpu.py --batch 2; python3 tools/host_vs_gpu.py --batch 16; python3 tools/host_vs_gpu.py --batch 16 --graphs; python3 tools/host_vs_gpu.py --batch 16 --tape) 2>/dev/null | grep batch > $OUT/host_vs_gpu.txt
+python3 bench.py --batch 16 --steps 30 --warmup 5 --sample-batch 0 --no-cpu-baseline --no-probe --tape > $OUT/bench_b16_tape.json 2>/dev/null
+python3 bench.py --batch 8 --steps 30 --warmup 5 --sample-batch 0 --no-cpu-baseline --no-probe --tape > $OUT/bench_b8_tape.json 2>/dev/null
+python3 bench.py --batch 8 --steps 30 --warmup 5 --sample-batch 0 --no-cpu-baseline --no-probe > $OUT/bench_b8_eager.json 2>/dev/null
 ls -la $OUT
