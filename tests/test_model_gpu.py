@@ -1148,7 +1148,8 @@ def test_graph_captured_training_step_is_bitwise_the_eager_step(dropout, tape):
             if tape:    # ... and what was replayed is the launch tape: launches, side-stream edges, few ATen segments
                 tp = ent["tape"]
                 print("tape:", tp.n_launches, "launches,", tp.n_edges, "edges,", len(tp.segments), "segments; ATen:", tp.aten_ops)
-                assert tp.n_launches > 100 and tp.n_edges >= 2 and len(tp.aten_ops) < 40
+                assert tp.n_launches > 100 and len(tp.aten_ops) < 40
+                assert tp.n_edges >= 2 if net._side is not None else tp.n_edges == 0      # PSLD_OVERLAP_WGRAD=0: one stream
             else:
                 assert ent["tape"] is None
     (la, pa, ma, va, ea, sa, lra), (lb, pb, mb, vb, eb, sb, lrb) = runs
