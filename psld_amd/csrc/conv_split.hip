@@ -2006,9 +2006,12 @@ extern "C" int psld_gemm_split_f32(const float* a1, int k1, const float* a2, int
     const PsldEpilogue e = make_epilogue(epi);
     PSLD_CHECK_ARG(!e.gn_part || (e.gn_hw > 0 && e.gn_hw % 64 == 0 && m % e.gn_hw == 0 && !e.accumulate),
                    "psld_gemm_split_f32: gn_part needs gn_hw (rows per image) a multiple of 64 dividing m, and no accumulation");
-    // eight-wave 128 x 256 tiles when they fill the chip (PSLD_PW8=0: the four-wave 128 x 128 kernel everywhere)
+    // eight-wave 128 x 256 tiles from 128 of them on (PSLD_PW8=0: the four-wave 128 x 128 kernel everywhere).  Half a
+    // chip of persistent workgroups still beats 256 four-wave tiles split in two K ranges plus their reduction launch:
+    // B=16 step 537 / 539 -> 550 / 547 images/s, B=64 903 -> 908; from 64 tiles on it does not (543 / 542).
     static const int pw8 = [] { const char* v = getenv("PSLD_PW8"); return v ? atoi(v) : 1; }();
-    const bool wide = pw8 && n % 256 == 0 && !e.gnb_part && (long long)cdiv(m, 128) * (n / 256) >= 256;
+    static const int pw8_min = [] { const char* v = getenv("PSLD_PW8_MIN_TILES"); return v ? atoi(v) : 128; }();
+    const bool wide = pw8 && n % 256 == 0 && !e.gnb_part && (long long)cdiv(m, 128) * (n / 256) >= pw8_min;
     const int ns = plan_split(a, e, y, ldy, wide ? nullptr : workspace, ws_bytes);
     PSLD_CHECK_ARG(a.v4, "limb kernels: y, residual, bias and rowbias need 16-byte aligned rows (pointer and row stride)");
     PSLD_CHECK_ARG(!e.gnb_part || (e.gnb_x && e.gnb_mean && e.gnb_rstd && e.gnb_gamma && e.gnb_beta && e.gnb_hw > 0 &&
