@@ -707,9 +707,10 @@ def test_fused_attention_forward(ops, b, hw, c, fused_buf):
 
 @pytest.mark.parametrize("m,n,k1,k2", [(256, 128, 64, 0), (1000, 256, 256, 0), (640, 128, 96, 32), (4096, 768, 256, 0),
                                        (130, 128, 512, 0),
-                                       # grids of >= 256 tiles of 128 x 256: the eight-wave kernel (ragged last tile, two
+                                       # grids of >= 128 tiles of 128 x 256: the eight-wave kernel (ragged last tile, two
                                        # sources, one stage only, three channel tiles)
-                                       (32838, 256, 256, 256), (16500, 512, 256, 0), (11000, 768, 64, 0), (32768, 256, 160, 96)])
+                                       (32838, 256, 256, 256), (16500, 512, 256, 0), (11000, 768, 64, 0), (32768, 256, 160, 96),
+                                       (16400, 256, 128, 0)])
 def test_gemm_split(ops, m, n, k1, k2):
     """Pointwise limb kernels (four waves, 128 x 128 tiles; eight waves, 128 x 256 tiles when those fill the chip):
     y = (concat(a1, a2) @ B^T + bias + residual) * scale, B from an [n][k] or a [k][n] matrix."""
