@@ -56,7 +56,7 @@ def _f64_bits(v) -> int:
 class LaunchTape:
     def __init__(self):
         self.lib = _lib.load_real()
-        self.segments: List[tuple] = []       # ("c", ndarray) | ("py", callable, name)
+        self.segments: List[tuple] = []       # ("c", entries ndarray, its address, count) | ("py", callable, name)
         self._cur: List[tuple] = []
         self._keep: List[object] = []         # structure copies, tensors of the ATen callables
         self._events: List[int] = []
