@@ -17,6 +17,10 @@ weight-gradient side stream overlaps almost nothing there.  The
   write into the recorded output tensors; they split the tape into segments.
 
 ``replay()`` then costs one ``psld_tape_replay`` call per segment (include/psld_hip.h), which walks the entries in C.
+
+Recording is process-wide (the proxy replaces what ``_lib.load()`` returns for every caller): nothing else may launch
+through the library from another thread while a tape records.  Host memory a taped call points into - by-reference
+structures (copied here) and the FIR taps of ``psld_upfirdn2d_f32`` (``_lib.keep_host_memory``) - lives as long as the tape.
 """
 from __future__ import annotations
 
