@@ -1463,6 +1463,7 @@ __global__ void __launch_bounds__(512) pw8_kernel(const DConvArgs a) {
                         acc[b0 + mb][nb], 0, 0, 0);
     };
 
+    const bool early = wave >= 4;           // staging slot of this wave within a stage (below)
     int m0, tn;
     tile_origin(0, m0, tn);
     const u32x4* wp = wbase + (long long)tn * 4 * tile_u4;
@@ -1483,6 +1484,14 @@ __global__ void __launch_bounds__(512) pw8_kernel(const DConvArgs a) {
         for (int st = 0; st < S; ++st, ++g) {
             const int img = g & 1;
             if (!(ABL & 2)) load_b(wp + (long long)(2 * st + 1) * TAP_U4, bq[1]);
+            // SIMD partners (waves w, w + 4) would split / store the next image at the same moment and leave the matrix
+            // pipe idle together: waves 4-7 do it at the head of the stage, waves 0-3 between the two K steps (512 -> 256
+            // @32x32 B=128: 213 -> 201 us; the smaller shapes do not move)
+            if (early && !(ABL & 1)) {
+                if (g + 1 < G) store_rows(img ^ 1);
+                if (g + 2 < G) load_rows();
+                __builtin_amdgcn_sched_barrier(0);
+            }
             read_q(img, 0, fa[0]);
 #define PW8_Q(J)                                                       \
             if (J < 7) read_q(img, J + 1, fa[(J + 1) & 1]);            \
@@ -1490,7 +1499,7 @@ __global__ void __launch_bounds__(512) pw8_kernel(const DConvArgs a) {
             mfma_q(std::integral_constant<int, J>{});                  \
             __builtin_amdgcn_sched_barrier(0);
             PW8_Q(0) PW8_Q(1) PW8_Q(2) PW8_Q(3)
-            if (!(ABL & 1)) {
+            if (!early && !(ABL & 1)) {
                 if (g + 1 < G) store_rows(img ^ 1);        // everyone left image img ^ 1 at the last barrier
                 if (g + 2 < G) load_rows();
             }
