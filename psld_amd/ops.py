@@ -254,7 +254,9 @@ def conv3x3_wino_wanted(c1: int, c2: int, b: int, h: int, w: int, cout: int) -> 
         return False
     # >= 384 workgroups (one per CU, 160 KB of LDS each: 1.5 rounds).  Measured (tools/ab_wino_batches.sh): at 256 workgroups
     # (32x32 level, batch 16) the step is 3 % SLOWER than with the direct kernels - a workgroup per CU leaves no room
-    # for the weight-gradient kernels of the side stream that small batches overlap with - from 512 on it is 7-16 % faster
+    # for the weight-gradient kernels of the side stream that small batches overlap with - from 512 on it is 7-16 % faster;
+    # the 8x8 level at batch 128 (128 workgroups, no side stream there): 213 vs 184-192 TFLOP/s per launch, but the step is
+    # 0.5 % slower (985.5 / 988.9 / 987.4 vs 993.0 / 992.2 / 992.0 images/s: its weight gradients lose the limb-plane input)
     return mode == 2 or (b * h * w // 128) * (cout // 128) >= 384
 
 
