@@ -371,8 +371,28 @@ def self_launch(args) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def psld_env():
+    """PSLD_* variables of this process (the kernel / policy switches): recorded in the JSON line so that a non-default run
+    cannot pass for the default one."""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("PSLD_")}
+
+
+def refuse_ablations():
+    """Timing-only ablation modes compute wrong results by construction.  They exist only in libpsld_hip_abl.so (make abl),
+    which tools/ab_*.sh load through PSLD_HIP_LIB; a benchmark line is never produced with them."""
+    bad = [k for k in os.environ if k.startswith("PSLD_") and k.endswith("_ABL")]
+    if "abl" in os.path.basename(os.environ.get("PSLD_HIP_LIB", "")):
+        bad.append("PSLD_HIP_LIB=" + os.environ["PSLD_HIP_LIB"])
+    if bad:
+        print("bench.py: refusing to run with ablation switches / the ablation library: " + ", ".join(sorted(bad)), file=sys.stderr)
+        return True
+    return False
+
+
 def main():
     args = parse_args()
+    if refuse_ablations():
+        return 2
     if args.cpu_baseline_only:
         from psld_amd import config as C
         print(json.dumps(cpu_baseline(C.c10_sota())), flush=True)
@@ -620,6 +640,7 @@ def main():
         if sampling is not None:
             out["sampling"] = sampling
         out["cpu_baseline"] = cpu_base
+        out["env"] = psld_env()
         import ctypes
         ctypes.CDLL(None).fflush(None)
         sys.stdout.flush()

@@ -1881,6 +1881,7 @@ extern "C" int psld_conv3x3_wgrad_split_f32(const float* dy, int lddy, int cout,
     a.slab_stride = (long long)cout * 9 * cin_total;
     a.hw_w = (w < 32 ? w : 32) + 2;
     a.hrows = w >= 32 ? 1 : 32 / w;
+#ifdef PSLD_ABLATIONS      // timing-only variants (wrong results): libpsld_hip_abl.so only (make abl), never the product library
     static const int abl = [] { const char* v = getenv("PSLD_DWGRAD_ABL"); return v ? atoi(v) : 0; }();
     if (abl && co_tile == 128) {
         switch (abl) {
@@ -1891,6 +1892,7 @@ extern "C" int psld_conv3x3_wgrad_split_f32(const float* dy, int lddy, int cout,
             case 6: return launch_dwgrad<4, false, 6>(a, nsplit, stream);
         }
     }
+#endif
     return co_tile == 128 ? launch_dwgrad<4, false>(a, nsplit, stream) : launch_dwgrad<2, false>(a, nsplit, stream);
 }
 
@@ -2030,6 +2032,7 @@ extern "C" int psld_gemm_split_f32(const float* a1, int k1, const float* a2, int
                    "limb kernels: gnb_part needs a contiguous output (ldy == n), gnb_hw a multiple of 64 dividing the rows, "
                    "groups of a multiple of 4 channels, 16-byte aligned operands and no accumulation");
     if (wide) {
+#ifdef PSLD_ABLATIONS      // timing-only variants (wrong results): libpsld_hip_abl.so only
         static const int abl = [] { const char* v = getenv("PSLD_PW8_ABL"); return v ? atoi(v) : 0; }();
         switch (abl) {
             case 1: return launch_pw8<1>(a, stream, "psld_gemm_split_f32");
@@ -2037,8 +2040,9 @@ extern "C" int psld_gemm_split_f32(const float* a1, int k1, const float* a2, int
             case 3: return launch_pw8<3>(a, stream, "psld_gemm_split_f32");
             case 4: return launch_pw8<4>(a, stream, "psld_gemm_split_f32");
             case 7: return launch_pw8<7>(a, stream, "psld_gemm_split_f32");
-            default: return launch_pw8<0>(a, stream, "psld_gemm_split_f32");
         }
+#endif
+        return launch_pw8<0>(a, stream, "psld_gemm_split_f32");
     }
     const int st = launch_dconv<8, 2, true>(a, ns, stream, "psld_gemm_split_f32");
     if (st != PSLD_OK) return st;

@@ -53,6 +53,9 @@ struct WinoArgs {
     PsldEpilogue e;
     const float* zero;
     int nmajor;
+    int tiles_m;            // wino_conv8p_kernel: pixel tiles of the launch (cdiv(M, 128))
+    int stagger;
+    int lg_tiles_x, lg_tps; // wino_conv8p_kernel: log2 of the tiles per tile row (cw / 2) and per image segment
 };
 
 // raw halo image: pixel hp, 16-byte slot q (4 channels) -> byte offset.  Pixels sit pairwise in 256-byte rows and the
@@ -131,583 +134,6 @@ __global__ void wino_pack_batch_kernel(const long long* __restrict__ tab, int nt
         const long long* d = tab + 8 * lo;
         wino_pack_item(reinterpret_cast<const float*>(d[0]), reinterpret_cast<u32x4*>(d[1]), idx - d[7], (int)d[3], d[5], d[6],
                        (int)d[4]);
-    }
-}
-
-// ---- forward / data gradient ----------------------------------------------------------------------------------
-// NI = float4 staging items per thread and chunk: the raw image has NI*64 halo pixels.
-// ABL: timing-only ablations (results wrong): 1 = transform only for the first chunk, 2 = weight fragments loaded once,
-// 4 = raw halo loaded once
-template <int NI, int ABL = 0>
-__global__ void __launch_bounds__(WINO_THREADS) wino_conv_kernel(const WinoArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* Vs = smem;
-    unsigned char* Rs = smem + VBYTES;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_n = a.N >> 7;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tiles_m = gridDim.x / tiles_n;
-    // n-major: an XCD's contiguous run of logical tiles then streams ONE 128-channel slice of U (3.1 MB at 256 input
-    // channels: it stays in the XCD's 4 MB L2) instead of alternating between all of them
-    const int tile_n = a.nmajor ? bid / tiles_m : bid % tiles_n;
-    const int tile_m = a.nmajor ? bid - tile_n * tiles_m : bid / tiles_n;
-    const int m0 = tile_m * 128, n0 = tile_n * 128;
-
-    const int W2 = a.W + 2, HW = a.H * a.W;
-    const int tiles_x = a.W >> 1;
-    const int tps = (a.rps >> 1) * tiles_x;          // tiles per segment
-    const int img0 = m0 / HW;
-    const int oy0 = (m0 - img0 * HW) / a.W;          // 0 when a tile holds whole images
-    const float* zp = a.zero;
-
-    // ---- raw staging items: halo pixel (tid + 512 i) >> 3, channel quad tid & 7 -------------------------------
-    const int c4 = tid & 7;
-    int hoff[NI], rdst[NI];
-    {
-        const int seg_px = (a.rps + 2) * W2;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int px = (tid + WINO_THREADS * i) >> 3;
-            const int seg = px / seg_px;
-            const int rem = px - seg * seg_px;
-            const int hr = rem / W2, hx = rem - hr * W2;
-            const int img = img0 + seg, iy = oy0 + hr - 1, ix = hx - 1;
-            const bool ok = seg < a.nseg && img < a.B && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            hoff[i] = ok ? (img * a.H + iy) * a.W + ix : -1;
-            rdst[i] = raw_off(px, c4);
-        }
-    }
-    f32x4 hv[NI];
-    auto load_raw = [&](int c) {
-        const int c0 = c * 32;
-        const bool second = c0 >= a.C1;
-        const float* src = second ? a.x2 : a.x1;
-        const int cs = second ? a.C2 : a.C1;
-        const int cc = (second ? c0 - a.C1 : c0) + c4 * 4;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) hv[i] = ld4(hoff[i] >= 0 ? src + ((long long)hoff[i] * cs + cc) : zp);
-    };
-    auto store_raw = [&]() {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) *reinterpret_cast<f32x4*>(Rs + rdst[i]) = hv[i];
-    };
-
-    // ---- transform role: (half of the positions, tile, channel quad) ----------------------------------------------
-    // waves 0-3 produce V rows 0,1 (positions 0-7) from d rows 0,1,2; waves 4-7 rows 2,3 (positions 8-15) from d rows 1,2,3
-    const int th = wave >> 2;
-    const int t_tile = (tid & 255) >> 3, t_q = tid & 7;
-    int t_src;      // halo pixel of d[th][0]
-    {
-        const int seg = t_tile / tps, rem = t_tile - seg * tps;
-        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
-        t_src = (seg * (a.rps + 2) + 2 * ty + th) * W2 + 2 * tx;
-    }
-    const int t_dst = t_tile * ROWB + (((t_q >> 1) ^ lds_swz(t_tile)) << 4) + (t_q & 1) * 8;
-    auto transform = [&]() {
-        f32x4 e[3][4];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) e[r][c] = *reinterpret_cast<const f32x4*>(Rs + raw_off(t_src + r * W2 + c, t_q));
-        // row stage of B^T d: V rows (0: d0 - d2, 1: d1 + d2) or (2: d2 - d1, 3: d1 - d3)
-        f32x4 ra[4], rb[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            ra[c] = e[0][c] - e[2][c];                      // V row 0 (th = 0) / V row 3 (th = 1)
-            rb[c] = th ? e[1][c] - e[0][c] : e[1][c] + e[2][c];     // V row 1 / V row 2
-        }
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const f32x4* r = half ? rb : ra;
-            const int vrow = th ? (half ? 2 : 3) : (half ? 1 : 0);
-            f32x4 v[4];
-            v[0] = r[0] - r[2];
-            v[1] = r[1] + r[2];
-            v[2] = r[2] - r[1];
-            v[3] = r[1] - r[3];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                unsigned h0, m0_, l0, h1, m1, l1;
-                split3(v[j][0], v[j][1], h0, m0_, l0);
-                split3(v[j][2], v[j][3], h1, m1, l1);
-                unsigned char* q = Vs + (vrow * 4 + j) * 3 * VPLANE + t_dst;
-                *reinterpret_cast<u32x2*>(q) = u32x2{h0, h1};
-                *reinterpret_cast<u32x2*>(q + VPLANE) = u32x2{m0_, m1};
-                *reinterpret_cast<u32x2*>(q + 2 * VPLANE) = u32x2{l0, l1};
-            }
-        }
-    };
-
-    // ---- MFMA role: 32 tiles x 16 channels x 16 positions ------------------------------------------------------------
-    const int r16 = lane & 15, kq = lane >> 4;
-    int aoff[2];
-#pragma unroll
-    for (int tb = 0; tb < 2; ++tb) {
-        const int row = tb * 16 + r16;
-        aoff[tb] = row * ROWB + ((kq ^ lds_swz(row)) << 4);
-    }
-    const u32x4* up = a.ufrag + ((long long)(tile_n * 8 + wave) * a.chunks) * (16 * 3 * 64) + lane;
-    const int sig_end = a.chunks * 16;
-    u32x4 bq[4][3];
-    auto load_b = [&](int sigma, u32x4 (&dst)[3]) {
-        const u32x4* p = up + (long long)min(sigma, sig_end - 1) * (3 * 64);
-#pragma unroll
-        for (int l = 0; l < 3; ++l) dst[l] = p[l * 64];
-    };
-
-    f32x4v acc[16][2];
-#pragma unroll
-    for (int p = 0; p < 16; ++p)
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb) acc[p][tb] = f32x4v{0.f, 0.f, 0.f, 0.f};
-
-    load_raw(0);
-    load_b(0, bq[0]);
-    load_b(1, bq[1]);
-    store_raw();
-    __syncthreads();
-    transform();
-    __syncthreads();
-
-    // One position = 12 MFMAs in three groups by ACTIVATION limb - (lo,hi) | (mid,mid) (mid,hi) | (hi,lo) (hi,mid) (hi,hi)
-    // [activation, weight]; lowest weight first within what that allows - so that a limb's fragment registers are dead after
-    // its group and are refilled IN PLACE with the next position's fragments while the remaining groups run: every
-    // ds_read_b128 has 6-10 MFMAs (plus the partner wave's) to land and no second fragment set is needed.  Weight fragments
-    // are loaded two positions ahead into a ring of four sets.  sched_barrier(0) keeps hipcc from sinking the reads to
-    // their first use (what it does on its own at 254 VGPRs: three exposed LDS latencies per position).
-    u32x4 fa[3][2];          // [limb hi | mid | lo][tile block]
-    auto read_a = [&](int p, int l) {
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb) fa[l][tb] = *reinterpret_cast<const u32x4*>(Vs + (p * 3 + l) * VPLANE + aoff[tb]);
-    };
-    auto mm = [&](int p, int la, int lb) {
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb)
-            acc[p][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(      // weights first: D^T[channel][tile]
-                __builtin_bit_cast(bf16x8, bq[p & 3][lb]), __builtin_bit_cast(bf16x8, fa[la][tb]), acc[p][tb], 0, 0, 0);
-    };
-    for (int c = 0; c < a.chunks; ++c) {
-        const bool more = c + 1 < a.chunks;
-        read_a(0, 2);
-        read_a(0, 1);
-        read_a(0, 0);
-        if (more && !(ABL & 4)) load_raw(c + 1);
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            if (!(ABL & 2)) load_b(c * 16 + p + 2, bq[(p + 2) & 3]);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(p, 2, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (p < 15) read_a(p + 1, 2);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(p, 1, 1);
-            mm(p, 1, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (p < 15) read_a(p + 1, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(p, 0, 2);
-            mm(p, 0, 1);
-            mm(p, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (p < 15) read_a(p + 1, 0);
-        }
-        if (more) {
-            if (!(ABL & 1)) store_raw();    // the raw image was last read by transform() of this chunk, two barriers ago
-            __syncthreads();                // every wave is done with V(c); raw(c + 1) is visible
-            if (!(ABL & 1)) transform();
-            __syncthreads();
-        }
-    }
-
-    // ---- output transform + fused epilogue ----------------------------------------------------------------------------
-    // lane: tile tb*16 + r16, channels cn .. cn+3
-    const PsldEpilogue& e = a.e;
-    const int cn = n0 + wave * 16 + 4 * kq;
-    const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
-    const f32x4v bias4 = e.bias ? *reinterpret_cast<const f32x4v*>(e.bias + cn) : zero4;
-#pragma unroll
-    for (int tb = 0; tb < 2; ++tb) {
-        const int tile = tb * 16 + r16;
-        const int seg = tile / tps, rem = tile - seg * tps;
-        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
-        const int gm00 = m0 + seg * (a.rps * a.W) + (2 * ty) * a.W + 2 * tx;
-        const bool ok = gm00 < a.M;                         // whole images only: a tile is in range or not
-        f32x4v s[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            s[i][0] = (acc[4 * i][tb] + acc[4 * i + 1][tb]) + acc[4 * i + 2][tb];
-            s[i][1] = (acc[4 * i + 1][tb] - acc[4 * i + 2][tb]) - acc[4 * i + 3][tb];
-        }
-        f32x4v y[2][2];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            y[0][b] = (s[0][b] + s[1][b]) + s[2][b];
-            y[1][b] = (s[1][b] - s[2][b]) - s[3][b];
-        }
-        float gs = 0.f, gss = 0.f;
-        const int gmc = ok ? gm00 : 0;                       // clamped: loads stay in range
-        f32x4v rv[2][2], cv[2][2], tbv[2][2];
-#pragma unroll
-        for (int ya = 0; ya < 2; ++ya)
-#pragma unroll
-            for (int xb = 0; xb < 2; ++xb) {
-                const int gm = gmc + ya * a.W + xb;
-                rv[ya][xb] = e.res ? *reinterpret_cast<const f32x4v*>(e.res + (long long)gm * e.ldres + cn) : zero4;
-                cv[ya][xb] = e.accumulate ? *reinterpret_cast<const f32x4v*>(a.C + (long long)gm * a.ldc + cn) : zero4;
-                tbv[ya][xb] = e.rowbias ? *reinterpret_cast<const f32x4v*>(e.rowbias + (long long)(gm / e.rows_per_img) * e.ld_rowbias + cn)
-                                        : zero4;
-            }
-#pragma unroll
-        for (int ya = 0; ya < 2; ++ya)
-#pragma unroll
-            for (int xb = 0; xb < 2; ++xb) {
-                const int gm = gmc + ya * a.W + xb;
-                // x = ((acc*alpha + bias + rowbias) + res) * out_scale + prev: the direct kernels' order
-                f32x4v o = y[ya][xb] * e.alpha + (bias4 + tbv[ya][xb]);
-                if (e.res) o += rv[ya][xb];
-                o *= e.out_scale;
-                if (e.accumulate) o += cv[ya][xb];
-                if (ok) {
-                    *reinterpret_cast<f32x4v*>(a.C + (long long)gm * a.ldc + cn) = o;
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        gs += o[v];
-                        gss += o[v] * o[v];
-                    }
-                }
-            }
-        if (e.gn_part) {
-            // tile block tb = 64 pixels of one image = one "run" of the partial-sum table (any fixed partition of the image
-            // into hw/64 runs serves: the consumer sums all of them).  Fine group = 8 channels = lane pairs kq (0,1) / (2,3).
-            float s1 = gs, s2 = gss;
-#pragma unroll
-            for (int sft = 1; sft <= 16; sft <<= 1) {
-                s1 += __shfl_xor(s1, sft, 64);
-                s2 += __shfl_xor(s2, sft, 64);
-            }
-            const int row0 = m0 + tb * 64;
-            if ((lane & 0x1f) == 0 && row0 < a.M) {
-                const int img = row0 / e.gn_hw, chunk = (row0 - img * e.gn_hw) >> 6, chunks = e.gn_hw >> 6;
-                const int f = ((n0 + wave * 16) >> 3) + (lane >> 5);
-                double* pp = e.gn_part + (((long long)img * chunks + chunk) * (a.N >> 3) + f) * 2;
-                pp[0] = (double)s1;
-                pp[1] = (double)s2;
-            }
-        }
-    }
-}
-
-// ---- the same convolution as ONE WAVE PER SIMD with the transform hidden under the MFMAs ---------------------------------
-// 256 threads, 512 registers per lane: wave w owns 32 tiles x 32 channels x 16 positions (256 accumulator registers), so
-// every weight fragment is still loaded by one wave and every A fragment is read by four waves instead of eight.  The V
-// image is used as two halves (positions 0-7 = V rows 0,1 | positions 8-15 = V rows 2,3) and a chunk runs as two
-// half-phases, each a single unrolled instruction stream:
-//   HP0(c): MFMAs on half 0 of chunk c   ||  transform of V rows 2,3 of chunk c     (raw(c)     -> half 1)
-//   HP1(c): MFMAs on half 1 of chunk c   ||  transform of V rows 0,1 of chunk c + 1 (raw(c + 1) -> half 0)
-// with one barrier after each: a half is rewritten only after every wave has left the half-phase that read it.  The raw
-// halo of chunk c + 1 is loaded to registers at the start of HP0(c) and stored to the OTHER raw image at its end (two
-// raw images: raw(c) is still being read in HP0(c)).  Per half-phase and thread: one (tile, channel quad) item = 12
-// ds_read_b128, 64 adds, 16 split3 pairs, 24 ds_write_b64, spread over the eight positions' 192 MFMAs.
-// Everything is branch-free inside a half-phase (the last chunk transforms a stale raw image into a half nobody reads).
-template <int NI, int ABL = 0>
-__global__ void __launch_bounds__(256, 1) wino_conv4_kernel(const WinoArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int RAWB = NI * 32 * 128;
-    unsigned char* Vs = smem;
-    unsigned char* Rs = smem + VBYTES;        // two raw images of RAWB bytes
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_n = a.N >> 7;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tiles_m = gridDim.x / tiles_n;
-    const int tile_n = a.nmajor ? bid / tiles_m : bid % tiles_n;
-    const int tile_m = a.nmajor ? bid - tile_n * tiles_m : bid / tiles_n;
-    const int m0 = tile_m * 128, n0 = tile_n * 128;
-
-    const int W2 = a.W + 2, HW = a.H * a.W;
-    const int tiles_x = a.W >> 1;
-    const int tps = (a.rps >> 1) * tiles_x;
-    const int img0 = m0 / HW;
-    const int oy0 = (m0 - img0 * HW) / a.W;
-    const float* zp = a.zero;
-
-    // ---- raw staging items: halo pixel (tid + 256 i) >> 3, channel quad tid & 7 ---------------------------------------
-    const int c4 = tid & 7;
-    int hoff[NI], rdst[NI];
-    {
-        const int seg_px = (a.rps + 2) * W2;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int px = (tid + 256 * i) >> 3;
-            const int seg = px / seg_px;
-            const int rem = px - seg * seg_px;
-            const int hr = rem / W2, hx = rem - hr * W2;
-            const int img = img0 + seg, iy = oy0 + hr - 1, ix = hx - 1;
-            const bool ok = seg < a.nseg && img < a.B && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            hoff[i] = ok ? (img * a.H + iy) * a.W + ix : -1;
-            rdst[i] = raw_off(px, c4);
-        }
-    }
-    f32x4 hv[NI];
-    auto load_raw = [&](int c) {
-        const int c0 = c * 32;
-        const bool second = c0 >= a.C1;
-        const float* src = second ? a.x2 : a.x1;
-        const int cs = second ? a.C2 : a.C1;
-        const int cc = (second ? c0 - a.C1 : c0) + c4 * 4;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) hv[i] = ld4(hoff[i] >= 0 ? src + ((long long)hoff[i] * cs + cc) : zp);
-    };
-    auto store_raw = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) *reinterpret_cast<f32x4*>(Rs + buf * RAWB + rdst[i]) = hv[i];
-    };
-
-    // ---- transform item of this thread: tile tid >> 3, channel quad tid & 7 -----------------------------------------------
-    const int t_tile = tid >> 3, t_q = tid & 7;
-    int t_src;      // halo pixel of d[0][0]
-    {
-        const int seg = t_tile / tps, rem = t_tile - seg * tps;
-        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
-        t_src = (seg * (a.rps + 2) + 2 * ty) * W2 + 2 * tx;
-    }
-    const int t_dst = t_tile * ROWB + (((t_q >> 1) ^ lds_swz(t_tile)) << 4) + (t_q & 1) * 8;
-    int t_roff[3][4];       // raw-image byte offsets of d[th + r][c], th added as a multiple of W2 pixels below
-    // (raw_off is not linear in the pixel index: keep the 2 x 12 offsets of both halves as 4 rows x 4 columns)
-    int t_raw[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) t_raw[r][c] = raw_off(t_src + r * W2 + c, t_q);
-    (void)t_roff;
-
-    // ---- MFMA role: 32 tiles x 32 channels x 16 positions --------------------------------------------------------------
-    const int r16 = lane & 15, kq = lane >> 4;
-    int aoff[2];
-#pragma unroll
-    for (int tb = 0; tb < 2; ++tb) {
-        const int row = tb * 16 + r16;
-        aoff[tb] = row * ROWB + ((kq ^ lds_swz(row)) << 4);
-    }
-    // fragments: [N/128][8 blocks of 16 channels][chunk][16 pos][3 limbs][64 lanes]; this wave's blocks 2*wave, 2*wave + 1
-    const long long blk_stride = (long long)a.chunks * (16 * 3 * 64);
-    // wave-uniform base + lane: scalar-base addressing, one s_add per position.  Positions past the end (the prefetch runs
-    // three ahead) read the next block's fragments or the buffer's padding (psld_conv3x3_wino_frag_bytes) and are never used.
-    const u32x4* ub0 = a.ufrag + (long long)(tile_n * 8 + wave * 2) * blk_stride;
-    const u32x4* ub1 = ub0 + blk_stride;
-    u32x4 bq[4][2][3];
-    auto load_b = [&](int sigma, u32x4 (&dst)[2][3]) {
-        const u32x4* p0 = ub0 + (long long)sigma * (3 * 64);
-        const u32x4* p1 = ub1 + (long long)sigma * (3 * 64);
-#pragma unroll
-        for (int l = 0; l < 3; ++l) {
-            dst[0][l] = p0[l * 64 + lane];
-            dst[1][l] = p1[l * 64 + lane];
-        }
-    };
-
-    f32x4v acc[16][2][2];
-#pragma unroll
-    for (int p = 0; p < 16; ++p)
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) acc[p][tb][nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
-
-    u32x4 fa[3][2];          // [limb hi | mid | lo][tile block]
-    auto read_a = [&](int p, int l) {
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb) fa[l][tb] = *reinterpret_cast<const u32x4*>(Vs + (p * 3 + l) * VPLANE + aoff[tb]);
-    };
-    auto mm = [&](int p, int la, int lb) {
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-                acc[p][tb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(      // weights first: D^T[channel][tile]
-                    __builtin_bit_cast(bf16x8, bq[p & 3][nb][lb]), __builtin_bit_cast(bf16x8, fa[la][tb]), acc[p][tb][nb], 0, 0, 0);
-    };
-
-    // one half-phase: MFMAs on positions 8h .. 8h+7 of chunk c, transform of V rows (th = 1 - h) from raw image rbuf
-    auto half_phase = [&](auto HH, int c, int rbuf) {
-        constexpr int h = decltype(HH)::value;
-        constexpr int th = 1 - h;
-        const unsigned char* Rb = Rs + rbuf * RAWB;
-        read_a(8 * h, 2);
-        read_a(8 * h, 1);
-        read_a(8 * h, 0);
-        f32x4 e[3][4];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) e[r][cc] = *reinterpret_cast<const f32x4*>(Rb + t_raw[th + r][cc]);
-        f32x4 ra[4], rb[4];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int p = 8 * h + i;
-            if (!(ABL & 2)) load_b(c * 16 + p + 3, bq[(p + 3) & 3]);
-            if (i == 0) {
-                // row stage of B^T d: V rows (0: d0 - d2, 1: d1 + d2) or (2: d2 - d1, 3: d1 - d3); e[r] = d[th + r]
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    ra[cc] = e[0][cc] - e[2][cc];                                   // V row 0 (th = 0) / V row 3 (th = 1)
-                    rb[cc] = th ? e[1][cc] - e[0][cc] : e[1][cc] + e[2][cc];       // V row 1 / V row 2
-                }
-            }
-            if (!(ABL & 1)) {   // transform slice i: V row by half, column j
-                const int half = i >> 2, j = i & 3;
-                const f32x4* r = half ? rb : ra;
-                const int vrow = th ? (half ? 2 : 3) : (half ? 1 : 0);
-                const f32x4 v = j == 0 ? r[0] - r[2] : j == 1 ? r[1] + r[2] : j == 2 ? r[2] - r[1] : r[1] - r[3];
-                unsigned h0, m0_, l0, h1, m1, l1;
-                split3(v[0], v[1], h0, m0_, l0);
-                split3(v[2], v[3], h1, m1, l1);
-                unsigned char* q = Vs + (vrow * 4 + j) * 3 * VPLANE + t_dst;
-                *reinterpret_cast<u32x2*>(q) = u32x2{h0, h1};
-                *reinterpret_cast<u32x2*>(q + VPLANE) = u32x2{m0_, m1};
-                *reinterpret_cast<u32x2*>(q + 2 * VPLANE) = u32x2{l0, l1};
-            }
-            mm(p, 2, 0);
-            if (i < 7) read_a(p + 1, 2);
-            mm(p, 1, 1);
-            mm(p, 1, 0);
-            if (i < 7) read_a(p + 1, 1);
-            mm(p, 0, 2);
-            mm(p, 0, 1);
-            mm(p, 0, 0);
-            if (i < 7) read_a(p + 1, 0);
-            // interleave: one MFMA, then up to two other instructions (vector ALU first, then LDS / global memory)
-#pragma unroll
-            for (int k = 0; k < 12; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
-    load_raw(0);
-    load_b(0, bq[0]);
-    load_b(1, bq[1]);
-    load_b(2, bq[2]);
-    store_raw(0);
-    __syncthreads();
-    {   // V rows 0,1 of chunk 0 (not overlapped)
-        f32x4 e[3][4];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) e[r][cc] = *reinterpret_cast<const f32x4*>(Rs + t_raw[r][cc]);
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            f32x4 r[4];
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) r[cc] = half ? e[1][cc] + e[2][cc] : e[0][cc] - e[2][cc];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 v = j == 0 ? r[0] - r[2] : j == 1 ? r[1] + r[2] : j == 2 ? r[2] - r[1] : r[1] - r[3];
-                unsigned h0, m0_, l0, h1, m1, l1;
-                split3(v[0], v[1], h0, m0_, l0);
-                split3(v[2], v[3], h1, m1, l1);
-                unsigned char* q = Vs + (half * 4 + j) * 3 * VPLANE + t_dst;
-                *reinterpret_cast<u32x2*>(q) = u32x2{h0, h1};
-                *reinterpret_cast<u32x2*>(q + VPLANE) = u32x2{m0_, m1};
-                *reinterpret_cast<u32x2*>(q + 2 * VPLANE) = u32x2{l0, l1};
-            }
-        }
-    }
-    __syncthreads();
-
-    for (int c = 0; c < a.chunks; ++c) {
-        load_raw(min(c + 1, a.chunks - 1));
-        half_phase(std::integral_constant<int, 0>{}, c, c & 1);
-        store_raw((c + 1) & 1);
-        __syncthreads();
-        half_phase(std::integral_constant<int, 1>{}, c, (c + 1) & 1);
-        __syncthreads();
-    }
-
-    // ---- output transform + fused epilogue: lane = tile tb*16 + r16, channels cn .. cn+3 of block nb ----------------
-    const PsldEpilogue& e = a.e;
-    const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        const int cn = n0 + wave * 32 + nb * 16 + 4 * kq;
-        const f32x4v bias4 = e.bias ? *reinterpret_cast<const f32x4v*>(e.bias + cn) : zero4;
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb) {
-            const int tile = tb * 16 + r16;
-            const int seg = tile / tps, rem = tile - seg * tps;
-            const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
-            const int gm00 = m0 + seg * (a.rps * a.W) + (2 * ty) * a.W + 2 * tx;
-            const bool ok = gm00 < a.M;
-            f32x4v s[4][2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                s[i][0] = (acc[4 * i][tb][nb] + acc[4 * i + 1][tb][nb]) + acc[4 * i + 2][tb][nb];
-                s[i][1] = (acc[4 * i + 1][tb][nb] - acc[4 * i + 2][tb][nb]) - acc[4 * i + 3][tb][nb];
-            }
-            f32x4v y[2][2];
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                y[0][b] = (s[0][b] + s[1][b]) + s[2][b];
-                y[1][b] = (s[1][b] - s[2][b]) - s[3][b];
-            }
-            float gs = 0.f, gss = 0.f;
-            const int gmc = ok ? gm00 : 0;
-            f32x4v rv[2][2], cv[2][2], tbv[2][2];
-#pragma unroll
-            for (int ya = 0; ya < 2; ++ya)
-#pragma unroll
-                for (int xb = 0; xb < 2; ++xb) {
-                    const int gm = gmc + ya * a.W + xb;
-                    rv[ya][xb] = e.res ? *reinterpret_cast<const f32x4v*>(e.res + (long long)gm * e.ldres + cn) : zero4;
-                    cv[ya][xb] = e.accumulate ? *reinterpret_cast<const f32x4v*>(a.C + (long long)gm * a.ldc + cn) : zero4;
-                    tbv[ya][xb] = e.rowbias ? *reinterpret_cast<const f32x4v*>(e.rowbias + (long long)(gm / e.rows_per_img) * e.ld_rowbias + cn)
-                                            : zero4;
-                }
-#pragma unroll
-            for (int ya = 0; ya < 2; ++ya)
-#pragma unroll
-                for (int xb = 0; xb < 2; ++xb) {
-                    const int gm = gmc + ya * a.W + xb;
-                    f32x4v o = y[ya][xb] * e.alpha + (bias4 + tbv[ya][xb]);
-                    if (e.res) o += rv[ya][xb];
-                    o *= e.out_scale;
-                    if (e.accumulate) o += cv[ya][xb];
-                    if (ok) {
-                        *reinterpret_cast<f32x4v*>(a.C + (long long)gm * a.ldc + cn) = o;
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) {
-                            gs += o[v];
-                            gss += o[v] * o[v];
-                        }
-                    }
-                }
-            if (e.gn_part) {
-                float s1 = gs, s2 = gss;
-#pragma unroll
-                for (int sft = 1; sft <= 16; sft <<= 1) {
-                    s1 += __shfl_xor(s1, sft, 64);
-                    s2 += __shfl_xor(s2, sft, 64);
-                }
-                const int row0 = m0 + tb * 64;
-                if ((lane & 0x1f) == 0 && row0 < a.M) {
-                    const int img = row0 / e.gn_hw, chunk = (row0 - img * e.gn_hw) >> 6, chunks = e.gn_hw >> 6;
-                    const int f = ((n0 + wave * 32 + nb * 16) >> 3) + (lane >> 5);
-                    double* pp = e.gn_part + (((long long)img * chunks + chunk) * (a.N >> 3) + f) * 2;
-                    pp[0] = (double)s1;
-                    pp[1] = (double)s2;
-                }
-            }
-        }
     }
 }
 
@@ -994,6 +420,10 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArg
     }
 }
 
+#ifdef PSLD_ABLATIONS
+#include "conv_wino_abl.inc"
+#endif
+
 template <int ABL = 0>
 int launch_wino8s(const WinoArgs& a, hipStream_t stream, const char* name) {
     constexpr size_t LDS = (size_t)VBYTES + 2 * (size_t)4 * 64 * 128;
@@ -1014,44 +444,15 @@ int launch_wino8s(const WinoArgs& a, hipStream_t stream, const char* name) {
     return PSLD_OK;
 }
 
-template <int NI, int ABL = 0>
-int launch_wino4(const WinoArgs& a, hipStream_t stream, const char* name) {
-    constexpr size_t LDS = (size_t)VBYTES + 2 * (size_t)NI * 32 * 128;
-    static_assert(LDS <= 163840, "LDS budget");
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv4_kernel<NI, ABL>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-        if (e != hipSuccess) {
-            psld_set_error("%s: hipFuncSetAttribute failed: %s", name, hipGetErrorString(e));
-            return PSLD_ERR_LAUNCH;
-        }
-        configured = true;
-    }
-    dim3 grid((unsigned)(cdiv(a.M, 128) * (a.N / 128)));
-    hipLaunchKernelGGL((wino_conv4_kernel<NI, ABL>), grid, dim3(256), LDS, stream, a);
-    PSLD_CHECK_LAUNCH(name);
-    return PSLD_OK;
-}
-
-template <int NI, int ABL = 0>
-int launch_wino(const WinoArgs& a, hipStream_t stream, const char* name) {
-    constexpr size_t LDS = (size_t)VBYTES + (size_t)NI * 64 * 128;
-    static_assert(LDS <= 163840, "LDS budget");
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel<NI, ABL>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-        if (e != hipSuccess) {
-            psld_set_error("%s: hipFuncSetAttribute failed: %s", name, hipGetErrorString(e));
-            return PSLD_ERR_LAUNCH;
-        }
-        configured = true;
-    }
-    dim3 grid((unsigned)(cdiv(a.M, 128) * (a.N / 128)));
-    hipLaunchKernelGGL((wino_conv_kernel<NI, ABL>), grid, dim3(WINO_THREADS), LDS, stream, a);
-    PSLD_CHECK_LAUNCH(name);
-    return PSLD_OK;
+int wino_cu_count() {
+    static const int n = [] {
+        int dev = 0, cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            cu <= 0)
+            cu = 256;
+        return cu;
+    }();
+    return n;
 }
 
 bool wino_geometry(int h, int w, int* nseg, int* rps, int* halo_px) {
@@ -1069,7 +470,8 @@ bool wino_geometry(int h, int w, int* nseg, int* rps, int* halo_px) {
     }
     if (*rps % 2) return false;
     *halo_px = *nseg * (*rps + 2) * (w + 2);
-    return *halo_px <= 5 * 64;
+    // wino_conv8s_kernel: the halo of a workgroup's region in one 256-pixel raw image; 64-wide maps run as 4 x 32 blocks
+    return w == 64 ? h % 4 == 0 : *halo_px <= 256;
 }
 
 }  // namespace
@@ -1133,45 +535,73 @@ extern "C" int psld_conv3x3_wino_f32(const float* x1, int c1, const float* x2, i
                    "limb kernels: y, residual, bias and rowbias need 16-byte aligned rows (pointer and row stride)");
     a.zero = psld_detail_zero_page("psld_conv3x3_wino_f32");
     if (!a.zero) return PSLD_ERR_LAUNCH;
-    static const int nmaj = [] { const char* v = getenv("PSLD_WINO_NMAJOR"); return v ? atoi(v) : 1; }();
-    a.nmajor = nmaj;
-    const int ni = cdiv((long long)halo_px * 8, WINO_THREADS);
+    a.nmajor = 1;       // channel-tile-major: an XCD streams ONE 128-channel slice of U at a time (pixel-tile-major measured 1-2 % slower)
     const char* name = "psld_conv3x3_wino_f32";
-    static const int w4 = [] { const char* v = getenv("PSLD_WINO_W4"); return v ? atoi(v) : 2; }();
     a.cw = w;
-    if (w4 == 2 && w == 64 && h % 4 == 0) {     // 4 x 32 pixel blocks: the 32x32 level's halo (6 x 34 = 204 pixels)
+    if (w == 64) {      // 4 x 32 pixel blocks: the 32x32 level's halo (6 x 34 = 204 pixels)
         a.cw = 32; a.rps = 4; a.nseg = 1;
         halo_px = 6 * 34;
     }
-    if (w4 == 2 && halo_px <= 256) {
-        static const int abl8 = [] { const char* v = getenv("PSLD_WINO_ABL"); return v ? atoi(v) : 0; }();
-        if (abl8 == 1) return launch_wino8s<1>(a, stream, name);
-        if (abl8 == 2) return launch_wino8s<2>(a, stream, name);
-        if (abl8 == 3) return launch_wino8s<3>(a, stream, name);
-        if (abl8 == 4) return launch_wino8s<4>(a, stream, name);
-        if (abl8 == 8) return launch_wino8s<8>(a, stream, name);
-        return launch_wino8s<0>(a, stream, name);
-    }
-    if (w4 == 1) {
-        const int ni4 = cdiv((long long)halo_px * 8, 256);
-        static const int abl4 = [] { const char* v = getenv("PSLD_WINO_ABL"); return v ? atoi(v) : 0; }();
-        if (abl4 == 1 && ni4 <= 7) return launch_wino4<7, 1>(a, stream, name);
-        if (abl4 == 2 && ni4 <= 7) return launch_wino4<7, 2>(a, stream, name);
-        if (abl4 == 3 && ni4 <= 7) return launch_wino4<7, 3>(a, stream, name);
-        if (ni4 <= 6) return launch_wino4<6>(a, stream, name);
-        if (ni4 <= 7) return launch_wino4<7>(a, stream, name);
-    }
-    static const int abl = [] { const char* v = getenv("PSLD_WINO_ABL"); return v ? atoi(v) : 0; }();
-    if (abl && ni <= 4) {
-        switch (abl) {
-            case 1: return launch_wino<4, 1>(a, stream, name);
-            case 2: return launch_wino<4, 2>(a, stream, name);
-            case 3: return launch_wino<4, 3>(a, stream, name);
-            case 6: return launch_wino<4, 6>(a, stream, name);
-            case 7: return launch_wino<4, 7>(a, stream, name);
+#ifdef PSLD_ABLATIONS      // libpsld_hip_abl.so only: the variants of conv_wino_abl.inc and the timing-only ablations (wrong results)
+    {
+        static const int nmaj = [] { const char* v = getenv("PSLD_WINO_NMAJOR"); return v ? atoi(v) : 1; }();
+        a.nmajor = nmaj;
+        static const int w4 = [] { const char* v = getenv("PSLD_WINO_W4"); return v ? atoi(v) : 2; }();
+        static const int abl = [] { const char* v = getenv("PSLD_WINO_ABL"); return v ? atoi(v) : 0; }();
+        // CU-resident form (wino_conv8p_kernel) when every workgroup gets at least two items; PSLD_WINO_PERSIST=1: on,
+        // =N > 1: N workgroups
+        static const int persist = [] { const char* v = getenv("PSLD_WINO_PERSIST"); return v ? atoi(v) : 0; }();
+        static const int stg = [] { const char* v = getenv("PSLD_WINO_STAGGER"); return v ? atoi(v) : 0; }();
+        static const int la = [] { const char* v = getenv("PSLD_WINO_LA"); return v ? atoi(v) : 2; }();
+        if (w4 == 2) {
+            a.tiles_m = cdiv(a.M, 128);
+            a.stagger = stg;
+            const int total = a.tiles_m * (a.N / 128);
+            const int cus = persist > 1 ? persist : wino_cu_count();
+            auto lg2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+            a.lg_tiles_x = lg2(a.cw >> 1);
+            a.lg_tps = lg2((a.rps >> 1) * (a.cw >> 1));
+            const long long span = (long long)a.M * (ldy > e.ldres ? ldy : e.ldres) + cout;       // 32-bit element offsets
+            if (persist && total >= 2 * cus && span < (1LL << 31)) {
+                if (abl == 1) return launch_wino8p<1>(a, cus, stream, name);
+                if (abl == 2) return launch_wino8p<2>(a, cus, stream, name);
+                if (abl == 16) return launch_wino8p<16>(a, cus, stream, name);
+                if (abl == 32) return launch_wino8p<32>(a, cus, stream, name);
+                if (abl == 48) return launch_wino8p<48>(a, cus, stream, name);
+                if (la == 3) return launch_wino8p<0, 3>(a, cus, stream, name);
+                return launch_wino8p<0>(a, cus, stream, name);
+            }
+            if (abl == 1) return launch_wino8s<1>(a, stream, name);
+            if (abl == 2) return launch_wino8s<2>(a, stream, name);
+            if (abl == 3) return launch_wino8s<3>(a, stream, name);
+            if (abl == 4) return launch_wino8s<4>(a, stream, name);
+            if (abl == 8) return launch_wino8s<8>(a, stream, name);
+        } else {
+            wino_geometry(h, w, &a.nseg, &a.rps, &halo_px);     // whole-width tiles
+            a.cw = w;
+            if (w4 == 1) {
+                const int ni4 = cdiv((long long)halo_px * 8, 256);
+                if (abl == 1 && ni4 <= 7) return launch_wino4<7, 1>(a, stream, name);
+                if (abl == 2 && ni4 <= 7) return launch_wino4<7, 2>(a, stream, name);
+                if (abl == 3 && ni4 <= 7) return launch_wino4<7, 3>(a, stream, name);
+                if (ni4 <= 6) return launch_wino4<6>(a, stream, name);
+                if (ni4 <= 7) return launch_wino4<7>(a, stream, name);
+            }
+            const int ni = cdiv((long long)halo_px * 8, WINO_THREADS);
+            if (abl && ni <= 4) {
+                switch (abl) {
+                    case 1: return launch_wino<4, 1>(a, stream, name);
+                    case 2: return launch_wino<4, 2>(a, stream, name);
+                    case 3: return launch_wino<4, 3>(a, stream, name);
+                    case 6: return launch_wino<4, 6>(a, stream, name);
+                    case 7: return launch_wino<4, 7>(a, stream, name);
+                }
+            }
+            if (ni <= 3) return launch_wino<3>(a, stream, name);
+            if (ni <= 4) return launch_wino<4>(a, stream, name);
+            return launch_wino<5>(a, stream, name);
         }
     }
-    if (ni <= 3) return launch_wino<3>(a, stream, name);
-    if (ni <= 4) return launch_wino<4>(a, stream, name);
-    return launch_wino<5>(a, stream, name);
+#endif
+    return launch_wino8s<0>(a, stream, name);
 }

@@ -365,7 +365,6 @@ def bgemm_split(ta: int, tb: int, M: int, N: int, K: int, A: Tensor, lda: int, s
 
 
 @functools.lru_cache(maxsize=None)
-@functools.lru_cache(maxsize=None)
 def attn_fwd_supported(hw: int, c: int) -> bool:
     return bool(lib().psld_attn_fwd_split_supported(hw, c))
 
@@ -378,6 +377,7 @@ def attn_fwd(q: Tensor, k: Tensor, v: Tensor, ld: int, batch: int, hw: int, c: i
                                         out.data_ptr(), c, _p(p), _stream()), "psld_attn_fwd_split_f32")
 
 
+@functools.lru_cache(maxsize=None)
 def conv3x3_wgrad_split_cout_tile(cout: int) -> int:
     return lib().psld_conv3x3_wgrad_split_cout_tile(cout)
 

@@ -1807,9 +1807,14 @@ class NCSNpp(nn.Module):
                 elif ck[-1] == "pfrag":
                     if ck[1] == "fwd":
                         self._pfrag(cv[2], ck[1], *cv[3])
-                elif not ck[1]:
-                    (self._frag(self._conv_by_weight[ck[0]], False) if len(ck) == 3
-                     else self._packed(self._conv_by_weight[ck[0]]))
+                elif ck[-1] == "wfrag":                         # Winograd fragments the captured forward reads
+                    if not ck[1]:
+                        self._wfrag(self._conv_by_weight[ck[0]], False)
+                elif ck[-1] == "frag":
+                    if not ck[1]:
+                        self._frag(self._conv_by_weight[ck[0]], False)
+                elif len(ck) == 2 and not ck[1]:
+                    self._packed(self._conv_by_weight[ck[0]])
             ent[4] = now
         sx.copy_(x)
         st.copy_(t)

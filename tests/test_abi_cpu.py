@@ -94,3 +94,18 @@ def test_launch_tape_packs_arguments_and_replay_validates_entries():
     bad["nargs"][0] = 3                                     # wrong argument count for that function
     assert lib.psld_tape_replay(bad.ctypes.data, 1, C.byref(failed)) == 1 and b"arguments" in lib.psld_last_error()
     assert lib.psld_tape_replay(bad.ctypes.data + bad.dtype.itemsize, 1, C.byref(failed)) == 1
+
+
+def test_product_library_has_no_ablation_modes():
+    """Timing-only ablation variants (wrong results by construction) and the kernel families that lost their A/B are
+    compiled only into libpsld_hip_abl.so (-DPSLD_ABLATIONS): the product library holds neither their switches nor
+    their kernels, and the benchmark refuses to run under them."""
+    import subprocess
+    import sys
+    data = open(_lib.LIB_PATH, "rb").read()
+    for needle in (b"_ABL", b"PSLD_WINO_W4", b"PSLD_WINO_NMAJOR", b"PSLD_WINO_PERSIST", b"wino_conv4_kernel", b"wino_conv8p_kernel"):
+        assert needle not in data, f"{needle!r} found in {_lib.LIB_PATH}"
+    assert b"wino_conv8s_kernel" in data
+    env = dict(os.environ, PSLD_WINO_ABL="2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], env=env, capture_output=True, text=True)
+    assert r.returncode == 2 and "PSLD_WINO_ABL" in r.stderr

@@ -946,30 +946,37 @@ def test_bbode_sampler_against_scipy_oracle(tol):
     assert err < 1e-5
 
 
-def test_hip_graph_forward_matches_eager_and_tracks_weight_updates():
+@pytest.mark.parametrize("name,winograd", [("tiny", None), ("c10_sota", 2)])
+def test_hip_graph_forward_matches_eager_and_tracks_weight_updates(name, winograd):
     """Inference forward replayed from a captured HIP graph: bit-identical to the eager launch sequence,
-    for new inputs and after the weights change (EMA-style raw-pointer update)."""
+    for new inputs and after the weights change (EMA-style raw-pointer update).  The C10-SOTA case runs its 3x3
+    convolutions in Winograd form: the replay must see refreshed Winograd fragments too."""
     from psld_amd import ops
-    net, cfg, _ = _build("tiny")
-    g = torch.Generator().manual_seed(11)
-    xs = [torch.randn(3, 6, 16, 16, generator=g).to(DEV) for _ in range(3)]
-    ts = [(torch.rand(3, generator=g) * 0.9 + 0.05).to(DEV) for _ in range(3)]
-    with torch.no_grad():
-        eager = [net(x, t).clone() for x, t in zip(xs, ts)]
-    net.enable_graphs(True)
-    with torch.no_grad():
-        for x, t, ref in zip(xs, ts, eager):
-            assert torch.equal(net(x, t), ref)
-        other = copy.deepcopy(net)
+    ops.set_winograd(winograd)
+    try:
+        net, cfg, _ = _build(name)
+        size = cfg.data.image_size
+        g = torch.Generator().manual_seed(11)
+        xs = [torch.randn(3, 6, size, size, generator=g).to(DEV) for _ in range(3)]
+        ts = [(torch.rand(3, generator=g) * 0.9 + 0.05).to(DEV) for _ in range(3)]
         with torch.no_grad():
-            for p in other.parameters():
-                p.mul_(1.01)
-        ops.ema(net.flatten_parameters(), other.flatten_parameters(), 0.5)   # raw-pointer write
-        net.weights_changed()
-        yg = net(xs[0], ts[0])
-        net.enable_graphs(False)
-        ye = net(xs[0], ts[0])
-    assert torch.equal(yg, ye) and not torch.equal(yg, eager[0])
+            eager = [net(x, t).clone() for x, t in zip(xs, ts)]
+        net.enable_graphs(True)
+        with torch.no_grad():
+            for x, t, ref in zip(xs, ts, eager):
+                assert torch.equal(net(x, t), ref)
+            other = copy.deepcopy(net)
+            with torch.no_grad():
+                for p in other.parameters():
+                    p.mul_(1.01)
+            ops.ema(net.flatten_parameters(), other.flatten_parameters(), 0.5)   # raw-pointer write
+            net.weights_changed()
+            yg = net(xs[0], ts[0])
+            net.enable_graphs(False)
+            ye = net(xs[0], ts[0])
+        assert torch.equal(yg, ye) and not torch.equal(yg, eager[0])
+    finally:
+        ops.set_winograd(None)
 
 
 def test_cli_train_checkpoint_sample_roundtrip(tmp_path):

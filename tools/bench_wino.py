@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--epi", default="res", help="epilogue of the timed launches: plain | bias | res (bias + residual + scale)")
     ap.add_argument("--shapes", default="256,256,32;512,256,32;256,256,16;512,256,16;256,256,8")
     args = ap.parse_args()
     ops.lib()
@@ -98,7 +99,8 @@ def main():
         uf = ops.conv3x3_wino_frag(w, False)
         bias = torch.randn(cout, device=DEV)
         res = torch.randn(B, s, s, cout, device=DEV)
-        epi = ops.epilogue(bias=bias, residual=res, ld_residual=cout, out_scale=0.7)
+        epi = (ops.epilogue() if args.epi == "plain" else ops.epilogue(bias=bias) if args.epi == "bias"
+               else ops.epilogue(bias=bias, residual=res, ld_residual=cout, out_scale=0.7))
         y0, y1, y2 = (torch.empty(B, s, s, cout, device=DEV) for _ in range(3))
         xl = ops.f32_to_limb(x)
         fl = 2.0 * B * s * s * cout * 9 * cin
@@ -110,8 +112,9 @@ def main():
                 ts[i].append(timeit(f, args.iters))
         m = [sorted(t)[len(t) // 2] for t in ts]
         nb = min(B, 4)
-        ref = (F.conv2d(x[:nb].permute(0, 3, 1, 2).double(), w.double(), bias.double(), padding=1)
-               + res[:nb].permute(0, 3, 1, 2).double()) * 0.7
+        ref = F.conv2d(x[:nb].permute(0, 3, 1, 2).double(), w.double(), bias.double() if args.epi != "plain" else None, padding=1)
+        if args.epi == "res":
+            ref = (ref + res[:nb].permute(0, 3, 1, 2).double()) * 0.7
         e1, e2 = rel_l2(y1[:nb].permute(0, 3, 1, 2), ref), rel_l2(y2[:nb].permute(0, 3, 1, 2), ref)
         print(f"conv fwd {cin}->{cout} @{s} B={B}: direct fp32-in {fl / m[0] / 1e12:6.1f} TF  direct limb-in {fl / m[1] / 1e12:6.1f} TF  "
               f"winograd {fl / m[2] / 1e12:6.1f} TF (best {fl / min(ts[2]) / 1e12:6.1f}; {m[2] * 1e6:7.1f} us)  x{m[1] / m[2]:.3f} vs limb-in   "
