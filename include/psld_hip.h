@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 
-#define PSLD_ABI_VERSION 9 /* 2: limb-MFMA convolutions, math mode, bias-gradient / batched-copy entry points; 3: pointwise weight gradient and batched activation GEMM on limb kernels; 4: GroupNorm statistics from the limb kernels' epilogue; 5: per-sample-time reverse SDE, ScoreLoss nll / l1; 6: limb-plane activations; 7: device-resident dropout seed / Adam scalars (captured training step), GroupNorm-backward sums from the producing epilogue; 8: Winograd F(2x2,3x3) limb convolution; 9: launch tape */
+#define PSLD_ABI_VERSION 10 /* 2: limb-MFMA convolutions, math mode, bias-gradient / batched-copy entry points; 3: pointwise weight gradient and batched activation GEMM on limb kernels; 4: GroupNorm statistics from the limb kernels' epilogue; 5: per-sample-time reverse SDE, ScoreLoss nll / l1; 6: limb-plane activations; 7: device-resident dropout seed / Adam scalars (captured training step), GroupNorm-backward sums from the producing epilogue; 8: Winograd F(2x2,3x3) limb convolution; 9: launch tape; 10: GroupNorm apply (+SiLU) fused into the Winograd convolution's input staging */
 #define PSLD_COEFF_STRIDE 12
 
 int psld_version(void);
@@ -170,6 +170,19 @@ int psld_pack_wino_batch(const long long* table_dev, int entries, long long tota
 int psld_conv3x3_wino_f32(const float* x1, int c1, const float* x2, int c2, int batch, int h, int w,
                           const void* ufrag, int cout, float* y, int ldy, const psld_epilogue_t* epi,
                           hipStream_t stream);
+/* The same convolution applied to act(GroupNorm(x)) without materialising it: x1 / x2 are the RAW tensors, scale* /
+ * shift* the per-(image, channel) rows psld_gn_stats_nhwc_f32 / psld_gn_stats_from_partials_f32 produce ([batch][c1],
+ * [batch][c2]; a two-source input is normalised per source, as the executor's concat-free up path does), act = 1: SiLU.
+ * The activation a = act(x * scale + shift) is formed on the float4 a thread has just loaded for the kernel's raw halo
+ * image; pixels outside the image stay zero (the reference pads the activated tensor).  For passes that need the
+ * activated tensor nowhere else - the inference forward the samplers drive (GroupNorm_0/1 + act + Conv_0/1,
+ * layerspp.py:245-263; no dropout in eval mode) - this removes psld_gn_apply_nhwc_f32's round trip through HBM.
+ * Shapes: psld_conv3x3_wino_supported and h*w >= 128 (one image per workgroup region). */
+int psld_conv3x3_wino_gn_supported(int c1, int c2, int batch, int h, int w, int cout);
+int psld_conv3x3_wino_gn_f32(const float* x1, int c1, const float* scale1, const float* shift1, const float* x2, int c2,
+                             const float* scale2, const float* shift2, int act, int batch, int h, int w,
+                             const void* ufrag, int cout, float* y, int ldy, const psld_epilogue_t* epi,
+                             hipStream_t stream);
 
 /* "Limb planes": an NHWC activation [rows][c] (c a multiple of 32) stored already decomposed, as bf16
  * [rows][c/32 chunks][3 limbs hi|mid|lo][32 channels] (6 bytes per element; hi + mid + lo == x bit for bit).  The

@@ -68,7 +68,7 @@ class SscsCoeffs(C.Structure):
 I, F, D, LL, P = C.c_int, C.c_float, C.c_double, C.c_longlong, C.c_void_p
 EP = C.POINTER(Epilogue)
 
-ABI_VERSION = 9    # PSLD_ABI_VERSION of include/psld_hip.h these signatures were written against
+ABI_VERSION = 10   # PSLD_ABI_VERSION of include/psld_hip.h these signatures were written against
 
 # name -> (restype, argtypes): every symbol include/psld_hip.h declares
 SIGNATURES = {
@@ -94,6 +94,8 @@ SIGNATURES = {
     "psld_pack_conv3x3_wino": (I, [P, P, I, I, I, P]),
     "psld_pack_wino_batch": (I, [P, I, LL, P]),
     "psld_conv3x3_wino_f32": (I, [P, I, P, I, I, I, I, P, I, P, I, EP, P]),
+    "psld_conv3x3_wino_gn_supported": (I, [I, I, I, I, I, I]),
+    "psld_conv3x3_wino_gn_f32": (I, [P, I, P, P, P, I, P, P, I, I, I, I, P, I, P, I, EP, P]),
     "psld_gn_apply_limb_nhwc": (I, [P, P, P, P, I, I, I, I, F, C.c_ulonglong, P, P]),
     "psld_limb_bytes": (LL, [LL, I]),
     "psld_f32_to_limb": (I, [P, LL, I, P, P]),

@@ -55,6 +55,10 @@ struct WinoArgs {
     int nmajor;
     int tiles_m;            // wino_conv8p_kernel: pixel tiles of the launch (cdiv(M, 128))
     int stagger;
+    // wino_conv8s_kernel<., GNF = true>: GroupNorm apply (+ SiLU) of the input inside the raw staging - per-(image, channel)
+    // scale / shift rows of source 1 and 2 ([B][C1], [B][C2]: psld_gn_stats_*), act = 1: SiLU
+    const float *gsc1, *gsh1, *gsc2, *gsh2;
+    int gn_act;
     int lg_tiles_x, lg_tps; // wino_conv8p_kernel: log2 of the tiles per tile row (cw / 2) and per image segment
 };
 
@@ -153,7 +157,17 @@ __global__ void wino_pack_batch_kernel(const long long* __restrict__ tab, int nt
 // lists, 480 vs 454 us on 256->256 @32x32 B=128, and one workgroup per pixel tile looping over the channel tiles with the
 // half-phase pipeline running across the passes, 522 vs 451 us - hipcc's code for the accumulators degrades once the
 // epilogue sits inside a loop.  One workgroup per (pixel tile, channel tile) it is.)
-template <int ABL = 0>
+// GNF: the input is the RAW tensor a GroupNorm (+ SiLU) is to be applied to, and the apply pass runs here, on the float4 a
+// thread has just loaded for the raw image: a = silu(x * scale[img][c] + shift[img][c]), zero outside the image (the
+// convolution pads the ACTIVATED tensor).  The inference forward (EM / SSCS sampling) needs the activated tensor nowhere
+// else, so psld_gn_apply_nhwc_f32's round trip through HBM disappears; one image per region only (maps of >= 128 pixels).
+// The scale / shift quad is loaded where it is used (L1 / L2 hits; holding it in registers through the MFMA phase, or
+// staging it through LDS two half-phases ahead, spills: the kernel sits at 256 VGPRs).  Measured (profiles/r04/
+// wino_fused_gn.txt): the launch gets 7-10 % longer - ~110 vector instructions per thread and chunk, two of them
+// transcendental per element, in a kernel that is short of vector issue slots - against the apply pass it replaces: 3-5 %
+// less time for the pair on the 32x32 level at B=512, nothing on 16x16.  Reference: GroupNorm_0/1 + act in front of
+// Conv_0/1, layerspp.py:245-263.
+template <int ABL = 0, bool GNF = false>
 __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NI = 4;                     // raw image: 256 halo pixels
@@ -209,9 +223,28 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArg
 #pragma unroll
         for (int i = 0; i < NI; ++i) hv[i] = ld4(hoff[i] >= 0 ? src + ((long long)hoff[i] * cs + cc) : zp);
     };
-    auto store_raw = [&](int buf) {
+    auto store_raw = [&](int buf, int c) {
+        if constexpr (GNF) {
+            const int c0 = c * 32;
+            const bool second = c0 >= a.C1;
+            const int cs = second ? a.C2 : a.C1;
+            const long long go = (long long)img0 * cs + (second ? c0 - a.C1 : c0) + c4 * 4;
+            const f32x4 sc = ld4((second ? a.gsc2 : a.gsc1) + go), sh = ld4((second ? a.gsh2 : a.gsh1) + go);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) *reinterpret_cast<f32x4*>(Rs + buf * RAWB + rdst[i]) = hv[i];
+            for (int i = 0; i < NI; ++i) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float z = hv[i][e] * sc[e] + sh[e];
+                    const float v = a.gn_act ? silu_f(z) : z;
+                    o[e] = hoff[i] >= 0 ? v : 0.f;          // the convolution pads the ACTIVATED tensor with zeros
+                }
+                *reinterpret_cast<f32x4*>(Rs + buf * RAWB + rdst[i]) = o;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) *reinterpret_cast<f32x4*>(Rs + buf * RAWB + rdst[i]) = hv[i];
+        }
     };
 
     // ---- transform share of this thread: item (tile, channel quad) = tid & 255, V row vr = wave >> 2 of the half -------------
@@ -321,7 +354,7 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArg
     load_raw(0);
     load_b(0, bq[0]);
     load_b(1, bq[1]);
-    store_raw(0);
+    store_raw(0, 0);
     __syncthreads();
     if (vr == 0) transform(I0{}, I0{}, 0); else transform(I0{}, I1{}, 0);      // V rows 0,1 of chunk 0
     __syncthreads();
@@ -334,7 +367,7 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArg
         mfma_half(I0{}, c);
         __builtin_amdgcn_sched_barrier(0);
         if (vr != 0 && !(ABL & 1)) transform(I1{}, I1{}, c & 1);             // waves 4-7: MFMAs, then transform
-        store_raw((c + 1) & 1);
+        store_raw((c + 1) & 1, min(c + 1, a.chunks - 1));
         __syncthreads();
         // HP1: MFMAs on V rows 2,3 of chunk c || V rows 0,1 of chunk c + 1 (raw image (c + 1) & 1; stale for the last chunk)
         if (vr == 0 && !(ABL & 1)) transform(I0{}, I0{}, (c + 1) & 1);
@@ -424,13 +457,13 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArg
 #include "conv_wino_abl.inc"
 #endif
 
-template <int ABL = 0>
+template <int ABL = 0, bool GNF = false>
 int launch_wino8s(const WinoArgs& a, hipStream_t stream, const char* name) {
     constexpr size_t LDS = (size_t)VBYTES + 2 * (size_t)4 * 64 * 128;
     static_assert(LDS <= 163840, "LDS budget");
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv8s_kernel<ABL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv8s_kernel<ABL, GNF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         if (e != hipSuccess) {
             psld_set_error("%s: hipFuncSetAttribute failed: %s", name, hipGetErrorString(e));
@@ -439,7 +472,7 @@ int launch_wino8s(const WinoArgs& a, hipStream_t stream, const char* name) {
         configured = true;
     }
     dim3 grid((unsigned)(cdiv(a.M, 128) * (a.N / 128)));
-    hipLaunchKernelGGL((wino_conv8s_kernel<ABL>), grid, dim3(WINO_THREADS), LDS, stream, a);
+    hipLaunchKernelGGL((wino_conv8s_kernel<ABL, GNF>), grid, dim3(WINO_THREADS), LDS, stream, a);
     PSLD_CHECK_LAUNCH(name);
     return PSLD_OK;
 }
@@ -509,9 +542,41 @@ extern "C" int psld_pack_wino_batch(const long long* table_dev, int entries, lon
     return PSLD_OK;
 }
 
+namespace {
+struct WinoGn {
+    const float *sc1, *sh1, *sc2, *sh2;
+    int act;
+};
+int wino_conv(const float* x1, int c1, const float* x2, int c2, int batch, int h, int w, const void* ufrag, int cout, float* y,
+              int ldy, const psld_epilogue_t* epi, const WinoGn* gn, hipStream_t stream);
+}  // namespace
+
 extern "C" int psld_conv3x3_wino_f32(const float* x1, int c1, const float* x2, int c2, int batch, int h, int w,
                                      const void* ufrag, int cout, float* y, int ldy, const psld_epilogue_t* epi,
                                      hipStream_t stream) {
+    return wino_conv(x1, c1, x2, c2, batch, h, w, ufrag, cout, y, ldy, epi, nullptr, stream);
+}
+
+extern "C" int psld_conv3x3_wino_gn_supported(int c1, int c2, int batch, int h, int w, int cout) {
+    return psld_conv3x3_wino_supported(c1, c2, batch, h, w, cout) && h * w >= 128;      // one image per workgroup region
+}
+
+extern "C" int psld_conv3x3_wino_gn_f32(const float* x1, int c1, const float* scale1, const float* shift1, const float* x2,
+                                        int c2, const float* scale2, const float* shift2, int act, int batch, int h, int w,
+                                        const void* ufrag, int cout, float* y, int ldy, const psld_epilogue_t* epi,
+                                        hipStream_t stream) {
+    PSLD_CHECK_ARG(scale1 && shift1 && (c2 == 0 || (scale2 && shift2)), "psld_conv3x3_wino_gn_f32: null scale / shift");
+    PSLD_CHECK_ARG(psld_conv3x3_wino_gn_supported(c1, c2, batch, h, w, cout),
+                   "psld_conv3x3_wino_gn_f32: unsupported shape c1=%d c2=%d %dx%d cout=%d (needs h*w >= 128)", c1, c2, h, w, cout);
+    PSLD_CHECK_ARG(aligned16(scale1) && aligned16(shift1) && (c2 == 0 || (aligned16(scale2) && aligned16(shift2))),
+                   "psld_conv3x3_wino_gn_f32: unaligned scale / shift");
+    const WinoGn gn{scale1, shift1, scale2, shift2, act};
+    return wino_conv(x1, c1, x2, c2, batch, h, w, ufrag, cout, y, ldy, epi, &gn, stream);
+}
+
+namespace {
+int wino_conv(const float* x1, int c1, const float* x2, int c2, int batch, int h, int w, const void* ufrag, int cout, float* y,
+              int ldy, const psld_epilogue_t* epi, const WinoGn* gn, hipStream_t stream) {
     PSLD_CHECK_ARG(x1 && ufrag && y && (c2 == 0 || x2), "psld_conv3x3_wino_f32: null pointer");
     PSLD_CHECK_ARG(psld_conv3x3_wino_supported(c1, c2, batch, h, w, cout),
                    "psld_conv3x3_wino_f32: unsupported shape c1=%d c2=%d %dx%d cout=%d", c1, c2, h, w, cout);
@@ -541,6 +606,10 @@ extern "C" int psld_conv3x3_wino_f32(const float* x1, int c1, const float* x2, i
     if (w == 64) {      // 4 x 32 pixel blocks: the 32x32 level's halo (6 x 34 = 204 pixels)
         a.cw = 32; a.rps = 4; a.nseg = 1;
         halo_px = 6 * 34;
+    }
+    if (gn) {
+        a.gsc1 = gn->sc1; a.gsh1 = gn->sh1; a.gsc2 = gn->sc2; a.gsh2 = gn->sh2; a.gn_act = gn->act;
+        return launch_wino8s<0, true>(a, stream, "psld_conv3x3_wino_gn_f32");
     }
 #ifdef PSLD_ABLATIONS      // libpsld_hip_abl.so only: the variants of conv_wino_abl.inc and the timing-only ablations (wrong results)
     {
@@ -605,3 +674,4 @@ extern "C" int psld_conv3x3_wino_f32(const float* x1, int c1, const float* x2, i
 #endif
     return launch_wino8s<0>(a, stream, name);
 }
+}  // namespace

@@ -260,6 +260,49 @@ def conv3x3_wino_wanted(c1: int, c2: int, b: int, h: int, w: int, cout: int) -> 
     return mode == 2 or (b * h * w // 128) * (cout // 128) >= 384
 
 
+@functools.lru_cache(maxsize=None)
+def conv3x3_wino_gn_supported(c1: int, c2: int, b: int, h: int, w: int, cout: int) -> bool:
+    return bool(lib().psld_conv3x3_wino_gn_supported(c1, c2, b, h, w, cout))
+
+
+_fused_gn_override: Optional[int] = None
+
+
+def set_fused_gn(mode: Optional[int]):
+    """Override ``PSLD_FUSED_GN`` for this process (None: back to the environment); see conv3x3_wino_gn_wanted."""
+    global _fused_gn_override
+    _fused_gn_override = mode
+    conv3x3_wino_gn_wanted.cache_clear()
+
+
+@functools.lru_cache(maxsize=None)
+def conv3x3_wino_gn_wanted(c1: int, c2: int, b: int, h: int, w: int, cout: int) -> bool:
+    """Should an inference-forward GroupNorm + SiLU + conv3x3 run as ONE launch (psld_conv3x3_wino_gn_f32)?  Only where the
+    convolution runs in Winograd form anyway; ``PSLD_FUSED_GN`` = 0: never, 1 (default): maps of at least 32x32, where the
+    pair measured 3-5 % shorter than apply pass + convolution at sampling batch sizes (on 16x16 the fused launch's extra
+    vector work costs what the apply pass saved: profiles/r04/wino_fused_gn.txt), 2: wherever the kernel takes the shape
+    (parity tests)."""
+    mode = _fused_gn_override if _fused_gn_override is not None else int(os.environ.get("PSLD_FUSED_GN", "1"))
+    if mode == 0 or not conv3x3_wino_wanted(c1, c2, b, h, w, cout) or not conv3x3_wino_gn_supported(c1, c2, b, h, w, cout):
+        return False
+    return mode == 2 or h * w >= 1024
+
+
+def conv3x3_wino_gn(x1: Tensor, st1: "GNStats", x2: Optional[Tensor], st2: Optional["GNStats"], act: bool, ufrag: Tensor,
+                    cout: int, y: Tensor, epi: Optional[Epilogue] = None):
+    """conv3x3_wino applied to act(GroupNorm(x)) with the apply pass inside the kernel's input staging: x1 / x2 are the
+    raw tensors, st1 / st2 their statistics (gn_stats / gn_stats_from_part).  Inference forward only (no dropout, the
+    activated tensor is not kept)."""
+    b, h, w, c1 = x1.shape
+    c2 = x2.shape[-1] if x2 is not None else 0
+    check(lib().psld_conv3x3_wino_gn_f32(x1.data_ptr(), c1, st1.scale.data_ptr(), st1.shift.data_ptr(), _p(x2), c2,
+                                         st2.scale.data_ptr() if st2 is not None else None,
+                                         st2.shift.data_ptr() if st2 is not None else None, 1 if act else 0, b, h, w,
+                                         ufrag.data_ptr(), cout, y.data_ptr(), y.shape[-1],
+                                         C.byref(epi) if epi is not None else None, _stream()),
+          "psld_conv3x3_wino_gn_f32")
+
+
 def conv3x3_wino(x1: Tensor, x2: Optional[Tensor], ufrag: Tensor, cout: int, y: Tensor,
                  epi: Optional[Epilogue] = None, ldy: Optional[int] = None):
     """conv3x3_split in Winograd F(2x2, 3x3) form (fp32 NHWC input(s), fragments of conv3x3_wino_frag)."""

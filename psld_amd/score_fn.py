@@ -593,16 +593,24 @@ class _Exec:
             ops.conv3x3_split_supported(cout, 0, b, ho_, wo_, cout) and \
             (not self.record or ops.conv3x3_wgrad_split_supported(cout, cout, b, ho_, wo_))
         apply0 = ops.gn_apply_limb if lp0 else ops.gn_apply
-        if xb is not None:
-            a0b = apply0(xb.v, st0b, True)
-        a0 = apply0(x.v, st0, True)
-        if up or down:
+        # Inference forward (no tape): GroupNorm's apply pass + SiLU run inside the Winograd convolution's input staging
+        # where that pays (ops.conv3x3_wino_gn_wanted) - the activated tensor is needed nowhere else
+        fuse0 = not self.record and not (up or down) and self.split and ops.conv3x3_wino_gn_wanted(c1, c2_, b, h, w, cout)
+        fuse1 = not self.record and self.split and self.drop_p == 0 and ops.conv3x3_wino_gn_wanted(cout, 0, b, ho_, wo_, cout)
+        a0 = None
+        if not fuse0:
+            if xb is not None:
+                a0b = apply0(xb.v, st0b, True)
+            a0 = apply0(x.v, st0, True)
+        if fuse0:
+            a0r, xr = None, x.v
+        elif up or down:
             a0r = self.resample(a0, up)
             xr = self.resample(x.v, up)
             del a0
         else:
             a0r, xr = a0, x.v
-        ho, wo = a0r.shape[1], a0r.shape[2]
+        ho, wo = ho_, wo_
         tp, tp_ld, tp_off = None, 0, None
         if self.temb_act is not None:
             tp_off = net._temb_offset(mod) if self.tp_all is not None else None
@@ -611,11 +619,13 @@ class _Exec:
             else:
                 tp = ops.linear(self.temb_act.v, mod.Dense_0.weight, mod.Dense_0.bias)
         h1 = torch.empty((b, ho, wo, cout), device=x.v.device, dtype=torch.float32)
-        c0_in2 = a0b.shape[-1] if a0b is not None else 0
-        h1p = self.part_for(b, ho * wo, cout, h1.device,
-                            ops.conv3x3_split_supported(a0r.shape[-1], c0_in2, b, ho, wo, cout))
-        self.conv3(a0r, mod.Conv_0, h1, ops.epilogue(bias=mod.Conv_0.bias, rowbias=tp, rows_per_img=ho * wo,
-                                                     ld_rowbias=tp_ld, gn_part=h1p, gn_hw=ho * wo), x2=a0b)
+        h1p = self.part_for(b, ho * wo, cout, h1.device, ops.conv3x3_split_supported(c1, c2_, b, ho, wo, cout))
+        epi0 = ops.epilogue(bias=mod.Conv_0.bias, rowbias=tp, rows_per_img=ho * wo, ld_rowbias=tp_ld, gn_part=h1p, gn_hw=ho * wo)
+        if fuse0:
+            ops.conv3x3_wino_gn(x.v, st0, xb.v if xb is not None else None, st0b, True, net._wfrag(mod.Conv_0, False), cout,
+                                h1, epi0)
+        else:
+            self.conv3(a0r, mod.Conv_0, h1, epi0, x2=a0b)
         st1 = self.node_stats(_Node(h1, h1p), gn1.weight, gn1.bias)
         drop_p, seed, seed_dev = 0.0, 0, None
         if self.drop_p > 0:
@@ -623,7 +633,8 @@ class _Exec:
             self.n_drop += 1
             seed = (self.n_drop * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF
             seed_dev = self.seed_dev
-        a1 = (ops.gn_apply_limb if lp1 else ops.gn_apply)(h1, st1, True, drop_p=drop_p, seed=seed, seed_dev=seed_dev)
+        a1 = None if fuse1 else \
+            (ops.gn_apply_limb if lp1 else ops.gn_apply)(h1, st1, True, drop_p=drop_p, seed=seed, seed_dev=seed_dev)
         out = torch.empty((b, ho, wo, cout), device=x.v.device, dtype=torch.float32)
         if mod.has_shortcut:
             c2 = mod.Conv_2
@@ -637,8 +648,11 @@ class _Exec:
         else:
             res = xr
         outp = self.part_for(b, ho * wo, cout, out.device, ops.conv3x3_split_supported(cout, 0, b, ho, wo, cout))
-        self.conv3(a1, mod.Conv_1, out, ops.epilogue(bias=mod.Conv_1.bias, residual=res, ld_residual=cout, out_scale=s,
-                                                     gn_part=outp, gn_hw=ho * wo))
+        epi1 = ops.epilogue(bias=mod.Conv_1.bias, residual=res, ld_residual=cout, out_scale=s, gn_part=outp, gn_hw=ho * wo)
+        if fuse1:
+            ops.conv3x3_wino_gn(h1, st1, None, None, True, net._wfrag(mod.Conv_1, False), cout, out, epi1)
+        else:
+            self.conv3(a1, mod.Conv_1, out, epi1)
         on = _Node(out, outp)
         if not self.record:
             return on

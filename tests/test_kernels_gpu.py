@@ -288,6 +288,51 @@ def test_conv3x3_wino_forward(ops, cfg):
     assert e < 3e-6 and e < 2.0 * max(ed, 2e-7)
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(b=2, c1=64, c2=32, co=128, h=16, w=16),     # two sources, each with its own statistics
+    dict(b=5, c1=96, c2=0, co=128, h=32, w=32),
+    dict(b=1, c1=32, c2=0, co=128, h=64, w=64),
+    dict(b=3, c1=256, c2=256, co=256, h=16, w=16),
+    dict(b=7, c1=256, c2=0, co=256, h=32, w=32),
+])
+@pytest.mark.parametrize("act", [True, False])
+def test_conv3x3_wino_fused_groupnorm(ops, cfg, act):
+    """psld_conv3x3_wino_gn_f32: GroupNorm apply (+SiLU) inside the Winograd kernel's input staging == the apply pass
+    followed by psld_conv3x3_wino_f32, bit for bit (same activation arithmetic, zero padding of the ACTIVATED tensor), and
+    within the kernel tolerance of fp64 GroupNorm + SiLU + conv.  Reference: GroupNorm_0/1 + act + Conv_0/1,
+    layerspp.py:245-263 in eval mode."""
+    b, c1, c2, co, h, w_ = (cfg[n] for n in ("b", "c1", "c2", "co", "h", "w"))
+    assert ops.conv3x3_wino_gn_supported(c1, c2, b, h, w_, co)
+    x = gen(b, c1 + c2, h, w_, seed=70) * 1.5 + 0.3
+    w = gen(co, c1 + c2, 3, 3, seed=71, scale=0.1)
+    bias, res = gen(co, seed=72), gen(b, co, h, w_, seed=73)
+    x1 = _nhwc(x[:, :c1]).to(DEV)
+    x2 = _nhwc(x[:, c1:]).to(DEV) if c2 else None
+    g1, b1 = (gen(c1, seed=74) * 0.2 + 1.0).to(DEV), (gen(c1, seed=75) * 0.1).to(DEV)
+    st1 = ops.gn_stats(x1, g1, b1)
+    st2 = None
+    if c2:
+        g2, b2 = (gen(c2, seed=76) * 0.2 + 1.0).to(DEV), (gen(c2, seed=77) * 0.1).to(DEV)
+        st2 = ops.gn_stats(x2, g2, b2)
+    uf = ops.conv3x3_wino_frag(w.to(DEV), False)
+    epi = ops.epilogue(bias=bias.to(DEV), residual=_nhwc(res).to(DEV), ld_residual=co, out_scale=0.7)
+    a1 = ops.gn_apply(x1, st1, act)
+    a2 = ops.gn_apply(x2, st2, act) if c2 else None
+    y_ref = torch.full((b, h, w_, co), float("nan"), device=DEV)
+    ops.conv3x3_wino(a1, a2, uf, co, y_ref, epi)
+    y = torch.full((b, h, w_, co), float("nan"), device=DEV)
+    ops.conv3x3_wino_gn(x1, st1, x2, st2, act, uf, co, y, epi)
+    assert torch.equal(y, y_ref)
+    # fp64: GroupNorm per source (its own groups), act, conv
+    def gn64(t, gamma, beta):
+        c = t.shape[1]
+        o = F.group_norm(t.double(), ops.gn_groups(c), gamma.double().cpu(), beta.double().cpu(), eps=1e-6)
+        return F.silu(o) if act else o
+    parts = [gn64(x[:, :c1], g1, b1)] + ([gn64(x[:, c1:], g2, b2)] if c2 else [])
+    ref = (F.conv2d(torch.cat(parts, 1), w.double(), bias.double(), padding=1) + res.double()) * 0.7
+    assert rel_l2(y.permute(0, 3, 1, 2), ref) < 5e-6
+
+
 def _wino_forward_errors(ops, cfg):
     b, c1, c2, co, h, w_ = (cfg[n] for n in ("b", "c1", "c2", "co", "h", "w"))
     assert ops.conv3x3_wino_supported(c1, c2, b, h, w_, co)

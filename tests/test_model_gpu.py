@@ -946,6 +946,34 @@ def test_bbode_sampler_against_scipy_oracle(tol):
     assert err < 1e-5
 
 
+@pytest.mark.parametrize("name", ["c10_sota", "celeba64"])
+def test_inference_forward_with_groupnorm_fused_into_the_winograd_staging(golden, name):
+    """The inference forward with GroupNorm apply + SiLU inside the Winograd convolutions' input staging
+    (psld_conv3x3_wino_gn_f32, every shape it takes: PSLD_FUSED_GN=2 on top of PSLD_WINOGRAD=2) is bit for bit the forward
+    with separate apply passes, and matches the reference golden.  layerspp.py:245-263 in eval mode."""
+    from psld_amd import ops
+    net, cfg, _ = _build(name)
+    g = golden(f"net_{name}.npz")
+    x, t = T(g["x"]).to(DEV), T(g["t"]).to(DEV)
+    try:
+        ops.set_winograd(2)
+        ops.set_fused_gn(0)
+        with torch.no_grad():
+            y0 = net(x, t)
+        ops.set_fused_gn(2)
+        with torch.no_grad():
+            y2 = net(x, t)
+        # with a tape (training forward) the fused form must not be taken: the backward needs the activated tensors
+        net.train()
+        y_tr = net(x, t)
+        y_tr.sum().backward()
+    finally:
+        ops.set_winograd(None)
+        ops.set_fused_gn(None)
+    assert torch.equal(y0, y2)
+    assert rel_l2(y2, T(g["y"])) < 2e-5
+
+
 @pytest.mark.parametrize("name,winograd", [("tiny", None), ("c10_sota", 2)])
 def test_hip_graph_forward_matches_eager_and_tracks_weight_updates(name, winograd):
     """Inference forward replayed from a captured HIP graph: bit-identical to the eager launch sequence,

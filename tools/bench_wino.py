@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--epi", default="res", help="epilogue of the timed launches: plain | bias | res (bias + residual + scale)")
+    ap.add_argument("--fused-gn", action="store_true", help="GroupNorm apply + SiLU: separate pass + convolution vs fused into the staging")
     ap.add_argument("--shapes", default="256,256,32;512,256,32;256,256,16;512,256,16;256,256,8")
     args = ap.parse_args()
     ops.lib()
@@ -102,6 +103,29 @@ def main():
         epi = (ops.epilogue() if args.epi == "plain" else ops.epilogue(bias=bias) if args.epi == "bias"
                else ops.epilogue(bias=bias, residual=res, ld_residual=cout, out_scale=0.7))
         y0, y1, y2 = (torch.empty(B, s, s, cout, device=DEV) for _ in range(3))
+        if args.fused_gn:
+            if not ops.conv3x3_wino_gn_supported(cin, 0, B, s, s, cout):
+                continue
+            gamma, beta = torch.rand(cin, device=DEV) + 0.5, torch.randn(cin, device=DEV) * 0.1
+            st = ops.gn_stats(x, gamma, beta)
+            act = torch.empty_like(x)
+            ya, yb = torch.empty(B, s, s, cout, device=DEV), torch.empty(B, s, s, cout, device=DEV)
+
+            def two_pass():
+                ops.gn_apply(x, st, True, out=act)
+                ops.conv3x3_wino(act, None, uf, cout, ya, epi)
+
+            fa, fb, fc = two_pass, (lambda: ops.conv3x3_wino_gn(x, st, None, None, True, uf, cout, yb, epi)), \
+                (lambda: ops.conv3x3_wino(act, None, uf, cout, ya, epi))
+            tt = [[], [], []]
+            for _ in range(args.rounds):
+                for i, f in enumerate((fa, fb, fc)):
+                    tt[i].append(timeit(f, args.iters))
+            ma, mb, mc = (sorted(t)[len(t) // 2] for t in tt)
+            print(f"conv fwd {cin}->{cout} @{s} B={B} GN+SiLU: apply pass + conv {ma * 1e6:7.1f} us (conv alone {mc * 1e6:7.1f})  "
+                  f"fused {mb * 1e6:7.1f} us  x{ma / mb:.3f} vs two passes, conv {mb / mc - 1:+.1%} per launch  bitwise equal: {torch.equal(ya, yb)}",
+                  flush=True)
+            continue
         xl = ops.f32_to_limb(x)
         fl = 2.0 * B * s * s * cout * 9 * cin
         fs = [lambda: ops.conv3x3_split(x, None, wf, cout, y0, epi), lambda: ops.conv3x3_split(xl, None, wf, cout, y1, epi),
