@@ -59,6 +59,7 @@ struct WinoArgs {
     // scale / shift rows of source 1 and 2 ([B][C1], [B][C2]: psld_gn_stats_*), act = 1: SiLU
     const float *gsc1, *gsh1, *gsc2, *gsh2;
     int gn_act;
+    unsigned long long* dbg;    // ablation library: s_memtime stamps of one chunk (ABL & 64), [workgroup][wave][8]
     int lg_tiles_x, lg_tps; // wino_conv8p_kernel: log2 of the tiles per tile row (cw / 2) and per image segment
 };
 
@@ -167,7 +168,12 @@ __global__ void wino_pack_batch_kernel(const long long* __restrict__ tab, int nt
 // transcendental per element, in a kernel that is short of vector issue slots - against the apply pass it replaces: 3-5 %
 // less time for the pair on the 32x32 level at B=512, nothing on 16x16.  Reference: GroupNorm_0/1 + act in front of
 // Conv_0/1, layerspp.py:245-263.
-template <int ABL = 0, bool GNF = false>
+// ERAW: the raw halo of chunk c + 1 is requested right after the MFMAs of HP1(c - 1) instead of at the head of HP0(c).
+// Vector-memory operations retire in issue order (one vmcnt): at the head of HP0 the four halo loads (HBM latency) sit in
+// front of every weight-fragment load of the half-phase, and the first s_waitcnt of the MFMA stream waits for them.
+// Issued behind the last fragment wait of the previous half-phase they have that phase's transform and the barrier to
+// land before anything younger is waited for.
+template <int ABL = 0, bool GNF = false, bool ERAW = false>
 __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NI = 4;                     // raw image: 256 halo pixels
@@ -355,27 +361,50 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArg
     load_b(0, bq[0]);
     load_b(1, bq[1]);
     store_raw(0, 0);
+    if constexpr (ERAW) load_raw(min(1, a.chunks - 1));
     __syncthreads();
     if (vr == 0) transform(I0{}, I0{}, 0); else transform(I0{}, I1{}, 0);      // V rows 0,1 of chunk 0
     __syncthreads();
 
+    // diagnostic build (ABL & 64): where a wave's time goes inside chunk 3 - stamps go to a buffer nothing else reads
+    auto stamp = [&](int c, int idx) {
+        if constexpr ((ABL & 64) != 0) {
+            if (c == 3 && a.dbg) {
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long t = __builtin_amdgcn_s_memtime();
+                if (lane == 0) a.dbg[((long long)blockIdx.x * 8 + wave) * 8 + idx] = t;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
     for (int c = 0; c < a.chunks; ++c) {
         // HP0: MFMAs on V rows 0,1 of chunk c || V rows 2,3 of chunk c (raw image c & 1)
-        load_raw(min(c + 1, a.chunks - 1));
+        stamp(c, 0);
+        if constexpr (!ERAW) load_raw(min(c + 1, a.chunks - 1));
         if (vr == 0 && !(ABL & 1)) transform(I1{}, I0{}, c & 1);             // waves 0-3: transform, then MFMAs
         __builtin_amdgcn_sched_barrier(0);
+        if (vr == 0) stamp(c, 1);
         mfma_half(I0{}, c);
         __builtin_amdgcn_sched_barrier(0);
+        if (vr != 0) stamp(c, 1);
         if (vr != 0 && !(ABL & 1)) transform(I1{}, I1{}, c & 1);             // waves 4-7: MFMAs, then transform
+        stamp(c, 2);
         store_raw((c + 1) & 1, min(c + 1, a.chunks - 1));
+        stamp(c, 3);
         __syncthreads();
         // HP1: MFMAs on V rows 2,3 of chunk c || V rows 0,1 of chunk c + 1 (raw image (c + 1) & 1; stale for the last chunk)
+        stamp(c, 4);
         if (vr == 0 && !(ABL & 1)) transform(I0{}, I0{}, (c + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
+        if (vr == 0) stamp(c, 5);
         mfma_half(I1{}, c);
         __builtin_amdgcn_sched_barrier(0);
+        if (vr != 0) stamp(c, 5);
+        if constexpr (ERAW) load_raw(min(c + 2, a.chunks - 1));
         if (vr != 0 && !(ABL & 1)) transform(I0{}, I1{}, (c + 1) & 1);
+        stamp(c, 6);
         __syncthreads();
+        stamp(c, 7);
     }
 
     // ---- output transform + fused epilogue (as wino_conv_kernel) -----------------------------------------------------
@@ -457,13 +486,13 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArg
 #include "conv_wino_abl.inc"
 #endif
 
-template <int ABL = 0, bool GNF = false>
+template <int ABL = 0, bool GNF = false, bool ERAW = false>
 int launch_wino8s(const WinoArgs& a, hipStream_t stream, const char* name) {
     constexpr size_t LDS = (size_t)VBYTES + 2 * (size_t)4 * 64 * 128;
     static_assert(LDS <= 163840, "LDS budget");
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv8s_kernel<ABL, GNF>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv8s_kernel<ABL, GNF, ERAW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         if (e != hipSuccess) {
             psld_set_error("%s: hipFuncSetAttribute failed: %s", name, hipGetErrorString(e));
@@ -472,7 +501,7 @@ int launch_wino8s(const WinoArgs& a, hipStream_t stream, const char* name) {
         configured = true;
     }
     dim3 grid((unsigned)(cdiv(a.M, 128) * (a.N / 128)));
-    hipLaunchKernelGGL((wino_conv8s_kernel<ABL, GNF>), grid, dim3(WINO_THREADS), LDS, stream, a);
+    hipLaunchKernelGGL((wino_conv8s_kernel<ABL, GNF, ERAW>), grid, dim3(WINO_THREADS), LDS, stream, a);
     PSLD_CHECK_LAUNCH(name);
     return PSLD_OK;
 }
@@ -541,6 +570,12 @@ extern "C" int psld_pack_wino_batch(const long long* table_dev, int entries, lon
     PSLD_CHECK_LAUNCH("psld_pack_wino_batch");
     return PSLD_OK;
 }
+
+#ifdef PSLD_ABLATIONS
+static unsigned long long* g_wino_dbg = nullptr;
+// ablation library only: device buffer for the s_memtime stamps of PSLD_WINO_ABL=64 ([workgroups][8 waves][8] uint64)
+extern "C" void psld_abl_set_wino_debug(unsigned long long* p) { g_wino_dbg = p; }
+#endif
 
 namespace {
 struct WinoGn {
@@ -622,6 +657,25 @@ int wino_conv(const float* x1, int c1, const float* x2, int c2, int batch, int h
         static const int persist = [] { const char* v = getenv("PSLD_WINO_PERSIST"); return v ? atoi(v) : 0; }();
         static const int stg = [] { const char* v = getenv("PSLD_WINO_STAGGER"); return v ? atoi(v) : 0; }();
         static const int la = [] { const char* v = getenv("PSLD_WINO_LA"); return v ? atoi(v) : 2; }();
+        static const int eraw = [] { const char* v = getenv("PSLD_WINO_ERAW"); return v ? atoi(v) : 0; }();
+        static const int qk = [] { const char* v = getenv("PSLD_WINO_Q"); return v ? atoi(v) : 0; }();
+        if (qk) {
+            if (abl == 1) return launch_wino8q<1>(a, stream, name);
+            if (abl == 2) return launch_wino8q<2>(a, stream, name);
+            if (abl == 3) return launch_wino8q<3>(a, stream, name);
+            return launch_wino8q<0>(a, stream, name);
+        }
+        if (w4 == 2 && abl >= 64) {     // stamped diagnostic builds: plain | no transforms | weights loaded once | both
+            a.dbg = g_wino_dbg;
+            if (abl == 65) return launch_wino8s<65>(a, stream, name);
+            if (abl == 66) return launch_wino8s<66>(a, stream, name);
+            if (abl == 67) return launch_wino8s<67>(a, stream, name);
+            return launch_wino8s<64>(a, stream, name);
+        }
+        if (w4 == 2 && eraw && !persist) {
+            if (abl == 2) return launch_wino8s<2, false, true>(a, stream, name);
+            return launch_wino8s<0, false, true>(a, stream, name);
+        }
         if (w4 == 2) {
             a.tiles_m = cdiv(a.M, 128);
             a.stagger = stg;
