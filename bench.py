@@ -306,27 +306,73 @@ def reduce_sampling(res, rank: int, world: int, on_dev: bool, dev, shard):
     return out
 
 
-def pmc_traffic_record():
-    """HBM bytes per launch of the dominant convolution from the committed PMC passes (profiles/r03/pmc_traffic.json,
-    written by tools/pmc_traffic.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs).  The record carries the hash of
-    the kernel sources it was measured on; a record measured on other sources is refused (traffic = null)."""
+def _guarded_record(name):
+    """A committed profile record (profiles/r04/<name>, else profiles/r03/<name>) that carries the hash of the kernel
+    sources it was measured on; a record measured on other sources is refused."""
     import hashlib
-    path = os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")
-    try:
-        with open(path) as fh:
-            rec = json.load(fh)
-    except Exception:  # noqa: BLE001
-        return None, "no PMC record (profiles/r03/pmc_traffic.json)"
+    rec, path = None, None
+    for rnd in ("r04", "r03"):
+        path = os.path.join(ROOT, "profiles", rnd, name)
+        try:
+            with open(path) as fh:
+                rec = json.load(fh)
+            break
+        except Exception:  # noqa: BLE001
+            continue
+    if rec is None:
+        return None, f"no record (profiles/r04/{name})"
     h = hashlib.sha256()
     for f in rec.get("sources", []):
         try:
             with open(os.path.join(ROOT, f), "rb") as fh:
                 h.update(fh.read())
         except OSError:
-            return None, f"PMC record names a missing source file {f}"
+            return None, f"{path} names a missing source file {f}"
     if h.hexdigest() != rec.get("sources_sha256"):
-        return None, "PMC record is stale: the kernel sources changed since it was measured (re-run tools/pmc_traffic.py)"
+        return None, f"{os.path.relpath(path, ROOT)} is stale: the kernel sources changed since it was measured"
+    rec["_path"] = os.path.relpath(path, ROOT)
     return rec, None
+
+
+def pmc_traffic_record():
+    """HBM bytes per launch of the dominant convolution from the committed PMC passes (pmc_traffic.json, written by
+    tools/pmc_traffic.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs)."""
+    return _guarded_record("pmc_traffic.json")
+
+
+def hbm_in_situ_record():
+    """Byte-weighted HBM rate of the bandwidth-bound kernels INSIDE the B=128 training step (hbm_in_situ.json, written by
+    tools/hbm_in_situ.py: algorithmic bytes from the launch arguments / rocprofv3 kernel durations of the same process)."""
+    return _guarded_record("hbm_in_situ.json")
+
+
+def forward_block(net, dev, batch, size, steps=5):
+    """SURVEY 8(d) 'Which roofline': the end-to-end eval forward at the training batch on BOTH axes - algorithmic FLOPs
+    against the 416.7 TFLOP/s ceiling of the limb algorithm and the fused plan's compulsory bytes (176.3 MB per image at
+    B=128) against 8 TB/s - timed with HIP events on the launch stream."""
+    was_training = net.training
+    net.eval()
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn(batch, 6, size, size, device=dev, generator=g)
+    t = torch.rand(batch, device=dev, generator=g) * 0.98 + 0.01
+    with torch.no_grad():
+        for _ in range(2):
+            net(x, t)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            net(x, t)
+        e1.record()
+        torch.cuda.synchronize()
+    net.train(was_training)
+    dt = e0.elapsed_time(e1) * 1e-3 / steps
+    fl, by = 76.46e9 * batch, (173.2e6 + 390.5e6 / batch) * batch
+    return {"batch": batch, "ms": dt * 1e3, "images_per_s": batch / dt, "tflops": fl / dt / 1e12,
+            "frac_of_limb_mfma_ceiling": fl / dt / 1e12 / (PEAK_BF16_MFMA_TFLOPS / LIMB_PRODUCTS),
+            "compulsory_bytes": by, "gb_per_s": by / dt / 1e9, "frac_of_hbm_8tbs": by / dt / 8.0e12,
+            "note": "eval forward, HIP events; 76.46 GFLOP and 173.2 MB + weights / B of compulsory traffic per image (SURVEY 8(d)): "
+                    "the forward is compute-bound (434 FLOP/B), the HBM line is met per bandwidth-bound kernel (roofline.hbm_bound_*)"}
 
 
 def parse_args():
@@ -549,6 +595,9 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         in_sync = bool(lo.item() == hi.item())
 
+    fwd_blk = None
+    if rank == 0 and not args.launch_check and torch.cuda.is_available() and args.config == "c10_sota":
+        fwd_blk = forward_block(net, dev, args.batch, size)
     sampling = None
     if args.sample_batch > 0 and args.config == "c10_sota":
         # second half of the metric: EVERY rank samples one batch of its own shard at the same time (eval/sample.py:100-109)
@@ -595,6 +644,7 @@ def main():
         pw, pd = probe.summary("wino"), probe.summary("split")
         pt = probe.summary("tile")
         pmc, pmc_err = pmc_traffic_record()
+        hbm, hbm_err = hbm_in_situ_record()
         if ps is not None:
             peak = PEAK_BF16_MFMA_TFLOPS / LIMB_PRODUCTS
             issued = ((pw["total_flop"] / 2.25 if pw else 0.0) + (pd["total_flop"] if pd else 0.0)) * LIMB_PRODUCTS / (ps["total_ms"] * 1e-3) / 1e12
@@ -615,8 +665,14 @@ def main():
                               "share_of_step": pw["total_ms"] / (1e3 * dt)} if pw else None),
                 "direct": ({"tflops": pd["tflops"], "launches": pd["launches"], "avg_launch_us": pd["avg_us"],
                             "share_of_step": pd["total_ms"] / (1e3 * dt)} if pd else None),
+                "frac_of_dense_bf16_peak": issued / PEAK_BF16_MFMA_TFLOPS,
                 "traffic": pmc.get("traffic_bytes") if pmc else None,
                 "traffic_note": pmc.get("note") if pmc else pmc_err,
+                "hbm_bound_aggregate_frac": hbm.get("hbm_bound_aggregate_frac") if hbm else None,
+                "hbm_bound_under_0.6": hbm.get("under_0.6") if hbm else None,
+                "hbm_bound_note": (f"{hbm['_path']}: {hbm['aggregate_gb_per_s']:.0f} GB/s byte-weighted over the bandwidth-bound kernels of "
+                                   f"the B=128 step ({hbm['bytes_per_step'] / 1e9:.1f} GB algorithmic in {hbm['ms_per_step']:.1f} ms per step)")
+                if hbm else hbm_err,
                 "launches": ps["launches"], "avg_launch_us": ps["avg_us"],
                 "share_of_step": ps["total_ms"] / (1e3 * dt)}
         elif pt is not None:        # PSLD_MATH=f32: the fp32 MFMA tile engine carries the convolutions
@@ -637,6 +693,8 @@ def main():
             out["metric"] = out["metric"].replace("CIFAR-10 PSLD (6ch 32x32)", f"{args.config} (6ch {size}x{size})")
             out["config"]["workload"] = f"{args.config} NCSN++ full HSM train step"
             out["config"]["image"] = f"6x{size}x{size}"
+        if fwd_blk is not None:
+            out["forward"] = fwd_blk
         if sampling is not None:
             out["sampling"] = sampling
         out["cpu_baseline"] = cpu_base

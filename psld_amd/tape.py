@@ -1,6 +1,6 @@
 """Launch tape: record the kernel launches of one training step, replay them from C.
 
-At the reference's per-GPU batch of 16 (scripts_psld/training_scripts/cifar10/.../train_uncond_psld.sh:25-30) the step
+At the reference's per-GPU batch of 16 (scripts_psld/sota/uncond/cifar10/train_uncond_psld.sh:25-30) the step
 is ~2700 launches and the Python executor needs longer to issue them (~11 us each) than the GPU needs to run them.  A
 hipGraph of the step removes the host cost but serialises: a cross-stream edge costs 3.5 us inside a graph and the
 weight-gradient side stream overlaps almost nothing there.  The tape keeps the launches ordinary:

@@ -168,6 +168,55 @@ def test_train_forward_backward_at_full_batch_equals_its_slices(golden, name, ba
     assert np.isfinite(lfull) and el < 2e-6 and eg2 < 1e-5
 
 
+def test_headline_configuration_with_dropout_is_repeatable_and_linear_in_the_batch():
+    """The exact bench configuration (configs[1]: C10-SOTA, B=128, dropout 0.15, default Winograd policy: the 32x32 / 16x16
+    convolutions in Winograd form, GroupNorm partial sums from their epilogues, dropout inside GroupNorm_1's apply pass).
+    The dropout mask is a function of (seed, element index), so with the same seed word (a) two passes are bitwise equal -
+    output and all 97.6 M gradients - and (b) the images do not couple: the gradient of sum(y * w) equals the sum of the
+    gradients of the two half-batch objectives (w zeroed on the other half), each from its own full-batch pass with the
+    SAME masks.  (The same network at dropout 0 is pinned against the direct kernels and the reference golden above.)"""
+    net, cfg, _ = _build("c10_sota", train=True)
+    assert abs(net.sf.dropout - 0.15) < 1e-12 and cfg.model.score_fn.dropout == 0.15
+    batch = 128
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(batch, 6, 32, 32, device=DEV, generator=gen)
+    t = torch.rand(batch, device=DEV, generator=gen) * 0.98 + 0.01
+    w = torch.randn(batch, 6, 32, 32, device=DEV, generator=gen)
+    seed_word = torch.tensor([0x1234567], dtype=torch.int64, device=DEV)
+
+    def run(ws):
+        for p in net.parameters():
+            p.grad = None
+        net.mark_grads_stale()
+        net._dropout_seed_dev = seed_word            # the per-step seed word a captured training step supplies
+        try:
+            y = net(x, t)
+            (y * ws).sum().backward()
+        finally:
+            net._dropout_seed_dev = None
+        return y.detach().clone(), net.flat_grad().clone()
+
+    y1, g1 = run(w)
+    y2, g2 = run(w)
+    assert bool(torch.isfinite(y1).all()) and bool(torch.isfinite(g1).all())
+    assert torch.equal(y1, y2) and torch.equal(g1, g2)
+    # dropout really is on: the eval forward differs
+    net.eval()
+    with torch.no_grad():
+        ye = net(x, t)
+    net.train()
+    assert rel_l2(y1, ye) > 1e-2
+    wa, wb = w.clone(), w.clone()
+    wa[batch // 2:] = 0
+    wb[:batch // 2] = 0
+    ya, ga = run(wa)
+    yb, gb = run(wb)
+    assert torch.equal(ya, y1) and torch.equal(yb, y1)
+    e = ((g1.double() - (ga.double() + gb.double())).norm() / g1.double().norm()).item()
+    print(f"B=128 dropout 0.15: gradient vs sum of the two half-batch objectives {e:.3e}")
+    assert e < 5e-6
+
+
 def test_taped_training_step_on_c10_sota_is_bitwise_the_eager_step():
     """configs[1]'s network at the reference's per-GPU batch of 16 (train_uncond_psld.sh:25-30): the launch-tape step
     (SDEWrapper.enable_graphs(tape=True): ~1700 launches + the side-stream edges replayed by psld_tape_replay) against

@@ -1,4 +1,4 @@
-"""HBM traffic per launch of the dominant convolution from rocprofv3 PMC passes -> profiles/r03/pmc_traffic.json
+"""HBM traffic per launch of the dominant convolution from rocprofv3 PMC passes -> profiles/r04/pmc_traffic.json
 (read by bench.py for roofline.traffic, which refuses it once the kernel sources change).  Round 3: the dominant launch
 is the Winograd kernel (wino_conv8s_kernel); the direct kernel and the weight gradient are recorded next to it.
 
@@ -66,7 +66,7 @@ def main():
         "ratio": (fetch_b + write_b) / algo,
         "sources": SOURCES, "sources_sha256": sources_sha(),
         "note": f"HBM bytes/launch of the conv3x3 256->256 @32x32 B=128 Winograd launch (PMC FETCH_SIZE x2 + WRITE_SIZE, "
-                f"round-3 build): {(fetch_b + write_b) / 1e6:.1f} MB vs {algo / 1e6:.1f} MB algorithmic "
+                f"this build): {(fetch_b + write_b) / 1e6:.1f} MB vs {algo / 1e6:.1f} MB algorithmic "
                 f"(input 134.2 + residual 134.2 + output 134.2 + Winograd limb fragments 6.3)",
     }
     for tag, label in (("dconv", "dconv_lp_kernel (direct, limb-plane input, same shape and epilogue)"),
@@ -74,7 +74,7 @@ def main():
                        ("dwgrad", "dwgrad_kernel<4> 256->256 @32x32 B=128")):
         if tag in fetch and tag in write:
             rec[label] = {"fetch_bytes_corrected": fetch[tag][0] * 2048, "write_bytes": write[tag][0] * 1024}
-    path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r03", "pmc_traffic.json")
+    path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r04", "pmc_traffic.json")
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "w") as fh:
         json.dump(rec, fh, indent=1)
