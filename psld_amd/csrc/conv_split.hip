@@ -1055,6 +1055,200 @@ __global__ void __launch_bounds__(256, CB == 2 ? 3 : 2) dwgrad_kernel(const DWgr
                 }
 }
 
+// ---- weight gradient, wave-specialised ---------------------------------------------------------------
+// The same 128 (c_out) x 64 (c_in) x 3-tap tile and the same staged images as dwgrad_kernel<4, false>, but in a 512-thread
+// workgroup whose waves 4-7 do nothing but load, split3 and ds_write the NEXT K tile's limb images while waves 0-3 issue
+// only transposed LDS reads and MFMAs on the current one: two images, ONE barrier per K tile, the raw rows of the tile after
+// next in the producers' registers.  Per SIMD one consumer and one producer wave instead of two waves that each alternate
+// between the two kinds of work.  Same products in the same order per output element: bitwise dwgrad_kernel.
+// Measured (profiles/r04/ab_dwgrad_specialised.txt, B=128, same box, alternating): 256->256 @32 226 -> 239, 512->256 @32
+// 228 -> 234, 256->256 @16 230 -> 240, 512->256 @16 231 -> 246 TFLOP/s (+3-7 %), 8x8 unchanged; faster than the limb-plane-x
+// form of the old kernel.  A second register set in the producers (three tiles ahead) and s_setprio 1 for the consumers:
+// no further change - a consumer wave needs ~4,000 cycles per K tile where its 144 MFMAs take 2,304: what is exposed is
+// the LDS latency of its 60 transposed fragment reads behind each barrier (no second fragment set fits beside 96
+// accumulators + 72 fragment registers), not the producers.
+__global__ void __launch_bounds__(512) dwgrad_ws_kernel(const DWgradArgs a) {
+    constexpr int CB = 4;
+    constexpr int CO_T = 32 * CB;
+    constexpr int RSA = CO_T * 2 + 32;           // 288
+    constexpr int ALIMB = WG_AROWS * RSA;
+    constexpr int IMG = 3 * (ALIMB + WG_BLIMB);  // one image pair (dy | x)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int tiles = a.cout_tiles * a.cin_tiles;
+    const int vid = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = vid / (tiles * 3);
+    const int rest = vid - split * tiles * 3;
+    const int ky = rest / tiles, tile = rest - ky * tiles;
+    const int co0 = (tile / a.cin_tiles) * CO_T;
+    const int ci_out = (tile % a.cin_tiles) * 64;
+    const int kt_beg = split * a.ktiles_per_split;
+    const int kt_end = min(a.ktiles, kt_beg + a.ktiles_per_split);
+    const int nkt = kt_end - kt_beg;
+
+    // The two roles are two disjoint code paths with the same number of barriers (one before the loop, one per K tile):
+    // their registers do not add up.
+    if (wave >= 4) {
+        // ---- producers: thread pt stages what thread pt of dwgrad_kernel stages ---------------------------------------------
+        const bool second = ci_out >= a.cin;
+        const float* xsrc = second ? a.x2 : a.x;
+        const int xc = second ? a.cin2 : a.cin;
+        const int ci0 = second ? ci_out - a.cin : ci_out;
+        const int HW = a.H * a.W;
+        const int pt = tid & 255;
+        const int qa = pt & 15, ra = pt >> 4;
+        unsigned xoff[WG_NB];
+        int xmeta[WG_NB];
+#pragma unroll
+        for (int i = 0; i < WG_NB; ++i) {
+            const int px = ra + 16 * i;
+            const int hr = px / a.hw_w, hc = px - hr * a.hw_w;
+            xoff[i] = (unsigned)(((hr * a.W + hc) * xc + qa * 4) * 4);
+            xmeta[i] = (hr < a.hrows ? hr : 31) | ((hc >= 1 && hc <= a.W) ? 32 : 0) | ((hc + 31 < a.W) ? 64 : 0);
+        }
+        unsigned aoff[CB];
+#pragma unroll
+        for (int i = 0; i < CB; ++i) aoff[i] = (unsigned)(((ra + 16 * (i & 1)) * a.lddy + (qa + 16 * (i >> 1)) * 4) * 4);
+        f32x4 va[CB], vb[WG_NB];
+        auto load_tile = [&](int kt) {
+            const int p0 = kt * 32;
+            const int img = p0 / HW;
+            const int rem = p0 - img * HW;
+            const int oy0 = rem / a.W, ox0 = rem - oy0 * a.W;
+            const int iy0 = oy0 + ky - 1;
+            unsigned rowmask = 0;
+            for (int rr = 0; rr < a.hrows; ++rr) rowmask |= (iy0 + rr >= 0 && iy0 + rr < a.H) ? 1u << rr : 0u;
+            const int colsel = 5 + (ox0 >> 5);
+            const unsigned char* xb8 = reinterpret_cast<const unsigned char*>(xsrc) + ((long long)((img * a.H + iy0) * a.W + ox0 - 1) * xc + ci0) * 4;
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(xb8), 0, 0x7fffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(a.dy + ((long long)p0 * a.lddy + co0)), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < CB; ++i) va[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, aoff[i], 0, 0));
+#pragma unroll
+            for (int i = 0; i < WG_NB; ++i) {
+                const bool ok = ((rowmask >> (xmeta[i] & 31)) & (unsigned)(xmeta[i] >> colsel) & 1u) != 0;
+                vb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? xoff[i] : 0xffffffffu, 0, 0));
+            }
+        };
+        auto store_rows = [&](unsigned char* d, int limb_stride, const f32x4& v) {
+            unsigned h0, m0, l0, h1, m1, l1;
+            split3(v[0], v[1], h0, m0, l0);
+            split3(v[2], v[3], h1, m1, l1);
+            *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(d + limb_stride) = u32x2{m0, m1};
+            *reinterpret_cast<u32x2*>(d + 2 * limb_stride) = u32x2{l0, l1};
+        };
+        auto store_tile = [&](int buf) {
+            unsigned char* As = smem + buf * IMG;
+            unsigned char* Bs = As + 3 * ALIMB;
+#pragma unroll
+            for (int i = 0; i < CB; ++i) store_rows(As + (ra + 16 * (i & 1)) * RSA + (qa + 16 * (i >> 1)) * 8, ALIMB, va[i]);
+#pragma unroll
+            for (int i = 0; i < WG_NB; ++i) store_rows(Bs + (ra + 16 * i) * WG_RS + qa * 8, WG_BLIMB, vb[i]);
+        };
+        // the raw rows of tile i + 2 are in flight while tile i + 1 is split and stored (a second register set, i.e. three
+        // tiles ahead, measured no different: the consumers, not the producers, set the pace)
+        if (nkt > 0) {
+            load_tile(kt_beg);
+            store_tile(0);
+            if (nkt > 1) load_tile(kt_beg + 1);
+        }
+        __syncthreads();
+        for (int i = 0; i < nkt; ++i) {
+            if (i + 1 < nkt) store_tile((i + 1) & 1);       // everyone left that image at the last barrier
+            if (i + 2 < nkt) load_tile(kt_beg + i + 2);
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---- consumers: dwgrad_kernel's wave tile (64 c_out x 32 c_in x 3 taps) and lane roles -----------------------------------
+    const int wr = wave >> 1, wc = wave & 1;
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3;
+    int a_base[2], b_base[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = 4 * g + 16 * j + q;
+        a_base[j] = k * RSA + (wr * 16 * CB + 4 * p4) * 2;
+        const int ry = a.W >= 32 ? 0 : k / a.W;
+        const int ox = a.W >= 32 ? k : k - ry * a.W;
+        b_base[j] = (ry * a.hw_w + ox) * WG_RS + (wc * 32 + 4 * p4) * 2;
+    }
+    auto frag = [&](const unsigned char* img, const int (&base)[2], int off) -> u32x4 {
+        const u32x2 lo = lds_tr16(img + base[0] + off), hi = lds_tr16(img + base[1] + off);
+        return u32x4{lo[0], lo[1], hi[0], hi[1]};
+    };
+    f32x4v acc[3][CB][2];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < CB; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    for (int i = 0; i < nkt; ++i) {
+        const unsigned char* As = smem + (i & 1) * IMG;
+        const unsigned char* Bs = As + 3 * ALIMB;
+        u32x4 fa[CB][3];
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) fa[cb][l] = frag(As, a_base, l * ALIMB + cb * 32);
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+            u32x4 fb[2][3];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int l = 0; l < 3; ++l) fb[nb][l] = frag(Bs, b_base, l * WG_BLIMB + nb * 32 + tx * WG_RS);
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int u = 0; u < 6; ++u)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+                        acc[tx][cb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, fa[cb][PA[u]]), __builtin_bit_cast(bf16x8, fb[nb][PB[u]]),
+                            acc[tx][cb][nb], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    float* S = a.slabs + (long long)split * a.slab_stride;
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int co = co0 + wr * 16 * CB + cb * 16 + 4 * g + v;
+                    S[((long long)co * 9 + ky * 3 + tx) * a.ld_tap + ci_out + wc * 32 + nb * 16 + i16] = acc[tx][cb][nb][v];
+                }
+}
+
+int launch_dwgrad_ws(const DWgradArgs& a, int nsplit, hipStream_t stream) {
+    constexpr size_t LDS = (size_t)2 * 3 * (WG_AROWS * (64 * 4 + 32) + WG_BLIMB);
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dwgrad_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        if (e != hipSuccess) {
+            psld_set_error("psld_conv3x3_wgrad_split_f32: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+            return PSLD_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL(dwgrad_ws_kernel, dim3((unsigned)(a.cout_tiles * a.cin_tiles * 3 * nsplit)), dim3(512), LDS, stream, a);
+    PSLD_CHECK_LAUNCH("psld_conv3x3_wgrad_split_f32");
+    return PSLD_OK;
+}
+
 // ---- pointwise weight gradient (TN GEMM) ---------------------------------------------------------------------
 // C[i][j] = sum_p A[p][i] * B[p][j]: the weight gradient of a 1x1 convolution / NIN projection (A = dy, B = x or the
 // other way round for NIN's [in][out] weights).  Same machinery as dwgrad_kernel without the halo: a workgroup owns
@@ -1882,6 +2076,8 @@ extern "C" int psld_conv3x3_wgrad_split_f32(const float* dy, int lddy, int cout,
     a.hw_w = (w < 32 ? w : 32) + 2;
     a.hrows = w >= 32 ? 1 : 32 / w;
 #ifdef PSLD_ABLATIONS      // timing-only variants (wrong results): libpsld_hip_abl.so only (make abl), never the product library
+    static const int ws = [] { const char* v = getenv("PSLD_DWGRAD_WS"); return v ? atoi(v) : 1; }();
+    if (!ws && co_tile == 128) return launch_dwgrad<4, false>(a, nsplit, stream);     // round 3's kernel, for A/B
     static const int abl = [] { const char* v = getenv("PSLD_DWGRAD_ABL"); return v ? atoi(v) : 0; }();
     if (abl && co_tile == 128) {
         switch (abl) {
@@ -1893,7 +2089,8 @@ extern "C" int psld_conv3x3_wgrad_split_f32(const float* dy, int lddy, int cout,
         }
     }
 #endif
-    return co_tile == 128 ? launch_dwgrad<4, false>(a, nsplit, stream) : launch_dwgrad<2, false>(a, nsplit, stream);
+    // 128-channel tiles: the wave-specialised kernel (512 threads, one workgroup per CU)
+    return co_tile == 128 ? launch_dwgrad_ws(a, nsplit, stream) : launch_dwgrad<2, false>(a, nsplit, stream);
 }
 
 extern "C" int psld_conv3x3_wgrad_xlimb_f32(const float* dy, int lddy, int cout, const void* x_limb, int cin,

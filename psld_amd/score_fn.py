@@ -306,10 +306,11 @@ class _Exec:
                 ops.conv3x3_wgrad_split_supported(cout, c1, b, oh, ow) and \
                 (x2 is None or ops.conv3x3_wgrad_split_supported(cout, c2, b, oh, ow)):
             ktiles = b * oh * ow // 32
-            # 64x64 tiles x 3 filter rows, 3 workgroups (46 KB LDS) resident per CU
+            # resident workgroups: 64-channel tiles 3 per CU (46 KB LDS); 128-channel tiles 2 per CU with x as limb planes
+            # (dwgrad_kernel<4, true>), ONE 512-thread workgroup per CU for fp32 x (the wave-specialised dwgrad_ws_kernel)
             co_tile = ops.conv3x3_wgrad_split_cout_tile(cout)
-            nsplit = _pick_nsplit((cout // co_tile) * (cin // 64) * 3, ktiles * 32, min_k=128,
-                                  resident=768 if co_tile == 64 else 512)
+            resident = 768 if co_tile == 64 else (512 if isinstance(x, ops.LimbPlanes) else 256)
+            nsplit = _pick_nsplit((cout // co_tile) * (cin // 64) * 3, ktiles * 32, min_k=128, resident=resident)
             per = -(-ktiles // nsplit)
             nsplit = -(-ktiles // per)                 # every slab non-empty
             slabs = ops.workspace(4 * n * nsplit, dy.device)
