@@ -1065,8 +1065,9 @@ __global__ void __launch_bounds__(256, CB == 2 ? 3 : 2) dwgrad_kernel(const DWgr
 // 228 -> 234, 256->256 @16 230 -> 240, 512->256 @16 231 -> 246 TFLOP/s (+3-7 %), 8x8 unchanged; faster than the limb-plane-x
 // form of the old kernel.  A second register set in the producers (three tiles ahead) and s_setprio 1 for the consumers:
 // no further change - a consumer wave needs ~4,000 cycles per K tile where its 144 MFMAs take 2,304: what is exposed is
-// the LDS latency of its 60 transposed fragment reads behind each barrier (no second fragment set fits beside 96
-// accumulators + 72 fragment registers), not the producers.
+// the LDS latency of its 60 transposed fragment reads behind each barrier, not the producers.  Reading the next tile's
+// first fragments before the barrier (three images, producers two tiles ahead) was built too: with 6 of the 30 fragments
+// 219 TFLOP/s (248 VGPRs; the fenced schedule costs more than the latency it hides), with 12 it spills (134).
 __global__ void __launch_bounds__(512) dwgrad_ws_kernel(const DWgradArgs a) {
     constexpr int CB = 4;
     constexpr int CO_T = 32 * CB;
