@@ -383,6 +383,7 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
+    ap.add_argument("--no-forward", action="store_true", help="skip the eval-forward block (kernel-stats profiles of the training steps only)")
     ap.add_argument("--bucket-mb", type=int, default=64)
     ap.add_argument("--config", default="c10_sota", choices=["c10_sota", "celeba64_sota"],
                     help="c10_sota = BASELINE.json configs[0..2] (headline); celeba64_sota = configs[3] (extra data point)")
@@ -596,7 +597,7 @@ def main():
         in_sync = bool(lo.item() == hi.item())
 
     fwd_blk = None
-    if rank == 0 and not args.launch_check and torch.cuda.is_available() and args.config == "c10_sota":
+    if rank == 0 and not args.launch_check and not args.no_forward and torch.cuda.is_available() and args.config == "c10_sota":
         fwd_blk = forward_block(net, dev, args.batch, size)
     sampling = None
     if args.sample_batch > 0 and args.config == "c10_sota":

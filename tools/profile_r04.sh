@@ -23,7 +23,7 @@ find $OUT/hbm_prof -name "*kernel_stats.csv" -exec cp {} $OUT/hbm_step_kernel_st
 rm -rf $OUT/hbm_prof
 cp $OUT/hbm_in_situ.json $OUT/hbm_in_situ.md $ROOT/profiles/r04/ 2>/dev/null
 # 4. per-kernel totals of the bench's training steps and of the sampling forward
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_step -o step -- python3 $ROOT/bench.py --steps 8 --warmup 3 --sample-batch 0 --no-cpu-baseline > $OUT/bench_train_b128_profiled_run.json 2> $OUT/prof_step.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_step -o step -- python3 $ROOT/bench.py --steps 6 --warmup 2 --sample-batch 0 --no-cpu-baseline --no-forward > $OUT/bench_train_b128_profiled_run.json 2> $OUT/prof_step.err
 find $OUT/prof_step -name "*kernel_stats.csv" -exec cp {} $OUT/bench_train_b128_kernel_stats.csv \;
 rm -rf $OUT/prof_step
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_sample -o sample -- python3 $ROOT/tools/profile_sample.py > $OUT/prof_sample.log 2>&1
