@@ -3,7 +3,7 @@
 At the reference's per-GPU batch of 16 (scripts_psld/sota/uncond/cifar10/train_uncond_psld.sh:25-30) the step
 is ~2700 launches and the Python executor needs longer to issue them (~11 us each) than the GPU needs to run them.  A
 hipGraph of the step removes the host cost but serialises: a cross-stream edge costs 3.5 us inside a graph and the
-weight-gradient side stream overlaps almost nothing there.  The tape keeps the launches ordinary:
+weight-gradient side stream overlaps almost nothing there (profiles/r02/README.md).  The tape keeps the launches ordinary:
 
 * recording happens while ``SDEWrapper`` runs the step once under stream capture (wrapper.py ``_graphed_step``), so every
   buffer the step allocates comes from the capture's private pool and keeps its address for as long as the graph object
