@@ -68,6 +68,7 @@ class LaunchTape:
         self.aten_ops: List[str] = []
         self.aten_outputs: List[tuple] = []   # (label, output tensors) of the functional ATen ops (debugging aid)
         self.stream = None                    # torch stream the step was recorded on (its compute stream)
+        self._streams: set = set()            # that stream and every stream an edge has forked to / joined from
         self._failed = C.c_int(-1)
         self.through_stubs = False            # tests: execute every recorded launch through its C stub while recording
 
@@ -108,10 +109,22 @@ class LaunchTape:
 
     def add_launch(self, fn_index: int, name: str, args):
         words = self._convert(name, args)
+        # Recording is process-wide (module docstring): a launch that some OTHER thread issues through the library while the
+        # step records would be replayed on every step.  The step itself launches only on its compute stream and on the
+        # streams it has forked to (every fork is noted as an edge BEFORE the launches behind it): anything else is refused.
+        if self.stream is not None and not self.through_stubs:      # (the stub self-test issues a whole EAGER step, any stream)
+            allowed = self._streams or {int(self.stream.cuda_stream)}
+            if words[-1] not in allowed:
+                raise RuntimeError(f"launch tape: {name} launched on stream {words[-1]:#x}, which is neither the recorded compute "
+                                   "stream nor a stream forked from it - another thread launching during the recording?")
         self._cur.append((fn_index, words))
         self.n_launches += 1
 
     def add_edge(self, src_stream: int, dst_stream: int):
+        if self.stream is not None:
+            if not self._streams:
+                self._streams.add(int(self.stream.cuda_stream))
+            self._streams.update((int(src_stream), int(dst_stream)))
         ev = self.lib.psld_tape_event_create()
         if not ev:
             raise RuntimeError("launch tape: hipEventCreate failed")

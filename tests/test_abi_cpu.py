@@ -89,6 +89,20 @@ def test_launch_tape_packs_arguments_and_replay_validates_entries():
     failed = C.c_int(-1)
     assert lib.psld_tape_replay(ptr, n, C.byref(failed)) != 0 and failed.value == 0
     assert b"psld_axpby_f32" in lib.psld_last_error()
+    # a recording tape refuses launches on a stream the step never forked to (another thread's launches)
+    class _S:
+        cuda_stream = 0x1000
+    t2 = T.LaunchTape()
+    t2.stream = _S()
+    idx = lib.psld_tape_fn_index(b"psld_axpby_f32")
+    t2.add_launch(idx, "psld_axpby_f32", (None, 1.0, None, 0.0, None, 4, 0, C.c_void_p(0x1000)))
+    t2._streams.update((0x1000, 0x2000))
+    t2.add_launch(idx, "psld_axpby_f32", (None, 1.0, None, 0.0, None, 4, 0, C.c_void_p(0x2000)))
+    try:
+        t2.add_launch(idx, "psld_axpby_f32", (None, 1.0, None, 0.0, None, 4, 0, C.c_void_p(0x3000)))
+        raise AssertionError("a launch on a foreign stream was recorded")
+    except RuntimeError as e:
+        assert "neither the recorded compute stream" in str(e)
     bad = np.zeros(2, dtype=T.ENTRY)
     bad["fn"][:] = (lib.psld_tape_fn_index(b"psld_axpby_f32"), 10 ** 6)
     bad["nargs"][0] = 3                                     # wrong argument count for that function
