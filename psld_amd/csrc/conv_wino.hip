@@ -301,7 +301,8 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArg
         const int row = tb * 16 + r16;
         aoff[tb] = row * ROWB + ((kq ^ lds_swz(row)) << 4);
     }
-    const u32x4* ub = a.ufrag + ((long long)(tile_n * 8 + wave) * a.chunks) * (16 * 3 * 64);      // wave-uniform
+    // ABL & 128 (timing only, wrong results): SIMD partners w, w + 4 stream the SAME fragments - what the L1 merges
+    const u32x4* ub = a.ufrag + ((long long)(tile_n * 8 + ((ABL & 128) ? (wave & 3) : wave)) * a.chunks) * (16 * 3 * 64);      // wave-uniform
     u32x4 bq[4][3];
     auto load_b = [&](int sigma, u32x4 (&dst)[3]) {
         const u32x4* p = ub + (long long)sigma * (3 * 64);
@@ -327,6 +328,7 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArg
     // the eight positions of half h of chunk c (see wino_conv_kernel for the group order and the in-place A prefetch)
     auto mfma_half = [&](auto HH, int c) {
         constexpr int h = decltype(HH)::value;
+        if constexpr ((ABL & 256) != 0) __builtin_amdgcn_s_setprio(2);       // experiment: the multiplying wave outranks its partner
         read_a(8 * h, 2);
         read_a(8 * h, 1);
         read_a(8 * h, 0);
@@ -350,12 +352,13 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArg
             __builtin_amdgcn_sched_barrier(0);
             if (i < 7) read_a(p + 1, 0);
         }
+        if constexpr ((ABL & 256) != 0) __builtin_amdgcn_s_setprio(0);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     // Static priority for the second-dispatched half (waves 4-7: the arbitration loser of every SIMD pair - MI355X_MICROARCH.md,
     // "Two waves per SIMD" item 4): 454 -> 443 us on 256->256 @32x32, 206 -> 201 us on 512->256 @16x16 (ABL & 4 switches it off).
-    if constexpr ((ABL & 4) == 0) { if (vr != 0) __builtin_amdgcn_s_setprio(1); }
+    if constexpr ((ABL & 4) == 0 && (ABL & 256) == 0) { if (vr != 0) __builtin_amdgcn_s_setprio(1); }
 
     load_raw(0);
     load_b(0, bq[0]);
@@ -665,6 +668,9 @@ int wino_conv(const float* x1, int c1, const float* x2, int c2, int batch, int h
             if (abl == 3) return launch_wino8q<3>(a, stream, name);
             return launch_wino8q<0>(a, stream, name);
         }
+        if (w4 == 2 && abl == 128) return launch_wino8s<128>(a, stream, name);
+        if (w4 == 2 && abl == 256) return launch_wino8s<256>(a, stream, name);
+        if (w4 == 2 && abl == 4) return launch_wino8s<4>(a, stream, name);
         if (w4 == 2 && abl >= 64) {     // stamped diagnostic builds: plain | no transforms | weights loaded once | both
             a.dbg = g_wino_dbg;
             if (abl == 65) return launch_wino8s<65>(a, stream, name);
