@@ -173,7 +173,7 @@ __global__ void wino_pack_batch_kernel(const long long* __restrict__ tab, int nt
 // front of every weight-fragment load of the half-phase, and the first s_waitcnt of the MFMA stream waits for them.
 // Issued behind the last fragment wait of the previous half-phase they have that phase's transform and the barrier to
 // land before anything younger is waited for.
-template <int ABL = 0, bool GNF = false, bool ERAW = false>
+template <int ABL = 0, bool GNF = false, bool ERAW = false, int LA = 2>
 __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NI = 4;                     // raw image: 256 halo pixels
@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArg
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int p = 8 * h + i;
-            if (!(ABL & 2)) load_b(c * 16 + p + 2, bq[(p + 2) & 3]);
+            if (!(ABL & 2)) load_b(c * 16 + p + LA, bq[(p + LA) & 3]);
             __builtin_amdgcn_sched_barrier(0);
             mm(p, 2, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -363,6 +363,7 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArg
     load_raw(0);
     load_b(0, bq[0]);
     load_b(1, bq[1]);
+    if (LA > 2) load_b(2, bq[2]);
     store_raw(0, 0);
     if constexpr (ERAW) load_raw(min(1, a.chunks - 1));
     __syncthreads();
@@ -489,13 +490,13 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArg
 #include "conv_wino_abl.inc"
 #endif
 
-template <int ABL = 0, bool GNF = false, bool ERAW = false>
+template <int ABL = 0, bool GNF = false, bool ERAW = false, int LA = 2>
 int launch_wino8s(const WinoArgs& a, hipStream_t stream, const char* name) {
     constexpr size_t LDS = (size_t)VBYTES + 2 * (size_t)4 * 64 * 128;
     static_assert(LDS <= 163840, "LDS budget");
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv8s_kernel<ABL, GNF, ERAW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv8s_kernel<ABL, GNF, ERAW, LA>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         if (e != hipSuccess) {
             psld_set_error("%s: hipFuncSetAttribute failed: %s", name, hipGetErrorString(e));
@@ -504,7 +505,7 @@ int launch_wino8s(const WinoArgs& a, hipStream_t stream, const char* name) {
         configured = true;
     }
     dim3 grid((unsigned)(cdiv(a.M, 128) * (a.N / 128)));
-    hipLaunchKernelGGL((wino_conv8s_kernel<ABL, GNF, ERAW>), grid, dim3(WINO_THREADS), LDS, stream, a);
+    hipLaunchKernelGGL((wino_conv8s_kernel<ABL, GNF, ERAW, LA>), grid, dim3(WINO_THREADS), LDS, stream, a);
     PSLD_CHECK_LAUNCH(name);
     return PSLD_OK;
 }
@@ -668,6 +669,7 @@ int wino_conv(const float* x1, int c1, const float* x2, int c2, int batch, int h
             if (abl == 3) return launch_wino8q<3>(a, stream, name);
             return launch_wino8q<0>(a, stream, name);
         }
+        if (w4 == 2 && la == 3 && !persist && !abl) return launch_wino8s<0, false, false, 3>(a, stream, name);
         if (w4 == 2 && abl == 128) return launch_wino8s<128>(a, stream, name);
         if (w4 == 2 && abl == 256) return launch_wino8s<256>(a, stream, name);
         if (w4 == 2 && abl == 4) return launch_wino8s<4>(a, stream, name);
