@@ -538,6 +538,29 @@ def test_conv3x3_wgrad_with_x_as_limb_planes(ops, cfg):
         assert torch.equal(got, ref), (cfg, rep, rel_l2(got, ref))
 
 
+@pytest.mark.parametrize("per", [1, 2, 3, 5])
+def test_wave_specialised_wgrad_on_short_k_ranges(ops, per):
+    """dwgrad_ws_kernel (128-channel tiles, fp32 x: producer waves stage the next K tile while consumer waves multiply) on K
+    ranges of 1, 2, 3 and 5 tiles - its prologue, its two-image hand-over and a short last range - against the
+    one-role-per-wave kernel on limb-plane x: bit for bit, and against fp64 autograd of nn.Conv2d (layers.py:103-109)."""
+    b, ci, co, h, w_ = 3, 128, 256, 16, 16
+    xt = gen(b, ci, h, w_, seed=80).requires_grad_(False)
+    x = _nhwc(xt).to(DEV)
+    gyt = gen(b, co, h, w_, seed=81)
+    gy = _nhwc(gyt).to(DEV)
+    ktiles = b * h * w_ // 32                                     # 24
+    nsplit = -(-ktiles // per)
+    got = torch.full((nsplit, co, 9, ci), float("nan"), device=DEV)
+    ops.conv3x3_wgrad_split(gy, co, x, got, ci, 0, nsplit)
+    ref = torch.full_like(got, float("nan"))
+    ops.conv3x3_wgrad_split(gy, co, ops.f32_to_limb(x), ref, ci, 0, nsplit)
+    assert torch.equal(got, ref)
+    w = torch.zeros(co, ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xt.double(), w, padding=1).backward(gyt.double())
+    dw = got.sum(0).reshape(co, 3, 3, ci).permute(0, 3, 1, 2)
+    assert rel_l2(dw, w.grad) < 3e-6
+
+
 def test_conv3x3_wgrad_limb_x_two_sources(ops):
     b, c1, c2, co, s_ = 2, 128, 256, 128, 16
     x = gen(b, c1 + c2, s_, s_, seed=70)
