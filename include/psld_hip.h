@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 
-#define PSLD_ABI_VERSION 10 /* 2: limb-MFMA convolutions, math mode, bias-gradient / batched-copy entry points; 3: pointwise weight gradient and batched activation GEMM on limb kernels; 4: GroupNorm statistics from the limb kernels' epilogue; 5: per-sample-time reverse SDE, ScoreLoss nll / l1; 6: limb-plane activations; 7: device-resident dropout seed / Adam scalars (captured training step), GroupNorm-backward sums from the producing epilogue; 8: Winograd F(2x2,3x3) limb convolution; 9: launch tape; 10: GroupNorm apply (+SiLU) fused into the Winograd convolution's input staging */
+#define PSLD_ABI_VERSION 11 /* 2: limb-MFMA convolutions, math mode, bias-gradient / batched-copy entry points; 3: pointwise weight gradient and batched activation GEMM on limb kernels; 4: GroupNorm statistics from the limb kernels' epilogue; 5: per-sample-time reverse SDE, ScoreLoss nll / l1; 6: limb-plane activations; 7: device-resident dropout seed / Adam scalars (captured training step), GroupNorm-backward sums from the producing epilogue; 8: Winograd F(2x2,3x3) limb convolution; 9: launch tape; 10: GroupNorm apply (+SiLU) fused into the Winograd convolution's input staging; 11: GroupNorm backward kernel selector */
 #define PSLD_COEFF_STRIDE 12
 
 int psld_version(void);
@@ -307,6 +307,17 @@ int psld_gn_apply_nhwc_f32(const float* x, const float* scale, const float* shif
 int psld_gn_apply_limb_nhwc(const float* x, const float* scale, const float* shift, void* y_limb, int batch,
                             int hw, int c, int act, float drop_p, unsigned long long seed,
                             const unsigned long long* seed_dev, hipStream_t stream);
+/* Which kernel psld_gn_bwd_nhwc_f32 takes when the backward runs in one pass over (dy, x) (no part_in; see there):
+ *   PSLD_GN_BWD_AUTO      the LDS-image kernel (gn_bwd_pipe_kernel: the next slab's x, or the third operand of the current
+ *                         one, lands in LDS by global_load_lds while the workgroup reduces) where its shape rules hold, else
+ *   PSLD_GN_BWD_ONE_SLAB  the register-resident one-slab kernel (gn_bwd_fused_kernel) for every shape.
+ * Both give bitwise equal dx / dgamma / dbeta (tests/test_kernels_gpu.py compares them through this switch).  Process-wide;
+ * the initial value comes from the environment variable PSLD_GN_BWD_PIPE ("0" = one slab). */
+#define PSLD_GN_BWD_AUTO 0
+#define PSLD_GN_BWD_ONE_SLAB 1
+int psld_set_gn_bwd_kernel(int kind);
+int psld_get_gn_bwd_kernel(void);
+
 /* Backward of y = act(GN(x)): dgamma[C], dbeta[C] (written, not accumulated) and
  * dx = d/dx (+ add_scale * add when add != NULL: the gradient of an identity branch parallel to the normalisation,
  * e.g. the residual `(x + h) / sqrt(2)` of layerspp.py:271-274) (+ the previous dx when accumulate_dx).

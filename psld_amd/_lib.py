@@ -68,7 +68,7 @@ class SscsCoeffs(C.Structure):
 I, F, D, LL, P = C.c_int, C.c_float, C.c_double, C.c_longlong, C.c_void_p
 EP = C.POINTER(Epilogue)
 
-ABI_VERSION = 10   # PSLD_ABI_VERSION of include/psld_hip.h these signatures were written against
+ABI_VERSION = 11   # PSLD_ABI_VERSION of include/psld_hip.h these signatures were written against
 
 # name -> (restype, argtypes): every symbol include/psld_hip.h declares
 SIGNATURES = {
@@ -76,6 +76,8 @@ SIGNATURES = {
     "psld_last_error": (C.c_char_p, []),
     "psld_set_math_mode": (I, [I]),
     "psld_get_math_mode": (I, []),
+    "psld_set_gn_bwd_kernel": (I, [I]),
+    "psld_get_gn_bwd_kernel": (I, []),
     "psld_gemm_f32": (I, [I, I, I, I, I, P, I, LL, P, I, LL, P, I, LL, I, EP, P]),
     "psld_gemm_tn_splitk_f32": (I, [I, I, I, P, I, P, I, P, I, P]),
     "psld_conv2d_nhwc_f32": (I, [P, I, P, I, I, I, I, P, I, I, I, I, I, I, I, I, P, I, EP, P]),

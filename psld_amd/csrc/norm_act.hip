@@ -426,6 +426,27 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
     }
 }
 
+#ifdef PSLD_ABLATIONS
+// ablation library only (tools/gnb_stamps.py): per-workgroup time stamps and timing-only modes of the fused backward
+__device__ unsigned long long* g_gnb_dbg = nullptr;     // [workgroups][8]
+__device__ int g_gnb_mode = 0;                          // bit 0 delay odd workgroups by (mode >> 8) x 3.4 us, bit 1 no reduction, bit 2 no stores
+#define GNB_STAMP(k)                                                                                                   \
+    do {                                                                                                               \
+        if (g_gnb_dbg && threadIdx.x == 0)                                                                             \
+            g_gnb_dbg[((long long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] =                                    \
+                (k) >= 6 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();                            \
+    } while (0)
+#define GNB_MODE g_gnb_mode
+#define GNP_STAMP(k)                                                                                                   \
+    do {                                                                                                               \
+        if (g_gnb_dbg && stamped && threadIdx.x == 0) g_gnb_dbg[(long long)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define GNB_STAMP(k)
+#define GNB_MODE 0
+#define GNP_STAMP(k)
+#endif
+
 // ---- backward in ONE pass over (dy, x) ----------------------------------------------------------------------------
 // A block owns image n and a slab of `gb` whole groups (cw = gb * cpg <= 32 channels); its threads keep the slab's dy and
 // x values in REGISTERS (ITEMS float4 of each per thread): pass 1 turns them into dz and xhat in place and reduces the
@@ -445,6 +466,14 @@ __global__ void __launch_bounds__(512) gn_bwd_fused_kernel(const float* __restri
                                                            float* __restrict__ dx, float* __restrict__ part) {
     extern __shared__ float red[];               // [pl][cq][8] thread sums, then (as doubles) [cw][2] channel sums + [gb][2]
     const int n = blockIdx.y, slab = blockIdx.x;
+    GNB_STAMP(6);
+    GNB_STAMP(0);
+    if ((GNB_MODE & 1) && ((blockIdx.x + blockIdx.y) & 1))
+        for (int i = 0; i < (GNB_MODE >> 8); ++i) __builtin_amdgcn_s_sleep(127);
+    if ((GNB_MODE & 8) && blockIdx.y * gridDim.x + blockIdx.x < 256) {      // first round only: phase (id / 8) % 4 of four
+        const int ph = ((blockIdx.y * gridDim.x + blockIdx.x) >> 3) & ((GNB_MODE & 16) ? 1 : 3);
+        for (int i = 0; i < ph * (GNB_MODE >> 8); ++i) __builtin_amdgcn_s_sleep(127);
+    }
     if (seed_dev) seed += seed_dev[0];
     const int tid = threadIdx.x;
     const int cpg = c / groups;
@@ -455,23 +484,31 @@ __global__ void __launch_bounds__(512) gn_bwd_fused_kernel(const float* __restri
     const int g = ch0 / cpg;                     // cpg % 4 == 0: a quad lies in one group
     const float mu = mean[n * groups + g], rs = rstd[n * groups + g];
     const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + ch0), be = *reinterpret_cast<const f32x4*>(beta + ch0);
-    const long long off = ((long long)n * hw) * c + ch0;
+    // byte offset of this thread's first element / between its items (tensors < 4 GB: gn_bwd_fused_plan): one uniform base
+    // and one 32-bit offset per access instead of a 64-bit address per item and tensor
+    const unsigned uo = (unsigned)((((long long)n * hw + l) * c + ch0) * 4), istride = (unsigned)pl * c * 4;
+    auto at = [&](const float* base, int i) {
+        return reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(base) + (uo + i * istride));
+    };
     const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     f32x4 xv[ITEMS], gv[ITEMS];
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const int p = l + i * pl;
         if (p < hw) {
-            xv[i] = *reinterpret_cast<const f32x4*>(x + off + (long long)p * c);
-            gv[i] = *reinterpret_cast<const f32x4*>(dy + off + (long long)p * c);
+            xv[i] = *at(x, i);
+            gv[i] = *at(dy, i);
+        } else {
+            xv[i] = gv[i] = f32x4{0.f, 0.f, 0.f, 0.f};      // (pass 2 computes on every item and stores the valid ones)
         }
     }
+    GNB_STAMP(1);
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const int p = l + i * pl;
         if (p < hw) {
-            const long long idx = off + (long long)p * c;
+            const long long idx = (long long)((uo + i * istride) >> 2);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float xh = (xv[i][e] - mu) * rs;
@@ -485,6 +522,7 @@ __global__ void __launch_bounds__(512) gn_bwd_fused_kernel(const float* __restri
             }
         }
     }
+    GNB_STAMP(2);
     float* my = red + ((long long)l * cq + q) * 8;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -492,8 +530,10 @@ __global__ void __launch_bounds__(512) gn_bwd_fused_kernel(const float* __restri
         my[4 + e] = s2[e];
     }
     __syncthreads();
+    GNB_STAMP(3);
     double* chs = reinterpret_cast<double*>(red + (long long)pl * cq * 8);      // [cw][2]: gamma-weighted channel sums
     double* grp = chs + cw * 2;                                                  // [gb][2]
+    if (!(GNB_MODE & 2))
     for (int i = tid; i < cq * 8; i += blockDim.x) {
         double acc = 0;
         for (int ll = 0; ll < pl; ++ll) acc += (double)red[(long long)ll * cq * 8 + i];
@@ -511,36 +551,214 @@ __global__ void __launch_bounds__(512) gn_bwd_fused_kernel(const float* __restri
         grp[gg * 2 + w] = t;
     }
     __syncthreads();
+    GNB_STAMP(4);
     const int gl = (q * 4) / cpg;
     const double cnt = (double)cpg * hw;
     const float k1 = (float)((double)rs * grp[gl * 2 + 0] / cnt), k2 = (float)((double)rs * grp[gl * 2 + 1] / cnt);
     f32x4 k0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) k0[e] = rs * ga[e];
+    // dx into gv; the parallel branch's gradient / the previous dx are loaded for ALL items before the first is used (xv is
+    // free by then): a load - wait - store chain per item costs one memory latency each
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gv[i][e] = k0[e] * gv[i][e] - k1 - xv[i][e] * k2;
+    if (add) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const int p = l + i * pl;
+            if (p < hw) xv[i] = *at(add, i);
+        }
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gv[i][e] += add_scale * xv[i][e];
+    }
+    if (accumulate) {
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const int p = l + i * pl;
+            if (p < hw) xv[i] = *at(dx, i);
+        }
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) gv[i] += xv[i];
+    }
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const int p = l + i * pl;
-        if (p < hw) {
-            const long long idx = off + (long long)p * c;
-            f32x4 o;
+        if (p < hw && (!(GNB_MODE & 4) || gv[i][0] == 12345.678f))
+            *const_cast<f32x4*>(at(dx, i)) = gv[i];
+    }
+    GNB_STAMP(5);
+    GNB_STAMP(7);
+}
+
+// ---- the one-pass backward as resident workgroups with the NEXT slab's x prefetched into LDS ---------------------------
+// Time stamps inside gn_bwd_fused_kernel (profiles/r04/gnb_stamps.md): a workgroup that holds a 32-channel slab of a
+// 32x32 image (128 KB of x + 128 KB of dy in registers) keeps its CU's memory pipe busy for 15 of the 21 us it lives -
+// loads 256 KB, THEN waits at the barrier, reduces, THEN stores 128 KB - and a CU moves ~25 GB/s whatever the other CUs
+// do (staggering the workgroups' phases changed nothing), so the idle quarter is lost bandwidth.  Registers hold one slab
+// per CU; LDS (160 KB) is free: a workgroup that walks `per` slabs of the same channels asks, as soon as its dy loads have
+// landed, for the NEXT slab's x by asynchronous global -> LDS loads (global_load_lds_dwordx4: no VGPR destination,
+// lane-linear 1 KB per wave instruction, every thread later reads back exactly the 16 bytes per item it asked for, so no
+// barrier guards the image), which then fly during the barriers, the reduction, pass 2 and the stores.  The loads of dy and of
+// the image are asm with hand-placed counted vmcnt waits (hipcc does not count asm loads, and a counted wait of its own
+// behind them would drain them); the barriers are raw s_barrier with an lgkmcnt-only wait (a __syncthreads waits
+// vmcnt(0)).  Arithmetic and summation order are those of gn_bwd_fused_kernel: bitwise equal results.  Only without a
+// third operand (the dropout GroupNorm of every block): with the parallel branch's gradient or a previous dx to add, a
+// variant that lands THAT operand in the image (asked for behind x and dy, read in pass 2) measured 128 / 118 us against 126 /
+// 126 us of the one-slab kernel on 128x32x32x256 - 512 KB per slab keep the CU's pipe busy for 20 of its 29 us anyway -
+// and was dropped; this form: 97 against 107-112 us.
+__device__ __forceinline__ void glds16(const float* base, unsigned byte_off, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(byte_off), "s"(base), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int ITEMS>
+__global__ void __launch_bounds__(512) gn_bwd_pipe_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          int hw, int c, int groups, int gb, int pl, int act, float drop_p,
+                                                          unsigned long long seed,
+                                                          const unsigned long long* __restrict__ seed_dev,
+                                                          float* __restrict__ dx, float* __restrict__ part, int slabs,
+                                                          int units, int per) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char psm[];   // [ITEMS][waves][1 KB] x image | thread sums | channel / group sums | (mean, rstd) per slab
+    if (seed_dev) seed += seed_dev[0];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nw = (blockDim.x + 63) >> 6;
+    const int cpg = c / groups;
+    const int cw = gb * cpg, cq = cw >> 2;
+    const int q = tid % cq, l = tid / cq;
+    const unsigned img0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)psm;
+    const unsigned my_img = img0 + wave * 1024;                         // + i * nw * 1024 (+ lane * 16 by the hardware)
+    const unsigned char* my_x = psm + wave * 1024 + lane * 16;
+    float* red = reinterpret_cast<float*>(psm + (size_t)ITEMS * nw * 1024);
+    double* chs = reinterpret_cast<double*>(red + (long long)pl * cq * 8);      // [cw][2]
+    double* grp = chs + cw * 2;                                                  // [gb][2]
+    float* tab = reinterpret_cast<float*>(grp + gb * 2);                         // [per][gb][2]
+    const unsigned istride = (unsigned)pl * c * 4;                               // bytes between a thread's items
+    const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    const double cnt = (double)cpg * hw;
+    // gridDim.x is a multiple of the slabs per image: this workgroup's slabs cover the same channels of `per` images.
+    // Everything that hipcc loads itself is loaded (and awaited) HERE: inside the loop the loads of dy and of the image are
+    // asm whose waits are placed by hand - hipcc does not count them, and a counted wait of its own for an older load
+    // would drain the image loads.
+    const int slab = blockIdx.x % slabs, n0 = blockIdx.x / slabs, nstep = gridDim.x / slabs;
+    const int c0 = slab * cw, ch0 = c0 + q * 4;
+    const int gl = (q * 4) / cpg;                                                // group of this quad inside the slab
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + ch0), be = *reinterpret_cast<const f32x4*>(beta + ch0);
+    const int ri = tid < cq * 8 ? tid : 0;                                       // reduction column of this thread
+    const float rgam = gamma[c0 + (ri >> 3) * 4 + (ri & 3)];
+    if (tid < per * gb) {
+        const int k = tid / gb, j = tid - k * gb, n = n0 + k * nstep;
+        const bool in = (long long)n * slabs + slab < units;
+        tab[tid * 2 + 0] = in ? mean[n * groups + slab * gb + j] : 0.f;
+        tab[tid * 2 + 1] = in ? rstd[n * groups + slab * gb + j] : 0.f;
+    }
+    asm volatile("" ::"v"(ga), "v"(be), "v"(rgam));
+    __syncthreads();
+    const unsigned nbytes = (unsigned)nstep * hw * c * 4;                        // from a slab to this workgroup's next
+    unsigned o = (unsigned)((((long long)n0 * hw + l) * c + ch0) * 4);           // this thread's first element (tensors < 4 GB)
+    auto x_to_image = [&](unsigned at) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = k0[e] * gv[i][e] - k1 - xv[i][e] * k2;
-            if (add) {
-                const f32x4 av = *reinterpret_cast<const f32x4*>(add + idx);
+        for (int i = 0; i < ITEMS; ++i)
+            glds16(x, at + i * istride, __builtin_amdgcn_readfirstlane(my_img + i * nw * 1024));
+    };
+    x_to_image(o);
+    for (int k = 0; k < per; ++k, o += nbytes) {
+        const int n = n0 + k * nstep;
+        if ((long long)n * slabs + slab >= units) break;
+        [[maybe_unused]] const bool stamped = k == 1;            // (ablation library: time stamps of the second slab)
+        GNP_STAMP(0);
+        const float mu = tab[(k * gb + gl) * 2], rs = tab[(k * gb + gl) * 2 + 1];
+        f32x4 xv[ITEMS], gv[ITEMS];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] += add_scale * av[e];
+        for (int i = 0; i < ITEMS; ++i)
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(gv[i]) : "v"(o + i * istride), "s"(dy) : "memory");
+        GNP_STAMP(1);
+        // the x image of this slab: everything older than the ITEMS dy loads has landed
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(ITEMS) : "memory");
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) xv[i] = *reinterpret_cast<const f32x4*>(my_x + (size_t)i * nw * 1024);
+        GNP_STAMP(2);
+        float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(gv[i]) : "i"(ITEMS - 1 - i));       // dy item i
+            const long long idx = (long long)((o + i * istride) >> 2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (xv[i][e] - mu) * rs;
+                float dz = gv[i][e];
+                if (drop_p > 0.f) dz = psld_dropout_keep(seed, (unsigned long long)(idx + e), drop_p) ? dz * keep_scale : 0.f;
+                if (act) dz *= dsilu_f(xh * ga[e] + be[e]);
+                s1[e] += dz;
+                s2[e] += dz * xh;
+                xv[i][e] = xh;
+                gv[i][e] = dz;
             }
-            if (accumulate) o += *reinterpret_cast<const f32x4*>(dx + idx);
-            *reinterpret_cast<f32x4*>(dx + idx) = o;
         }
+        GNP_STAMP(3);
+        // this thread's part of the image has been read (the values above depend on it): the next slab's x may land there,
+        // in flight during the barriers, the reduction, pass 2 and the stores
+        if (k + 1 < per && (long long)(n + nstep) * slabs + slab < units) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            x_to_image(o + nbytes);
+        }
+        GNP_STAMP(4);
+        float* my = red + ((long long)l * cq + q) * 8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            my[e] = s1[e];
+            my[4 + e] = s2[e];
+        }
+        lds_barrier();
+        GNP_STAMP(5);
+        if (tid < cq * 8) {
+            double acc = 0;
+            for (int ll = 0; ll < pl; ++ll) acc += (double)red[(long long)ll * cq * 8 + tid];
+            const int qq = tid >> 3, kk = tid & 7;
+            const int chl = qq * 4 + (kk & 3);
+            const float rounded = (float)acc;
+            part[(((long long)n * 2 + (kk >> 2))) * c + c0 + chl] = rounded;
+            chs[chl * 2 + (kk >> 2)] = (double)rounded * (double)rgam;
+        }
+        lds_barrier();
+        if (tid < gb * 2) {
+            const int gg = tid >> 1, w = tid & 1;
+            double t = 0;
+            for (int i = 0; i < cpg; ++i) t += chs[(gg * cpg + i) * 2 + w];
+            grp[gg * 2 + w] = t;
+        }
+        lds_barrier();
+        GNP_STAMP(6);
+        const float k1 = (float)((double)rs * grp[gl * 2 + 0] / cnt), k2 = (float)((double)rs * grp[gl * 2 + 1] / cnt);
+        f32x4 k0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) k0[e] = rs * ga[e];
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = k0[e] * gv[i][e] - k1 - xv[i][e] * k2;
+            *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(dx) + (o + i * istride)) = r;
+        }
+        GNP_STAMP(7);
+        // (no barrier here: a wave that rewrites the thread sums has passed the barrier behind their last read)
     }
 }
 
 // groups per block / pixel lanes / items per thread of the fused backward, or false when the slab does not fit registers
-inline bool gn_bwd_fused_plan(int hw, int c, int groups, int* gb, int* pl, int* items) {
+inline bool gn_bwd_fused_plan(int batch, int hw, int c, int groups, int* gb, int* pl, int* items) {
     static const int on = [] { const char* v = getenv("PSLD_GN_BWD_FUSED"); return v ? atoi(v) : 1; }();
     const int cpg = c / groups;
-    if (!on || cpg % 4 || cpg > 32) return false;
+    if (!on || cpg % 4 || cpg > 32 || (long long)batch * hw * c * 4 >= (1ll << 32)) return false;
     int g = 32 / cpg;                              // as many whole groups as fit 32 channels (whole 128-byte lines; 16-channel
                                                    // slabs measured 136 vs 112 us on 128x32x32x256) ...
     while (g > 1 && groups % g) --g;               // ... dividing the group count
@@ -550,7 +768,61 @@ inline bool gn_bwd_fused_plan(int hw, int c, int groups, int* gb, int* pl, int* 
     if (it > 16) return false;
     *gb = g;
     *pl = lanes;
-    *items = it <= 1 ? 1 : it <= 2 ? 2 : it <= 4 ? 4 : it <= 8 ? 8 : 16;
+    *items = it <= 1 ? 1 : it <= 2 ? 2 : it <= 4 ? 4 : 16;      // (5..8 pixels per thread - non-square maps only - run the 16-item kernel half empty)
+    return true;
+}
+
+// PSLD_GN_BWD_AUTO / PSLD_GN_BWD_ONE_SLAB (psld_set_gn_bwd_kernel); initial value from PSLD_GN_BWD_PIPE
+inline int& gn_bwd_kind() {
+    static int kind = [] { const char* v = getenv("PSLD_GN_BWD_PIPE"); return v && atoi(v) == 0 ? PSLD_GN_BWD_ONE_SLAB : PSLD_GN_BWD_AUTO; }();
+    return kind;
+}
+
+// The resident form: when every workgroup would walk at least two slabs.  Returns the grid (all workgroups resident, equal
+// shares) or false.  items in {4, 16} with hw == items * pl exactly (no guarded items: the counted vmcnt needs them all).
+template <int ITEMS>
+inline bool gn_bwd_pipe_setup(size_t lds, int threads, int* per_cu) {
+    static int blocks = -1;
+    static size_t configured = 0;
+    if (lds > configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_bwd_pipe_kernel<ITEMS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return false;
+        configured = lds;
+        blocks = -1;
+    }
+    if (blocks < 0 &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, reinterpret_cast<const void*>(&gn_bwd_pipe_kernel<ITEMS>), threads,
+                                                     lds) != hipSuccess)
+        blocks = 0;
+    *per_cu = blocks;
+    return blocks > 0;
+}
+
+inline bool gn_bwd_pipe_plan(int batch, int hw, int c, int slabs, int gb, int threads, int pl, int items, size_t fused_lds,
+                             int* grid, int* per_out, size_t* lds_out) {
+    if (gn_bwd_kind() != PSLD_GN_BWD_AUTO) return false;
+    constexpr int MAXPER = 8;
+    if ((items != 4 && items != 16) || hw != items * pl || (long long)batch * hw * c * 4 >= (1ll << 32)) return false;
+    const size_t lds = (size_t)items * ((threads + 63) / 64) * 1024 + fused_lds + (size_t)MAXPER * gb * 2 * sizeof(float);
+    if (lds > 160 * 1024) return false;
+    int per_cu = 0;
+    const bool ok = items == 4 ? gn_bwd_pipe_setup<4>(lds, threads, &per_cu) : gn_bwd_pipe_setup<16>(lds, threads, &per_cu);
+    if (!ok) return false;
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        return n;
+    }();
+    if (cus <= 0) return false;
+    // whole images per round: the grid is a multiple of the slabs per image (a workgroup keeps its channels), everything resident
+    const int images_per_round = cus * per_cu / slabs;
+    if (images_per_round < 1) return false;
+    const int per = cdiv(batch, images_per_round);        // slabs per workgroup
+    if (per < 2 || per > MAXPER || per * gb > threads) return false;      // one slab: nothing to prefetch for - the one-slab kernel
+    *grid = cdiv(batch, per) * slabs;
+    *per_out = per;
+    *lds_out = lds;
     return true;
 }
 
@@ -639,10 +911,26 @@ extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float
     const size_t lds = (size_t)m.pl * m.cq * 8 * sizeof(float);
     int chunks = m.chunks;
     int gb = 0, fpl = 0, items = 0;
-    if (!part_in && gn_bwd_fused_plan(hw, c, groups, &gb, &fpl, &items)) {
+    if (!part_in && gn_bwd_fused_plan(batch, hw, c, groups, &gb, &fpl, &items)) {
         const int cpg = c / groups, cw = gb * cpg, cq = cw / 4;
         const dim3 grid(groups / gb, batch), block(cq * fpl);
         const size_t flds = (size_t)fpl * cq * 8 * sizeof(float) + (size_t)(cw + gb) * 2 * sizeof(double);
+        int pipe_grid = 0, pipe_per = 0;
+        size_t plds = 0;
+        if (!add && !accumulate_dx &&       // (a third operand: the one-slab kernel, see gn_bwd_pipe_kernel)
+            gn_bwd_pipe_plan(batch, hw, c, groups / gb, gb, (int)block.x, fpl, items, flds, &pipe_grid, &pipe_per, &plds)) {
+            const int slabs = groups / gb;
+#define PSLD_GN_PIPE(IT)                                                                                               \
+    hipLaunchKernelGGL((gn_bwd_pipe_kernel<IT>), dim3(pipe_grid), block, plds, stream, dy, x, mean, rstd, gamma, beta, hw, \
+                       c, groups, gb, fpl, act, drop_p, seed, seed_dev, dx, part, slabs, slabs * batch, pipe_per)
+            if (items == 4) PSLD_GN_PIPE(4); else PSLD_GN_PIPE(16);
+#undef PSLD_GN_PIPE
+            PSLD_CHECK_LAUNCH("gn_bwd_pipe_kernel");
+            hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(2 * cdiv(c, 64)), dim3(1024), 0, stream, part, rstd, gamma, batch,
+                               hw, c, groups, 1, coef, dgamma, dbeta, batch);
+            PSLD_CHECK_LAUNCH("gn_bwd_finalize_kernel");
+            return PSLD_OK;
+        }
 #define PSLD_GN_FUSED(IT)                                                                                              \
     hipLaunchKernelGGL((gn_bwd_fused_kernel<IT>), grid, block, flds, stream, dy, x, mean, rstd, gamma, beta, hw, c, groups, \
                        gb, fpl, act, drop_p, seed, seed_dev, accumulate_dx, add, add_scale, dx, part)
@@ -650,7 +938,6 @@ extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float
             case 1: PSLD_GN_FUSED(1); break;
             case 2: PSLD_GN_FUSED(2); break;
             case 4: PSLD_GN_FUSED(4); break;
-            case 8: PSLD_GN_FUSED(8); break;
             default: PSLD_GN_FUSED(16); break;
         }
 #undef PSLD_GN_FUSED
@@ -680,3 +967,17 @@ extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float
     PSLD_CHECK_LAUNCH("gn_bwd_apply_kernel");
     return PSLD_OK;
 }
+
+extern "C" int psld_set_gn_bwd_kernel(int kind) {
+    PSLD_CHECK_ARG(kind == PSLD_GN_BWD_AUTO || kind == PSLD_GN_BWD_ONE_SLAB, "psld_set_gn_bwd_kernel: unknown kind %d", kind);
+    gn_bwd_kind() = kind;
+    return PSLD_OK;
+}
+extern "C" int psld_get_gn_bwd_kernel(void) { return gn_bwd_kind(); }
+
+#ifdef PSLD_ABLATIONS
+extern "C" void psld_abl_set_gnb_debug(unsigned long long* p, int mode) {
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gnb_dbg), &p, sizeof(p));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gnb_mode), &mode, sizeof(mode));
+}
+#endif

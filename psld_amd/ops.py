@@ -572,6 +572,16 @@ def gn_apply_limb(x: Tensor, st: GNStats, act: bool, drop_p: float = 0.0, seed: 
     return out
 
 
+def set_gn_bwd_kernel(kind: str):
+    """"auto": the LDS-image kernel where its shape rules hold; "one_slab": the register-resident one-slab kernel for every
+    shape (bitwise the same results; for tests and A/B runs)."""
+    check(lib().psld_set_gn_bwd_kernel({"auto": 0, "one_slab": 1}[kind]), "psld_set_gn_bwd_kernel")
+
+
+def get_gn_bwd_kernel() -> str:
+    return ("auto", "one_slab")[lib().psld_get_gn_bwd_kernel()]
+
+
 def gn_bwd(dy: Tensor, x: Tensor, st: GNStats, gamma: Tensor, beta: Tensor, act: bool, dx: Tensor, dgamma: Tensor,
            dbeta: Tensor, accumulate_dx: bool = False, drop_p: float = 0.0, seed: int = 0, groups: Optional[int] = None,
            add: Optional[Tensor] = None, add_scale: float = 1.0, seed_dev: Optional[Tensor] = None,

@@ -920,6 +920,59 @@ def test_groupnorm_fwd_bwd(ops, b, c, s, act):
         assert rel_l2(ycat.permute(0, 3, 1, 2), y) < 2e-6
 
 
+@pytest.mark.parametrize("b,s,c", [(64, 32, 256), (128, 16, 256), (128, 16, 512), (16, 32, 256), (5, 16, 128)])
+@pytest.mark.parametrize("variant", ["plain", "branch", "dropout", "accumulate", "branch_accumulate", "no_act"])
+def test_groupnorm_backward_lds_image_kernel(ops, b, s, c, variant):
+    """gn_bwd_pipe_kernel (resident workgroups, the next slab's x landing in LDS by global_load_lds while the current one is
+    reduced and stored) against the register-resident one-slab kernel, selected through psld_set_gn_bwd_kernel: dx,
+    dgamma, dbeta bit for bit; the last image against an fp64 reference.  (Small batches and the variants with a third
+    operand stay on the one-slab kernel either way: they check its batched loads of that operand.)"""
+    x = (gen(b, s, s, c, seed=60) * 1.5 + 0.3).to(DEV)
+    dy = gen(b, s, s, c, seed=61).to(DEV)
+    gamma, beta = (1 + 0.2 * gen(c, seed=62)).to(DEV), (0.1 * gen(c, seed=63)).to(DEV)
+    act = variant != "no_act"
+    kw = {}
+    if "branch" in variant:
+        kw = {"add": gen(b, s, s, c, seed=64).to(DEV), "add_scale": 0.5}
+    if "accumulate" in variant:
+        kw["accumulate_dx"] = True
+    if variant == "dropout":
+        kw.update(drop_p=0.15, seed=1234)
+    st = ops.gn_stats(x, gamma, beta)
+    base = gen(b, s, s, c, seed=65).to(DEV) if "accumulate" in variant else torch.full_like(x, float("nan"))
+    out = {}
+    initial = ops.get_gn_bwd_kernel()         # "auto" unless the suite runs under PSLD_GN_BWD_PIPE=0
+    try:
+        for kind in ("auto", "one_slab"):
+            ops.set_gn_bwd_kernel(kind)
+            dx = base.clone()
+            dg, db = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+            ops.gn_bwd(dy, x, st, gamma, beta, act, dx, dg, db, **kw)
+            out[kind] = (dx, dg, db)
+    finally:
+        ops.set_gn_bwd_kernel(initial)
+    for got, want in zip(out["auto"], out["one_slab"]):
+        assert torch.equal(got, want)
+    dx = out["auto"][0]
+    # the last image in fp64 (dropout: the mask read off the forward pass with the same seed)
+    n = b - 1
+    xr = x[n:n + 1].permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
+    y = F.group_norm(xr, min(c // 4, 32), gamma.double().cpu(), beta.double().cpu(), 1e-6)
+    if act:
+        y = F.silu(y)
+    if variant == "dropout":
+        keep = ops.gn_apply(x, st, act, drop_p=0.15, seed=1234)[n:n + 1] != 0
+        assert 0.83 < keep.float().mean().item() < 0.87
+        y = y * keep.permute(0, 3, 1, 2).double().cpu() / 0.85
+    y.backward(dy[n:n + 1].permute(0, 3, 1, 2).double().cpu())
+    want = xr.grad
+    if "branch" in variant:
+        want = want + 0.5 * kw["add"][n:n + 1].permute(0, 3, 1, 2).double().cpu()
+    if "accumulate" in variant:
+        want = want + base[n:n + 1].permute(0, 3, 1, 2).double().cpu()
+    assert rel_l2(dx[n:n + 1].permute(0, 3, 1, 2), want) < 1e-5
+
+
 # ---------------------------------------------------------------------------------------------------
 # FIR resampling (the reference's native op)
 # ---------------------------------------------------------------------------------------------------

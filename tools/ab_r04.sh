@@ -2,7 +2,7 @@
 # Round-4 same-box A/Bs (run on the GPU box through gpurun; results in profiles/r04/).  The kernel variants and timing-only
 # ablations live in libpsld_hip_abl.so (make -C psld_amd/csrc abl); bench.py refuses that library by name, so the two
 # step-level A/Bs of product-equivalent kernels load a copy under a neutral name.
-#   bash tools/ab_r04.sh wino | dwgrad | fusedgn | stamps | l2
+#   bash tools/ab_r04.sh wino | dwgrad | fusedgn | stamps | l2 | gnb | gnprev
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 ABL=$PWD/psld_amd/libpsld_hip_abl.so
 S="256,256,32;512,256,32;256,256,16;512,256,16"
@@ -30,6 +30,21 @@ fusedgn)    # GroupNorm apply + SiLU: separate pass + convolution vs fused into 
   for r in 1 2; do for m in 0 1 2; do echo "PSLD_FUSED_GN=$m"; ONLY512=1 PSLD_FUSED_GN=$m python3 tools/bench_sample.py 2>&1 | grep "graphs=0"; done; done ;;
 stamps)     # s_memtime timeline of the product Winograd kernel and of its ablated builds
   for a in 64 65 66 67; do echo "=== PSLD_WINO_ABL=$a"; PSLD_HIP_LIB=$ABL PSLD_WINO_ABL=$a python3 tools/wino_stamps.py 256 256 32 128; done ;;
+gnb)        # GroupNorm backward: time stamps of the one-slab kernel and its timing-only modes, the resident kernel, per-variant
+            # launch times of both, and the full step with either (PSLD_GN_BWD_PIPE is a product switch: psld_set_gn_bwd_kernel)
+  for m in 0 2 4 6 0x218; do PSLD_GN_BWD_PIPE=0 PSLD_HIP_LIB=$ABL python3 tools/gnb_stamps.py 128 32 256 $m 2>&1 | grep -E "^B=|median|last end"; done
+  PSLD_HIP_LIB=$ABL python3 tools/gnb_stamps.py 128 32 256 0 2>&1 | grep -E "^B=|median"
+  PSLD_HIP_LIB=$ABL python3 tools/gnb_stamps.py 128 16 256 0 2>&1 | grep -E "^B=|median"
+  python3 tools/bench_gnb.py > /tmp/gnb_a.txt 2>&1; PSLD_GN_BWD_PIPE=0 python3 tools/bench_gnb.py > /tmp/gnb_b.txt 2>&1
+  echo "(left: default; right: PSLD_GN_BWD_PIPE=0, the one-slab kernel for every shape)"; paste /tmp/gnb_a.txt /tmp/gnb_b.txt | cut -c1-82,140-170
+  for r in 1 2 3; do echo "one-slab kernel everywhere"; step PSLD_GN_BWD_PIPE=0; echo "resident kernel where it applies"; step PSLD_X=1; done
+  for r in 1 2; do echo "B=16 one-slab"; env PSLD_GN_BWD_PIPE=0 python3 bench.py --batch 16 --steps 40 --warmup 5 --sample-batch 0 --no-cpu-baseline --no-probe --no-forward 2>/dev/null | tail -1 | cut -c1-90; echo "B=16 default"; python3 bench.py --batch 16 --steps 40 --warmup 5 --sample-batch 0 --no-cpu-baseline --no-probe --no-forward 2>/dev/null | tail -1 | cut -c1-90; done ;;
+gnprev)     # full step: this build against the same build with the GroupNorm kernels of commit d5c7866.  The library is built in
+            # the development container (needs the git history), in psld_amd/csrc:
+            #   git show d5c7866:psld_amd/csrc/norm_act.hip > prev.hip; append "extern \"C\" int psld_set_gn_bwd_kernel(int) { return 0; }
+            #   extern \"C\" int psld_get_gn_bwd_kernel(void) { return 0; }"; hipcc -O3 -fPIC --offload-arch=gfx950 -std=c++17 -I../../include -I. -c prev.hip
+            #   hipcc -shared -fPIC --offload-arch=gfx950 <the other objects> prev.o -o ../libpsld_hip_prevgn.so
+  for r in 1 2 3 4; do echo "round-4 committed GroupNorm kernels"; step PSLD_HIP_LIB=$PWD/psld_amd/libpsld_hip_prevgn.so; echo "this build"; step PSLD_X=1; done ;;
 l2)         # fragment-stream micro-benchmark (hipcc -O3 --offload-arch=gfx950 tools/l2_stream.hip -o tools/l2_stream)
   tools/l2_stream ;;
 esac
