@@ -239,9 +239,9 @@ class _Exec:
         self.limb_planes = _os.environ.get("PSLD_LIMB_PLANES", "1") != "0"    # A/B switch for tools/bench_sample.py
         # pass 1 of GroupNorm's backward from the epilogue of the kernel that produces its dy (A/B switch)
         self.fuse_gn_bwd = _os.environ.get("PSLD_FUSE_GN_BWD", "0") == "1"    # measured: -0.8 % on the step
-        # forward attention in one kernel (attention.hip): 1 = where it is faster (8x8 maps: 18.8 vs 54.1 us at B=128; on
-        # 16x16 maps every 64-query workgroup re-splits all 256 keys and values and the kernel is vector-issue-bound: 121 vs
-        # 71 us for the three-kernel path, tools/bench_attn.py), 2 = wherever the kernel takes the shape, 0 = never
+        # forward attention in one kernel (attention.hip): 1 (= 2) wherever the kernel takes the shape (B=128: 8x8 maps 17 vs
+        # 54 us of the three-kernel path, 16x16 maps 62-65 vs 72 us since the 128-query workgroup with prefetched chunks,
+        # tools/bench_attn.py), 3 = 8x8 maps only (the policy up to round 3), 0 = never
         self.fused_attn = int(_os.environ.get("PSLD_FUSED_ATTN", "1"))
         self.dx_nchw = None
 
@@ -824,7 +824,7 @@ class _Exec:
             q, k, v = qkv
             ld = c
         ho = torch.empty((b, hw, c), device=dev, dtype=torch.float32)
-        if self.split and (self.fused_attn == 2 or (self.fused_attn == 1 and hw <= 64)) and ops.attn_fwd_supported(hw, c):
+        if self.split and (self.fused_attn in (1, 2) or (self.fused_attn == 3 and hw <= 64)) and ops.attn_fwd_supported(hw, c):
             # QK^T -> softmax -> PV in ONE kernel: the [B, HW, HW] scores never reach HBM; the probabilities are written
             # only when a backward pass will read them
             p = torch.empty((b, hw, hw), device=dev, dtype=torch.float32) if self.record else None
