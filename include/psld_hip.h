@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 
-#define PSLD_ABI_VERSION 11 /* 2: limb-MFMA convolutions, math mode, bias-gradient / batched-copy entry points; 3: pointwise weight gradient and batched activation GEMM on limb kernels; 4: GroupNorm statistics from the limb kernels' epilogue; 5: per-sample-time reverse SDE, ScoreLoss nll / l1; 6: limb-plane activations; 7: device-resident dropout seed / Adam scalars (captured training step), GroupNorm-backward sums from the producing epilogue; 8: Winograd F(2x2,3x3) limb convolution; 9: launch tape; 10: GroupNorm apply (+SiLU) fused into the Winograd convolution's input staging; 11: GroupNorm backward kernel selector */
+#define PSLD_ABI_VERSION 12 /* 2: limb-MFMA convolutions, math mode, bias-gradient / batched-copy entry points; 3: pointwise weight gradient and batched activation GEMM on limb kernels; 4: GroupNorm statistics from the limb kernels' epilogue; 5: per-sample-time reverse SDE, ScoreLoss nll / l1; 6: limb-plane activations; 7: device-resident dropout seed / Adam scalars (captured training step), GroupNorm-backward sums from the producing epilogue; 8: Winograd F(2x2,3x3) limb convolution; 9: launch tape; 10: GroupNorm apply (+SiLU) fused into the Winograd convolution's input staging; 11: GroupNorm backward kernel selector; 12: column sums of dx from the GroupNorm backward */
 #define PSLD_COEFF_STRIDE 12
 
 int psld_version(void);
@@ -308,8 +308,8 @@ int psld_gn_apply_limb_nhwc(const float* x, const float* scale, const float* shi
                             int hw, int c, int act, float drop_p, unsigned long long seed,
                             const unsigned long long* seed_dev, hipStream_t stream);
 /* Which kernel psld_gn_bwd_nhwc_f32 takes when the backward runs in one pass over (dy, x) (no part_in; see there):
- *   PSLD_GN_BWD_AUTO      the LDS-image kernel (gn_bwd_pipe_kernel: the next slab's x, or the third operand of the current
- *                         one, lands in LDS by global_load_lds while the workgroup reduces) where its shape rules hold, else
+ *   PSLD_GN_BWD_AUTO      the resident-workgroup kernel (gn_bwd_pipe_kernel: the next slab's x lands in LDS by global_load_lds
+ *                         while the workgroup reduces and stores) where its shape rules hold and there is no third operand, else
  *   PSLD_GN_BWD_ONE_SLAB  the register-resident one-slab kernel (gn_bwd_fused_kernel) for every shape.
  * Both give bitwise equal dx / dgamma / dbeta (tests/test_kernels_gpu.py compares them through this switch).  Process-wide;
  * the initial value comes from the environment variable PSLD_GN_BWD_PIPE ("0" = one slab). */
@@ -329,6 +329,20 @@ int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float* mean, con
                          float* dx, float* dgamma, float* dbeta, int accumulate_dx,
                          const float* add, float add_scale, const float* part_in, int part_chunks,
                          void* workspace, hipStream_t stream);
+/* The same backward (no add, no accumulate_dx, no part_in) that ALSO returns the column sums of dx - the bias gradient and
+ * the per-image time-embedding gradient of the convolution whose output gradient this dx is (layerspp.py:258-263: Conv_0 +
+ * Dense_0(act(temb))[:, :, None, None]) - without a pass over dx: per channel sum_p dx = k0 sum_p dz - hw k1 - k2 sum_p xhat,
+ * formed from the sums the one-pass kernels reduce anyway (and one more, sum_p xhat) with the coefficients dx is stored with.
+ *   colsum_img (may be NULL): [batch] rows of ld_img floats, columns [0, c) written: sum over the pixels of image n;
+ *   colsum (may be NULL): [c] = colsum_alpha * sum over the batch of those rows.
+ * Only where the one-pass kernels take the shape: psld_gn_bwd_colsum_supported. */
+int psld_gn_bwd_colsum_supported(int batch, int hw, int c, int groups);
+int psld_gn_bwd_colsum_nhwc_f32(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                const float* beta, int batch, int hw, int c, int groups, int act, float drop_p,
+                                unsigned long long seed, const unsigned long long* seed_dev, float* dx, float* dgamma,
+                                float* dbeta, float* colsum_img, int ld_img, float* colsum, float colsum_alpha, void* workspace,
+                                hipStream_t stream);
+
 
 /* ---- FIR resampling: the replacement of the pybind op upfirdn2d_op.upfirdn2d
  *      (op/upfirdn2d.cpp:12-22, op/upfirdn2d_kernel.cu:209-369).  Same semantics: zero-insert

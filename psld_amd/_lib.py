@@ -68,7 +68,7 @@ class SscsCoeffs(C.Structure):
 I, F, D, LL, P = C.c_int, C.c_float, C.c_double, C.c_longlong, C.c_void_p
 EP = C.POINTER(Epilogue)
 
-ABI_VERSION = 11   # PSLD_ABI_VERSION of include/psld_hip.h these signatures were written against
+ABI_VERSION = 12   # PSLD_ABI_VERSION of include/psld_hip.h these signatures were written against
 
 # name -> (restype, argtypes): every symbol include/psld_hip.h declares
 SIGNATURES = {
@@ -125,6 +125,8 @@ SIGNATURES = {
     "psld_gn_stats_from_partials_f32": (I, [P, I, I, I, I, F, P, P, P, P, P, P, P]),
     "psld_gn_apply_nhwc_f32": (I, [P, P, P, P, I, I, I, I, F, C.c_ulonglong, P, P]),
     "psld_gn_bwd_nhwc_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, F, C.c_ulonglong, P, P, P, P, I, P, F, P, I, P, P]),
+    "psld_gn_bwd_colsum_supported": (I, [I, I, I, I]),
+    "psld_gn_bwd_colsum_nhwc_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, F, C.c_ulonglong, P, P, P, P, P, I, P, F, P, P]),
     "psld_upfirdn2d_f32": (I, [P, P, I, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "psld_fused_bias_act_f32": (I, [P, P, P, LL, I, I, I, F, F, P]),
     "psld_fused_bias_act_grad_f32": (I, [P, P, P, P, LL, I, I, I, I, F, F, P]),

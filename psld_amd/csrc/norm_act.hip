@@ -298,18 +298,24 @@ __global__ void __launch_bounds__(1024) gn_bwd_finalize_kernel(const float* __re
                                                                const float* __restrict__ gamma, int batch, int hw, int c,
                                                                int groups, int chunks, float* __restrict__ coef,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                               int first_block) {
+                                                               int first_block, const float* __restrict__ csum_img = nullptr,
+                                                               int ld_img = 0, float* __restrict__ csum = nullptr,
+                                                               float csum_alpha = 1.f) {
     __shared__ double sh[2 * MAXT * 4];          // image role: s1*gamma, s2*gamma per channel; param role: [16][64]
     __shared__ double g1[MAXG], g2[MAXG];
     const int tid = threadIdx.x;
     const int bid = (int)blockIdx.x + first_block;      // first_block = batch: parameter-gradient blocks only
     if (bid >= batch) {
         const int r = bid - batch;
-        const int which = r & 1;
-        const int col = (r >> 1) * 64 + (tid & 63);
+        const int roles = csum ? 3 : 2;             // dbeta, dgamma (, column sums of dx over the batch)
+        const int which = r % roles;
+        const int col = (r / roles) * 64 + (tid & 63);
         const int lane = tid >> 6;
         double acc = 0.0;
-        if (col < c)
+        if (which == 2) {
+            if (col < c)
+                for (int n = lane; n < batch; n += 16) acc += (double)csum_img[(long long)n * ld_img + col];
+        } else if (col < c)
             for (int n = lane; n < batch; n += 16) {
                 const float* p = part + (((long long)n * chunks) * 2 + which) * c + col;
 #pragma unroll 8
@@ -321,7 +327,10 @@ __global__ void __launch_bounds__(1024) gn_bwd_finalize_kernel(const float* __re
             double t = 0.0;
 #pragma unroll
             for (int l = 0; l < 16; ++l) t += sh[l * 64 + tid];
-            (which ? dgamma : dbeta)[col] = (float)t;
+            if (which == 2)
+                csum[col] = (float)(t * (double)csum_alpha);
+            else
+                (which ? dgamma : dbeta)[col] = (float)t;
         }
         return;
     }
@@ -463,8 +472,10 @@ __global__ void __launch_bounds__(512) gn_bwd_fused_kernel(const float* __restri
                                                            unsigned long long seed,
                                                            const unsigned long long* __restrict__ seed_dev, int accumulate,
                                                            const float* __restrict__ add, float add_scale,
-                                                           float* __restrict__ dx, float* __restrict__ part) {
-    extern __shared__ float red[];               // [pl][cq][8] thread sums, then (as doubles) [cw][2] channel sums + [gb][2]
+                                                           float* __restrict__ dx, float* __restrict__ part,
+                                                           float* __restrict__ csum_img, int ld_img) {
+    extern __shared__ float red[];               // [pl][cq][8] thread sums, then (as doubles) [cw][2] channel sums + [gb][2],
+                                                 // then (column sums of dx) [pl][cq][4] thread sums of xhat, [cw] + [cw] channel sums
     const int n = blockIdx.y, slab = blockIdx.x;
     GNB_STAMP(6);
     GNB_STAMP(0);
@@ -503,7 +514,7 @@ __global__ void __launch_bounds__(512) gn_bwd_fused_kernel(const float* __restri
         }
     }
     GNB_STAMP(1);
-    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0}, s3[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const int p = l + i * pl;
@@ -517,6 +528,7 @@ __global__ void __launch_bounds__(512) gn_bwd_fused_kernel(const float* __restri
                 if (act) dz *= dsilu_f(xh * ga[e] + be[e]);
                 s1[e] += dz;
                 s2[e] += dz * xh;
+                s3[e] += xh;
                 xv[i][e] = xh;
                 gv[i][e] = dz;
             }
@@ -529,10 +541,19 @@ __global__ void __launch_bounds__(512) gn_bwd_fused_kernel(const float* __restri
         my[e] = s1[e];
         my[4 + e] = s2[e];
     }
-    __syncthreads();
-    GNB_STAMP(3);
     double* chs = reinterpret_cast<double*>(red + (long long)pl * cq * 8);      // [cw][2]: gamma-weighted channel sums
     double* grp = chs + cw * 2;                                                  // [gb][2]
+    // column sums of dx per image (the bias / time-embedding gradient of the convolution whose output gradient this dx is)
+    // without a pass over dx: sum_p dx = k0 sum_p dz - hw k1 - k2 sum_p xhat per channel
+    float* red3 = reinterpret_cast<float*>(grp + gb * 2);                        // [pl][cq][4]
+    float* cs1 = red3 + (long long)pl * cq * 4;                                  // [cw] sum_p dz (as stored in part)
+    float* cs3 = cs1 + cw;                                                       // [cw] sum_p xhat
+    if (csum_img) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red3[((long long)l * cq + q) * 4 + e] = s3[e];
+    }
+    __syncthreads();
+    GNB_STAMP(3);
     if (!(GNB_MODE & 2))
     for (int i = tid; i < cq * 8; i += blockDim.x) {
         double acc = 0;
@@ -542,6 +563,13 @@ __global__ void __launch_bounds__(512) gn_bwd_fused_kernel(const float* __restri
         const float rounded = (float)acc;                                          // what the three-kernel path stores
         part[(((long long)n * 2 + (k >> 2))) * c + c0 + chl] = rounded;
         chs[chl * 2 + (k >> 2)] = (double)rounded * (double)gamma[c0 + chl];
+        if (csum_img && k < 4) cs1[chl] = rounded;
+    }
+    if (csum_img && tid >= cq * 8 && tid < cq * 12) {
+        const int j = tid - cq * 8;
+        double acc = 0;
+        for (int ll = 0; ll < pl; ++ll) acc += (double)red3[(long long)ll * cq * 4 + j];
+        cs3[j] = (float)acc;
     }
     __syncthreads();
     if (tid < gb * 2) {
@@ -558,6 +586,14 @@ __global__ void __launch_bounds__(512) gn_bwd_fused_kernel(const float* __restri
     f32x4 k0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) k0[e] = rs * ga[e];
+    if (csum_img && tid < cw) {      // one thread per channel of the slab, with the coefficients the stores below use
+        const int gc = tid / cpg;
+        const float rc = rstd[n * groups + (c0 + tid) / cpg];
+        const float c0k = rc * gamma[c0 + tid];
+        const float c1k = (float)((double)rc * grp[gc * 2 + 0] / cnt), c2k = (float)((double)rc * grp[gc * 2 + 1] / cnt);
+        csum_img[(long long)n * ld_img + c0 + tid] =
+            (float)((double)c0k * (double)cs1[tid] - (double)hw * (double)c1k - (double)c2k * (double)cs3[tid]);
+    }
     // dx into gv; the parallel branch's gradient / the previous dx are loaded for ALL items before the first is used (xv is
     // free by then): a load - wait - store chain per item costs one memory latency each
 #pragma unroll
@@ -627,7 +663,7 @@ __global__ void __launch_bounds__(512) gn_bwd_pipe_kernel(const float* __restric
                                                           unsigned long long seed,
                                                           const unsigned long long* __restrict__ seed_dev,
                                                           float* __restrict__ dx, float* __restrict__ part, int slabs,
-                                                          int units, int per) {
+                                                          int units, int per, float* __restrict__ csum_img, int ld_img) {
     extern __shared__ __attribute__((aligned(16))) unsigned char psm[];   // [ITEMS][waves][1 KB] x image | thread sums | channel / group sums | (mean, rstd) per slab
     if (seed_dev) seed += seed_dev[0];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -641,7 +677,10 @@ __global__ void __launch_bounds__(512) gn_bwd_pipe_kernel(const float* __restric
     float* red = reinterpret_cast<float*>(psm + (size_t)ITEMS * nw * 1024);
     double* chs = reinterpret_cast<double*>(red + (long long)pl * cq * 8);      // [cw][2]
     double* grp = chs + cw * 2;                                                  // [gb][2]
-    float* tab = reinterpret_cast<float*>(grp + gb * 2);                         // [per][gb][2]
+    float* red3 = reinterpret_cast<float*>(grp + gb * 2);                        // [pl][cq][4] thread sums of xhat (column sums of dx)
+    float* cs1 = red3 + (long long)pl * cq * 4;                                  // [cw] sum_p dz, [cw] sum_p xhat
+    float* cs3 = cs1 + cw;
+    float* tab = cs3 + cw;                                                       // [per][gb][2]
     const unsigned istride = (unsigned)pl * c * 4;                               // bytes between a thread's items
     const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     const double cnt = (double)cpg * hw;
@@ -655,13 +694,14 @@ __global__ void __launch_bounds__(512) gn_bwd_pipe_kernel(const float* __restric
     const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + ch0), be = *reinterpret_cast<const f32x4*>(beta + ch0);
     const int ri = tid < cq * 8 ? tid : 0;                                       // reduction column of this thread
     const float rgam = gamma[c0 + (ri >> 3) * 4 + (ri & 3)];
+    const float cgam = gamma[c0 + (tid < cw ? tid : 0)];                         // (column sums of dx: one thread per channel)
     if (tid < per * gb) {
         const int k = tid / gb, j = tid - k * gb, n = n0 + k * nstep;
         const bool in = (long long)n * slabs + slab < units;
         tab[tid * 2 + 0] = in ? mean[n * groups + slab * gb + j] : 0.f;
         tab[tid * 2 + 1] = in ? rstd[n * groups + slab * gb + j] : 0.f;
     }
-    asm volatile("" ::"v"(ga), "v"(be), "v"(rgam));
+    asm volatile("" ::"v"(ga), "v"(be), "v"(rgam), "v"(cgam));
     __syncthreads();
     const unsigned nbytes = (unsigned)nstep * hw * c * 4;                        // from a slab to this workgroup's next
     unsigned o = (unsigned)((((long long)n0 * hw + l) * c + ch0) * 4);           // this thread's first element (tensors < 4 GB)
@@ -687,7 +727,7 @@ __global__ void __launch_bounds__(512) gn_bwd_pipe_kernel(const float* __restric
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) xv[i] = *reinterpret_cast<const f32x4*>(my_x + (size_t)i * nw * 1024);
         GNP_STAMP(2);
-        float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+        float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0}, s3[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             asm volatile("s_waitcnt vmcnt(%1)" : "+v"(gv[i]) : "i"(ITEMS - 1 - i));       // dy item i
@@ -700,6 +740,7 @@ __global__ void __launch_bounds__(512) gn_bwd_pipe_kernel(const float* __restric
                 if (act) dz *= dsilu_f(xh * ga[e] + be[e]);
                 s1[e] += dz;
                 s2[e] += dz * xh;
+                s3[e] += xh;
                 xv[i][e] = xh;
                 gv[i][e] = dz;
             }
@@ -718,6 +759,10 @@ __global__ void __launch_bounds__(512) gn_bwd_pipe_kernel(const float* __restric
             my[e] = s1[e];
             my[4 + e] = s2[e];
         }
+        if (csum_img) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red3[((long long)l * cq + q) * 4 + e] = s3[e];
+        }
         lds_barrier();
         GNP_STAMP(5);
         if (tid < cq * 8) {
@@ -728,6 +773,12 @@ __global__ void __launch_bounds__(512) gn_bwd_pipe_kernel(const float* __restric
             const float rounded = (float)acc;
             part[(((long long)n * 2 + (kk >> 2))) * c + c0 + chl] = rounded;
             chs[chl * 2 + (kk >> 2)] = (double)rounded * (double)rgam;
+            if (csum_img && kk < 4) cs1[chl] = rounded;
+        } else if (csum_img && tid < cq * 12) {
+            const int j = tid - cq * 8;
+            double acc = 0;
+            for (int ll = 0; ll < pl; ++ll) acc += (double)red3[(long long)ll * cq * 4 + j];
+            cs3[j] = (float)acc;
         }
         lds_barrier();
         if (tid < gb * 2) {
@@ -742,6 +793,14 @@ __global__ void __launch_bounds__(512) gn_bwd_pipe_kernel(const float* __restric
         f32x4 k0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) k0[e] = rs * ga[e];
+        if (csum_img && tid < cw) {  // one thread per channel of the slab, with the coefficients the stores below use
+            const int gc = tid / cpg;
+            const float rc = tab[(k * gb + gc) * 2 + 1];
+            const float c0k = rc * cgam;
+            const float c1k = (float)((double)rc * grp[gc * 2 + 0] / cnt), c2k = (float)((double)rc * grp[gc * 2 + 1] / cnt);
+            csum_img[(long long)n * ld_img + c0 + tid] =
+                (float)((double)c0k * (double)cs1[tid] - (double)hw * (double)c1k - (double)c2k * (double)cs3[tid]);
+        }
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
             f32x4 r;
@@ -892,12 +951,14 @@ extern "C" int psld_gn_apply_limb_nhwc(const float* x, const float* scale, const
     return PSLD_OK;
 }
 
-extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float* mean, const float* rstd,
-                                    const float* gamma, const float* beta, int batch, int hw, int c, int groups,
-                                    int act, float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* dx,
-                                    float* dgamma,
-                                    float* dbeta, int accumulate_dx, const float* add, float add_scale,
-                                    const float* part_in, int part_chunks, void* workspace, hipStream_t stream) {
+namespace {
+// csum_img ([batch] rows of ld_img floats, c used) / csum ([c]): the column sums of dx per image and alpha * their sum over
+// the batch - only on the one-pass paths without a third operand (psld_gn_bwd_colsum_supported)
+int gn_bwd_impl(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                int batch, int hw, int c, int groups, int act, float drop_p, unsigned long long seed,
+                const unsigned long long* seed_dev, float* dx, float* dgamma, float* dbeta, int accumulate_dx,
+                const float* add, float add_scale, const float* part_in, int part_chunks, void* workspace,
+                float* csum_img, int ld_img, float* csum, float csum_alpha, hipStream_t stream) {
     PSLD_CHECK_ARG(dy && x && mean && rstd && gamma && beta && dx && dgamma && dbeta && workspace,
                    "psld_gn_bwd: null pointer");
     PSLD_CHECK_ARG(c % 4 == 0 && c / 4 <= MAXT && groups <= MAXG && c % groups == 0,
@@ -906,15 +967,23 @@ extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float
     char* ws = reinterpret_cast<char*>(workspace);
     float* part = reinterpret_cast<float*>(ws);
     ws += align256((size_t)batch * m.chunks * 2 * c * sizeof(float));
-    ws += align256((size_t)batch * 2 * c * sizeof(float));      // (formerly the per-image sums; the size query is unchanged)
+    float* own_img = reinterpret_cast<float*>(ws);              // per-image column sums of dx when the caller keeps only their total
+    ws += align256((size_t)batch * 2 * c * sizeof(float));
     float* coef = reinterpret_cast<float*>(ws);
+    if (csum && !csum_img) {
+        csum_img = own_img;
+        ld_img = c;
+    }
     const size_t lds = (size_t)m.pl * m.cq * 8 * sizeof(float);
     int chunks = m.chunks;
     int gb = 0, fpl = 0, items = 0;
     if (!part_in && gn_bwd_fused_plan(batch, hw, c, groups, &gb, &fpl, &items)) {
         const int cpg = c / groups, cw = gb * cpg, cq = cw / 4;
         const dim3 grid(groups / gb, batch), block(cq * fpl);
-        const size_t flds = (size_t)fpl * cq * 8 * sizeof(float) + (size_t)(cw + gb) * 2 * sizeof(double);
+        const size_t flds = (size_t)fpl * cq * 8 * sizeof(float) + (size_t)(cw + gb) * 2 * sizeof(double) +
+                            ((size_t)fpl * cq * 4 + 2 * cw) * sizeof(float);
+        PSLD_CHECK_ARG(!csum_img || (!add && !accumulate_dx), "psld_gn_bwd_colsum: column sums of dx only without add / accumulate_dx");
+        const int fin_blocks = (csum ? 3 : 2) * cdiv(c, 64);
         int pipe_grid = 0, pipe_per = 0;
         size_t plds = 0;
         if (!add && !accumulate_dx &&       // (a third operand: the one-slab kernel, see gn_bwd_pipe_kernel)
@@ -922,18 +991,19 @@ extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float
             const int slabs = groups / gb;
 #define PSLD_GN_PIPE(IT)                                                                                               \
     hipLaunchKernelGGL((gn_bwd_pipe_kernel<IT>), dim3(pipe_grid), block, plds, stream, dy, x, mean, rstd, gamma, beta, hw, \
-                       c, groups, gb, fpl, act, drop_p, seed, seed_dev, dx, part, slabs, slabs * batch, pipe_per)
+                       c, groups, gb, fpl, act, drop_p, seed, seed_dev, dx, part, slabs, slabs * batch, pipe_per, csum_img,  \
+                       ld_img)
             if (items == 4) PSLD_GN_PIPE(4); else PSLD_GN_PIPE(16);
 #undef PSLD_GN_PIPE
             PSLD_CHECK_LAUNCH("gn_bwd_pipe_kernel");
-            hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(2 * cdiv(c, 64)), dim3(1024), 0, stream, part, rstd, gamma, batch,
-                               hw, c, groups, 1, coef, dgamma, dbeta, batch);
+            hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(fin_blocks), dim3(1024), 0, stream, part, rstd, gamma, batch,
+                               hw, c, groups, 1, coef, dgamma, dbeta, batch, csum_img, ld_img, csum, csum_alpha);
             PSLD_CHECK_LAUNCH("gn_bwd_finalize_kernel");
             return PSLD_OK;
         }
 #define PSLD_GN_FUSED(IT)                                                                                              \
     hipLaunchKernelGGL((gn_bwd_fused_kernel<IT>), grid, block, flds, stream, dy, x, mean, rstd, gamma, beta, hw, c, groups, \
-                       gb, fpl, act, drop_p, seed, seed_dev, accumulate_dx, add, add_scale, dx, part)
+                       gb, fpl, act, drop_p, seed, seed_dev, accumulate_dx, add, add_scale, dx, part, csum_img, ld_img)
         switch (items) {
             case 1: PSLD_GN_FUSED(1); break;
             case 2: PSLD_GN_FUSED(2); break;
@@ -943,11 +1013,12 @@ extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float
 #undef PSLD_GN_FUSED
         PSLD_CHECK_LAUNCH("gn_bwd_fused_kernel");
         // dgamma / dbeta: the parameter blocks of the finalize kernel over the per-image sums (chunks = 1)
-        hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(2 * cdiv(c, 64)), dim3(1024), 0, stream, part, rstd, gamma, batch, hw,
-                           c, groups, 1, coef, dgamma, dbeta, batch);
+        hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(fin_blocks), dim3(1024), 0, stream, part, rstd, gamma, batch, hw,
+                           c, groups, 1, coef, dgamma, dbeta, batch, csum_img, ld_img, csum, csum_alpha);
         PSLD_CHECK_LAUNCH("gn_bwd_finalize_kernel");
         return PSLD_OK;
     }
+    PSLD_CHECK_ARG(!csum_img, "psld_gn_bwd_colsum: not on the three-pass path (psld_gn_bwd_colsum_supported)");
     if (part_in) {        // pass 1 came with dy (the producing kernel's epilogue, psld_epilogue_t.gnb_part)
         PSLD_CHECK_ARG(part_chunks >= 1, "psld_gn_bwd: part_chunks must be >= 1 with part_in");
         part = const_cast<float*>(part_in);
@@ -966,6 +1037,35 @@ extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float
                        dx);
     PSLD_CHECK_LAUNCH("gn_bwd_apply_kernel");
     return PSLD_OK;
+}
+}  // namespace
+
+extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float* mean, const float* rstd,
+                                    const float* gamma, const float* beta, int batch, int hw, int c, int groups,
+                                    int act, float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* dx,
+                                    float* dgamma,
+                                    float* dbeta, int accumulate_dx, const float* add, float add_scale,
+                                    const float* part_in, int part_chunks, void* workspace, hipStream_t stream) {
+    return gn_bwd_impl(dy, x, mean, rstd, gamma, beta, batch, hw, c, groups, act, drop_p, seed, seed_dev, dx, dgamma, dbeta,
+                       accumulate_dx, add, add_scale, part_in, part_chunks, workspace, nullptr, 0, nullptr, 1.f, stream);
+}
+
+extern "C" int psld_gn_bwd_colsum_supported(int batch, int hw, int c, int groups) {
+    int gb = 0, pl = 0, items = 0;
+    return batch > 0 && hw > 0 && c > 0 && c % 4 == 0 && c / 4 <= MAXT && groups > 0 && groups <= MAXG && c % groups == 0 &&
+           gn_bwd_fused_plan(batch, hw, c, groups, &gb, &pl, &items);
+}
+
+extern "C" int psld_gn_bwd_colsum_nhwc_f32(const float* dy, const float* x, const float* mean, const float* rstd,
+                                           const float* gamma, const float* beta, int batch, int hw, int c, int groups, int act,
+                                           float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* dx,
+                                           float* dgamma, float* dbeta, float* colsum_img, int ld_img, float* colsum,
+                                           float colsum_alpha, void* workspace, hipStream_t stream) {
+    PSLD_CHECK_ARG(colsum || colsum_img, "psld_gn_bwd_colsum: no output requested");
+    PSLD_CHECK_ARG(!colsum_img || ld_img >= c, "psld_gn_bwd_colsum: ld_img < c");
+    PSLD_CHECK_ARG(psld_gn_bwd_colsum_supported(batch, hw, c, groups), "psld_gn_bwd_colsum: unsupported shape B=%d hw=%d C=%d", batch, hw, c);
+    return gn_bwd_impl(dy, x, mean, rstd, gamma, beta, batch, hw, c, groups, act, drop_p, seed, seed_dev, dx, dgamma, dbeta, 0,
+                       nullptr, 1.f, nullptr, 0, workspace, colsum_img, ld_img, colsum, colsum_alpha, stream);
 }
 
 extern "C" int psld_set_gn_bwd_kernel(int kind) {

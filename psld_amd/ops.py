@@ -598,6 +598,27 @@ def gn_bwd(dy: Tensor, x: Tensor, st: GNStats, gamma: Tensor, beta: Tensor, act:
                                      ws.data_ptr(), _stream()), "psld_gn_bwd_nhwc_f32")
 
 
+@functools.lru_cache(maxsize=None)
+def gn_bwd_colsum_supported(b: int, hw: int, c: int, groups: Optional[int] = None) -> bool:
+    return bool(lib().psld_gn_bwd_colsum_supported(b, hw, c, groups if groups is not None else gn_groups(c)))
+
+
+def gn_bwd_colsum(dy: Tensor, x: Tensor, st: GNStats, gamma: Tensor, beta: Tensor, act: bool, dx: Tensor, dgamma: Tensor,
+                  dbeta: Tensor, colsum: Optional[Tensor], colsum_alpha: float = 1.0, per_image: Optional[Tensor] = None,
+                  ld_per_image: int = 0, drop_p: float = 0.0, seed: int = 0, seed_dev: Optional[Tensor] = None):
+    """``gn_bwd`` (no add / accumulate / part) that also returns the column sums of dx: ``colsum`` [c] = colsum_alpha * sum over
+    batch and pixels (a bias gradient), ``per_image`` ([b] rows, row stride ``ld_per_image`` or c) the sums per image (the
+    time-embedding gradient) - formed from the per-channel sums of the one-pass kernels instead of a pass over dx."""
+    b, h, w, c = x.shape
+    g = gn_groups(c)
+    ws = workspace(lib().psld_gn_workspace_bytes(b, h * w, c, g), x.device)
+    check(lib().psld_gn_bwd_colsum_nhwc_f32(dy.data_ptr(), x.data_ptr(), st.mean.data_ptr(), st.rstd.data_ptr(),
+                                            gamma.data_ptr(), beta.data_ptr(), b, h * w, c, g, 1 if act else 0, drop_p, seed,
+                                            _p(seed_dev), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _p(per_image),
+                                            (ld_per_image or c) if per_image is not None else 0, _p(colsum), colsum_alpha,
+                                            ws.data_ptr(), _stream()), "psld_gn_bwd_colsum_nhwc_f32")
+
+
 # ------------------------------------------------------------------------------------------------
 # FIR resampling
 # ------------------------------------------------------------------------------------------------

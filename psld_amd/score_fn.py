@@ -243,6 +243,9 @@ class _Exec:
         # 54 us of the three-kernel path, 16x16 maps 62-65 vs 72 us since the 128-query workgroup with prefetched chunks,
         # tools/bench_attn.py), 3 = 8x8 maps only (the policy up to round 3), 0 = never
         self.fused_attn = int(_os.environ.get("PSLD_FUSED_ATTN", "1"))
+        # Conv_0's bias / time-embedding gradient from the sums of the GroupNorm backward that writes its output gradient
+        # (ops.gn_bwd_colsum) instead of a column-sum pass over that tensor (A/B switch)
+        self.gn_bwd_colsum = _os.environ.get("PSLD_GN_BWD_COLSUM", "1") == "1"
         self.dx_nchw = None
 
     # -- helpers ------------------------------------------------------------------------------
@@ -680,15 +683,31 @@ class _Exec:
             gnb1 = self.gnb_for(h1, st1, gn1, True, drop_p, seed, seed_dev) if limb1 else None
             self.dgrad(dout, mod.Conv_1, 3, 1, 1, ho, wo, da1, alpha=s, gnb=gnb1)
             dh1 = torch.empty_like(h1)
-            ops.gn_bwd(da1, h1, st1, gn1.weight, gn1.bias, True, dh1, self.g(gn1.weight), self.g(gn1.bias),
-                       drop_p=drop_p, seed=seed, seed_dev=seed_dev, part=gnb1["part"] if gnb1 is not None else None)
+            # Conv_0's bias gradient and the per-image sums of dh1 (the time-embedding gradient) as a by-product of the
+            # GroupNorm backward that writes dh1 (no pass over dh1), where its one-pass kernels take the shape
+            csum = gnb1 is None and self.gn_bwd_colsum and ops.gn_bwd_colsum_supported(b, ho * wo, cout)
+            dtp_pre = None
+            if csum:
+                if temb_act is None:
+                    per_img, ldp = None, 0
+                elif tp_off is not None and dtp_all is not None:
+                    per_img, ldp = dtp_all[:, tp_off:tp_off + cout], dtp_all.shape[1]
+                else:
+                    per_img, ldp = torch.empty((b, cout), device=dout.device, dtype=torch.float32), cout
+                dtp_pre = per_img
+                ops.gn_bwd_colsum(da1, h1, st1, gn1.weight, gn1.bias, True, dh1, self.g(gn1.weight), self.g(gn1.bias),
+                                  self.g(mod.Conv_0.bias), 1.0, per_img, ldp, drop_p=drop_p, seed=seed, seed_dev=seed_dev)
+            else:
+                ops.gn_bwd(da1, h1, st1, gn1.weight, gn1.bias, True, dh1, self.g(gn1.weight), self.g(gn1.bias),
+                           drop_p=drop_p, seed=seed, seed_dev=seed_dev, part=gnb1["part"] if gnb1 is not None else None)
             del da1
 
             # Conv_0 + time-embedding bias
             def side0():
                 self.wgrad(dh1, a0r, mod.Conv_0, 3, 1, 1, x2=a0b)
                 if temb_act is None:
-                    self.bias_grad(dh1, self.g(mod.Conv_0.bias))
+                    if not csum:
+                        self.bias_grad(dh1, self.g(mod.Conv_0.bias))
                     return
                 d0 = mod.Dense_0
                 kd = d0.weight.shape[1]
@@ -697,14 +716,15 @@ class _Exec:
                     # by ONE GEMM over all blocks at the end (time_embedding.bwd)
                     ldt = dtp_all.shape[1]
                     dtp = dtp_all[:, tp_off:tp_off + cout]
-                    self.bias_grad(dh1, self.g(mod.Conv_0.bias), per_image=dtp, ld_per_image=ldt)
+                    if not csum:
+                        self.bias_grad(dh1, self.g(mod.Conv_0.bias), per_image=dtp, ld_per_image=ldt)
                     if self.split and ops.gemm_tn_split_supported(cout, kd, b) and dtp.data_ptr() % 16 == 0:
                         # one "slab" = the gradient itself: K = batch is short enough for a single range
                         ops.gemm_tn_split(cout, kd, b, dtp, ldt, temb_act.v, kd, self.g(d0.weight), kd, 1)
                     else:
                         ops.gemm_raw(1, 0, cout, kd, b, dtp, ldt, 0, temb_act.v, kd, 0, self.g(d0.weight), kd, 0)
                 else:
-                    dtp = self.bias_grad(dh1, self.g(mod.Conv_0.bias), per_image=True)
+                    dtp = dtp_pre if csum else self.bias_grad(dh1, self.g(mod.Conv_0.bias), per_image=True)
                     ops.gemm_raw(1, 0, cout, kd, b, dtp, cout, 0, temb_act.v, kd, 0, self.g(d0.weight), kd, 0)
                     gb, acc = _gbuf(temb_act)
                     ops.gemm_raw(0, 0, b, kd, cout, dtp, cout, 0, d0.weight, kd, 0, gb, kd, 0,

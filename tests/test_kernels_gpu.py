@@ -973,6 +973,40 @@ def test_groupnorm_backward_lds_image_kernel(ops, b, s, c, variant):
     assert rel_l2(dx[n:n + 1].permute(0, 3, 1, 2), want) < 1e-5
 
 
+@pytest.mark.parametrize("b,s,c", [(64, 32, 256), (128, 16, 256), (16, 32, 256), (5, 16, 128), (3, 8, 256), (2, 4, 512), (4, 16, 384)])
+@pytest.mark.parametrize("variant", ["plain", "dropout", "no_act"])
+def test_groupnorm_backward_column_sums_of_dx(ops, b, s, c, variant):
+    """psld_gn_bwd_colsum_nhwc_f32: dx, dgamma, dbeta bit for bit those of psld_gn_bwd_nhwc_f32; the per-image column sums of
+    dx (written into a wider buffer) and alpha x their batch total against fp64 sums of the dx it wrote - on every one-pass
+    kernel (1 / 2 / 4 / 16 items per thread, resident workgroups)."""
+    assert ops.gn_bwd_colsum_supported(b, s * s, c)
+    x = (gen(b, s, s, c, seed=70) * 1.5 + 0.3).to(DEV)
+    dy = gen(b, s, s, c, seed=71).to(DEV)
+    gamma, beta = (1 + 0.2 * gen(c, seed=72)).to(DEV), (0.1 * gen(c, seed=73)).to(DEV)
+    act = variant != "no_act"
+    kw = {"drop_p": 0.15, "seed": 99} if variant == "dropout" else {}
+    st = ops.gn_stats(x, gamma, beta)
+    dx0 = torch.full_like(x, float("nan"))
+    dg0, db0 = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    ops.gn_bwd(dy, x, st, gamma, beta, act, dx0, dg0, db0, **kw)
+    dx1 = torch.full_like(x, float("nan"))
+    dg1, db1 = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    wide = torch.full((b, c + 24), float("nan"), device=DEV)
+    per_image = wide[:, 8:8 + c]
+    total = torch.full((c,), float("nan"), device=DEV)
+    ops.gn_bwd_colsum(dy, x, st, gamma, beta, act, dx1, dg1, db1, total, 0.5, per_image, c + 24, **kw)
+    assert torch.equal(dx1, dx0) and torch.equal(dg1, dg0) and torch.equal(db1, db0)
+    assert torch.isnan(wide[:, :8]).all() and torch.isnan(wide[:, 8 + c:]).all()
+    want_img = dx0.double().sum(dim=(1, 2))
+    scale = dx0.double().abs().sum(dim=(1, 2)).clamp_min(1e-30)       # a column sum cancels: compare against the sum of magnitudes
+    assert ((per_image.double() - want_img).abs() / scale).max().item() < 2e-6
+    assert ((total.double() - 0.5 * want_img.sum(0)).abs() / (0.5 * scale.sum(0))).max().item() < 2e-6
+    # the total alone (the per-image sums in the workspace)
+    total2 = torch.full((c,), float("nan"), device=DEV)
+    ops.gn_bwd_colsum(dy, x, st, gamma, beta, act, dx1, dg1, db1, total2, 0.5, None, 0, **kw)
+    assert torch.equal(total2, total)
+
+
 # ---------------------------------------------------------------------------------------------------
 # FIR resampling (the reference's native op)
 # ---------------------------------------------------------------------------------------------------

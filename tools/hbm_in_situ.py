@@ -36,6 +36,7 @@ BYTES = {
     "psld_gn_apply_nhwc_f32": _b("gn_apply", lambda a: 8 * a[4] * a[5] * a[6]),
     "psld_gn_apply_limb_nhwc": _b("gn_apply_limb", lambda a: 10 * a[4] * a[5] * a[6]),
     "psld_gn_bwd_nhwc_f32": _b("gn_bwd", lambda a: (12 + (4 if a[17] else 0) + (4 if a[18] else 0)) * a[6] * a[7] * a[8]),
+    "psld_gn_bwd_colsum_nhwc_f32": _b("gn_bwd", lambda a: 12 * a[6] * a[7] * a[8]),
     "psld_upfirdn2d_f32": _b("fir", lambda a: 4 * a[2] * a[3] * (a[4] * a[5] + _fir_out(a) * (2 if a[18] else 1))),
     "psld_axpby_f32": _b("axpby", lambda a: 4 * a[5] * (2 + (1 if a[2] else 0) + (1 if a[6] else 0))),
     "psld_silu_f32": _b("silu", lambda a: 8 * a[2]),
