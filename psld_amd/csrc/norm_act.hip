@@ -379,6 +379,12 @@ __global__ void __launch_bounds__(1024) gn_bwd_finalize_kernel(const float* __re
     }
 }
 
+// dx = k0 dz - k1 - xhat k2 in ONE spelled-out order (two fused multiply-adds): the three kernels that form it must agree bit
+// for bit, and left to itself hipcc contracts the expression differently from kernel to kernel
+__device__ __forceinline__ float gn_dx(float k0, float dz, float k1, float xh, float k2) {
+    return __builtin_fmaf(-xh, k2, __builtin_fmaf(k0, dz, -k1));
+}
+
 // pass 3: dx = coef0*dz - coef1 - xhat*coef2
 __global__ void gn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                     const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -419,7 +425,7 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
             float dz = gv[e];
             if (drop_p > 0.f) dz = psld_dropout_keep(seed, (unsigned long long)(idx + e), drop_p) ? dz * keep_scale : 0.f;
             if (act) dz *= dsilu_f(xh * ga[e] + be[e]);
-            o[e] = c0[e] * dz - c1[e] - xh * c2[e];
+            o[e] = gn_dx(c0[e], dz, c1[e], xh, c2[e]);
         }
         float* dp = dx + idx;
         if (add) {                       // gradient of a parallel identity branch: dx += add_scale * add
@@ -599,7 +605,7 @@ __global__ void __launch_bounds__(512) gn_bwd_fused_kernel(const float* __restri
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) gv[i][e] = k0[e] * gv[i][e] - k1 - xv[i][e] * k2;
+        for (int e = 0; e < 4; ++e) gv[i][e] = gn_dx(k0[e], gv[i][e], k1, xv[i][e], k2);
     if (add) {
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i) {
@@ -805,7 +811,7 @@ __global__ void __launch_bounds__(512) gn_bwd_pipe_kernel(const float* __restric
         for (int i = 0; i < ITEMS; ++i) {
             f32x4 r;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = k0[e] * gv[i][e] - k1 - xv[i][e] * k2;
+            for (int e = 0; e < 4; ++e) r[e] = gn_dx(k0[e], gv[i][e], k1, xv[i][e], k2);
             *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned char*>(dx) + (o + i * istride)) = r;
         }
         GNP_STAMP(7);

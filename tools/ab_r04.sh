@@ -2,7 +2,7 @@
 # Round-4 same-box A/Bs (run on the GPU box through gpurun; results in profiles/r04/).  The kernel variants and timing-only
 # ablations live in libpsld_hip_abl.so (make -C psld_amd/csrc abl); bench.py refuses that library by name, so the two
 # step-level A/Bs of product-equivalent kernels load a copy under a neutral name.
-#   bash tools/ab_r04.sh wino | dwgrad | fusedgn | stamps | l2 | gnb | gnprev
+#   bash tools/ab_r04.sh wino | dwgrad | fusedgn | stamps | l2 | gnb | gnprev | colsum | attn
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 ABL=$PWD/psld_amd/libpsld_hip_abl.so
 S="256,256,32;512,256,32;256,256,16;512,256,16"
@@ -45,6 +45,13 @@ gnprev)     # full step: this build against the same build with the GroupNorm ke
             #   extern \"C\" int psld_get_gn_bwd_kernel(void) { return 0; }"; hipcc -O3 -fPIC --offload-arch=gfx950 -std=c++17 -I../../include -I. -c prev.hip
             #   hipcc -shared -fPIC --offload-arch=gfx950 <the other objects> prev.o -o ../libpsld_hip_prevgn.so
   for r in 1 2 3 4; do echo "round-4 committed GroupNorm kernels"; step PSLD_HIP_LIB=$PWD/psld_amd/libpsld_hip_prevgn.so; echo "this build"; step PSLD_X=1; done ;;
+colsum)     # Conv_0's bias / time-embedding gradient: column-sum pass over dh1 vs by-product of the GroupNorm backward
+  for r in 1 2 3 4; do echo "column-sum pass over dh1 (PSLD_GN_BWD_COLSUM=0)"; step PSLD_GN_BWD_COLSUM=0; echo "by-product of the GroupNorm backward (default)"; step PSLD_X=1; done ;;
+attn)       # fused attention forward: kernel level, then step and EM step with the 16x16 maps on the three-kernel path (=3) or fused
+  python3 tools/bench_attn.py; python3 tools/bench_attn.py --batch 512
+  PSLD_HIP_LIB=$ABL PSLD_ATTN_QW4=1 python3 tools/bench_attn.py | grep "HW=256"
+  for r in 1 2 3; do echo "fused on 8x8 only (PSLD_FUSED_ATTN=3)"; step PSLD_FUSED_ATTN=3; echo "fused on 16x16 too (default)"; step PSLD_X=1; done
+  for r in 1 2; do for m in 3 1; do echo "EM step, PSLD_FUSED_ATTN=$m"; ONLY512=1 PSLD_FUSED_ATTN=$m python3 tools/bench_sample.py 2>&1 | grep "graphs=0"; done; done ;;
 l2)         # fragment-stream micro-benchmark (hipcc -O3 --offload-arch=gfx950 tools/l2_stream.hip -o tools/l2_stream)
   tools/l2_stream ;;
 esac
