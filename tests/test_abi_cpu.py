@@ -33,6 +33,27 @@ def test_error_reporting_without_gpu():
     assert st != 0 and b"psld_axpby_f32" in lib.psld_last_error()
 
 
+def test_shape_rules_are_host_side():
+    """The *_supported queries are pure host logic (shape rules of the kernels behind them): they answer without a GPU,
+    the way the host side decides which entry point to call."""
+    lib = _lib.load()
+    # GroupNorm backward in one pass (and with it the column sums of dx): an (image, 32-channel) slab in registers
+    assert lib.psld_gn_bwd_colsum_supported(128, 32 * 32, 256, 32) == 1
+    assert lib.psld_gn_bwd_colsum_supported(16, 16 * 16, 512, 32) == 1
+    assert lib.psld_gn_bwd_colsum_supported(128, 64 * 64, 128, 32) == 0        # 64 pixels per thread: the three-pass form
+    assert lib.psld_gn_bwd_colsum_supported(2, 8 * 8, 6, 1) == 0               # channels per group not a multiple of 4
+    assert lib.psld_gn_bwd_colsum_supported(0, 64, 256, 32) == 0
+    # fused attention forward: 16x16 and 8x8 maps, 128 or 256 channels
+    assert lib.psld_attn_fwd_split_supported(256, 256) == 1 and lib.psld_attn_fwd_split_supported(64, 128) == 1
+    assert lib.psld_attn_fwd_split_supported(1024, 256) == 0 and lib.psld_attn_fwd_split_supported(256, 64) == 0
+    # the kernel selector is a process-wide setting with validated values
+    assert lib.psld_get_gn_bwd_kernel() in (0, 1)
+    before = lib.psld_get_gn_bwd_kernel()
+    assert lib.psld_set_gn_bwd_kernel(7) != 0 and b"psld_set_gn_bwd_kernel" in lib.psld_last_error()
+    assert lib.psld_set_gn_bwd_kernel(1) == 0 and lib.psld_get_gn_bwd_kernel() == 1
+    assert lib.psld_set_gn_bwd_kernel(before) == 0
+
+
 def test_graft_entry_build_runs():
     """The driver's build check: make (a no-op when the objects are current) + import + symbol binding."""
     import __graft_entry__ as g
