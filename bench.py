@@ -299,19 +299,27 @@ def reduce_sampling(res, rank: int, world: int, on_dev: bool, dev, shard):
                 "fwd_tflops": res["fwd_tflops"] / scale})
     steps_scale = 1000.0 / res["n_discrete_steps"]
     out["wallclock_50k_samples_s"] = shard["batches"] * float(mx[0]) * steps_scale
+    how = f"batches per rank ({shard['batches']}) x that"
+    if res.get("partial_batch"):       # the shard's last batch is partial and was measured too: max over ranks of it
+        pm = torch.tensor([res["partial_batch"]["measured_batch_s"]], device=where, dtype=torch.float64)
+        dist.all_reduce(pm, op=dist.ReduceOp.MAX)
+        out["partial_batch"] = dict(res["partial_batch"], measured_batch_s=float(pm[0]))
+        out["wallclock_50k_samples_s"] = ((shard["batches"] - 1) * float(mx[0]) + float(pm[0])) * steps_scale
+        how = (f"{shard['batches'] - 1} full batches x that + the measured partial batch of "
+               f"{res['partial_batch']['batch']} samples (max over ranks)")
     out.pop("per_gpu_50k_samples_8gpu_s", None)
     out["note"] = (f"every one of the {world} ranks sampled ONE batch of its own shard concurrently (seed + rank, no "
-                   "collective); measured_batch_s = max over ranks; wallclock_50k_samples_s = batches per rank "
-                   f"({shard['batches']}) x that, scaled to 1000 discretisation steps if the run was shortened")
+                   f"collective); measured_batch_s = max over ranks; wallclock_50k_samples_s = {how}, scaled to 1000 "
+                   "discretisation steps if the run was shortened")
     return out
 
 
 def _guarded_record(name):
-    """A committed profile record (profiles/r04/<name>, else profiles/r03/<name>) that carries the hash of the kernel
+    """A committed profile record (the newest of profiles/r05 ... r03/<name>) that carries the hash of the kernel
     sources it was measured on; a record measured on other sources is refused."""
     import hashlib
     rec, path = None, None
-    for rnd in ("r04", "r03"):
+    for rnd in ("r05", "r04", "r03"):
         path = os.path.join(ROOT, "profiles", rnd, name)
         try:
             with open(path) as fh:
@@ -320,7 +328,7 @@ def _guarded_record(name):
         except Exception:  # noqa: BLE001
             continue
     if rec is None:
-        return None, f"no record (profiles/r04/{name})"
+        return None, f"no record (profiles/r05/{name})"
     h = hashlib.sha256()
     for f in rec.get("sources", []):
         try:
@@ -344,6 +352,12 @@ def hbm_in_situ_record():
     """Byte-weighted HBM rate of the bandwidth-bound kernels INSIDE the B=128 training step (hbm_in_situ.json, written by
     tools/hbm_in_situ.py: algorithmic bytes from the launch arguments / rocprofv3 kernel durations of the same process)."""
     return _guarded_record("hbm_in_situ.json")
+
+
+def hbm_in_situ_forward_record():
+    """The same for the EVAL FORWARD at B=128 alone - the figure north_star names ("the U-Net forward at batch
+    128x6x32x32"): hbm_in_situ_forward.json, written by `tools/hbm_in_situ.py run-forward` / `join`."""
+    return _guarded_record("hbm_in_situ_forward.json")
 
 
 def forward_block(net, dev, batch, size, steps=5):
@@ -398,13 +412,21 @@ def parse_args():
     ap.add_argument("--launch-check", action="store_true",
                     help="form the process group, all-reduce ones, print the JSON line and exit (no model work; runs on "
                          "CPU with gloo: how the self-launch path is tested without a GPU)")
+    ap.add_argument("--no-partial-sample", action="store_true",
+                    help="skip the second sampling run (the last, partial batch of a GPU's shard of the 50 000 samples)")
+    ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("PSLD_LAUNCH_TIMEOUT_S", "1500")),
+                    help="self-launched --gpus N > 1: seconds after which the parent kills the job and exits 124")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--test-hang-rank", type=int, default=-1, help=argparse.SUPPRESS)   # tests: this rank never joins
     return ap.parse_args()
 
 
 def self_launch(args) -> int:
     """--gpus N > 1 without a launcher: start N ranks as a child `torch.distributed.run` and return its exit code.
-    The parent has made no HIP call (importing torch does not initialise the GPU)."""
+    The parent has made no HIP call (importing torch does not initialise the GPU).  The child runs in its own session; if
+    it has not finished after --launch-timeout seconds the parent kills exactly that process group (agent and ranks) and
+    exits 124 - a watchdog only ever kills the child and exits non-zero, it never re-executes anything."""
+    import signal
     import socket
     import subprocess
     with socket.socket() as s:
@@ -415,7 +437,25 @@ def self_launch(args) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
-    return subprocess.run(cmd, env=env).returncode
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return child.wait(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        print(f"bench.py: the {args.gpus}-rank job (pid {child.pid}) did not finish within --launch-timeout "
+              f"{args.launch_timeout:.0f} s; killing its process group", file=sys.stderr, flush=True)
+    except KeyboardInterrupt:
+        pass
+    for sig in (signal.SIGTERM, signal.SIGKILL):
+        try:
+            os.killpg(child.pid, sig)          # start_new_session: pgid == the child's pid, nobody else is in it
+        except ProcessLookupError:
+            break
+        try:
+            child.wait(timeout=10)
+            break
+        except subprocess.TimeoutExpired:
+            continue
+    return 124
 
 
 def psld_env():
@@ -461,7 +501,14 @@ def main():
     share_gpu = os.environ.get("PSLD_SHARE_GPU", "0") == "1"
     if args.launch_check and backend is None and torch.cuda.device_count() < max(1, args.gpus):
         backend = "gloo"
-    rank, local, world = init_distributed(backend=backend, force=force_pg)
+    if args.test_hang_rank >= 0 and int(os.environ.get("RANK", "0")) == args.test_hang_rank:
+        time.sleep(3600)
+    from psld_amd.ddp import RendezvousTimeout
+    try:
+        rank, local, world = init_distributed(backend=backend, force=force_pg)
+    except RendezvousTimeout as e:
+        print(f"bench.py: {e}", file=sys.stderr, flush=True)
+        return 4
     if share_gpu:
         local = 0
     if world != max(1, args.gpus):
@@ -570,21 +617,32 @@ def main():
         barrier()
         torch.cuda.synchronize()
 
+    def timed_pass(first_step):
+        """K steps bracketed by barrier + device synchronize on both sides; wall clock, max over ranks."""
+        fence()
+        t0 = time.perf_counter()
+        last_ = None
+        for i in range(args.steps):
+            last_ = step(first_step + i)
+        fence()
+        dt_ = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt_], device=dev if backend_name == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_ = float(tt.item())
+        return dt_, last_
+
     fence()
     if reducer is not None:
         reducer.stats()                                       # drop the warm-up steps' events
-    probe.enabled = not args.no_probe
-    t0 = time.perf_counter()
-    last = None
-    for i in range(args.steps):
-        last = step(args.warmup + i)
-    fence()
-    dt = time.perf_counter() - t0
-    probe.enabled = False
-    if world > 1:
-        tt = torch.tensor([dt], device=dev if backend_name == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    # pass 1 = the headline: the product's step, no per-launch HIP-event brackets inside the timed region
+    dt, last = timed_pass(args.warmup)
+    # pass 2 = the same K steps with every 3x3 limb convolution bracketed by HIP events -> `roofline`
+    dt_probed = None
+    if not args.no_probe:
+        probe.enabled = True
+        dt_probed, _ = timed_pass(args.warmup + args.steps)
+        probe.enabled = False
     loss_val = float(last.item())
     # replicas stay identical: same seed, same averaged gradient -> same parameters on every rank
     in_sync = None
@@ -596,26 +654,46 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         in_sync = bool(lo.item() == hi.item())
 
-    fwd_blk = None
-    if rank == 0 and not args.launch_check and not args.no_forward and torch.cuda.is_available() and args.config == "c10_sota":
-        fwd_blk = forward_block(net, dev, args.batch, size)
     sampling = None
     if args.sample_batch > 0 and args.config == "c10_sota":
         # second half of the metric: EVERY rank samples one batch of its own shard at the same time (eval/sample.py:100-109)
+        # and then the LAST, partial batch of that shard (50 000 / 8 = 6250 = 12 x 512 + 106 per GPU on 8 GPUs)
         shard = sampling_shard(rank, world, int(cfg.evaluation.seed), batch=args.sample_batch)
         if world > 1:
             torch.manual_seed(shard["seed"])                  # wrapper.py:93-99: seed + global_rank
-        sampling = sampling_run(cfg, ema, sde, dev, args.sample_batch, max(3, args.sample_steps))
+        n_steps = max(3, args.sample_steps)
+        sampling = sampling_run(cfg, ema, sde, dev, args.sample_batch, n_steps)
+        own = -(-50000 // (world if world > 1 else 8))        # the same on every rank (shard_range: ceil(n / world) per rank)
+        partial_n = own % args.sample_batch
+        if partial_n and not args.no_partial_sample:
+            part = sampling_run(cfg, ema, sde, dev, partial_n, n_steps)
+            sampling["partial_batch"] = {"batch": partial_n, "measured_batch_s": part["measured_batch_s"],
+                                         "finite": part["finite"], "ms_per_em_step": part["ms_per_em_step"]}
+            full_batches = own // args.sample_batch
+            sampling["per_gpu_50k_samples_8gpu_s"] = (full_batches * sampling["measured_batch_s"] +
+                                                      part["measured_batch_s"]) * (1000.0 / n_steps)
+            sampling["note"] = sampling["note"].split("per_gpu_50k")[0] + \
+                (f"per_gpu_50k = {full_batches} full batches x measured_batch_s + ONE measured partial batch of {partial_n} "
+                 f"samples ({own} samples per GPU on 8 GPUs): each GPU samples its own shard, no collective (SURVEY 8(e))")
         if world > 1:
             sampling = reduce_sampling(sampling, rank, world, backend_name == "nccl", dev, shard)
         fence()
+    fwd_blk = None
+    if rank == 0 and not args.launch_check and not args.no_forward and torch.cuda.is_available() and args.config == "c10_sota":
+        fwd_blk = forward_block(net, dev, args.batch, size)
+    fence()
 
     if rank == 0:
         total_imgs = world * args.batch * args.steps
         out = {
             "metric": "train images/sec, CIFAR-10 PSLD (6ch 32x32) NCSN++ HSM step",
             "value": total_imgs / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "ms_per_step_probed_pass": (1e3 * dt_probed / args.steps) if dt_probed is not None else None,
+            "timing_note": ("value / ms_per_step: K steps of the product path, no instrumentation inside the timed region; "
+                            "ms_per_step_probed_pass: the SAME K steps run a second time with every 3x3 limb convolution "
+                            "bracketed by two hipEventRecord calls (what `roofline` is computed from)"),
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "math": ("f32 in / f32 accumulate; 3x3 convolutions, 1x1 / NIN projections, attention products and their gradients as exact "
                      "3-limb bf16 splits, 6 bf16 MFMA products per fp32 product (dropped terms < 2^-23 of the product); the 3x3 "
@@ -646,6 +724,8 @@ def main():
         pt = probe.summary("tile")
         pmc, pmc_err = pmc_traffic_record()
         hbm, hbm_err = hbm_in_situ_record()
+        if hbm is not None and (args.batch != hbm.get("batch", 128) or args.config != "c10_sota"):
+            hbm, hbm_err = None, f"the in-situ record was measured at C10-SOTA B={hbm.get('batch', 128)}, this run is {args.config} B={args.batch}"
         if ps is not None:
             peak = PEAK_BF16_MFMA_TFLOPS / LIMB_PRODUCTS
             issued = ((pw["total_flop"] / 2.25 if pw else 0.0) + (pd["total_flop"] if pd else 0.0)) * LIMB_PRODUCTS / (ps["total_ms"] * 1e-3) / 1e12
@@ -654,7 +734,9 @@ def main():
                 "kernel": "3x3 limb-MFMA convolutions, forward + data gradient: wino_conv8s_kernel (Winograd F(2x2,3x3), "
                           "32x32 and 16x16 levels) + dconv_kernel / dconv_lp_kernel (direct, 8x8 level), bf16x6",
                 "achieved": ps["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": ps["tflops"] / peak,
-                "peak_note": "achieved = ALGORITHMIC (direct-convolution) 2*M*N*9*Cin of every launch / its HIP-event duration; "
+                "peak_note": f"hardware utilisation first: frac_of_dense_bf16_peak = {issued / PEAK_BF16_MFMA_TFLOPS:.3f} (the bf16 MFMA "
+                             "FLOPs the matrix pipe really issues / the 2500 TFLOP/s dense peak).  frac is algorithmic: "
+                             "achieved = ALGORITHMIC (direct-convolution) 2*M*N*9*Cin of every launch / its HIP-event duration; "
                              "peak = 2500 TFLOP/s dense bf16 MFMA / 6 limb products per fp32 product = the fp32-equivalent "
                              "ceiling of a DIRECT limb convolution.  The Winograd launches issue 2.25x fewer MFMAs than "
                              "that count (mfma_issued_tflops is what the matrix pipe really runs); a register-only loop "
@@ -663,9 +745,9 @@ def main():
                 "frac_of_sustained_mfma": issued / SUSTAINED_BF16_MFMA_TFLOPS,
                 "frac_of_f32_mfma_peak": ps["tflops"] / PEAK_F32_MFMA_TFLOPS,
                 "winograd": ({"tflops_direct_equivalent": pw["tflops"], "launches": pw["launches"], "avg_launch_us": pw["avg_us"],
-                              "share_of_step": pw["total_ms"] / (1e3 * dt)} if pw else None),
+                              "share_of_step": pw["total_ms"] / (1e3 * (dt_probed or dt))} if pw else None),
                 "direct": ({"tflops": pd["tflops"], "launches": pd["launches"], "avg_launch_us": pd["avg_us"],
-                            "share_of_step": pd["total_ms"] / (1e3 * dt)} if pd else None),
+                            "share_of_step": pd["total_ms"] / (1e3 * (dt_probed or dt))} if pd else None),
                 "frac_of_dense_bf16_peak": issued / PEAK_BF16_MFMA_TFLOPS,
                 "traffic": pmc.get("traffic_bytes") if pmc else None,
                 "traffic_note": pmc.get("note") if pmc else pmc_err,
@@ -675,18 +757,18 @@ def main():
                                    f"the B=128 step ({hbm['bytes_per_step'] / 1e9:.1f} GB algorithmic in {hbm['ms_per_step']:.1f} ms per step)")
                 if hbm else hbm_err,
                 "launches": ps["launches"], "avg_launch_us": ps["avg_us"],
-                "share_of_step": ps["total_ms"] / (1e3 * dt)}
+                "share_of_step": ps["total_ms"] / (1e3 * (dt_probed or dt))}
         elif pt is not None:        # PSLD_MATH=f32: the fp32 MFMA tile engine carries the convolutions
             out["roofline"] = {"bound": "mfma", "kernel": "tile_kernel_fast<IM2COL,KC> (fp32 MFMA convolutions)",
                                "achieved": pt["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": pt["tflops"] / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                                "launches": pt["launches"], "avg_launch_us": pt["avg_us"],
-                               "share_of_step": pt["total_ms"] / (1e3 * dt)}
+                               "share_of_step": pt["total_ms"] / (1e3 * (dt_probed or dt))}
         else:
             out["roofline"] = None
         if ps is not None and pt is not None:
             out["other_convs_f32_mfma"] = {"tflops": pt["tflops"], "launches": pt["launches"],
-                                           "share_of_step": pt["total_ms"] / (1e3 * dt)}
+                                           "share_of_step": pt["total_ms"] / (1e3 * (dt_probed or dt))}
         fwd_gflop = {"c10_sota": 76.46, "celeba64_sota": 84.17}[args.config]   # measured fwd GFLOP/img
         step_flops = 3 * fwd_gflop * 1e9 * args.batch           # train step = 3 x forward
         out["whole_step_tflops_per_gpu"] = step_flops * args.steps / dt / 1e12
@@ -695,6 +777,14 @@ def main():
             out["config"]["workload"] = f"{args.config} NCSN++ full HSM train step"
             out["config"]["image"] = f"6x{size}x{size}"
         if fwd_blk is not None:
+            fh_, fh_err = hbm_in_situ_forward_record()
+            if fh_ is not None and args.batch != fh_.get("batch", 128):
+                fh_, fh_err = None, f"the forward in-situ record was measured at B={fh_.get('batch', 128)}, this run is B={args.batch}"
+            fwd_blk["hbm_bound_aggregate_frac"] = fh_.get("hbm_bound_aggregate_frac") if fh_ else None
+            fwd_blk["hbm_bound_under_0.6"] = fh_.get("under_0.6") if fh_ else None
+            fwd_blk["hbm_bound_note"] = (f"{fh_['_path']}: {fh_['aggregate_gb_per_s']:.0f} GB/s byte-weighted over the bandwidth-bound "
+                                         f"kernels of the B={fh_.get('batch', 128)} eval forward ({fh_['bytes_per_step'] / 1e9:.2f} GB "
+                                         f"algorithmic in {fh_['ms_per_step']:.2f} ms per forward)") if fh_ else fh_err
             out["forward"] = fwd_blk
         if sampling is not None:
             out["sampling"] = sampling

@@ -24,12 +24,60 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend: Optional[str] = None, force: bool = False) -> Tuple[int, int, int]:
+class RendezvousTimeout(RuntimeError):
+    """Not every rank reached the rendezvous in time; ``missing`` lists the ranks that did not (as far as this rank can
+    tell: rank 0 hosts the store and sees everyone, another rank may only know that rank 0 never answered)."""
+
+    def __init__(self, msg: str, missing: List[int]):
+        super().__init__(msg)
+        self.missing = missing
+
+
+def _rendezvous(rank: int, world: int, timeout_s: float):
+    """The env:// store of this job (torchrun's agent store when there is one, else a TCPStore hosted by rank 0) with
+    every rank checked in: each rank writes ``psld/arrived/<rank>`` and waits for the others.  A rank that never shows
+    up is NAMED after ``timeout_s`` instead of leaving the job to hang in the first collective."""
+    import datetime
+    import time
+    timeout = datetime.timedelta(seconds=timeout_s)
+    # torchrun's agent hosts the store itself (TORCHELASTIC_USE_AGENT_STORE): then every rank is a client
+    hosted_by_agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "False") == "True"
+    try:
+        store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world_size=world,
+                              is_master=(rank == 0 and not hosted_by_agent), timeout=timeout, wait_for_workers=False)
+    except Exception as e:  # noqa: BLE001 - a client that cannot reach rank 0's store
+        raise RendezvousTimeout(f"rank {rank}: no rendezvous store at {os.environ.get('MASTER_ADDR')}:"
+                                f"{os.environ.get('MASTER_PORT')} within {timeout_s:.0f} s (rank 0 never arrived?): {e!r}",
+                                [0]) from e
+    store.set_timeout(timeout)
+    # the agent store of a restarted torchrun job outlives its workers: keys carry the restart count
+    gen = os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+    key = lambda r: f"psld/arrived/{gen}/{r}"  # noqa: E731
+    store.set(key(rank), "1")
+    deadline = time.monotonic() + timeout_s
+    missing = [r for r in range(world) if r != rank]
+    while missing:
+        missing = [r for r in missing if not store.check([key(r)])]
+        if not missing:
+            break
+        if time.monotonic() > deadline:
+            raise RendezvousTimeout(f"rank {rank}: rank(s) {missing} of {world} did not reach the rendezvous within "
+                                    f"{timeout_s:.0f} s", missing)
+        time.sleep(0.05)
+    return store, timeout
+
+
+def init_distributed(backend: Optional[str] = None, force: bool = False,
+                     timeout_s: Optional[float] = None) -> Tuple[int, int, int]:
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun); returns (rank, local_rank, world).
-    ``force`` creates the process group even for world size 1."""
+    ``force`` creates the process group even for world size 1.  ``timeout_s`` (default PSLD_DIST_TIMEOUT_S or 180)
+    bounds the rendezvous - a rank that never joins raises ``RendezvousTimeout`` naming it - and every later collective
+    (the process group's watchdog aborts a rank stuck in one)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("PSLD_DIST_TIMEOUT_S", "180"))
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
@@ -42,9 +90,11 @@ def init_distributed(backend: Optional[str] = None, force: bool = False) -> Tupl
                 os.environ["MASTER_PORT"] = "29500"
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
+        store, timeout = _rendezvous(rank, world, timeout_s)       # before any HIP call: a missing rank costs no GPU state
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout,
+                                store=dist.PrefixStore("psld/pg", store))
     return rank, local, world
 
 

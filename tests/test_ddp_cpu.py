@@ -150,3 +150,57 @@ def test_bench_refuses_a_world_that_is_not_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--launch-check"],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 2 and "refusing" in r.stderr
+
+
+def test_a_rank_that_never_joins_is_named_and_the_job_exits_nonzero():
+    """VERDICT r04 #2b: the first N > 1 run must not be able to hang silently.  Rank 0 of a 2-rank world whose rank 1
+    never starts: the rendezvous gives up after PSLD_DIST_TIMEOUT_S, names the missing rank on stderr and exits 4."""
+    import subprocess
+    import sys
+    import time
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()), PSLD_DIST_TIMEOUT_S="5", PSLD_DIST_BACKEND="gloo")
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"],
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 4, (r.returncode, r.stderr[-2000:])
+    assert "rank(s) [1] of 2 did not reach the rendezvous" in r.stderr
+    assert time.monotonic() - t0 < 60
+
+
+def test_self_launch_kills_a_hung_job_and_exits_nonzero():
+    """The self-launching parent (`bench.py --gpus 2`, no torchrun) bounds its child job: with rank 1 asleep before the
+    rendezvous and a rendezvous timeout longer than --launch-timeout, the parent kills the child's process group and
+    exits 124; no rank survives it."""
+    import subprocess
+    import sys
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(PSLD_DIST_TIMEOUT_S="600", PSLD_DIST_BACKEND="gloo")
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check",
+                        "--test-hang-rank", "1", "--launch-timeout", "15"],
+                       capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 124, (r.returncode, r.stderr[-2000:])
+    assert "killing its process group" in r.stderr
+    assert time.monotonic() - t0 < 60
+    time.sleep(0.5)
+    left = subprocess.run(["ps", "-eo", "pid,args"], capture_output=True, text=True).stdout
+    assert not [ln for ln in left.splitlines() if "--test-hang-rank" in ln and "ps -eo" not in ln], left
+
+
+def test_self_launch_reports_the_missing_rank_when_the_rendezvous_times_out_first():
+    """Same hang, rendezvous timeout SHORTER than the launch timeout: rank 0 names rank 1, torchrun tears the job down,
+    the parent returns non-zero well inside a minute."""
+    import subprocess
+    import sys
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(PSLD_DIST_TIMEOUT_S="5", PSLD_DIST_BACKEND="gloo")
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check",
+                        "--test-hang-rank", "1", "--launch-timeout", "100"],
+                       capture_output=True, text=True, timeout=150, env=env)
+    assert r.returncode not in (0, 124), (r.returncode, r.stderr[-2000:])
+    assert "rank(s) [1] of 2 did not reach the rendezvous" in r.stderr
+    assert time.monotonic() - t0 < 60

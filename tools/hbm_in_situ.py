@@ -5,6 +5,7 @@ library, joined with rocprofv3's per-kernel durations of the same process.
     # on the GPU box
     rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r04/hbm_prof -- python3 tools/hbm_in_situ.py run gpurun_out/r04/hbm_bytes.json
     python3 tools/hbm_in_situ.py join gpurun_out/r04/hbm_prof gpurun_out/r04/hbm_bytes.json profiles/r04/hbm_in_situ
+    # the eval forward alone (north_star's figure): `run-forward` instead of `run`, joined into .../hbm_in_situ_forward
 
 Algorithmic bytes = every distinct input read once + every output written once (fp32 unless noted), from the launch
 arguments: GroupNorm statistics 4 B/element (nothing when the producer's epilogue left partial sums), apply 8 (10 into limb
@@ -138,6 +139,35 @@ def run(out_path, steps=8, warmup=2):
     print("wrote", out_path)
 
 
+def run_forward(out_path, steps=20, warmup=3, batch=128):
+    """The eval forward alone at the training batch (north_star: ">= 70 % of the per-GPU HBM roofline on the U-Net
+    forward at batch 128x6x32x32"): the EMA network's inference path, i.e. GroupNorm + SiLU fused into the Winograd
+    staging where the executor does that (those bytes then ride on an MFMA-bound kernel and are not counted here)."""
+    import torch
+    import psld_amd
+    from psld_amd import _lib, config as C
+    from psld_amd.registry import get_module
+    log = _Log(_lib.load_real())
+    _lib.set_proxy(log)
+    psld_amd.import_modules_into_registry()
+    cfg = C.c10_sota()
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    net = get_module("score_fn", "ncsnpp")(cfg).to(dev).eval()
+    x = torch.randn(batch, 6, 32, 32, device=dev)
+    t = torch.rand(batch, device=dev) * 0.98 + 0.01
+    with torch.no_grad():
+        for _ in range(warmup + steps):
+            net(x, t)
+    torch.cuda.synchronize()
+    _lib.set_proxy(None)
+    os.makedirs(os.path.dirname(out_path) or ".", exist_ok=True)
+    with open(out_path, "w") as fh:
+        json.dump({"steps": warmup + steps, "batch": batch, "config": "c10_sota", "phase": "eval forward",
+                   "bytes": dict(log.bytes), "calls": dict(log.calls)}, fh, indent=1)
+    print("wrote", out_path)
+
+
 def join(prof_dir, bytes_path, out_prefix):
     rec = json.load(open(bytes_path))
     files = glob.glob(os.path.join(prof_dir, "**", "*kernel_stats.csv"), recursive=True)
@@ -163,15 +193,18 @@ def join(prof_dir, bytes_path, out_prefix):
     h = hashlib.sha256()
     for f in SOURCES:
         h.update(open(os.path.join(ROOT, f), "rb").read())
+    phase = rec.get("phase", "training step")
+    what = "eval forwards" if phase == "eval forward" else "training steps"
     out = {"source": "tools/hbm_in_situ.py: algorithmic bytes from the launch arguments of the bandwidth-bound entry points of "
-                     f"{steps} C10-SOTA B=128 training steps (model set-up included) / rocprofv3 --kernel-trace --stats durations of their "
+                     f"{steps} C10-SOTA B={rec.get('batch', 128)} {what} (model set-up included) / rocprofv3 --kernel-trace --stats durations of their "
                      "kernels in the same process",
+           "batch": rec.get("batch", 128), "phase": phase,
            "aggregate_gb_per_s": tb / tt / 1e9, "hbm_bound_aggregate_frac": tb / tt / PEAK, "bytes_per_step": tb / steps,
            "ms_per_step": tt * 1e3 / steps, "under_0.6": [r["family"] for r in rows if r["frac_of_8tbs"] < 0.6],
            "families": rows, "sources": SOURCES, "sources_sha256": h.hexdigest()}
     json.dump(out, open(out_prefix + ".json", "w"), indent=1)
     with open(out_prefix + ".md", "w") as fh:
-        fh.write("| kernel family (in the B=128 training step) | launches / step | MB / step (algorithmic) | ms / step | GB/s | of 8 TB/s |\n|---|---|---|---|---|---|\n")
+        fh.write(f"| kernel family (in the B={rec.get('batch', 128)} {phase}) | launches / step | MB / step (algorithmic) | ms / step | GB/s | of 8 TB/s |\n|---|---|---|---|---|---|\n")
         for r in rows:
             fh.write(f"| {r['family']} | {r['kernel_launches'] / steps:.0f} | {r['bytes_per_step'] / 1e6:.1f} | {r['ms_per_step']:.3f} | "
                      f"{r['gb_per_s']:.0f} | {r['frac_of_8tbs']:.3f} |\n")
@@ -182,5 +215,7 @@ def join(prof_dir, bytes_path, out_prefix):
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         run(sys.argv[2])
+    elif sys.argv[1] == "run-forward":
+        run_forward(sys.argv[2])
     else:
         join(sys.argv[2], sys.argv[3], sys.argv[4])
