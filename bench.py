@@ -406,9 +406,6 @@ def parse_args():
                     help="n_discrete_steps of the sampling run (1000 = configs[4], ~3 min at B=512; fewer = scaled estimate)")
     ap.add_argument("--graphs", action="store_true",
                     help="hipGraph-captured training step (SDEWrapper.enable_graphs): for the launch-bound small-batch regime")
-    ap.add_argument("--tape", action="store_true",
-                    help="training step replayed from a launch tape (SDEWrapper.enable_graphs(tape=True), psld_tape_replay): "
-                         "the same launches as the eager step, issued from C on the two streams")
     ap.add_argument("--launch-check", action="store_true",
                     help="form the process group, all-reduce ones, print the JSON line and exit (no model work; runs on "
                          "CPU with gloo: how the self-launch path is tested without a GPU)")
@@ -590,8 +587,8 @@ def main():
     crit = get_module("losses", "psld_score_loss")(cfg, sde)
     wrapper = get_module("pl_modules", "sde_wrapper")(cfg, sde, net, ema_score_fn=ema, criterion=crit)
     ema_cb = EMAWeightUpdate(cfg.training.ema_decay)
-    if args.graphs or args.tape:
-        wrapper.enable_graphs(True, tape=args.tape)
+    if args.graphs:
+        wrapper.enable_graphs(True)
         args.no_probe = True          # per-launch HIP-event brackets cannot sit inside a captured graph
         args.warmup = max(args.warmup, 3)   # two eager steps, then the capture
     reducer = None
@@ -706,11 +703,8 @@ def main():
                        "parallelism": f"dp{world}", "image": "6x32x32"},
             "images_per_sec_per_gpu": total_imgs / dt / world,
             "final_loss": loss_val,
-            "captured_step": bool((args.graphs or args.tape) and getattr(wrapper, "_graph_steps", None) and
+            "captured_step": bool(args.graphs and getattr(wrapper, "_graph_steps", None) and
                                   any("graph" in e for e in wrapper._graph_steps.values())),
-            "launch_tape": next(({"launches": e["tape"].n_launches, "stream_edges": e["tape"].n_edges,
-                                  "segments": len(e["tape"].segments), "aten_ops": len(e["tape"].aten_ops)}
-                                 for e in getattr(wrapper, "_graph_steps", {}).values() if e.get("tape") is not None), None),
         }
         if dist_on:
             st = reducer.stats()

@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 
-#define PSLD_ABI_VERSION 12 /* 2: limb-MFMA convolutions, math mode, bias-gradient / batched-copy entry points; 3: pointwise weight gradient and batched activation GEMM on limb kernels; 4: GroupNorm statistics from the limb kernels' epilogue; 5: per-sample-time reverse SDE, ScoreLoss nll / l1; 6: limb-plane activations; 7: device-resident dropout seed / Adam scalars (captured training step), GroupNorm-backward sums from the producing epilogue; 8: Winograd F(2x2,3x3) limb convolution; 9: launch tape; 10: GroupNorm apply (+SiLU) fused into the Winograd convolution's input staging; 11: GroupNorm backward kernel selector; 12: column sums of dx from the GroupNorm backward */
+#define PSLD_ABI_VERSION 13 /* 2: limb-MFMA convolutions, math mode, bias-gradient / batched-copy entry points; 3: pointwise weight gradient and batched activation GEMM on limb kernels; 4: GroupNorm statistics from the limb kernels' epilogue; 5: per-sample-time reverse SDE, ScoreLoss nll / l1; 6: limb-plane activations; 7: device-resident dropout seed / Adam scalars (captured training step), GroupNorm-backward sums from the producing epilogue; 8: Winograd F(2x2,3x3) limb convolution; 9: launch tape; 10: GroupNorm apply (+SiLU) fused into the Winograd convolution's input staging; 11: GroupNorm backward kernel selector; 12: column sums of dx from the GroupNorm backward; 13: GroupNorm backward returns per-image sums (dgamma / dbeta / bias gradients and split-K slab reductions of a whole backward pass in batched launches), the GroupNorm-backward by-product of the limb epilogue and the launch tape (9) removed */
 #define PSLD_COEFF_STRIDE 12
 
 int psld_version(void);
@@ -69,25 +69,6 @@ typedef struct psld_epilogue {
      * psld_gn_stats_from_partials_f32 turns them into the statistics of any group size that is a multiple of 8. */
     double* gn_part;
     int gn_hw;
-    /* Optional (same kernels, same no-split rule): pass 1 of a GroupNorm BACKWARD as a by-product.  The call's OUTPUT is
-     * the gradient dy w.r.t. y = dropout(act(GroupNorm(gnb_x))) - e.g. the data gradient of the convolution that
-     * consumed y - and must be a contiguous [rows][N] tensor (ldy == N); the kernel also accumulates, per image, 64-row
-     * run and channel, s1 = sum dz and s2 = sum dz * xhat with dz = dy * (dropout mask / keep) * act'(gamma*xhat + beta),
-     * xhat = (gnb_x - mean) * rstd, into gnb_part[((img*chunks + chunk)*2 + {0,1})*N + n] (chunks = gnb_hw / 64): what
-     * psld_gn_bwd_nhwc_f32 takes as part_in instead of reading dy and x a first time.  gnb_mean / gnb_rstd: [img][groups]
-     * of the forward statistics; N / gnb_groups a multiple of 4; dropout seed as in psld_gn_apply_nhwc_f32. */
-    const float* gnb_x;
-    const float* gnb_mean;
-    const float* gnb_rstd;
-    const float* gnb_gamma;
-    const float* gnb_beta;
-    float* gnb_part;
-    const unsigned long long* gnb_seed_dev;
-    unsigned long long gnb_seed;
-    float gnb_drop_p;
-    int gnb_groups;
-    int gnb_act;
-    int gnb_hw;
 } psld_epilogue_t;
 
 /* C[b] = epilogue(op(A[b]) * op(B[b])), fp32 MFMA (v_mfma_f32_32x32x2_f32), batched.
@@ -307,41 +288,54 @@ int psld_gn_apply_nhwc_f32(const float* x, const float* scale, const float* shif
 int psld_gn_apply_limb_nhwc(const float* x, const float* scale, const float* shift, void* y_limb, int batch,
                             int hw, int c, int act, float drop_p, unsigned long long seed,
                             const unsigned long long* seed_dev, hipStream_t stream);
-/* Which kernel psld_gn_bwd_nhwc_f32 takes when the backward runs in one pass over (dy, x) (no part_in; see there):
+/* Which kernel psld_gn_bwd_nhwc_f32 takes when the backward runs in one pass over (dy, x):
  *   PSLD_GN_BWD_AUTO      the resident-workgroup kernel (gn_bwd_pipe_kernel: the next slab's x lands in LDS by global_load_lds
  *                         while the workgroup reduces and stores) where its shape rules hold and there is no third operand, else
  *   PSLD_GN_BWD_ONE_SLAB  the register-resident one-slab kernel (gn_bwd_fused_kernel) for every shape.
- * Both give bitwise equal dx / dgamma / dbeta (tests/test_kernels_gpu.py compares them through this switch).  Process-wide;
+ * Both give bitwise equal dx / sums / colsum_img (tests/test_kernels_gpu.py compares them through this switch).  Process-wide;
  * the initial value comes from the environment variable PSLD_GN_BWD_PIPE ("0" = one slab). */
 #define PSLD_GN_BWD_AUTO 0
 #define PSLD_GN_BWD_ONE_SLAB 1
 int psld_set_gn_bwd_kernel(int kind);
 int psld_get_gn_bwd_kernel(void);
 
-/* Backward of y = act(GN(x)): dgamma[C], dbeta[C] (written, not accumulated) and
- * dx = d/dx (+ add_scale * add when add != NULL: the gradient of an identity branch parallel to the normalisation,
- * e.g. the residual `(x + h) / sqrt(2)` of layerspp.py:271-274) (+ the previous dx when accumulate_dx).
- * part_in (may be NULL): the pass-1 sums [batch][part_chunks][2][c] left by the producer of dy (psld_epilogue_t.gnb_part);
- * then dy and x are read once (the apply pass) instead of twice. */
+/* Backward of y = dropout(act(GN(x))) (autograd of nn.GroupNorm + nn.SiLU + nn.Dropout, layerspp.py:256-265):
+ *   dx = d/dx (+ add_scale * add when add != NULL: the gradient of an identity branch parallel to the normalisation,
+ *        e.g. the residual `(x + h) / sqrt(2)` of layerspp.py:271-274) (+ the previous dx when accumulate_dx);
+ *   sums [batch][2][c] (written): per image and channel sum_p dz and sum_p dz * xhat, dz = dy * mask/keep * act'(.).  The
+ *        parameter gradients are their sums over the batch - dbeta[c] = sum_n sums[n][0][c], dgamma[c] = sum_n sums[n][1][c] -
+ *        formed by psld_param_reduce2_f32 for one layer or, for all layers of a backward pass in ONE launch, by
+ *        psld_param_reduce_batch_f32 (the reference computes them inside one autograd graph; here they leave the
+ *        dependency chain of the backward pass);
+ *   colsum_img (may be NULL; only where psld_gn_bwd_colsum_supported): [batch] rows of ld_img floats, columns [0, c)
+ *        written: the column sums over the pixels of image n of the dx values THIS call stores (add / previous dx included) -
+ *        the bias gradient and per-image time-embedding gradient of the layer whose output gradient this dx is
+ *        (layerspp.py:258-263: Conv_0 + Dense_0(act(temb))[:, :, None, None]; :268-274: Conv_1 / Conv_2 when this call is
+ *        the last writer of the residual stream's gradient) without a pass over dx.  Without a third operand from a
+ *        closed form, per channel sum_p dx = k0 sum_p dz - hw k1 - k2 sum_p xhat, of sums the kernel reduces anyway; with
+ *        one by summing the stored values (fp32 per thread, fp64 across threads, fixed order). */
 int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float* mean, const float* rstd,
                          const float* gamma, const float* beta, int batch, int hw, int c, int groups,
                          int act, float drop_p, unsigned long long seed, const unsigned long long* seed_dev,
-                         float* dx, float* dgamma, float* dbeta, int accumulate_dx,
-                         const float* add, float add_scale, const float* part_in, int part_chunks,
-                         void* workspace, hipStream_t stream);
-/* The same backward (no add, no accumulate_dx, no part_in) that ALSO returns the column sums of dx - the bias gradient and
- * the per-image time-embedding gradient of the convolution whose output gradient this dx is (layerspp.py:258-263: Conv_0 +
- * Dense_0(act(temb))[:, :, None, None]) - without a pass over dx: per channel sum_p dx = k0 sum_p dz - hw k1 - k2 sum_p xhat,
- * formed from the sums the one-pass kernels reduce anyway (and one more, sum_p xhat) with the coefficients dx is stored with.
- *   colsum_img (may be NULL): [batch] rows of ld_img floats, columns [0, c) written: sum over the pixels of image n;
- *   colsum (may be NULL): [c] = colsum_alpha * sum over the batch of those rows.
- * Only where the one-pass kernels take the shape: psld_gn_bwd_colsum_supported. */
+                         float* dx, int accumulate_dx, const float* add, float add_scale, float* sums,
+                         float* colsum_img, int ld_img, void* workspace, hipStream_t stream);
 int psld_gn_bwd_colsum_supported(int batch, int hw, int c, int groups);
-int psld_gn_bwd_colsum_nhwc_f32(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                                const float* beta, int batch, int hw, int c, int groups, int act, float drop_p,
-                                unsigned long long seed, const unsigned long long* seed_dev, float* dx, float* dgamma,
-                                float* dbeta, float* colsum_img, int ld_img, float* colsum, float colsum_alpha, void* workspace,
-                                hipStream_t stream);
+
+/* ---- parameter gradients that are sums over the batch (or over split-K slabs), off the backward chain ----------------
+ * dst1[col] (and dst2[col] when non-NULL) = alpha * sum over r in [0, rows) of src[r * ld + col], col in [0, c): fp64
+ * accumulation in a fixed order (16 row lanes r, r + 16, ... combined in lane order): bitwise repeatable.  What
+ * nn.GroupNorm's dgamma / dbeta, the bias gradients and nn.Linear's bias gradient are in the reference's autograd graph.
+ * psld_param_reduce2_f32: two jobs of the same shape in one launch (dbeta = rows of `sums`, dgamma = rows of `sums + c`).
+ * psld_param_reduce_batch_f32: `jobs` rows of a DEVICE table of 8 int64
+ *   [src pointer, rows, ld, c, dst1 pointer, dst2 pointer or 0, bit pattern of (float) alpha, first 64-column block],
+ * blocks = sum over the jobs of ceil(c / 64). */
+int psld_param_reduce2_f32(const float* src_a, const float* src_b, int rows, int ld, int c, float* dst_a, float* dst_b,
+                           float alpha, hipStream_t stream);
+int psld_param_reduce_batch_f32(const long long* table_dev, int jobs, int blocks, hipStream_t stream);
+/* Split-K slab reductions of MANY weight gradients in one launch (psld_reduce_slabs_f32 per job): rows of a DEVICE table of
+ * 10 int64 [slabs pointer, nsplit, n, out pointer, layout, taps, cin, bit pattern of (float) alpha, first float4 item, 0];
+ * every job needs n and cin multiples of 4 and 16-byte aligned slabs; items = sum of n / 4. */
+int psld_reduce_slabs_batch_f32(const long long* table_dev, int jobs, long long items, hipStream_t stream);
 
 
 /* ---- FIR resampling: the replacement of the pybind op upfirdn2d_op.upfirdn2d
@@ -382,6 +376,10 @@ int psld_colsum_f32(const float* x, int ld, int batch, int hw, int c, float* out
  * time-embedding gradient needs them, layerspp.py:262-263).  Same workspace as psld_colsum_f32; c % 4 == 0, c <= 1024, 16-byte aligned x. */
 int psld_bias_grad_f32(const float* x, int ld, int batch, int hw, int c, float* per_image, int ld_per_image,
                        float* out, float alpha, void* workspace, hipStream_t stream);
+/* The same over a [batch*hw][3*seg] buffer (row stride ld) whose three column segments are the output gradients of three
+ * layers computed by one GEMM (the q | k | v projections of AttnBlockpp, layerspp.py:78-80): out0 / out1 / out2 [seg]. */
+int psld_bias_grad_seg_f32(const float* x, int ld, int batch, int hw, int seg, float* out0, float* out1, float* out2,
+                           float alpha, void* workspace, hipStream_t stream);
 /* Many contiguous copies in one launch: table_dev = `entries` x 4 int64 {src pointer, dst pointer, float4 count, first
  * float4 index}; total4 = sum of the counts.  Used to gather the Dense_0 (time-embedding projection,
  * layerspp.py:225-228) weights of all ResBlocks into one [sum C_out][4*nf] matrix per optimizer step, so that their
@@ -559,27 +557,6 @@ int psld_adam_step_scalars_dev(double lr, double beta1, double beta2, int step, 
 /* target = target*tau + src*(1-tau) (callbacks.py:62-64); hyper-parameters are doubles so that
  * (1 - tau), (1 - beta) are formed in double and rounded once, as torch does for python floats. */
 int psld_ema_f32(float* target, const float* src, long long n, double tau, hipStream_t stream);
-
-/* ---- launch tape ------------------------------------------------------------------------------------------------
- * Replays a recorded list of the launches above from C: the training step at the reference's per-GPU batch of 16
- * (scripts_psld/.../train_uncond_psld.sh:25-30) issues ~2700 launches, and what bounds it is the host getting through
- * them, not the GPU.  A caller records (function index, argument words) once - while the step runs under stream
- * capture, which pins every buffer of the step at a fixed address - and then replays the list per step; the launches
- * are ordinary stream launches on the recorded streams (unlike a hipGraph replay: no per-node edge cost, and the
- * side stream really overlaps), joined by PSLD_TAPE_EDGE entries.
- * Every status-returning entry point of this header whose last parameter is the stream can be taped. */
-#define PSLD_TAPE_MAX_ARGS 24
-#define PSLD_TAPE_EDGE (-1) /* a[0] = source stream, a[1] = destination stream, a[2] = event from psld_tape_event_create */
-typedef struct psld_tape_entry {
-    int fn;                                   /* psld_tape_fn_index(name), or PSLD_TAPE_EDGE */
-    int nargs;
-    unsigned long long a[PSLD_TAPE_MAX_ARGS]; /* integers and pointers as they are; float / double as their bit patterns */
-} psld_tape_entry;
-int psld_tape_fn_index(const char* name);     /* -1: not a launching entry point */
-void* psld_tape_event_create(void);           /* a hipEvent_t without timing; NULL on failure */
-int psld_tape_event_destroy(void* event);
-/* Issues entries[0..n) in order; stops at the first non-zero status, returns it and stores the entry's index. */
-int psld_tape_replay(const psld_tape_entry* entries, int n, int* failed_at);
 
 #ifdef __cplusplus
 }

@@ -35,10 +35,6 @@ class Epilogue(C.Structure):
         ("accumulate", C.c_int),
         ("gn_part", C.c_void_p),
         ("gn_hw", C.c_int),
-        ("gnb_x", C.c_void_p), ("gnb_mean", C.c_void_p), ("gnb_rstd", C.c_void_p), ("gnb_gamma", C.c_void_p),
-        ("gnb_beta", C.c_void_p), ("gnb_part", C.c_void_p), ("gnb_seed_dev", C.c_void_p),
-        ("gnb_seed", C.c_ulonglong), ("gnb_drop_p", C.c_float), ("gnb_groups", C.c_int), ("gnb_act", C.c_int),
-        ("gnb_hw", C.c_int),
     ]
 
 
@@ -68,7 +64,7 @@ class SscsCoeffs(C.Structure):
 I, F, D, LL, P = C.c_int, C.c_float, C.c_double, C.c_longlong, C.c_void_p
 EP = C.POINTER(Epilogue)
 
-ABI_VERSION = 12   # PSLD_ABI_VERSION of include/psld_hip.h these signatures were written against
+ABI_VERSION = 13   # PSLD_ABI_VERSION of include/psld_hip.h these signatures were written against
 
 # name -> (restype, argtypes): every symbol include/psld_hip.h declares
 SIGNATURES = {
@@ -124,9 +120,11 @@ SIGNATURES = {
     "psld_gn_stats_nhwc_f32": (I, [P, I, I, I, I, F, P, P, P, P, P, P, P, P]),
     "psld_gn_stats_from_partials_f32": (I, [P, I, I, I, I, F, P, P, P, P, P, P, P]),
     "psld_gn_apply_nhwc_f32": (I, [P, P, P, P, I, I, I, I, F, C.c_ulonglong, P, P]),
-    "psld_gn_bwd_nhwc_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, F, C.c_ulonglong, P, P, P, P, I, P, F, P, I, P, P]),
+    "psld_gn_bwd_nhwc_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, F, C.c_ulonglong, P, P, I, P, F, P, P, I, P, P]),
     "psld_gn_bwd_colsum_supported": (I, [I, I, I, I]),
-    "psld_gn_bwd_colsum_nhwc_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, F, C.c_ulonglong, P, P, P, P, P, I, P, F, P, P]),
+    "psld_param_reduce2_f32": (I, [P, P, I, I, I, P, P, F, P]),
+    "psld_param_reduce_batch_f32": (I, [P, I, I, P]),
+    "psld_reduce_slabs_batch_f32": (I, [P, I, LL, P]),
     "psld_upfirdn2d_f32": (I, [P, P, I, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "psld_fused_bias_act_f32": (I, [P, P, P, LL, I, I, I, F, F, P]),
     "psld_fused_bias_act_grad_f32": (I, [P, P, P, P, LL, I, I, I, I, F, F, P]),
@@ -136,6 +134,7 @@ SIGNATURES = {
     "psld_colsum_workspace_bytes": (LL, [I, I, I]),
     "psld_colsum_f32": (I, [P, I, I, I, I, P, F, P, P]),
     "psld_bias_grad_f32": (I, [P, I, I, I, I, P, I, P, F, P, P]),
+    "psld_bias_grad_seg_f32": (I, [P, I, I, I, I, P, P, P, F, P, P]),
     "psld_copy_batch_f32": (I, [P, I, LL, P]),
     "psld_copy2d_f32": (I, [P, I, P, I, LL, I, I, P]),
     "psld_im2col3x3_small_f32": (I, [P, I, I, I, I, I, I, I, I, I, P, I, P]),
@@ -173,21 +172,15 @@ SIGNATURES = {
     "psld_adam_step_scalars": (None, [D, D, D, I, P]),
     "psld_adam_step_scalars_dev": (I, [D, D, D, I, P, P]),
     "psld_ema_f32": (I, [P, P, LL, D, P]),
-    "psld_tape_fn_index": (I, [C.c_char_p]),
-    "psld_tape_event_create": (P, []),
-    "psld_tape_event_destroy": (I, [P]),
-    "psld_tape_replay": (I, [P, I, C.POINTER(C.c_int)]),
 }
-
-TAPE_HOST_ONLY = ("psld_tape_event_destroy",)
 
 
 def is_launch(name: str) -> bool:
-    """Entry points that enqueue work on a stream (status-returning, ``hipStream_t stream`` last): the ones a launch
-    tape (psld_amd/tape.py) records.  Queries (``*_supported``, ``*_bytes``), the math-mode switch and the tape's own
-    entry points are host-only.  tests/test_abi_cpu.py checks this rule against the header's parameter names."""
+    """Entry points that enqueue work on a stream (status-returning, ``hipStream_t stream`` last).  Queries
+    (``*_supported``, ``*_bytes``) and the math-mode switch are host-only.  tests/test_abi_cpu.py checks this rule
+    against the header's parameter names."""
     res, args = SIGNATURES[name]
-    return res is I and bool(args) and args[-1] is P and name not in TAPE_HOST_ONLY
+    return res is I and bool(args) and args[-1] is P
 
 PSLD_ERR_NUMERIC = 3
 
@@ -198,7 +191,7 @@ class PsldHipError(RuntimeError):
     pass
 
 
-_proxy = None     # psld_amd/tape.py: a recording stand-in for the library while a launch tape is being recorded
+_proxy = None     # a stand-in that forwards every call to the loaded library (tools/hbm_in_situ.py sizes the launches with one)
 
 
 def set_proxy(proxy):
@@ -206,17 +199,8 @@ def set_proxy(proxy):
     _proxy = proxy
 
 
-def keep_host_memory(obj):
-    """A launch is about to be handed a pointer into ``obj``'s HOST memory (the FIR taps of psld_upfirdn2d_f32 are the
-    only such argument of the ABI; structures passed by reference are copied by the tape itself).  The launcher reads it
-    during the call, so eager and captured launches need nothing; a recording launch tape replays the call later and
-    keeps the object alive."""
-    if _proxy is not None:
-        _proxy._tape._keep.append(obj)
-
-
 def load():
-    """The loaded library (or, while a launch tape records, the proxy that notes every launch it forwards)."""
+    """The loaded library (or the stand-in set by ``set_proxy``)."""
     if _proxy is not None:
         return _proxy
     return _lib if _lib is not None else load_real()

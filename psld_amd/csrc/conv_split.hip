@@ -133,157 +133,14 @@ struct DConvArgs {
     int v4;                 // rows of C / residual / bias / row bias are 16-byte aligned: dwordx4 epilogue (set by plan_split)
 };
 
-// Fused epilogue of a 64 x 64 wave tile (4 x 4 accumulators of v_mfma_f32_16x16x32_bf16) at (m0 + wr*64, n0 + wc*64).
-// The kernels issue the MFMAs with the WEIGHT fragment as the first operand, i.e. they accumulate the transposed
-// block D^T[channel][pixel]: in the 16x16 C/D layout (col = lane & 15, row = 4*(lane >> 4) + v) a lane then holds
-// FOUR CONSECUTIVE CHANNELS of ONE pixel per block - a 16-byte run of the NHWC row - so output, residual, previous
-// output and biases move as dwordx4 (16 memory instructions per block row instead of 64 single-dword ones).  Rows of
-// C / residual / bias / row bias must be 16-byte aligned (checked by the entry points).
-__device__ __forceinline__ void dconv_epilogue(const DConvArgs& a, f32x4v (&acc)[4][4], int m0, int n0, int wr, int wc,
-                                               int lane, int split) {
-    const int r16 = lane & 15, kq = lane >> 4;
-    float* Cb = a.C + (long long)split * a.c_stride_split;
-    const PsldEpilogue& e = a.e;
-    const bool rb_uniform = e.rowbias && (e.rows_per_img % 16 == 0);
-    const int cn0 = n0 + wc * 64 + 4 * kq;           // this lane's first channel in block column nb: cn0 + nb*16
-    const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4v bias4[4];
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
-        bias4[nb] = e.bias ? *reinterpret_cast<const f32x4v*>(e.bias + cn0 + nb * 16) : zero4;
-    float gs[4], gss[4];                 // GroupNorm by-product: sums of this lane's 4 channels x 4 pixels per block column
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb) gs[nb] = gss[nb] = 0.f;
-    // GroupNorm-BACKWARD by-product (e.gnb_part): the output is dy of y = dropout(act(GN(gnb_x))); per channel
-    // s1 = sum dz, s2 = sum dz*xhat over this wave's 64 pixels (norm_act.hip: gn_bwd_partial_kernel, same arithmetic)
-    const bool gnb = e.gnb_part != nullptr;
-    f32x4v b1[4], b2[4], bga[4], bbe[4];
-    float bmu[4], brs[4];
-    const float keep_scale = e.gnb_drop_p > 0.f ? 1.0f / (1.0f - e.gnb_drop_p) : 1.0f;
-    unsigned long long bseed = e.gnb_seed;
-    if (gnb) {
-        if (e.gnb_seed_dev) bseed += e.gnb_seed_dev[0];
-        const int img = (m0 + wr * 64) / e.gnb_hw;          // one image per wave (gnb_hw % 64 == 0)
-        const int cpg = a.N / e.gnb_groups;
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            const int gn = cn0 + nb * 16;
-            b1[nb] = b2[nb] = zero4;
-            bga[nb] = *reinterpret_cast<const f32x4v*>(e.gnb_gamma + gn);
-            bbe[nb] = *reinterpret_cast<const f32x4v*>(e.gnb_beta + gn);
-            const int grp = gn / cpg;                        // the lane's 4 channels share a group (cpg % 4 == 0)
-            const int ii = min(img, (a.M - 1) / e.gnb_hw);
-            bmu[nb] = e.gnb_mean[ii * e.gnb_groups + grp];
-            brs[nb] = e.gnb_rstd[ii * e.gnb_groups + grp];
-        }
-    }
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-        const int row_base = m0 + wr * 64 + mb * 16;
-        if (row_base >= a.M) continue;                      // wave-uniform
-        const int gm = min(row_base + r16, a.M - 1);        // this lane's pixel (clamped: loads stay in range)
-        const bool ok = row_base + r16 < a.M;
-        const long long coff = (long long)gm * a.ldc, roff = (long long)gm * e.ldres;
-        const long long toff = (long long)((rb_uniform ? row_base : gm) / e.rows_per_img) * e.ld_rowbias;
-        // Residual / previous-output values of the whole block row are loaded BEFORE its stores: a load placed after a
-        // store to memory the compiler cannot tell apart waits out its own latency (measured on the scalar form).
-        f32x4v rv[4], cv[4];
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            const int gn = cn0 + nb * 16;
-            rv[nb] = e.res ? *reinterpret_cast<const f32x4v*>(e.res + roff + gn) : zero4;
-            cv[nb] = e.accumulate ? *reinterpret_cast<const f32x4v*>(Cb + coff + gn) : zero4;
-            const f32x4v tb = e.rowbias ? *reinterpret_cast<const f32x4v*>(e.rowbias + toff + gn) : zero4;
-            // x = ((acc*alpha + bias + rowbias) + res) * out_scale + prev: the additive terms in the scalar form's order
-            acc[mb][nb] = acc[mb][nb] * e.alpha + (bias4[nb] + tb);
-        }
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            const int gn = cn0 + nb * 16;
-            f32x4v o = acc[mb][nb];
-            if (e.res) o += rv[nb];
-            o *= e.out_scale;
-            if (e.accumulate) o += cv[nb];
-            if (ok) {
-                *reinterpret_cast<f32x4v*>(Cb + coff + gn) = o;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    gs[nb] += o[v];
-                    gss[nb] += o[v] * o[v];
-                }
-                if (gnb) {
-                    const f32x4v xv = *reinterpret_cast<const f32x4v*>(e.gnb_x + (long long)gm * a.N + gn);
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const float xh = (xv[v] - bmu[nb]) * brs[nb];
-                        float dz = o[v];
-                        if (e.gnb_drop_p > 0.f)
-                            dz = psld_dropout_keep(bseed, (unsigned long long)((long long)gm * a.N + gn + v), e.gnb_drop_p)
-                                     ? dz * keep_scale : 0.f;
-                        if (e.gnb_act) dz *= dsilu_f(xh * bga[nb][v] + bbe[nb][v]);
-                        b1[nb][v] += dz;
-                        b2[nb][v] += dz * xh;
-                    }
-                }
-            }
-        }
-    }
-    if (gnb) {
-        const int row0 = m0 + wr * 64;
-        if (row0 < a.M) {
-            const int img = row0 / e.gnb_hw, chunk = (row0 - img * e.gnb_hw) >> 6, chunks = e.gnb_hw >> 6;
-            float* pp = e.gnb_part + ((long long)img * chunks + chunk) * 2 * a.N;
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    float s1 = b1[nb][v], s2 = b2[nb][v];
-#pragma unroll
-                    for (int sft = 1; sft <= 8; sft <<= 1) {      // the 16 pixels of a block row sit in lanes r16
-                        s1 += __shfl_xor(s1, sft, 64);
-                        s2 += __shfl_xor(s2, sft, 64);
-                    }
-                    b1[nb][v] = s1;
-                    b2[nb][v] = s2;
-                }
-                if (r16 == 0) {                                   // one writer per (wave, channel quad)
-                    *reinterpret_cast<f32x4v*>(pp + cn0 + nb * 16) = b1[nb];
-                    *reinterpret_cast<f32x4v*>(pp + a.N + cn0 + nb * 16) = b2[nb];
-                }
-            }
-        }
-    }
-    if (e.gn_part) {
-        // 64 pixels x 64 channels of one image per wave.  A fine group = 8 channels = the lane pairs kq = (0,1) / (2,3) of
-        // block column nb; pixels run over the 16 lanes r16 (and the 4 block rows already summed per lane).  Fixed
-        // butterfly, one writer per (wave, fine group): repeatable.
-        const int row0 = m0 + wr * 64;
-        if (row0 < a.M) {
-            const int img = row0 / e.gn_hw, chunk = (row0 - img * e.gn_hw) >> 6, chunks = e.gn_hw >> 6;
-            const int fine = a.N >> 3;
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                float s1 = gs[nb], s2 = gss[nb];
-#pragma unroll
-                for (int sft = 1; sft <= 16; sft <<= 1) {        // 16 pixels (1, 2, 4, 8), then the partner channel quad (16)
-                    s1 += __shfl_xor(s1, sft, 64);
-                    s2 += __shfl_xor(s2, sft, 64);
-                }
-                if ((lane & 0x1f) == 0) {        // lanes 0 (channels 0-7 of the block column) and 32 (channels 8-15)
-                    const int f = ((n0 + wc * 64 + nb * 16) >> 3) + (lane >> 5);
-                    double* pp = e.gn_part + (((long long)img * chunks + chunk) * fine + f) * 2;
-                    pp[0] = (double)s1;
-                    pp[1] = (double)s2;
-                }
-            }
-        }
-    }
-}
-
-// The same epilogue for a 128 (pixels) x 32 (channels) wave tile: 8 x 2 accumulator blocks at (m0, n0 + wave*32) - the
-// wave decomposition of dconv_lp_kernel<.., N32 = true>, where the four waves of a workgroup split the 128 output
-// channels instead of sharing them two by two (each weight fragment is then loaded by ONE wave: half the L2 -> CU
-// fragment stream).  GroupNorm partial sums per 64-row run (block rows 0-3 / 4-7).  No gnb by-product here.
+// Fused epilogue of the limb kernels.  They issue the MFMAs with the WEIGHT fragment as the first operand, i.e. they
+// accumulate the transposed block D^T[channel][pixel]: in the 16x16 C/D layout (col = lane & 15, row = 4*(lane >> 4) + v)
+// a lane then holds FOUR CONSECUTIVE CHANNELS of ONE pixel per block - a 16-byte run of the NHWC row - so output, residual,
+// previous output and biases move as dwordx4 (16 memory instructions per block row instead of 64 single-dword ones).  Rows
+// of C / residual / bias / row bias must be 16-byte aligned (checked by the entry points).
+// Wave tile: 128 (pixels) x 32 (channels), 8 x 2 accumulator blocks at (m0, n0 + wave*32): the four waves of a workgroup
+// split the 128 output channels (each weight fragment is loaded by ONE wave: half the L2 -> CU fragment stream of a 2 x 2
+// arrangement of 64 x 64 tiles).  GroupNorm partial sums per 64-row run (block rows 0-3 / 4-7).
 // Wave-uniform values pinned to scalar registers.  The epilogue parameters arrive in the by-value kernel argument; left to
 // itself hipcc keeps part of that structure in SCRATCH and reloads out_scale / accumulate in front of every store - and a
 // scratch load is a vector-memory load, so each reload waits (vmcnt(0)) for every store issued before it: the 16 stores
@@ -417,21 +274,21 @@ __device__ __forceinline__ void dconv_epilogue_n32(const DConvArgs& a, f32x4v (&
 // the image is the halo tile of ONE 32-channel chunk, >= nseg*(rps+2)*(W+2) rows), or, for the pointwise kernel
 // (PW = true: plain NT GEMM / 1x1 convolution, the image is the tile's 128 rows), TAPS consecutive 32-channel chunks
 // stored one after the other (NH = 4*TAPS).
-// N32: the four waves of a workgroup split the 128 output channels (wave tile 128 x 32: each weight fragment is loaded by
-// one wave) instead of a 2 x 2 arrangement of 64 x 64 tiles (every fragment loaded by two waves).
-// MT: pixel rows per workgroup tile, 128 or - with N32, 3x3 only - 64 (wave tile 64 x 32): twice the workgroups for output
+// The four waves of a workgroup split the 128 output channels (wave tile 128 x 32: each weight fragment is loaded by one
+// wave; the 2 x 2 arrangement of 64 x 64 tiles of round 1 loaded every fragment twice).
+// MT: pixel rows per workgroup tile, 128 or - 3x3 only - 64 (wave tile 64 x 32): twice the workgroups for output
 // grids too small to fill the chip, instead of (or with a shallower) split of the K range.
-template <int NH, int TAPS, bool PW, bool N32, int MT = 128>
+template <int NH, int TAPS, bool PW, int MT = 128>
 __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
-    static_assert(MT == 128 || (MT == 64 && N32 && !PW), "64-row tiles exist for the 1 x 4 wave layout of the 3x3 kernels");
-    constexpr int MBK = N32 ? MT / 16 : 4, NBK = N32 ? 2 : 4;
+    static_assert(MT == 128 || (MT == 64 && !PW), "64-row tiles exist for the 3x3 kernels");
+    constexpr int MBK = MT / 16, NBK = 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LIMB = NH * 32 * ROWB;
     static_assert(!PW || NH == 4 * TAPS, "pointwise staging: 128 rows x 8 quads per 32-channel chunk");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wr = N32 ? 0 : wave >> 1, wc = N32 ? wave >> 1 : wave & 1;
+    const int wc = wave >> 1;
     const int c4 = tid & 7;
 
     const int tiles_n = a.N >> 7;
@@ -496,13 +353,13 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
     };
 
     // v_mfma_f32_16x16x32_bf16 (under this load it sustains a ~15 % higher clock than 32x32x16: measured 212 vs 184
-    // TFLOP/s on 256->256 @32x32): the 64x64 wave tile is 4x4 blocks, one 32-deep K step per tap and chunk.
+    // TFLOP/s on 256->256 @32x32): the 128x32 wave tile is 8x2 blocks, one 32-deep K step per tap and chunk.
     // Lane l holds A[row = l & 15][k = 8*(l >> 4) + j]: LDS pixel row of its rows at tap (0, 0)
     const int r16 = lane & 15, kq = lane >> 4;
     int abase[MBK];
 #pragma unroll
     for (int mb = 0; mb < MBK; ++mb) {
-        const int ml = wr * 64 + mb * 16 + r16;
+        const int ml = mb * 16 + r16;
         if constexpr (PW) {
             abase[mb] = ml;
         } else {
@@ -515,7 +372,7 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
 
     // B fragments of K step sigma = stage*TAPS + tap for this wave's 64 columns
     const u32x4* wp = a.wfrag + ((long long)(tile_n * 2 + wc) * a.chunks * TAPS) * TAP_U4 + lane +
-                      (N32 ? (wave & 1) * 2 * 3 * 64 : 0);      // a 32-column wave: blocks 2*(wave & 1), +1 of its half
+                      (wave & 1) * 2 * 3 * 64;                  // a 32-column wave: blocks 2*(wave & 1), +1 of its half
     const int sig_beg = c_beg * TAPS, sig_end = c_end * TAPS;
     u32x4 bq[2][NBK][3];
     auto load_b = [&](int sigma, u32x4 (&dst)[NBK][3]) {
@@ -561,7 +418,7 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
             for (int mb = 0; mb < MBK; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < NBK; ++nb)
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(       // weights first: D^T (see dconv_epilogue)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(       // weights first: D^T (see dconv_epilogue_n32)
                         __builtin_bit_cast(bf16x8, bq[pp][nb][PB[t]]), __builtin_bit_cast(bf16x8, fa[mb][PA[t]]),
                         acc[mb][nb], 0, 0, 0);
         if (++tap == TAPS) {            // stage done: swap in the next image
@@ -583,8 +440,7 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
         if (sigma + 1 < sig_end) step(sigma + 1, std::integral_constant<int, 1>{});
     }
 
-    if constexpr (N32) dconv_epilogue_n32<MBK>(a, acc, m0, n0 + wave * 32, lane, split);
-    else dconv_epilogue(a, acc, m0, n0, wr, wc, lane, split);
+    dconv_epilogue_n32<MBK>(a, acc, m0, n0 + wave * 32, lane, split);
 }
 
 // ---- forward / data-gradient on pre-split activations ("limb planes") ----------------------------------------------
@@ -597,11 +453,11 @@ __global__ void __launch_bounds__(256, 2) dconv_kernel(const DConvArgs a) {
 // RG = 16-row groups per image (>= halo pixels / 16); wave w moves row groups w, w + 4, ...
 constexpr int LP_PIX_BYTES_PER_CH = 6;     // bytes per element of a limb-plane tensor
 
-template <int RG, bool DB, bool N32, int MT = 128>
+template <int RG, bool DB, int MT = 128>
 __global__ void __launch_bounds__(256, 2) dconv_lp_kernel(const DConvArgs a) {
-    static_assert(MT == 128 || (MT == 64 && N32), "64-row tiles exist for the 1 x 4 wave layout");
-    // accumulator blocks per wave: 64 x 64 (2 x 2 waves), 128 x 32 (1 x 4) or, on 64-row tiles, 64 x 32
-    constexpr int MBK = N32 ? MT / 16 : 4, NBK = N32 ? 2 : 4;
+    static_assert(MT == 128 || MT == 64, "128- or 64-row tiles");
+    // accumulator blocks per wave: 128 x 32 (1 x 4 waves) or, on 64-row tiles, 64 x 32
+    constexpr int MBK = MT / 16, NBK = 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LIMB = RG * 16 * ROWB;
     constexpr int BUF = 3 * LIMB;
@@ -610,7 +466,7 @@ __global__ void __launch_bounds__(256, 2) dconv_lp_kernel(const DConvArgs a) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: uniform branches below
-    const int wr = N32 ? 0 : wave >> 1, wc = N32 ? wave >> 1 : wave & 1;
+    const int wc = wave >> 1;
 
     const int tiles_n = a.N >> 7;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -673,7 +529,7 @@ __global__ void __launch_bounds__(256, 2) dconv_lp_kernel(const DConvArgs a) {
     int abase[MBK];
 #pragma unroll
     for (int mb = 0; mb < MBK; ++mb) {
-        const int ml = wr * 64 + mb * 16 + r16;
+        const int ml = mb * 16 + r16;
         const int seg = ml / (a.rps * a.W);
         const int rem = ml - seg * (a.rps * a.W);
         const int ry = rem / a.W, ox = rem - ry * a.W;
@@ -683,8 +539,7 @@ __global__ void __launch_bounds__(256, 2) dconv_lp_kernel(const DConvArgs a) {
     const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
     // fragment buffer: [n tile][64-column half wc][chunk][tap][16-column block nb 4][limb 3][lane]; a 32-column wave takes
     // blocks 2*(wave & 1) and 2*(wave & 1) + 1 of its half
-    const u32x4* wp = a.wfrag + ((long long)(tile_n * 2 + wc) * a.chunks * TAPS) * TAP_U4 + lane +
-                      (N32 ? (wave & 1) * 2 * 3 * 64 : 0);
+    const u32x4* wp = a.wfrag + ((long long)(tile_n * 2 + wc) * a.chunks * TAPS) * TAP_U4 + lane + (wave & 1) * 2 * 3 * 64;
     const int sig_beg = c_beg * TAPS, sig_end = c_end * TAPS;
     u32x4 bq[2][NBK][3];
     auto load_b = [&](int sigma, u32x4 (&dst)[NBK][3]) {
@@ -752,7 +607,7 @@ __global__ void __launch_bounds__(256, 2) dconv_lp_kernel(const DConvArgs a) {
             for (int mb = 0; mb < MBK; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < NBK; ++nb)
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(       // weights first: D^T (see dconv_epilogue)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(       // weights first: D^T (see dconv_epilogue_n32)
                         __builtin_bit_cast(bf16x8, bq[pp][nb][PB[t]]), __builtin_bit_cast(bf16x8, fa[mb][PA[t]]),
                         acc[mb][nb], 0, 0, 0);
         }
@@ -782,8 +637,7 @@ __global__ void __launch_bounds__(256, 2) dconv_lp_kernel(const DConvArgs a) {
         if (sigma + 1 < sig_end) step(sigma + 1, std::integral_constant<int, 1>{});
     }
 
-    if constexpr (N32) dconv_epilogue_n32<MBK>(a, acc, m0, n0 + wave * 32, lane, split);
-    else dconv_epilogue(a, acc, m0, n0, wr, wc, lane, split);
+    dconv_epilogue_n32<MBK>(a, acc, m0, n0 + wave * 32, lane, split);
 }
 
 // fp32 NHWC [rows][c] -> limb planes [rows][c/32][3][32] (tests, and producers without a fused writer)
@@ -1755,12 +1609,12 @@ int launch_dwgrad(const DWgradArgs& a, int nsplit, hipStream_t stream) {
     return PSLD_OK;
 }
 
-template <int NH, int TAPS, bool PW, bool N32, int MT = 128>
-int launch_dconv_impl(const DConvArgs& a, int nsplit, hipStream_t stream, const char* name) {
+template <int NH, int TAPS, bool PW, int MT = 128>
+int launch_dconv(const DConvArgs& a, int nsplit, hipStream_t stream, const char* name) {
     constexpr size_t LDS = (size_t)3 * NH * 32 * ROWB;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv_kernel<NH, TAPS, PW, N32, MT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv_kernel<NH, TAPS, PW, MT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         if (e != hipSuccess) {
             psld_set_error("%s: hipFuncSetAttribute failed: %s", name, hipGetErrorString(e));
@@ -1769,28 +1623,17 @@ int launch_dconv_impl(const DConvArgs& a, int nsplit, hipStream_t stream, const 
         configured = true;
     }
     dim3 grid((unsigned)(cdiv(a.M, MT) * (a.N / 128)), (unsigned)nsplit);
-    hipLaunchKernelGGL((dconv_kernel<NH, TAPS, PW, N32, MT>), grid, dim3(256), LDS, stream, a);
+    hipLaunchKernelGGL((dconv_kernel<NH, TAPS, PW, MT>), grid, dim3(256), LDS, stream, a);
     PSLD_CHECK_LAUNCH(name);
     return PSLD_OK;
 }
 
-inline bool dconv_n32(const DConvArgs& a) {
-    static const int n32env = [] { const char* v = getenv("PSLD_DCONV_N32"); return v ? atoi(v) : 1; }();
-    return n32env && !a.e.gnb_part;        // the GroupNorm-backward by-product exists in the 2 x 2 layout only
-}
-
-template <int NH, int TAPS, bool PW>
-int launch_dconv(const DConvArgs& a, int nsplit, hipStream_t stream, const char* name) {
-    return dconv_n32(a) ? launch_dconv_impl<NH, TAPS, PW, true>(a, nsplit, stream, name)
-                        : launch_dconv_impl<NH, TAPS, PW, false>(a, nsplit, stream, name);
-}
-
-template <int RG, bool DB, bool N32, int MT = 128>
+template <int RG, bool DB, int MT = 128>
 int launch_dconv_lp(const DConvArgs& a, int nsplit, hipStream_t stream, const char* name) {
     constexpr size_t LDS = (size_t)(DB ? 2 : 1) * 3 * RG * 16 * ROWB;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv_lp_kernel<RG, DB, N32, MT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv_lp_kernel<RG, DB, MT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         if (e != hipSuccess) {
             psld_set_error("%s: hipFuncSetAttribute failed: %s", name, hipGetErrorString(e));
@@ -1799,7 +1642,7 @@ int launch_dconv_lp(const DConvArgs& a, int nsplit, hipStream_t stream, const ch
         configured = true;
     }
     dim3 grid((unsigned)(cdiv(a.M, MT) * (a.N / 128)), (unsigned)nsplit);
-    hipLaunchKernelGGL((dconv_lp_kernel<RG, DB, N32, MT>), grid, dim3(256), LDS, stream, a);
+    hipLaunchKernelGGL((dconv_lp_kernel<RG, DB, MT>), grid, dim3(256), LDS, stream, a);
     PSLD_CHECK_LAUNCH(name);
     return PSLD_OK;
 }
@@ -1809,7 +1652,7 @@ int launch_dconv_lp(const DConvArgs& a, int nsplit, hipStream_t stream, const ch
 int plan_split(DConvArgs& a, const PsldEpilogue& e, float* y, int ldy, void* workspace, long long ws_bytes, int mt = 128) {
     const long long tiles = (long long)cdiv(a.M, mt) * (a.N / 128);
     int ns = 1;
-    if (workspace && tiles < 384 && !e.gn_part && !e.gnb_part && ldy % 4 == 0 && aligned16(y) && (!e.bias || aligned16(e.bias)) &&
+    if (workspace && tiles < 384 && !e.gn_part && ldy % 4 == 0 && aligned16(y) && (!e.bias || aligned16(e.bias)) &&
         (!e.rowbias || (aligned16(e.rowbias) && e.ld_rowbias % 4 == 0)) && (!e.res || (aligned16(e.res) && e.ldres % 4 == 0))) {
         ns = (int)(512 / tiles);
         if (ns > 8) ns = 8;
@@ -1847,11 +1690,8 @@ int plan_split(DConvArgs& a, const PsldEpilogue& e, float* y, int ldy, void* wor
 // -> 0.504 / 0.516 -> 0.541, 74.2 -> 73.1 / 71.3 -> 68.8 us under the counters (profiles/r03/pmc_lds_w8_pitch{0,1}.md) and
 // nothing in an interleaved A/B (profiles/r03/ab_w8.txt: 181.1 vs 181.6 TFLOP/s at B=128, 58.5 vs 60.0 at B=16): the
 // conflict cycles sat in the shadow of the MFMAs; what holds these launches at half the pipe is their grid (256
-// workgroups of 64 rows at B=128: one per CU).  PSLD_DCONV_W8_PITCH16=0 restores the pitch of 10.
-int dconv_pitch(int w, int mt) {
-    static const int on = [] { const char* v = getenv("PSLD_DCONV_W8_PITCH16"); return v ? atoi(v) : 1; }();
-    return (w == 8 && mt == 64 && on) ? 16 : w + 2;
-}
+// workgroups of 64 rows at B=128: one per CU).
+int dconv_pitch(int w, int mt) { return (w == 8 && mt == 64) ? 16 : w + 2; }
 
 bool dconv_geometry(int h, int w, int* nseg, int* rps, int* halo_px, int mt = 128) {
     if (w != 8 && w != 16 && w != 32 && w != 64) return false;
@@ -1869,19 +1709,14 @@ bool dconv_geometry(int h, int w, int* nseg, int* rps, int* halo_px, int mt = 12
     return *halo_px <= 9 * 32;
 }
 
-// Tile height of a 3x3 limb convolution: 64-row tiles (1 x 4 wave layout only) when 128-row tiles leave the grid short of
-// 384 workgroups - the same bound under which plan_split starts cutting the K range - and the geometry allows them.
-// PSLD_DCONV_MT64=0 switches them off.
-int dconv_tile_rows(const DConvArgs& a, bool n32, int h, int w) {
-    static const int on = [] { const char* v = getenv("PSLD_DCONV_MT64"); return v ? atoi(v) : 1; }();
-    // PSLD_DCONV_W8_MT64=1: 8-wide maps on 64-row tiles at every batch size (the 128-row tile has no room for the wider
-    // pitch of dconv_pitch).  Measured slower at large batches (B=512: 236-251 vs 244-267 TFLOP/s): off by default
-    static const int w8 = [] { const char* v = getenv("PSLD_DCONV_W8_MT64"); return v ? atoi(v) : 0; }();
+// Tile height of a 3x3 limb convolution: 64-row tiles when 128-row tiles leave the grid short of 384 workgroups - the same
+// bound under which plan_split starts cutting the K range - and the geometry allows them.  (8-wide maps on 64-row tiles at
+// every batch size measured slower at large batches - B=512: 236-251 vs 244-267 TFLOP/s - and are not offered.)
+int dconv_tile_rows(const DConvArgs& a, int h, int w) {
     int nseg, rps, halo;
     const long long tiles128 = (long long)cdiv(a.M, 128) * (a.N / 128);
     // halo of a 64-row tile <= 160 pixel rows: the images the 64-row instances are built with (10 row groups / 5 items)
-    return (on && n32 && (tiles128 < 384 || (w == 8 && w8)) && a.M % 64 == 0 && dconv_geometry(h, w, &nseg, &rps, &halo, 64) &&
-            halo <= 160) ? 64 : 128;
+    return (tiles128 < 384 && a.M % 64 == 0 && dconv_geometry(h, w, &nseg, &rps, &halo, 64) && halo <= 160) ? 64 : 128;
 }
 
 }  // namespace
@@ -1940,7 +1775,7 @@ extern "C" int psld_conv3x3_split_f32(const float* x1, int c1, const float* x2, 
     int halo_px = 0;
     const PsldEpilogue e = make_epilogue(epi);
     a.e = e;
-    const int mt = dconv_tile_rows(a, dconv_n32(a), h, w);
+    const int mt = dconv_tile_rows(a, h, w);
     dconv_geometry(h, w, &a.nseg, &a.rps, &halo_px, mt);
     a.pitch = dconv_pitch(w, mt);
     a.zero = psld_detail_zero_page("psld_conv3x3_split_f32");
@@ -1949,17 +1784,11 @@ extern "C" int psld_conv3x3_split_f32(const float* x1, int c1, const float* x2, 
                    "psld_conv3x3_split_f32: gn_part needs gn_hw = h*w, a multiple of 64, and no accumulation");
     const int ns = plan_split(a, e, y, ldy, workspace, ws_bytes, mt);
     PSLD_CHECK_ARG(a.v4, "limb kernels: y, residual, bias and rowbias need 16-byte aligned rows (pointer and row stride)");
-    PSLD_CHECK_ARG(!e.gnb_part || (e.gnb_x && e.gnb_mean && e.gnb_rstd && e.gnb_gamma && e.gnb_beta && e.gnb_hw > 0 &&
-                                   e.gnb_hw % 64 == 0 && a.M % e.gnb_hw == 0 && ldy == a.N && e.gnb_groups > 0 &&
-                                   a.N % e.gnb_groups == 0 && (a.N / e.gnb_groups) % 4 == 0 && !e.accumulate &&
-                                   aligned16(e.gnb_x) && aligned16(e.gnb_gamma) && aligned16(e.gnb_beta) && aligned16(e.gnb_part)),
-                   "limb kernels: gnb_part needs a contiguous output (ldy == n), gnb_hw a multiple of 64 dividing the rows, "
-                   "groups of a multiple of 4 channels, 16-byte aligned operands and no accumulation");
     const int nh = cdiv((long long)halo_px * 8, 256);
     const char* name = "psld_conv3x3_split_f32";
     int st;
-    if (mt == 64) st = nh <= 4 ? launch_dconv_impl<4, 9, false, true, 64>(a, ns, stream, name)
-                               : launch_dconv_impl<5, 9, false, true, 64>(a, ns, stream, name);
+    if (mt == 64) st = nh <= 4 ? launch_dconv<4, 9, false, 64>(a, ns, stream, name)
+                               : launch_dconv<5, 9, false, 64>(a, ns, stream, name);
     else if (nh <= 6) st = launch_dconv<6, 9, false>(a, ns, stream, name);
     else if (nh <= 7) st = launch_dconv<7, 9, false>(a, ns, stream, name);
     else st = launch_dconv<9, 9, false>(a, ns, stream, name);
@@ -2003,12 +1832,7 @@ extern "C" int psld_conv3x3_limb_f32(const void* x1, int c1, const void* x2, int
     a.chunks = (c1 + c2) / 32;
     int halo_px = 0;
     const PsldEpilogue e = make_epilogue(epi);
-    static const int n32env = [] { const char* v = getenv("PSLD_DCONV_N32"); return v ? atoi(v) : 1; }();
-    static const int single = [] { const char* v = getenv("PSLD_LP_SINGLE_BUFFER"); return v ? atoi(v) : 0; }();
-    // wave decomposition: 1 x 4 waves of 128 x 32 (each weight fragment loaded once per workgroup) unless the epilogue has
-    // to produce the GroupNorm-backward by-product (2 x 2 layout only) or PSLD_DCONV_N32=0 asks for the old layout
-    const bool n32 = n32env && !e.gnb_part;
-    const int mt = dconv_tile_rows(a, n32 && !single, h, w);
+    const int mt = dconv_tile_rows(a, h, w);
     dconv_geometry(h, w, &a.nseg, &a.rps, &halo_px, mt);
     a.pitch = dconv_pitch(w, mt);
     a.zero = psld_detail_zero_page("psld_conv3x3_limb_f32");
@@ -2017,24 +1841,16 @@ extern "C" int psld_conv3x3_limb_f32(const void* x1, int c1, const void* x2, int
                    "psld_conv3x3_limb_f32: gn_part needs gn_hw = h*w, a multiple of 64, and no accumulation");
     const int ns = plan_split(a, e, y, ldy, workspace, ws_bytes, mt);
     PSLD_CHECK_ARG(a.v4, "limb kernels: y, residual, bias and rowbias need 16-byte aligned rows (pointer and row stride)");
-    PSLD_CHECK_ARG(!e.gnb_part || (e.gnb_x && e.gnb_mean && e.gnb_rstd && e.gnb_gamma && e.gnb_beta && e.gnb_hw > 0 &&
-                                   e.gnb_hw % 64 == 0 && a.M % e.gnb_hw == 0 && ldy == a.N && e.gnb_groups > 0 &&
-                                   a.N % e.gnb_groups == 0 && (a.N / e.gnb_groups) % 4 == 0 && !e.accumulate &&
-                                   aligned16(e.gnb_x) && aligned16(e.gnb_gamma) && aligned16(e.gnb_beta) && aligned16(e.gnb_part)),
-                   "limb kernels: gnb_part needs a contiguous output (ldy == n), gnb_hw a multiple of 64 dividing the rows, "
-                   "groups of a multiple of 4 channels, 16-byte aligned operands and no accumulation");
     const int rg = cdiv(halo_px, 16);
     const char* name = "psld_conv3x3_limb_f32";
     int st;
     // two images of RG <= 13 row groups (79,872 B) leave room for two workgroups per CU (163,840 B of LDS)
-    if (mt == 64) st = rg <= 7 ? launch_dconv_lp<7, true, true, 64>(a, ns, stream, name)
-                     : rg <= 9 ? launch_dconv_lp<9, true, true, 64>(a, ns, stream, name)
-                               : launch_dconv_lp<10, true, true, 64>(a, ns, stream, name);
-    else if (rg <= 12) st = single ? launch_dconv_lp<12, false, false>(a, ns, stream, name)
-                   : (n32 ? launch_dconv_lp<12, true, true>(a, ns, stream, name) : launch_dconv_lp<12, true, false>(a, ns, stream, name));
-    else if (rg <= 13) st = single ? launch_dconv_lp<13, false, false>(a, ns, stream, name)
-                        : (n32 ? launch_dconv_lp<13, true, true>(a, ns, stream, name) : launch_dconv_lp<13, true, false>(a, ns, stream, name));
-    else st = n32 ? launch_dconv_lp<18, false, true>(a, ns, stream, name) : launch_dconv_lp<18, false, false>(a, ns, stream, name);
+    if (mt == 64) st = rg <= 7 ? launch_dconv_lp<7, true, 64>(a, ns, stream, name)
+                     : rg <= 9 ? launch_dconv_lp<9, true, 64>(a, ns, stream, name)
+                               : launch_dconv_lp<10, true, 64>(a, ns, stream, name);
+    else if (rg <= 12) st = launch_dconv_lp<12, true>(a, ns, stream, name);
+    else if (rg <= 13) st = launch_dconv_lp<13, true>(a, ns, stream, name);
+    else st = launch_dconv_lp<18, false>(a, ns, stream, name);
     if (st != PSLD_OK) return st;
     if (ns >= 2) return psld_detail_conv_reduce_epilogue(a.C, ns, a.M, cout, y, ldy, e, stream);
     return PSLD_OK;
@@ -2045,14 +1861,7 @@ extern "C" int psld_conv3x3_wgrad_split_supported(int cout, int cin, int batch, 
            (w == 8 || w == 16 || w == 32 || w == 64) && (h * w) % 32 == 0;
 }
 
-extern "C" int psld_conv3x3_wgrad_split_cout_tile(int cout) {
-    static const int forced = [] {
-        const char* e = getenv("PSLD_WGRAD_COUT_TILE");      // tuning aid: 64 or 128
-        return e ? atoi(e) : 0;
-    }();
-    if (forced == 64 || cout % 128) return 64;
-    return 128;
-}
+extern "C" int psld_conv3x3_wgrad_split_cout_tile(int cout) { return cout % 128 ? 64 : 128; }
 
 extern "C" int psld_conv3x3_wgrad_split_f32(const float* dy, int lddy, int cout, const float* x, int cin,
                                             const float* x2, int cin2, int batch, int h, int w, float* slabs,
@@ -2215,20 +2024,12 @@ extern "C" int psld_gemm_split_f32(const float* a1, int k1, const float* a2, int
     const PsldEpilogue e = make_epilogue(epi);
     PSLD_CHECK_ARG(!e.gn_part || (e.gn_hw > 0 && e.gn_hw % 64 == 0 && m % e.gn_hw == 0 && !e.accumulate),
                    "psld_gemm_split_f32: gn_part needs gn_hw (rows per image) a multiple of 64 dividing m, and no accumulation");
-    // eight-wave 128 x 256 tiles from 128 of them on (PSLD_PW8=0: the four-wave 128 x 128 kernel everywhere).  Half a
-    // chip of persistent workgroups still beats 256 four-wave tiles split in two K ranges plus their reduction launch:
-    // B=16 step 537 / 539 -> 550 / 547 images/s, B=64 903 -> 908; from 64 tiles on it does not (543 / 542).
-    static const int pw8 = [] { const char* v = getenv("PSLD_PW8"); return v ? atoi(v) : 1; }();
-    static const int pw8_min = [] { const char* v = getenv("PSLD_PW8_MIN_TILES"); return v ? atoi(v) : 128; }();
-    const bool wide = pw8 && n % 256 == 0 && !e.gnb_part && (long long)cdiv(m, 128) * (n / 256) >= pw8_min;
+    // eight-wave 128 x 256 tiles from 128 of them on (below: the four-wave 128 x 128 kernel).  Half a chip of persistent
+    // workgroups still beats 256 four-wave tiles split in two K ranges plus their reduction launch: B=16 step 537 / 539 ->
+    // 550 / 547 images/s, B=64 903 -> 908; from 64 tiles on it does not (543 / 542).
+    const bool wide = n % 256 == 0 && (long long)cdiv(m, 128) * (n / 256) >= 128;
     const int ns = plan_split(a, e, y, ldy, wide ? nullptr : workspace, ws_bytes);
     PSLD_CHECK_ARG(a.v4, "limb kernels: y, residual, bias and rowbias need 16-byte aligned rows (pointer and row stride)");
-    PSLD_CHECK_ARG(!e.gnb_part || (e.gnb_x && e.gnb_mean && e.gnb_rstd && e.gnb_gamma && e.gnb_beta && e.gnb_hw > 0 &&
-                                   e.gnb_hw % 64 == 0 && a.M % e.gnb_hw == 0 && ldy == a.N && e.gnb_groups > 0 &&
-                                   a.N % e.gnb_groups == 0 && (a.N / e.gnb_groups) % 4 == 0 && !e.accumulate &&
-                                   aligned16(e.gnb_x) && aligned16(e.gnb_gamma) && aligned16(e.gnb_beta) && aligned16(e.gnb_part)),
-                   "limb kernels: gnb_part needs a contiguous output (ldy == n), gnb_hw a multiple of 64 dividing the rows, "
-                   "groups of a multiple of 4 channels, 16-byte aligned operands and no accumulation");
     if (wide) {
 #ifdef PSLD_ABLATIONS      // timing-only variants (wrong results): libpsld_hip_abl.so only
         static const int abl = [] { const char* v = getenv("PSLD_PW8_ABL"); return v ? atoi(v) : 0; }();

@@ -631,7 +631,6 @@ int wino_conv(const float* x1, int c1, const float* x2, int c2, int batch, int h
     wino_geometry(h, w, &a.nseg, &a.rps, &halo_px);
     a.e = make_epilogue(epi);
     const PsldEpilogue& e = a.e;
-    PSLD_CHECK_ARG(!e.gnb_part, "psld_conv3x3_wino_f32: no GroupNorm-backward by-product in this kernel");
     PSLD_CHECK_ARG(!e.gn_part || (e.gn_hw == h * w && e.gn_hw % 64 == 0 && !e.accumulate),
                    "psld_conv3x3_wino_f32: gn_part needs gn_hw = h*w, a multiple of 64, and no accumulation");
     PSLD_CHECK_ARG(ldy % 4 == 0 && aligned16(y) && (!e.res || (e.ldres % 4 == 0 && aligned16(e.res))) &&
@@ -651,88 +650,7 @@ int wino_conv(const float* x1, int c1, const float* x2, int c2, int batch, int h
         return launch_wino8s<0, true>(a, stream, "psld_conv3x3_wino_gn_f32");
     }
 #ifdef PSLD_ABLATIONS      // libpsld_hip_abl.so only: the variants of conv_wino_abl.inc and the timing-only ablations (wrong results)
-    {
-        static const int nmaj = [] { const char* v = getenv("PSLD_WINO_NMAJOR"); return v ? atoi(v) : 1; }();
-        a.nmajor = nmaj;
-        static const int w4 = [] { const char* v = getenv("PSLD_WINO_W4"); return v ? atoi(v) : 2; }();
-        static const int abl = [] { const char* v = getenv("PSLD_WINO_ABL"); return v ? atoi(v) : 0; }();
-        // CU-resident form (wino_conv8p_kernel) when every workgroup gets at least two items; PSLD_WINO_PERSIST=1: on,
-        // =N > 1: N workgroups
-        static const int persist = [] { const char* v = getenv("PSLD_WINO_PERSIST"); return v ? atoi(v) : 0; }();
-        static const int stg = [] { const char* v = getenv("PSLD_WINO_STAGGER"); return v ? atoi(v) : 0; }();
-        static const int la = [] { const char* v = getenv("PSLD_WINO_LA"); return v ? atoi(v) : 2; }();
-        static const int eraw = [] { const char* v = getenv("PSLD_WINO_ERAW"); return v ? atoi(v) : 0; }();
-        static const int qk = [] { const char* v = getenv("PSLD_WINO_Q"); return v ? atoi(v) : 0; }();
-        if (qk) {
-            if (abl == 1) return launch_wino8q<1>(a, stream, name);
-            if (abl == 2) return launch_wino8q<2>(a, stream, name);
-            if (abl == 3) return launch_wino8q<3>(a, stream, name);
-            return launch_wino8q<0>(a, stream, name);
-        }
-        if (w4 == 2 && la == 3 && !persist && !abl) return launch_wino8s<0, false, false, 3>(a, stream, name);
-        if (w4 == 2 && abl == 128) return launch_wino8s<128>(a, stream, name);
-        if (w4 == 2 && abl == 256) return launch_wino8s<256>(a, stream, name);
-        if (w4 == 2 && abl == 4) return launch_wino8s<4>(a, stream, name);
-        if (w4 == 2 && abl >= 64) {     // stamped diagnostic builds: plain | no transforms | weights loaded once | both
-            a.dbg = g_wino_dbg;
-            if (abl == 65) return launch_wino8s<65>(a, stream, name);
-            if (abl == 66) return launch_wino8s<66>(a, stream, name);
-            if (abl == 67) return launch_wino8s<67>(a, stream, name);
-            return launch_wino8s<64>(a, stream, name);
-        }
-        if (w4 == 2 && eraw && !persist) {
-            if (abl == 2) return launch_wino8s<2, false, true>(a, stream, name);
-            return launch_wino8s<0, false, true>(a, stream, name);
-        }
-        if (w4 == 2) {
-            a.tiles_m = cdiv(a.M, 128);
-            a.stagger = stg;
-            const int total = a.tiles_m * (a.N / 128);
-            const int cus = persist > 1 ? persist : wino_cu_count();
-            auto lg2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
-            a.lg_tiles_x = lg2(a.cw >> 1);
-            a.lg_tps = lg2((a.rps >> 1) * (a.cw >> 1));
-            const long long span = (long long)a.M * (ldy > e.ldres ? ldy : e.ldres) + cout;       // 32-bit element offsets
-            if (persist && total >= 2 * cus && span < (1LL << 31)) {
-                if (abl == 1) return launch_wino8p<1>(a, cus, stream, name);
-                if (abl == 2) return launch_wino8p<2>(a, cus, stream, name);
-                if (abl == 16) return launch_wino8p<16>(a, cus, stream, name);
-                if (abl == 32) return launch_wino8p<32>(a, cus, stream, name);
-                if (abl == 48) return launch_wino8p<48>(a, cus, stream, name);
-                if (la == 3) return launch_wino8p<0, 3>(a, cus, stream, name);
-                return launch_wino8p<0>(a, cus, stream, name);
-            }
-            if (abl == 1) return launch_wino8s<1>(a, stream, name);
-            if (abl == 2) return launch_wino8s<2>(a, stream, name);
-            if (abl == 3) return launch_wino8s<3>(a, stream, name);
-            if (abl == 4) return launch_wino8s<4>(a, stream, name);
-            if (abl == 8) return launch_wino8s<8>(a, stream, name);
-        } else {
-            wino_geometry(h, w, &a.nseg, &a.rps, &halo_px);     // whole-width tiles
-            a.cw = w;
-            if (w4 == 1) {
-                const int ni4 = cdiv((long long)halo_px * 8, 256);
-                if (abl == 1 && ni4 <= 7) return launch_wino4<7, 1>(a, stream, name);
-                if (abl == 2 && ni4 <= 7) return launch_wino4<7, 2>(a, stream, name);
-                if (abl == 3 && ni4 <= 7) return launch_wino4<7, 3>(a, stream, name);
-                if (ni4 <= 6) return launch_wino4<6>(a, stream, name);
-                if (ni4 <= 7) return launch_wino4<7>(a, stream, name);
-            }
-            const int ni = cdiv((long long)halo_px * 8, WINO_THREADS);
-            if (abl && ni <= 4) {
-                switch (abl) {
-                    case 1: return launch_wino<4, 1>(a, stream, name);
-                    case 2: return launch_wino<4, 2>(a, stream, name);
-                    case 3: return launch_wino<4, 3>(a, stream, name);
-                    case 6: return launch_wino<4, 6>(a, stream, name);
-                    case 7: return launch_wino<4, 7>(a, stream, name);
-                }
-            }
-            if (ni <= 3) return launch_wino<3>(a, stream, name);
-            if (ni <= 4) return launch_wino<4>(a, stream, name);
-            return launch_wino<5>(a, stream, name);
-        }
-    }
+#include "conv_wino_abl_dispatch.inc"
 #endif
     return launch_wino8s<0>(a, stream, name);
 }

@@ -286,55 +286,21 @@ __global__ void gn_bwd_partial_kernel(const float* __restrict__ dy, const float*
     }
 }
 
-// pass 2, one launch with two block roles.
-// blocks [0, batch): per image: sum chunks -> s1[c], s2[c]; group means m1, m2; write coefficient rows
+// pass 2 (three-pass form only: maps whose (image, 32-channel) slab does not fit registers), one block per image: sum the
+// chunk partials -> sums[n][0][c] = sum_p dz, sums[n][1][c] = sum_p dz * xhat (what the one-pass kernels write directly; the
+// parameter gradients dbeta / dgamma are their sums over the batch: psld_param_reduce*_f32), group means m1, m2 and the
+// coefficient rows
 //   coef[n][0][c] = rstd*gamma  (multiplies dz)
 //   coef[n][1][c] = rstd*m1_g   (subtracted)
 //   coef[n][2][c] = rstd*m2_g   (multiplies xhat, subtracted)
-// blocks [batch, batch + 2*ceil(c/64)): dbeta[c] = sum_n s1[n,c] / dgamma[c] = sum_n s2[n,c] straight from the chunk
-// partials: 64 columns x 16 image lanes, every lane adds its (image, chunk) terms in index order, lanes combined in
-// lane order.  No atomics anywhere: bitwise repeatable.
-__global__ void __launch_bounds__(1024) gn_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ rstd,
-                                                               const float* __restrict__ gamma, int batch, int hw, int c,
-                                                               int groups, int chunks, float* __restrict__ coef,
-                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                               int first_block, const float* __restrict__ csum_img = nullptr,
-                                                               int ld_img = 0, float* __restrict__ csum = nullptr,
-                                                               float csum_alpha = 1.f) {
-    __shared__ double sh[2 * MAXT * 4];          // image role: s1*gamma, s2*gamma per channel; param role: [16][64]
+// No atomics anywhere: bitwise repeatable.
+__global__ void __launch_bounds__(1024) gn_bwd_coef_kernel(const float* __restrict__ part, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, int hw, int c, int groups,
+                                                           int chunks, float* __restrict__ coef, float* __restrict__ sums) {
+    __shared__ double sh[2 * MAXT * 4];          // s1*gamma, s2*gamma per channel
     __shared__ double g1[MAXG], g2[MAXG];
     const int tid = threadIdx.x;
-    const int bid = (int)blockIdx.x + first_block;      // first_block = batch: parameter-gradient blocks only
-    if (bid >= batch) {
-        const int r = bid - batch;
-        const int roles = csum ? 3 : 2;             // dbeta, dgamma (, column sums of dx over the batch)
-        const int which = r % roles;
-        const int col = (r / roles) * 64 + (tid & 63);
-        const int lane = tid >> 6;
-        double acc = 0.0;
-        if (which == 2) {
-            if (col < c)
-                for (int n = lane; n < batch; n += 16) acc += (double)csum_img[(long long)n * ld_img + col];
-        } else if (col < c)
-            for (int n = lane; n < batch; n += 16) {
-                const float* p = part + (((long long)n * chunks) * 2 + which) * c + col;
-#pragma unroll 8
-                for (int k = 0; k < chunks; ++k) acc += (double)p[(long long)k * 2 * c];
-            }
-        sh[lane * 64 + (tid & 63)] = acc;
-        __syncthreads();
-        if (lane == 0 && col < c) {
-            double t = 0.0;
-#pragma unroll
-            for (int l = 0; l < 16; ++l) t += sh[l * 64 + tid];
-            if (which == 2)
-                csum[col] = (float)(t * (double)csum_alpha);
-            else
-                (which ? dgamma : dbeta)[col] = (float)t;
-        }
-        return;
-    }
-    const int n = bid;
+    const int n = blockIdx.x;
     const int cpg = c / groups;
     for (int ch = tid; ch < c; ch += blockDim.x) {
         double a = 0, b = 0;
@@ -355,6 +321,8 @@ __global__ void __launch_bounds__(1024) gn_bwd_finalize_kernel(const float* __re
                     b += (double)vb[j];
                 }
         }
+        sums[((long long)n * 2 + 0) * c + ch] = (float)a;
+        sums[((long long)n * 2 + 1) * c + ch] = (float)b;
         sh[ch] = a * (double)gamma[ch];
         sh[MAXT * 4 + ch] = b * (double)gamma[ch];
     }
@@ -467,8 +435,12 @@ __device__ int g_gnb_mode = 0;                          // bit 0 delay odd workg
 // x values in REGISTERS (ITEMS float4 of each per thread): pass 1 turns them into dz and xhat in place and reduces the
 // per-channel sums (fp32 per thread, fp64 across the pixel lanes through LDS, like the three-kernel path), the group
 // terms follow from those, pass 2 writes dx straight from the registers.  dy and x are read once instead of twice (20 ->
-// 12 bytes per element) and two of the three launches go away; the per-image channel sums land in part[n][2][c], from
-// which the parameter-gradient blocks of gn_bwd_finalize_kernel form dgamma / dbeta as before.
+// 12 bytes per element) and two of the three launches go away; the per-image channel sums land in part[n][2][c] (the
+// caller's `sums`), whose sums over the batch are dbeta / dgamma (psld_param_reduce*_f32, one launch for many layers).
+// csum_img: column sums per image of the FINAL dx values this block writes - the bias gradient of the layer whose output
+// gradient dx is.  Without a third operand from a closed form of the sums the kernel reduces anyway; with one (add /
+// accumulate_dx: this block is the last writer of a residual stream's gradient) by summing the written values: per-thread
+// fp32 over its items, fp64 across the pixel lanes, like every other reduction here.
 // Thread -> (channel quad q = tid % cq, pixel lane l = tid / cq), pixels l, l + pl, ...
 template <int ITEMS>
 __global__ void __launch_bounds__(512) gn_bwd_fused_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -554,7 +526,9 @@ __global__ void __launch_bounds__(512) gn_bwd_fused_kernel(const float* __restri
     float* red3 = reinterpret_cast<float*>(grp + gb * 2);                        // [pl][cq][4]
     float* cs1 = red3 + (long long)pl * cq * 4;                                  // [cw] sum_p dz (as stored in part)
     float* cs3 = cs1 + cw;                                                       // [cw] sum_p xhat
-    if (csum_img) {
+    const bool third = add != nullptr || accumulate != 0;
+    const bool closed = csum_img != nullptr && !third;     // column sums of dx from the channel sums
+    if (closed) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) red3[((long long)l * cq + q) * 4 + e] = s3[e];
     }
@@ -569,9 +543,9 @@ __global__ void __launch_bounds__(512) gn_bwd_fused_kernel(const float* __restri
         const float rounded = (float)acc;                                          // what the three-kernel path stores
         part[(((long long)n * 2 + (k >> 2))) * c + c0 + chl] = rounded;
         chs[chl * 2 + (k >> 2)] = (double)rounded * (double)gamma[c0 + chl];
-        if (csum_img && k < 4) cs1[chl] = rounded;
+        if (closed && k < 4) cs1[chl] = rounded;
     }
-    if (csum_img && tid >= cq * 8 && tid < cq * 12) {
+    if (closed && tid >= cq * 8 && tid < cq * 12) {
         const int j = tid - cq * 8;
         double acc = 0;
         for (int ll = 0; ll < pl; ++ll) acc += (double)red3[(long long)ll * cq * 4 + j];
@@ -592,7 +566,7 @@ __global__ void __launch_bounds__(512) gn_bwd_fused_kernel(const float* __restri
     f32x4 k0;
 #pragma unroll
     for (int e = 0; e < 4; ++e) k0[e] = rs * ga[e];
-    if (csum_img && tid < cw) {      // one thread per channel of the slab, with the coefficients the stores below use
+    if (closed && tid < cw) {        // one thread per channel of the slab, with the coefficients the stores below use
         const int gc = tid / cpg;
         const float rc = rstd[n * groups + (c0 + tid) / cpg];
         const float c0k = rc * gamma[c0 + tid];
@@ -631,6 +605,25 @@ __global__ void __launch_bounds__(512) gn_bwd_fused_kernel(const float* __restri
         const int p = l + i * pl;
         if (p < hw && (!(GNB_MODE & 4) || gv[i][0] == 12345.678f))
             *const_cast<f32x4*>(at(dx, i)) = gv[i];
+    }
+    if (csum_img && third) {         // column sums of the values just written (red3 is unused on this path until here)
+        float s4[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const int p = l + i * pl;
+            if (p < hw) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s4[e] += gv[i][e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red3[((long long)l * cq + q) * 4 + e] = s4[e];
+        __syncthreads();
+        if (tid < cw) {
+            double acc = 0;
+            for (int ll = 0; ll < pl; ++ll) acc += (double)red3[(long long)ll * cw + tid];
+            csum_img[(long long)n * ld_img + c0 + tid] = (float)acc;
+        }
     }
     GNB_STAMP(5);
     GNB_STAMP(7);
@@ -821,9 +814,8 @@ __global__ void __launch_bounds__(512) gn_bwd_pipe_kernel(const float* __restric
 
 // groups per block / pixel lanes / items per thread of the fused backward, or false when the slab does not fit registers
 inline bool gn_bwd_fused_plan(int batch, int hw, int c, int groups, int* gb, int* pl, int* items) {
-    static const int on = [] { const char* v = getenv("PSLD_GN_BWD_FUSED"); return v ? atoi(v) : 1; }();
     const int cpg = c / groups;
-    if (!on || cpg % 4 || cpg > 32 || (long long)batch * hw * c * 4 >= (1ll << 32)) return false;
+    if (cpg % 4 || cpg > 32 || (long long)batch * hw * c * 4 >= (1ll << 32)) return false;
     int g = 32 / cpg;                              // as many whole groups as fit 32 channels (whole 128-byte lines; 16-channel
                                                    // slabs measured 136 vs 112 us on 128x32x32x256) ...
     while (g > 1 && groups % g) --g;               // ... dividing the group count
@@ -957,39 +949,21 @@ extern "C" int psld_gn_apply_limb_nhwc(const float* x, const float* scale, const
     return PSLD_OK;
 }
 
-namespace {
-// csum_img ([batch] rows of ld_img floats, c used) / csum ([c]): the column sums of dx per image and alpha * their sum over
-// the batch - only on the one-pass paths without a third operand (psld_gn_bwd_colsum_supported)
-int gn_bwd_impl(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                int batch, int hw, int c, int groups, int act, float drop_p, unsigned long long seed,
-                const unsigned long long* seed_dev, float* dx, float* dgamma, float* dbeta, int accumulate_dx,
-                const float* add, float add_scale, const float* part_in, int part_chunks, void* workspace,
-                float* csum_img, int ld_img, float* csum, float csum_alpha, hipStream_t stream) {
-    PSLD_CHECK_ARG(dy && x && mean && rstd && gamma && beta && dx && dgamma && dbeta && workspace,
-                   "psld_gn_bwd: null pointer");
+extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float* mean, const float* rstd,
+                                    const float* gamma, const float* beta, int batch, int hw, int c, int groups,
+                                    int act, float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* dx,
+                                    int accumulate_dx, const float* add, float add_scale, float* sums, float* colsum_img,
+                                    int ld_img, void* workspace, hipStream_t stream) {
+    PSLD_CHECK_ARG(dy && x && mean && rstd && gamma && beta && dx && sums && workspace, "psld_gn_bwd: null pointer");
     PSLD_CHECK_ARG(c % 4 == 0 && c / 4 <= MAXT && groups <= MAXG && c % groups == 0,
                    "psld_gn_bwd: unsupported C=%d groups=%d", c, groups);
-    const Map m = make_map(batch, hw, c);
-    char* ws = reinterpret_cast<char*>(workspace);
-    float* part = reinterpret_cast<float*>(ws);
-    ws += align256((size_t)batch * m.chunks * 2 * c * sizeof(float));
-    float* own_img = reinterpret_cast<float*>(ws);              // per-image column sums of dx when the caller keeps only their total
-    ws += align256((size_t)batch * 2 * c * sizeof(float));
-    float* coef = reinterpret_cast<float*>(ws);
-    if (csum && !csum_img) {
-        csum_img = own_img;
-        ld_img = c;
-    }
-    const size_t lds = (size_t)m.pl * m.cq * 8 * sizeof(float);
-    int chunks = m.chunks;
+    PSLD_CHECK_ARG(!colsum_img || ld_img >= c, "psld_gn_bwd: ld_img < c");
     int gb = 0, fpl = 0, items = 0;
-    if (!part_in && gn_bwd_fused_plan(batch, hw, c, groups, &gb, &fpl, &items)) {
+    if (gn_bwd_fused_plan(batch, hw, c, groups, &gb, &fpl, &items)) {
         const int cpg = c / groups, cw = gb * cpg, cq = cw / 4;
         const dim3 grid(groups / gb, batch), block(cq * fpl);
         const size_t flds = (size_t)fpl * cq * 8 * sizeof(float) + (size_t)(cw + gb) * 2 * sizeof(double) +
                             ((size_t)fpl * cq * 4 + 2 * cw) * sizeof(float);
-        PSLD_CHECK_ARG(!csum_img || (!add && !accumulate_dx), "psld_gn_bwd_colsum: column sums of dx only without add / accumulate_dx");
-        const int fin_blocks = (csum ? 3 : 2) * cdiv(c, 64);
         int pipe_grid = 0, pipe_per = 0;
         size_t plds = 0;
         if (!add && !accumulate_dx &&       // (a third operand: the one-slab kernel, see gn_bwd_pipe_kernel)
@@ -997,19 +971,16 @@ int gn_bwd_impl(const float* dy, const float* x, const float* mean, const float*
             const int slabs = groups / gb;
 #define PSLD_GN_PIPE(IT)                                                                                               \
     hipLaunchKernelGGL((gn_bwd_pipe_kernel<IT>), dim3(pipe_grid), block, plds, stream, dy, x, mean, rstd, gamma, beta, hw, \
-                       c, groups, gb, fpl, act, drop_p, seed, seed_dev, dx, part, slabs, slabs * batch, pipe_per, csum_img,  \
+                       c, groups, gb, fpl, act, drop_p, seed, seed_dev, dx, sums, slabs, slabs * batch, pipe_per, colsum_img, \
                        ld_img)
             if (items == 4) PSLD_GN_PIPE(4); else PSLD_GN_PIPE(16);
 #undef PSLD_GN_PIPE
             PSLD_CHECK_LAUNCH("gn_bwd_pipe_kernel");
-            hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(fin_blocks), dim3(1024), 0, stream, part, rstd, gamma, batch,
-                               hw, c, groups, 1, coef, dgamma, dbeta, batch, csum_img, ld_img, csum, csum_alpha);
-            PSLD_CHECK_LAUNCH("gn_bwd_finalize_kernel");
             return PSLD_OK;
         }
 #define PSLD_GN_FUSED(IT)                                                                                              \
     hipLaunchKernelGGL((gn_bwd_fused_kernel<IT>), grid, block, flds, stream, dy, x, mean, rstd, gamma, beta, hw, c, groups, \
-                       gb, fpl, act, drop_p, seed, seed_dev, accumulate_dx, add, add_scale, dx, part, csum_img, ld_img)
+                       gb, fpl, act, drop_p, seed, seed_dev, accumulate_dx, add, add_scale, dx, sums, colsum_img, ld_img)
         switch (items) {
             case 1: PSLD_GN_FUSED(1); break;
             case 2: PSLD_GN_FUSED(2); break;
@@ -1018,25 +989,22 @@ int gn_bwd_impl(const float* dy, const float* x, const float* mean, const float*
         }
 #undef PSLD_GN_FUSED
         PSLD_CHECK_LAUNCH("gn_bwd_fused_kernel");
-        // dgamma / dbeta: the parameter blocks of the finalize kernel over the per-image sums (chunks = 1)
-        hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(fin_blocks), dim3(1024), 0, stream, part, rstd, gamma, batch, hw,
-                           c, groups, 1, coef, dgamma, dbeta, batch, csum_img, ld_img, csum, csum_alpha);
-        PSLD_CHECK_LAUNCH("gn_bwd_finalize_kernel");
         return PSLD_OK;
     }
-    PSLD_CHECK_ARG(!csum_img, "psld_gn_bwd_colsum: not on the three-pass path (psld_gn_bwd_colsum_supported)");
-    if (part_in) {        // pass 1 came with dy (the producing kernel's epilogue, psld_epilogue_t.gnb_part)
-        PSLD_CHECK_ARG(part_chunks >= 1, "psld_gn_bwd: part_chunks must be >= 1 with part_in");
-        part = const_cast<float*>(part_in);
-        chunks = part_chunks;
-    } else {
-        hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(m.chunks, batch), dim3(m.threads), lds, stream, dy, x, mean, rstd,
-                           gamma, beta, hw, c, groups, m.cq, m.pl, m.chunk_px, m.chunks, act, drop_p, seed, seed_dev, part);
-        PSLD_CHECK_LAUNCH("gn_bwd_partial_kernel");
-    }
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(batch + 2 * cdiv(c, 64)), dim3(1024), 0, stream, part, rstd, gamma,
-                       batch, hw, c, groups, chunks, coef, dgamma, dbeta, 0);
-    PSLD_CHECK_LAUNCH("gn_bwd_finalize_kernel");
+    PSLD_CHECK_ARG(!colsum_img, "psld_gn_bwd: column sums of dx are not formed on the three-pass path (psld_gn_bwd_colsum_supported)");
+    const Map m = make_map(batch, hw, c);
+    char* ws = reinterpret_cast<char*>(workspace);
+    float* part = reinterpret_cast<float*>(ws);
+    ws += align256((size_t)batch * m.chunks * 2 * c * sizeof(float));
+    ws += align256((size_t)batch * 2 * c * sizeof(float));
+    float* coef = reinterpret_cast<float*>(ws);
+    const size_t lds = (size_t)m.pl * m.cq * 8 * sizeof(float);
+    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(m.chunks, batch), dim3(m.threads), lds, stream, dy, x, mean, rstd,
+                       gamma, beta, hw, c, groups, m.cq, m.pl, m.chunk_px, m.chunks, act, drop_p, seed, seed_dev, part);
+    PSLD_CHECK_LAUNCH("gn_bwd_partial_kernel");
+    hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(batch), dim3(1024), 0, stream, part, rstd, gamma, hw, c, groups, m.chunks,
+                       coef, sums);
+    PSLD_CHECK_LAUNCH("gn_bwd_coef_kernel");
     const Map ma = make_map(batch, hw, c, true);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ma.chunks, batch), dim3(ma.threads), 0, stream, dy, x, mean, rstd,
                        gamma, beta, coef, hw, c, groups, ma.cq, ma.pl, ma.chunk_px, act, drop_p, seed, seed_dev, accumulate_dx, add, add_scale,
@@ -1044,34 +1012,11 @@ int gn_bwd_impl(const float* dy, const float* x, const float* mean, const float*
     PSLD_CHECK_LAUNCH("gn_bwd_apply_kernel");
     return PSLD_OK;
 }
-}  // namespace
-
-extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float* mean, const float* rstd,
-                                    const float* gamma, const float* beta, int batch, int hw, int c, int groups,
-                                    int act, float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* dx,
-                                    float* dgamma,
-                                    float* dbeta, int accumulate_dx, const float* add, float add_scale,
-                                    const float* part_in, int part_chunks, void* workspace, hipStream_t stream) {
-    return gn_bwd_impl(dy, x, mean, rstd, gamma, beta, batch, hw, c, groups, act, drop_p, seed, seed_dev, dx, dgamma, dbeta,
-                       accumulate_dx, add, add_scale, part_in, part_chunks, workspace, nullptr, 0, nullptr, 1.f, stream);
-}
 
 extern "C" int psld_gn_bwd_colsum_supported(int batch, int hw, int c, int groups) {
     int gb = 0, pl = 0, items = 0;
     return batch > 0 && hw > 0 && c > 0 && c % 4 == 0 && c / 4 <= MAXT && groups > 0 && groups <= MAXG && c % groups == 0 &&
            gn_bwd_fused_plan(batch, hw, c, groups, &gb, &pl, &items);
-}
-
-extern "C" int psld_gn_bwd_colsum_nhwc_f32(const float* dy, const float* x, const float* mean, const float* rstd,
-                                           const float* gamma, const float* beta, int batch, int hw, int c, int groups, int act,
-                                           float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* dx,
-                                           float* dgamma, float* dbeta, float* colsum_img, int ld_img, float* colsum,
-                                           float colsum_alpha, void* workspace, hipStream_t stream) {
-    PSLD_CHECK_ARG(colsum || colsum_img, "psld_gn_bwd_colsum: no output requested");
-    PSLD_CHECK_ARG(!colsum_img || ld_img >= c, "psld_gn_bwd_colsum: ld_img < c");
-    PSLD_CHECK_ARG(psld_gn_bwd_colsum_supported(batch, hw, c, groups), "psld_gn_bwd_colsum: unsupported shape B=%d hw=%d C=%d", batch, hw, c);
-    return gn_bwd_impl(dy, x, mean, rstd, gamma, beta, batch, hw, c, groups, act, drop_p, seed, seed_dev, dx, dgamma, dbeta, 0,
-                       nullptr, 1.f, nullptr, 0, workspace, colsum_img, ld_img, colsum, colsum_alpha, stream);
 }
 
 extern "C" int psld_set_gn_bwd_kernel(int kind) {

@@ -111,6 +111,117 @@ __global__ void reduce_slabs4_kernel(const float* __restrict__ slabs, int nsplit
     }
 }
 
+// The same reduction for MANY weight gradients in one launch: rows of a device table
+// [slabs, nsplit, n, out, layout, taps, cin, alpha bits, first float4 item, 0].  A workgroup owns 2048 consecutive float4
+// items (eight per thread, 256 apart), so it looks its job up once (binary search on the first items) and afterwards only
+// steps to the next row when its items run past the current one; within an item the slabs are added in slab order exactly
+// like reduce_slabs4_kernel (bitwise the per-layer launches).
+__global__ void __launch_bounds__(256) reduce_slabs_batch_kernel(const long long* __restrict__ table, int jobs, long long items) {
+    const long long chunk0 = (long long)blockIdx.x * 2048;
+    int lo = 0, hi = jobs - 1;                 // last job whose first item <= chunk0 (uniform: scalar loads)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[(long long)mid * 10 + 8] <= chunk0) lo = mid; else hi = mid - 1;
+    }
+    int j = lo;
+    long long first = table[(long long)j * 10 + 8];
+    long long n4 = table[(long long)j * 10 + 2] >> 2;
+#pragma unroll 1
+    for (int k = 0; k < 8; ++k) {
+        const long long item = chunk0 + k * 256 + threadIdx.x;
+        if (item >= items) break;
+        while (item >= first + n4) {
+            ++j;
+            first = table[(long long)j * 10 + 8];
+            n4 = table[(long long)j * 10 + 2] >> 2;
+        }
+        const long long* row = table + (long long)j * 10;
+        const long long q = item - first;
+        const int nsplit = (int)row[1];
+        const f32x4* p = reinterpret_cast<const f32x4*>(row[0]) + q;
+        f32x4 acc = p[0];
+        int sidx = 1;
+        for (; sidx + 3 < nsplit; sidx += 4) {
+            const f32x4 v0 = p[(long long)sidx * n4], v1 = p[(long long)(sidx + 1) * n4];
+            const f32x4 v2 = p[(long long)(sidx + 2) * n4], v3 = p[(long long)(sidx + 3) * n4];
+            acc += v0;
+            acc += v1;
+            acc += v2;
+            acc += v3;
+        }
+        for (; sidx < nsplit; ++sidx) acc += p[(long long)sidx * n4];
+        acc *= __builtin_bit_cast(float, (unsigned)row[7]);
+        float* out = reinterpret_cast<float*>(row[3]);
+        const long long i = q << 2;
+        if (row[4] == 1) {  // [co][tap][ci] -> [co][ci][tap]
+            const int taps = (int)row[5], cin = (int)row[6];
+            const int ci = (int)(i % cin);
+            const long long t = i / cin;
+            const int tap = (int)(t % taps);
+            const long long co = t / taps;
+            float* o = out + (co * cin + ci) * taps + tap;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[(long long)e * taps] = acc[e];
+        } else {
+            reinterpret_cast<f32x4*>(out)[q] = acc;
+        }
+    }
+}
+
+// dst[col] = alpha * sum_r src[r * ld + col]: parameter gradients that are sums over the batch (GroupNorm dgamma / dbeta from
+// the per-image sums of psld_gn_bwd_nhwc_f32, bias gradients from per-image column sums).  A block = 64 columns x 16 row
+// lanes; every lane adds its rows r, r + 16, ... in index order (fp64), the lanes are combined in lane order.  Jobs from a
+// device table (psld_param_reduce_batch_f32) or, two of one shape, from the arguments (psld_param_reduce2_f32).
+struct ParamJob {
+    const float* src;
+    int rows, ld, c;
+    float* dst1;
+    float* dst2;
+    float alpha;
+};
+__global__ void __launch_bounds__(1024) param_reduce_kernel(const long long* __restrict__ table, int jobs, ParamJob ja,
+                                                             ParamJob jb, int blocks_a) {
+    __shared__ double sh[16 * 64];
+    const int tid = threadIdx.x;
+    ParamJob job;
+    int local;
+    if (table) {
+        int lo = 0, hi = jobs - 1;             // last job whose first block <= blockIdx.x
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (table[(long long)mid * 8 + 7] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        const long long* row = table + (long long)lo * 8;
+        job.src = reinterpret_cast<const float*>(row[0]);
+        job.rows = (int)row[1]; job.ld = (int)row[2]; job.c = (int)row[3];
+        job.dst1 = reinterpret_cast<float*>(row[4]);
+        job.dst2 = reinterpret_cast<float*>(row[5]);
+        job.alpha = __builtin_bit_cast(float, (unsigned)row[6]);
+        local = (int)blockIdx.x - (int)row[7];
+    } else if ((int)blockIdx.x < blocks_a) {
+        job = ja;
+        local = (int)blockIdx.x;
+    } else {
+        job = jb;
+        local = (int)blockIdx.x - blocks_a;
+    }
+    const int col = local * 64 + (tid & 63);
+    const int lane = tid >> 6;
+    double acc = 0.0;
+    if (col < job.c)
+        for (int r = lane; r < job.rows; r += 16) acc += (double)job.src[(long long)r * job.ld + col];
+    sh[lane * 64 + (tid & 63)] = acc;
+    __syncthreads();
+    if (lane == 0 && col < job.c) {
+        double t = 0.0;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) t += sh[l * 64 + tid];
+        const float v = (float)(t * (double)job.alpha);
+        job.dst1[col] = v;
+        if (job.dst2) job.dst2[col] = v;
+    }
+}
+
 // im2col of a few-channel NHWC tensor (the 6-channel network input / output gradient) for a 3x3 convolution:
 // cols[m][ch*9 + t] = x[n][oy*stride + ky - pad][ox*stride + kx - pad][ch] (0 outside), t = ky*3 + kx, zero-filled up
 // to ld_out columns; flip = 1 (stride 1) mirrors the taps: the column of tap t holds tap 8 - t.  With 9*c <= 64 the
@@ -379,9 +490,13 @@ __global__ void colsum_final_kernel(const double* __restrict__ part, int chunks,
 // 16 columns x 64 image lanes (two images per lane at B=128, their chunk loads all in flight together: a version
 // with 4 blocks and 128 dependent loads per thread took 57 us); every lane adds its images in index order, the lanes
 // are combined in lane order (fixed order, no atomics: bitwise repeatable)
+// seg > 0: the total is cut into column segments of `seg` that go to out, out1, out2 (the q | k | v bias gradients of one
+// [rows][3c] gradient buffer)
 __global__ void __launch_bounds__(1024) colsum_final_total_kernel(const double* __restrict__ part, int chunks, int batch,
                                                                   int c, float* __restrict__ per_image, int ld,
-                                                                  float* __restrict__ out, float alpha) {
+                                                                  float* __restrict__ out, float alpha,
+                                                                  float* __restrict__ out1 = nullptr,
+                                                                  float* __restrict__ out2 = nullptr, int seg = 0) {
     __shared__ double red[64][16];
     const int cl = threadIdx.x & 15, bl = threadIdx.x >> 4;
     const int col = blockIdx.x * 16 + cl;
@@ -402,7 +517,10 @@ __global__ void __launch_bounds__(1024) colsum_final_total_kernel(const double* 
         double t = 0.0;
 #pragma unroll
         for (int l = 0; l < 64; ++l) t += red[l][cl];
-        out[col] = (float)(t * (double)alpha);
+        const float v = (float)(t * (double)alpha);
+        if (seg <= 0 || col < seg) out[col] = v;
+        else if (col < 2 * seg) out1[col - seg] = v;
+        else out2[col - 2 * seg] = v;
     }
 }
 // scalar fallback: grid (c/64, batch); block 256 = 64 columns x 4 row lanes
@@ -625,6 +743,32 @@ extern "C" int psld_reduce_slabs_f32(const float* slabs, int nsplit, long long n
     return PSLD_OK;
 }
 
+extern "C" int psld_reduce_slabs_batch_f32(const long long* table_dev, int jobs, long long items, hipStream_t stream) {
+    PSLD_CHECK_ARG(table_dev && jobs > 0 && items > 0, "psld_reduce_slabs_batch_f32: bad args");
+    hipLaunchKernelGGL(reduce_slabs_batch_kernel, dim3((unsigned)((items + 2047) / 2048)), dim3(256), 0, stream, table_dev, jobs,
+                       items);
+    PSLD_CHECK_LAUNCH("psld_reduce_slabs_batch_f32");
+    return PSLD_OK;
+}
+
+extern "C" int psld_param_reduce2_f32(const float* src_a, const float* src_b, int rows, int ld, int c, float* dst_a,
+                                      float* dst_b, float alpha, hipStream_t stream) {
+    PSLD_CHECK_ARG(src_a && dst_a && rows > 0 && c > 0 && ld >= c && (!src_b) == (!dst_b), "psld_param_reduce2_f32: bad args");
+    const ParamJob ja{src_a, rows, ld, c, dst_a, nullptr, alpha}, jb{src_b, rows, ld, c, dst_b, nullptr, alpha};
+    const int per = cdiv(c, 64);
+    hipLaunchKernelGGL(param_reduce_kernel, dim3(src_b ? 2 * per : per), dim3(1024), 0, stream, nullptr, 0, ja, jb, per);
+    PSLD_CHECK_LAUNCH("psld_param_reduce2_f32");
+    return PSLD_OK;
+}
+
+extern "C" int psld_param_reduce_batch_f32(const long long* table_dev, int jobs, int blocks, hipStream_t stream) {
+    PSLD_CHECK_ARG(table_dev && jobs > 0 && blocks > 0, "psld_param_reduce_batch_f32: bad args");
+    const ParamJob none{nullptr, 0, 0, 0, nullptr, nullptr, 0.f};
+    hipLaunchKernelGGL(param_reduce_kernel, dim3(blocks), dim3(1024), 0, stream, table_dev, jobs, none, none, 0);
+    PSLD_CHECK_LAUNCH("psld_param_reduce_batch_f32");
+    return PSLD_OK;
+}
+
 extern "C" int psld_im2col3x3_small_f32(const float* x, int batch, int ih, int iw, int c, int oh, int ow, int stride,
                                         int pad, int flip, float* out, int ld_out, hipStream_t stream) {
     PSLD_CHECK_ARG(x && out && batch > 0 && c > 0 && 9 * c <= ld_out && oh > 0 && ow > 0 && stride >= 1,
@@ -810,6 +954,34 @@ extern "C" int psld_bias_grad_f32(const float* x, int ld, int batch, int hw, int
     PSLD_CHECK_LAUNCH("colsum_partial_kernel");
     hipLaunchKernelGGL(colsum_final_total_kernel, dim3(cdiv(c, 16)), dim3(1024), 0, stream, part, chunks, batch, c, pim, ldp,
                        out, alpha);
+    PSLD_CHECK_LAUNCH("colsum_final_total_kernel");
+    return PSLD_OK;
+}
+// psld_bias_grad_f32 over a [batch*hw][3*seg] buffer whose three column segments belong to three parameters.
+extern "C" int psld_bias_grad_seg_f32(const float* x, int ld, int batch, int hw, int seg, float* out0, float* out1,
+                                      float* out2, float alpha, void* workspace, hipStream_t stream) {
+    const int c = 3 * seg;
+    PSLD_CHECK_ARG(x && out0 && out1 && out2 && workspace && batch > 0 && hw > 0 && seg > 0, "psld_bias_grad_seg_f32: bad args");
+    PSLD_CHECK_ARG(c % 4 == 0 && ld % 4 == 0 && c / 4 <= 256 && (reinterpret_cast<uintptr_t>(x) & 15) == 0,
+                   "psld_bias_grad_seg_f32: needs 3*seg %%4 == 0 (<= 1024), ld %%4 == 0 and a 16-byte aligned input");
+    const int cq = c / 4;
+    int pl = 256 / cq;
+    if (pl < 1) pl = 1;
+    if (pl > hw) pl = hw;
+    int chunks = cdiv(1024, batch);
+    const int max_chunks = cdiv(hw, pl * 4);
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks > 16) chunks = 16;
+    if (chunks < 1) chunks = 1;
+    const int chunk_px = cdiv(hw, chunks);
+    chunks = cdiv(hw, chunk_px);
+    double* part = reinterpret_cast<double*>(workspace);
+    float* pim = reinterpret_cast<float*>(part + (long long)batch * 16 * c);     // per-image sums: scratch behind the partials
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(chunks, batch), dim3(cq * pl), (size_t)pl * cq * 4 * sizeof(double),
+                       stream, x, ld, hw, c, cq, pl, chunk_px, chunks, part);
+    PSLD_CHECK_LAUNCH("colsum_partial_kernel");
+    hipLaunchKernelGGL(colsum_final_total_kernel, dim3(cdiv(c, 16)), dim3(1024), 0, stream, part, chunks, batch, c, pim, c,
+                       out0, alpha, out1, out2, seg);
     PSLD_CHECK_LAUNCH("colsum_final_total_kernel");
     return PSLD_OK;
 }

@@ -217,8 +217,7 @@ extern "C" int psld_upfirdn2d_f32(const float* x, float* y, int batch, int c, in
     if (layout == 1) {
         PSLD_CHECK_ARG(c % 4 == 0, "psld_upfirdn2d_f32: NHWC needs C%%4==0 (C=%d)", c);
         const bool k4 = kh == 4 && kw == 4 && up_x == up_y && down_x == down_y && (long long)batch * out_h < 65536;
-        static const int quad = [] { const char* v = getenv("PSLD_FIR_QUAD"); return v ? atoi(v) : 1; }();
-        if (quad && k4 && up_x == 2 && down_x == 1) {
+        if (k4 && up_x == 2 && down_x == 1) {
             // x2 up, 2 x 2 outputs per thread: 42.9 -> 34.8 us on 128x16x16x256 (a pure fill of the output: 20.6 us).  The
             // same form for x2 down (6 x 6 inputs -> 2 x 2 outputs, 9 loads per output instead of 16) measured SLOWER
             // (56.5 vs 47.4 us), and so did a branch-free one-output form with all sixteen loads issued up front (48.9 us): the

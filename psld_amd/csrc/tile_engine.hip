@@ -817,7 +817,7 @@ extern "C" int psld_gemm_f32(int trans_a, int trans_b, int M, int N, int K,
     a.C = C; a.c_stride_z = stride_c; a.c_stride_split = 0; a.ldc = ldc;
     a.nsplit = 1; a.kper = cdiv(K, BK) * BK;
     a.e = make_epilogue(epi);
-    PSLD_CHECK_ARG(!a.e.gn_part && !a.e.gnb_part, "fp32 tile engine: psld_epilogue_t.gn_part / gnb_part are limb-kernel features");
+    PSLD_CHECK_ARG(!a.e.gn_part, "fp32 tile engine: psld_epilogue_t.gn_part is a limb-kernel feature");
     // op(A) is M x K.  trans_a == 0: A stored [M][K] (K contiguous);  1: stored [K][M].
     // op(B) is K x N.  trans_b == 0: B stored [K][N] (N contiguous);  1: stored [N][K].
     if (!trans_a) a.A.vec = aligned16(A) && lda % 4 == 0 && K % 4 == 0 && stride_a % 4 == 0;
@@ -885,7 +885,7 @@ extern "C" int psld_conv2d_nhwc_ws_f32(const float* x1, int c1, const float* x2,
     a.nsplit = 1; a.kper = cdiv(a.K, BK) * BK;
     a.g = {ih, iw, c1, c2, oh, ow, kh, kw, stride, pad, transposed_stride};
     a.e = make_epilogue(epi);
-    PSLD_CHECK_ARG(!a.e.gn_part && !a.e.gnb_part, "fp32 tile engine: psld_epilogue_t.gn_part / gnb_part are limb-kernel features");
+    PSLD_CHECK_ARG(!a.e.gn_part, "fp32 tile engine: psld_epilogue_t.gn_part is a limb-kernel feature");
     if (a.A.vec && a.B.vec && c1 % BK == 0 && c2 % BK == 0 && transposed_stride == 1 && a.M > 0 && kh * kw <= 31) {
         FastGeom fg{kh * kw, 0, 0, ct / BK, nullptr};
         const long long tiles128 = (long long)cdiv(a.M, BM) * cdiv(a.N, BN);

@@ -17,17 +17,6 @@ struct PsldEpilogue {
     int accumulate;         // C += result
     double* gn_part;        // limb kernels only: GroupNorm partial sums of the output (psld_epilogue_t.gn_part)
     int gn_hw;
-    // limb kernels only: GroupNorm-backward pass 1 of the output seen as dy (psld_epilogue_t.gnb_*)
-    const float* gnb_x;
-    const float* gnb_mean;
-    const float* gnb_rstd;
-    const float* gnb_gamma;
-    const float* gnb_beta;
-    float* gnb_part;
-    const unsigned long long* gnb_seed_dev;
-    unsigned long long gnb_seed;
-    float gnb_drop_p;
-    int gnb_groups, gnb_act, gnb_hw;
 };
 
 static inline PsldEpilogue make_epilogue(const psld_epilogue_t* e) {
@@ -35,19 +24,12 @@ static inline PsldEpilogue make_epilogue(const psld_epilogue_t* e) {
     o.alpha = 1.f; o.bias = nullptr; o.rowbias = nullptr; o.ld_rowbias = 0; o.rows_per_img = 1;
     o.res = nullptr; o.ldres = 0; o.res_stride_z = 0; o.out_scale = 1.f; o.accumulate = 0;
     o.gn_part = nullptr; o.gn_hw = 0;
-    o.gnb_x = o.gnb_mean = o.gnb_rstd = o.gnb_gamma = o.gnb_beta = nullptr; o.gnb_part = nullptr; o.gnb_seed_dev = nullptr;
-    o.gnb_seed = 0; o.gnb_drop_p = 0.f; o.gnb_groups = 1; o.gnb_act = 0; o.gnb_hw = 0;
     if (e) {
         o.alpha = e->alpha; o.bias = e->bias; o.rowbias = e->rowbias; o.ld_rowbias = e->ld_rowbias;
         o.rows_per_img = e->rows_per_img > 0 ? e->rows_per_img : 1;
         o.res = e->residual; o.ldres = e->ld_residual; o.res_stride_z = e->residual_stride_batch;
         o.out_scale = e->out_scale; o.accumulate = e->accumulate;
         o.gn_part = e->gn_part; o.gn_hw = e->gn_hw;
-        if (e->gnb_part) {
-            o.gnb_x = e->gnb_x; o.gnb_mean = e->gnb_mean; o.gnb_rstd = e->gnb_rstd; o.gnb_gamma = e->gnb_gamma;
-            o.gnb_beta = e->gnb_beta; o.gnb_part = e->gnb_part; o.gnb_seed_dev = e->gnb_seed_dev; o.gnb_seed = e->gnb_seed;
-            o.gnb_drop_p = e->gnb_drop_p; o.gnb_groups = e->gnb_groups; o.gnb_act = e->gnb_act; o.gnb_hw = e->gnb_hw;
-        }
     }
     return o;
 }

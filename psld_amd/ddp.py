@@ -192,6 +192,10 @@ class BucketReducer:
                     torch.cuda.current_stream().synchronize()
                 self._cur.append(_time.perf_counter() - t0)
 
+    def would_launch(self, offset: int) -> bool:
+        """Would ``ready_from(offset)`` exchange a bucket now?  (The network reduces its parked parameter gradients first.)"""
+        return self._next >= 0 and self._bounds[self._next][0] >= offset
+
     def ready_from(self, offset: int):
         """All gradients at flat offsets >= ``offset`` are final."""
         while self._next >= 0 and self._bounds[self._next][0] >= offset:

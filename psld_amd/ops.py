@@ -63,9 +63,8 @@ def _chk(t: Tensor, dtype=torch.float32):
 def epilogue(alpha: float = 1.0, bias: Optional[Tensor] = None, rowbias: Optional[Tensor] = None,
              rows_per_img: int = 1, residual: Optional[Tensor] = None, ld_residual: int = 0,
              residual_stride_batch: int = 0, out_scale: float = 1.0, accumulate: bool = False,
-             ld_rowbias: int = 0, gn_part: Optional[Tensor] = None, gn_hw: int = 0, gnb=None) -> Epilogue:
-    """``gn_part`` (limb kernels only; see gn_part_buffer): GroupNorm partial sums of the output as a by-product.
-    ``gnb`` (limb kernels only; see gn_bwd_part): pass 1 of a GroupNorm backward whose dy IS the output."""
+             ld_rowbias: int = 0, gn_part: Optional[Tensor] = None, gn_hw: int = 0) -> Epilogue:
+    """``gn_part`` (limb kernels only; see gn_part_buffer): GroupNorm partial sums of the output as a by-product."""
     e = Epilogue()
     e.alpha = alpha
     e.bias = _p(bias)
@@ -79,31 +78,8 @@ def epilogue(alpha: float = 1.0, bias: Optional[Tensor] = None, rowbias: Optiona
     e.accumulate = 1 if accumulate else 0
     e.gn_part = _p(gn_part)
     e.gn_hw = gn_hw if gn_part is not None else 0
-    e._keep = (bias, rowbias, residual, gn_part, gnb)  # the struct holds raw pointers: keep the tensors alive
-    if gnb is not None:
-        e.gnb_x, e.gnb_mean, e.gnb_rstd = gnb["x"].data_ptr(), gnb["st"].mean.data_ptr(), gnb["st"].rstd.data_ptr()
-        e.gnb_gamma, e.gnb_beta, e.gnb_part = gnb["gamma"].data_ptr(), gnb["beta"].data_ptr(), gnb["part"].data_ptr()
-        e.gnb_seed_dev = _p(gnb.get("seed_dev"))
-        e.gnb_seed, e.gnb_drop_p = int(gnb.get("seed", 0)), float(gnb.get("drop_p", 0.0))
-        e.gnb_groups, e.gnb_act, e.gnb_hw = int(gnb["groups"]), 1 if gnb["act"] else 0, int(gnb["hw"])
+    e._keep = (bias, rowbias, residual, gn_part)  # the struct holds raw pointers: keep the tensors alive
     return e
-
-
-def gn_bwd_part_supported(b: int, hw: int, c: int, groups: Optional[int] = None) -> bool:
-    """Can a limb kernel's epilogue produce pass 1 of the GroupNorm backward of its [b, hw, c] output?  (Whole 64-row runs
-    per image, a lane's four channels inside one group, and a grid large enough that the kernel does not split K.)"""
-    g = groups if groups is not None else gn_groups(c)
-    return hw % 64 == 0 and c % 128 == 0 and (c // g) % 4 == 0 and ((b * hw + 127) // 128) * (c // 128) >= 384
-
-
-def gn_bwd_part(x: Tensor, st: "GNStats", gamma: Tensor, beta: Tensor, act: bool, drop_p: float = 0.0, seed: int = 0,
-                seed_dev: Optional[Tensor] = None, groups: Optional[int] = None) -> dict:
-    """Descriptor for ``epilogue(gnb=...)``: x = the GroupNorm's input, st its forward statistics; the kernel fills
-    ``part`` [b][hw/64][2][c], which ``gn_bwd(..., part=...)`` consumes instead of its first pass over (dy, x)."""
-    b, h, w, c = x.shape
-    return {"x": x, "st": st, "gamma": gamma, "beta": beta, "act": act, "drop_p": drop_p, "seed": seed, "seed_dev": seed_dev,
-            "groups": groups if groups is not None else gn_groups(c), "hw": h * w,
-            "part": torch.empty((b, (h * w) // 64, 2, c), device=x.device, dtype=torch.float32)}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -582,20 +558,32 @@ def get_gn_bwd_kernel() -> str:
     return ("auto", "one_slab")[lib().psld_get_gn_bwd_kernel()]
 
 
-def gn_bwd(dy: Tensor, x: Tensor, st: GNStats, gamma: Tensor, beta: Tensor, act: bool, dx: Tensor, dgamma: Tensor,
-           dbeta: Tensor, accumulate_dx: bool = False, drop_p: float = 0.0, seed: int = 0, groups: Optional[int] = None,
-           add: Optional[Tensor] = None, add_scale: float = 1.0, seed_dev: Optional[Tensor] = None,
-           part: Optional[Tensor] = None):
-    """``add`` (same shape as x): dx additionally receives add_scale * add (gradient of a parallel identity branch)."""
+def gn_bwd(dy: Tensor, x: Tensor, st: GNStats, gamma: Tensor, beta: Tensor, act: bool, dx: Tensor,
+           dgamma: Optional[Tensor] = None, dbeta: Optional[Tensor] = None, accumulate_dx: bool = False, drop_p: float = 0.0,
+           seed: int = 0, groups: Optional[int] = None, add: Optional[Tensor] = None, add_scale: float = 1.0,
+           seed_dev: Optional[Tensor] = None, sums: Optional[Tensor] = None, colsum_img: Optional[Tensor] = None,
+           ld_img: int = 0) -> Tensor:
+    """Backward of y = dropout(act(GN(x))).  ``add`` (same shape as x): dx additionally receives add_scale * add (gradient of
+    a parallel identity branch).  Returns ``sums`` [b][2][c] (per image sum dz, sum dz * xhat): the parameter gradients are
+    their sums over the batch - formed here (one more launch) when ``dgamma`` / ``dbeta`` are given, or by the caller for
+    many layers at once (param_reduce_batch).  ``colsum_img`` ([b] rows, row stride ``ld_img`` or c; where
+    gn_bwd_colsum_supported): the per-image column sums of the dx values this call stores - a bias / time-embedding
+    gradient without a pass over dx."""
     b, h, w, c = x.shape
     g = groups if groups is not None else gn_groups(c)
+    if sums is None:
+        sums = torch.empty((b, 2, c), device=x.device, dtype=torch.float32)
     ws = workspace(lib().psld_gn_workspace_bytes(b, h * w, c, g), x.device)
     check(lib().psld_gn_bwd_nhwc_f32(dy.data_ptr(), x.data_ptr(), st.mean.data_ptr(), st.rstd.data_ptr(),
                                      gamma.data_ptr(), beta.data_ptr(), b, h * w, c, g, 1 if act else 0,
-                                     drop_p, seed, _p(seed_dev), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-                                     1 if accumulate_dx else 0,
-                                     _p(add), add_scale, _p(part), part.shape[1] if part is not None else 0,
-                                     ws.data_ptr(), _stream()), "psld_gn_bwd_nhwc_f32")
+                                     drop_p, seed, _p(seed_dev), dx.data_ptr(), 1 if accumulate_dx else 0,
+                                     _p(add), add_scale, sums.data_ptr(), _p(colsum_img),
+                                     (ld_img or c) if colsum_img is not None else 0, ws.data_ptr(), _stream()),
+          "psld_gn_bwd_nhwc_f32")
+    if dgamma is not None or dbeta is not None:
+        assert dgamma is not None and dbeta is not None
+        param_reduce2(sums, sums.view(-1)[c:], b, 2 * c, c, dbeta, dgamma)
+    return sums
 
 
 @functools.lru_cache(maxsize=None)
@@ -603,20 +591,96 @@ def gn_bwd_colsum_supported(b: int, hw: int, c: int, groups: Optional[int] = Non
     return bool(lib().psld_gn_bwd_colsum_supported(b, hw, c, groups if groups is not None else gn_groups(c)))
 
 
-def gn_bwd_colsum(dy: Tensor, x: Tensor, st: GNStats, gamma: Tensor, beta: Tensor, act: bool, dx: Tensor, dgamma: Tensor,
-                  dbeta: Tensor, colsum: Optional[Tensor], colsum_alpha: float = 1.0, per_image: Optional[Tensor] = None,
-                  ld_per_image: int = 0, drop_p: float = 0.0, seed: int = 0, seed_dev: Optional[Tensor] = None):
-    """``gn_bwd`` (no add / accumulate / part) that also returns the column sums of dx: ``colsum`` [c] = colsum_alpha * sum over
-    batch and pixels (a bias gradient), ``per_image`` ([b] rows, row stride ``ld_per_image`` or c) the sums per image (the
-    time-embedding gradient) - formed from the per-channel sums of the one-pass kernels instead of a pass over dx."""
-    b, h, w, c = x.shape
-    g = gn_groups(c)
-    ws = workspace(lib().psld_gn_workspace_bytes(b, h * w, c, g), x.device)
-    check(lib().psld_gn_bwd_colsum_nhwc_f32(dy.data_ptr(), x.data_ptr(), st.mean.data_ptr(), st.rstd.data_ptr(),
-                                            gamma.data_ptr(), beta.data_ptr(), b, h * w, c, g, 1 if act else 0, drop_p, seed,
-                                            _p(seed_dev), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _p(per_image),
-                                            (ld_per_image or c) if per_image is not None else 0, _p(colsum), colsum_alpha,
-                                            ws.data_ptr(), _stream()), "psld_gn_bwd_colsum_nhwc_f32")
+def param_reduce2(src_a: Tensor, src_b: Optional[Tensor], rows: int, ld: int, c: int, dst_a: Tensor,
+                  dst_b: Optional[Tensor], alpha: float = 1.0):
+    """dst[col] = alpha * sum over rows of src[r * ld + col] for one or two sources of the same shape (one launch)."""
+    check(lib().psld_param_reduce2_f32(src_a.data_ptr(), _p(src_b), rows, ld, c, dst_a.data_ptr(), _p(dst_b), alpha,
+                                       _stream()), "psld_param_reduce2_f32")
+
+
+def _f32_bits(v: float) -> int:
+    return int(np.float32(v).view(np.uint32))
+
+
+def param_job(src: Tensor, rows: int, ld: int, c: int, dst1: Tensor, dst2: Optional[Tensor] = None, alpha: float = 1.0,
+              src_off: int = 0):
+    """Table row (without the running block index) of ``param_reduce_batch``: dst1[col] (and dst2[col]) = alpha * sum over
+    ``rows`` rows of src[src_off + r * ld + col], col < c."""
+    return (src.data_ptr() + 4 * src_off, rows, ld, c, dst1.data_ptr(), dst2.data_ptr() if dst2 is not None else 0,
+            _f32_bits(alpha))
+
+
+def param_reduce_batch(table: Tensor, jobs: int, blocks: int):
+    """table rows: param_job(...) + (first 64-column block,); a job has ceil(c / 64) blocks."""
+    check(lib().psld_param_reduce_batch_f32(table.data_ptr(), jobs, blocks, _stream()), "psld_param_reduce_batch_f32")
+
+
+def slab_job(slabs: Tensor, nsplit: int, n: int, out: Tensor, layout: int = 0, taps: int = 1, cin: int = 1,
+             alpha: float = 1.0):
+    """Table row (without the running item index) of ``reduce_slabs_batch`` equivalent to reduce_slabs(...)."""
+    assert n % 4 == 0 and (layout == 0 or cin % 4 == 0) and slabs.data_ptr() % 16 == 0
+    return (slabs.data_ptr(), nsplit, n, out.data_ptr(), layout, taps, cin, _f32_bits(alpha))
+
+
+def reduce_slabs_batch(table: Tensor, jobs: int, items: int):
+    """table rows: slab_job(...) + (first float4 item, 0); a job has n / 4 items."""
+    check(lib().psld_reduce_slabs_batch_f32(table.data_ptr(), jobs, items, _stream()), "psld_reduce_slabs_batch_f32")
+
+
+class Arena:
+    """Bump allocator over ONE persistent device buffer: scratch whose ADDRESSES repeat from step to step (the batched
+    reduction tables hold raw pointers and are cached by their contents; a hipGraph-captured step must see the addresses
+    of its eager warm-up steps).  ``reset()`` rewinds; growing allocates a new buffer (the old one stays alive as long as
+    views of it do).  Users order their accesses by stream like any other scratch."""
+
+    def __init__(self, device, nbytes: int = 1 << 24):
+        self.device = device
+        self.buf = torch.empty(int(nbytes), device=device, dtype=torch.uint8)
+        self.off = 0
+        self.high = 0
+        self.retired = []       # outgrown buffers: alive until the next reset (pending tables hold raw pointers into them)
+
+    def reset(self):
+        self.high = max(self.high, self.off)
+        self.off = 0
+        self.retired = []
+
+    def alloc(self, nbytes: int) -> Tensor:
+        nbytes = (int(nbytes) + 255) & ~255
+        if self.off + nbytes > self.buf.numel():
+            self.high = max(self.high, self.off)
+            self.retired.append(self.buf)
+            self.buf = torch.empty(max(2 * self.buf.numel(), self.off + nbytes, 2 * self.high), device=self.device, dtype=torch.uint8)
+            self.off = 0
+        out = self.buf[self.off:self.off + nbytes]
+        self.off += nbytes
+        return out
+
+    def floats(self, *shape) -> Tensor:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        return self.alloc(4 * n).view(torch.float32)[:n].view(*shape)
+
+
+class TableCache:
+    """Device copies of int64 job tables keyed by their contents (a step builds the same tables every time: the upload -
+    a synchronous host-to-device copy - happens in the first steps only)."""
+
+    def __init__(self, limit: int = 64):
+        self.limit = limit
+        self.tabs = {}
+
+    def get(self, rows, device) -> Tensor:
+        key = hash(tuple(rows))
+        ent = self.tabs.get(key)
+        if ent is not None and ent[0] == rows:
+            return ent[1]
+        if len(self.tabs) >= self.limit:
+            self.tabs.pop(next(iter(self.tabs)))
+        t = torch.tensor(rows, dtype=torch.int64, device=device)
+        self.tabs[key] = (list(rows), t)
+        return t
 
 
 # ------------------------------------------------------------------------------------------------
@@ -649,7 +713,6 @@ def upfirdn2d_raw(x: Tensor, kernel: np.ndarray, up: int, down: int, pad, layout
     if out is None:
         shape = (b, c, oh, ow) if layout == 0 else (b, oh, ow, c)
         out = torch.empty(shape, device=x.device, dtype=torch.float32)
-    _lib.keep_host_memory(k)      # the one HOST pointer of the ABI: a recording launch tape must outlive a temporary k
     check(lib().psld_upfirdn2d_f32(_chk(x).data_ptr(), out.data_ptr(), b, c, h, w, k.ctypes.data, kh, kw, up, up,
                                    down, down, px0, px1, py0, py1, layout, 1 if accumulate else 0,
                                    _stream()), "psld_upfirdn2d_f32")
@@ -707,6 +770,13 @@ def bias_grad(x: Tensor, ld: int, batch: int, hw: int, c: int, out: Tensor, alph
     check(lib().psld_bias_grad_f32(x.data_ptr(), ld, batch, hw, c, _p(per_image), ld_per_image, out.data_ptr(), alpha,
                                    ws.data_ptr(), _stream()), "psld_bias_grad_f32")
     return out
+
+
+def bias_grad_seg(x: Tensor, ld: int, batch: int, hw: int, outs: Sequence[Tensor], seg: int, alpha: float = 1.0):
+    """outs[k][seg] = alpha * column sums over (batch, hw) of columns [k*seg, (k+1)*seg) of x, k = 0, 1, 2 (one pass)."""
+    ws = workspace(lib().psld_colsum_workspace_bytes(batch, hw, 3 * seg), x.device)
+    check(lib().psld_bias_grad_seg_f32(x.data_ptr(), ld, batch, hw, seg, outs[0].data_ptr(), outs[1].data_ptr(),
+                                       outs[2].data_ptr(), alpha, ws.data_ptr(), _stream()), "psld_bias_grad_seg_f32")
 
 
 def copy_batch(table: Tensor, entries: int, total4: int):

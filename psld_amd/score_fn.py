@@ -30,7 +30,6 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from . import tape as _tape
 from .registry import register_module
 
 Tensor = torch.Tensor
@@ -144,13 +143,19 @@ class Downsample(nn.Module):
 # ----------------------------------------------------------------------------------------------
 class _Node:
     """``gp``: GroupNorm partial sums of ``v`` left behind by the limb kernel that produced it (ops.gn_part_buffer),
-    or None: the GroupNorm that reads the node then skips its statistics pass over the tensor."""
-    __slots__ = ("v", "g", "gp")
+    or None: the GroupNorm that reads the node then skips its statistics pass over the tensor.
+    ``used``: a consumer has read the node (forward order): the FIRST consumer's backward is the last writer of ``g``.
+    ``want_gsum``: the producer has a bias whose gradient is the column sum of ``g``; ``gsum`` [b][c]: those sums per
+    image, left by the last writer when it was a one-pass GroupNorm backward (_Exec.gn_backward), else None."""
+    __slots__ = ("v", "g", "gp", "used", "want_gsum", "gsum")
 
-    def __init__(self, v, gp=None):
+    def __init__(self, v, gp=None, want_gsum=False):
         self.v = v
         self.g = None
         self.gp = gp
+        self.used = False
+        self.want_gsum = want_gsum
+        self.gsum = None
 
 
 class _CatNode:
@@ -165,6 +170,7 @@ class _CatNode:
 
 
 _OVERLAP_MAX_PIXELS = 65536     # batch x H x W at the input resolution up to which weight gradients go to a side stream
+_SLAB_FLUSH_BYTES = 1 << 30     # parked split-K slabs are reduced (one launch) once they pass this many bytes
 
 
 def _gbuf(node: _Node):
@@ -237,16 +243,20 @@ class _Exec:
         self.split = ops.math_mode() == "bf16x6"   # 3x3 convs on the bf16 limb kernels (csrc/conv_split.hip)
         import os as _os
         self.limb_planes = _os.environ.get("PSLD_LIMB_PLANES", "1") != "0"    # A/B switch for tools/bench_sample.py
-        # pass 1 of GroupNorm's backward from the epilogue of the kernel that produces its dy (A/B switch)
-        self.fuse_gn_bwd = _os.environ.get("PSLD_FUSE_GN_BWD", "0") == "1"    # measured: -0.8 % on the step
-        # forward attention in one kernel (attention.hip): 1 (= 2) wherever the kernel takes the shape (B=128: 8x8 maps 17 vs
-        # 54 us of the three-kernel path, 16x16 maps 62-65 vs 72 us since the 128-query workgroup with prefetched chunks,
-        # tools/bench_attn.py), 3 = 8x8 maps only (the policy up to round 3), 0 = never
-        self.fused_attn = int(_os.environ.get("PSLD_FUSED_ATTN", "1"))
-        # Conv_0's bias / time-embedding gradient from the sums of the GroupNorm backward that writes its output gradient
-        # (ops.gn_bwd_colsum) instead of a column-sum pass over that tensor (A/B switch)
+        # forward attention in one kernel (attention.hip) wherever it takes the shape (B=128: 8x8 maps 17 vs 54 us of the
+        # three-kernel path, 16x16 maps 62-65 vs 72 us, tools/bench_attn.py); PSLD_FUSED_ATTN=0: the three kernels
+        self.fused_attn = _os.environ.get("PSLD_FUSED_ATTN", "1") != "0"
+        # bias / time-embedding gradients as column sums a one-pass GroupNorm backward forms of the dx it writes
+        # (ops.gn_bwd colsum_img) instead of a column-sum pass over that tensor (PSLD_GN_BWD_COLSUM=0: the passes)
         self.gn_bwd_colsum = _os.environ.get("PSLD_GN_BWD_COLSUM", "1") == "1"
         self.dx_nchw = None
+        # Parameter gradients that are reductions over the batch (GroupNorm dgamma / dbeta, bias gradients) or over split-K
+        # slabs are not on the dependency chain of backward: their inputs are parked in two persistent arenas and reduced
+        # by ONE launch per kind at the end of the pass (net.defer_param_grads; earlier when a gradient bucket is about to
+        # be exchanged, or when the parked slabs pass _SLAB_FLUSH_BYTES)
+        self.defer = bool(net.defer_param_grads) and record
+        self.pjobs, self.pblocks = [], 0
+        self.sjobs, self.sitems, self.sbytes = [], 0, 0
 
     # -- helpers ------------------------------------------------------------------------------
     def push(self, fn, module=None):
@@ -277,7 +287,6 @@ class _Exec:
         cur = torch.cuda.current_stream()
         ev.record(cur)
         self.side.wait_event(ev)
-        _tape.note_edge(cur, self.side)
         with torch.cuda.stream(self.side), ops.stream_scope():
             for fn, _ in queue:
                 fn()
@@ -291,7 +300,102 @@ class _Exec:
             self.flush_side()
             cur = torch.cuda.current_stream()
             cur.wait_stream(self.side)
-            _tape.note_edge(self.side, cur)
+
+    # -- deferred reductions ------------------------------------------------------------------------------------
+    @staticmethod
+    def use(node: _Node) -> bool:
+        """Mark ``node`` as read by a consumer; True for the first one (forward order) - its backward runs last among
+        the consumers', so whatever it writes into ``node.g`` last is the final gradient."""
+        first = not node.used
+        node.used = True
+        return first
+
+    def defer_param(self, src: Tensor, rows: int, ld: int, c: int, dst1: Tensor, dst2: Optional[Tensor] = None,
+                    alpha: float = 1.0, src_off: int = 0):
+        """dst1 (and dst2) [c] = alpha * sum over ``rows`` rows of ``src`` (row stride ld): now, or with every other such
+        reduction of the pass in one launch (flush_params)."""
+        if not self.defer:
+            flat = src.reshape(-1)[src_off:]
+            ops.param_reduce2(flat, None, rows, ld, c, dst1, None, alpha)
+            if dst2 is not None:
+                ops.axpby(dst1, 1.0, None, 0.0, dst2)
+            return
+        self.pjobs.append(ops.param_job(src, rows, ld, c, dst1, dst2, alpha, src_off) + (self.pblocks,))
+        self.pblocks += (c + 63) // 64
+
+    def flush_params(self):
+        if self.pjobs:
+            jobs, blocks = self.pjobs, self.pblocks
+            self.pjobs, self.pblocks = [], 0
+            rows = [v for job in jobs for v in job]
+            table = self.net._tables.get(rows, self.net._params()[0].device)
+            ops.param_reduce_batch(table, len(jobs), blocks)
+
+    def slabs_for(self, nbytes: int, device) -> Tensor:
+        """Split-K slab storage: the stream's workspace when the reduction follows at once, else a slice of the slab arena
+        that stays untouched until flush_slabs."""
+        if not self.defer:
+            return ops.workspace(nbytes, device)
+        return self.net._slab_arena().alloc(nbytes)
+
+    def reduce_slabs(self, slabs: Tensor, nsplit: int, n: int, out: Tensor, layout: int = 0, cout: int = 1, taps: int = 1,
+                     cin: int = 1, alpha: float = 1.0):
+        if not self.defer or n % 4 or (layout == 1 and cin % 4):
+            ops.reduce_slabs(slabs, nsplit, n, out, layout=layout, cout=cout, taps=taps, cin=cin, alpha=alpha)
+            return
+        self.sjobs.append(ops.slab_job(slabs, nsplit, n, out, layout, taps, cin, alpha) + (self.sitems, 0))
+        self.sitems += n // 4
+        self.sbytes += 4 * n * nsplit
+        if self.sbytes >= _SLAB_FLUSH_BYTES:
+            self.flush_slabs()
+
+    def flush_slabs(self):
+        """One reduction launch for every parked weight gradient - on the stream their producers ran on (callers are
+        on_side closures) - after which the arena is reused."""
+        if self.sjobs:
+            jobs, items = self.sjobs, self.sitems
+            self.sjobs, self.sitems, self.sbytes = [], 0, 0
+            rows = [v for job in jobs for v in job]
+            table = self.net._tables.get(rows, self.net._params()[0].device)
+            ops.reduce_slabs_batch(table, len(jobs), items)
+            self.net._slab_arena().reset()
+
+    def flush_deferred(self):
+        self.on_side(self.flush_slabs)
+        self.flush_params()
+
+    def gn_backward(self, dy: Tensor, x: Tensor, st, gamma: Tensor, beta: Tensor, dgamma: Tensor, dbeta: Tensor, act: bool,
+                    dx: Tensor, accumulate_dx: bool = False, add: Optional[Tensor] = None, add_scale: float = 1.0,
+                    drop_p: float = 0.0, seed: int = 0, seed_dev=None, groups: Optional[int] = None,
+                    colsum_img: Optional[Tensor] = None, ld_img: int = 0, last_writer_of: Optional[_Node] = None):
+        """GroupNorm(+SiLU, dropout) backward; dgamma / dbeta follow from its per-image sums by a deferred reduction.
+        ``last_writer_of``: the node whose gradient ``dx`` is, when this call writes it last: if the node's producer wants
+        the column sums of that gradient (a bias gradient) and a one-pass kernel takes the shape, they are formed here."""
+        b, h, w, c = x.shape
+        pa = self.net._param_arena()
+        sums = pa.floats(b, 2, c)
+        node = last_writer_of
+        fold = node is not None and node.want_gsum and colsum_img is None and self.gn_bwd_colsum and \
+            ops.gn_bwd_colsum_supported(b, h * w, c, groups)
+        if fold:
+            colsum_img, ld_img = pa.floats(b, c), c
+        ops.gn_bwd(dy, x, st, gamma, beta, act, dx, accumulate_dx=accumulate_dx, drop_p=drop_p, seed=seed, groups=groups,
+                   add=add, add_scale=add_scale, seed_dev=seed_dev, sums=sums, colsum_img=colsum_img, ld_img=ld_img)
+        self.defer_param(sums, b, 2 * c, c, dbeta)
+        self.defer_param(sums, b, 2 * c, c, dgamma, src_off=c)
+        if fold:
+            node.gsum = colsum_img
+
+    def bias_from(self, node: _Node, dout: Tensor, bias: nn.Parameter, alpha: float = 1.0,
+                  bias2: Optional[nn.Parameter] = None) -> bool:
+        """Bias gradient(s) = alpha * column sums of a node's final gradient ``dout``: from the sums its last writer left
+        (True: nothing launched now), else by a pass over ``dout`` (False; call it where that pass may run)."""
+        gsum, node.gsum = node.gsum, None
+        if gsum is not None:
+            self.defer_param(gsum, gsum.shape[0], gsum.shape[1], gsum.shape[1], self.g(bias),
+                             self.g(bias2) if bias2 is not None else None, alpha)
+            return True
+        return False
 
     def wgrad(self, dy: Tensor, x: Tensor, conv: _Affine, k: int, stride: int, pad: int, alpha: float = 1.0,
               x2: Optional[Tensor] = None):
@@ -316,23 +420,23 @@ class _Exec:
             nsplit = _pick_nsplit((cout // co_tile) * (cin // 64) * 3, ktiles * 32, min_k=128, resident=resident)
             per = -(-ktiles // nsplit)
             nsplit = -(-ktiles // per)                 # every slab non-empty
-            slabs = ops.workspace(4 * n * nsplit, dy.device)
+            slabs = self.slabs_for(4 * n * nsplit, dy.device)
             ops.conv3x3_wgrad_split(dy, cout, x, slabs, cin, 0, nsplit, x2)
-            ops.reduce_slabs(slabs, nsplit, n, self.g(conv.weight), layout=1, cout=cout, taps=taps, cin=cin, alpha=alpha)
+            self.reduce_slabs(slabs, nsplit, n, self.g(conv.weight), layout=1, cout=cout, taps=taps, cin=cin, alpha=alpha)
             return
         if self.split and k == 1 and stride == 1 and pad == 0 and ops.gemm_tn_split_supported(cout, c1, b * oh * ow) and \
                 c2 % 128 == 0:
             nsplit = self._tn_split(cout, cin, b * oh * ow)
-            slabs = ops.workspace(4 * n * nsplit, dy.device)
+            slabs = self.slabs_for(4 * n * nsplit, dy.device)
             ops.gemm_tn_split(cout, c1, b * oh * ow, dy, cout, x, c1, slabs, cin, nsplit, x2, c2, c2)
-            ops.reduce_slabs(slabs, nsplit, n, self.g(conv.weight), alpha=alpha)
+            self.reduce_slabs(slabs, nsplit, n, self.g(conv.weight), alpha=alpha)
             return
         assert x2 is None, "unsupported two-source weight gradient"
         tiles = ((cout + 127) // 128) * ((cin + 127) // 128) * taps
         nsplit = _pick_nsplit(tiles, b * oh * ow)
-        slabs = ops.workspace(4 * n * nsplit, dy.device)
+        slabs = self.slabs_for(4 * n * nsplit, dy.device)
         ops.conv2d_wgrad_nhwc(dy, cout, x, k, k, stride, pad, oh, ow, slabs, cin, 0, nsplit)
-        ops.reduce_slabs(slabs, nsplit, n, self.g(conv.weight), layout=1, cout=cout, taps=taps, cin=cin, alpha=alpha)
+        self.reduce_slabs(slabs, nsplit, n, self.g(conv.weight), layout=1, cout=cout, taps=taps, cin=cin, alpha=alpha)
 
     @staticmethod
     def node_stats(node: _Node, gamma: Tensor, beta: Tensor, groups: Optional[int] = None):
@@ -454,23 +558,11 @@ class _Exec:
             self.bias_grad(dy, self.g(conv.bias))
         self.on_side(side, dy, a, cols)
 
-    def gnb_for(self, x: Tensor, st, gn: _Affine, act: bool, drop_p: float = 0.0, seed: int = 0, seed_dev=None,
-                gamma: Optional[Tensor] = None, beta: Optional[Tensor] = None, groups: Optional[int] = None):
-        """Descriptor that lets the limb kernel producing dy of GroupNorm ``gn`` (input ``x``, statistics ``st``) also
-        produce pass 1 of its backward (ops.gn_bwd_part), or None when the shape does not qualify."""
-        b, h, w, c = x.shape
-        if not (self.split and self.fuse_gn_bwd and ops.gn_bwd_part_supported(b, h * w, c, groups)):
-            return None
-        return ops.gn_bwd_part(x, st, gamma if gamma is not None else gn.weight.detach(),
-                               beta if beta is not None else gn.bias.detach(), act, drop_p, seed, seed_dev, groups)
-
     def dgrad(self, dy: Tensor, conv: _Affine, k: int, stride: int, pad: int, ih: int, iw: int, out: Tensor,
-              alpha: float = 1.0, accumulate: bool = False, gnb=None):
-        """``gnb``: see gnb_for - only honoured on the limb path (the caller checks ``limb_dgrad_ok`` first)."""
+              alpha: float = 1.0, accumulate: bool = False):
         cin = conv.weight.shape[1]
-        epi = ops.epilogue(alpha=alpha, accumulate=accumulate, gnb=gnb) if (alpha != 1.0 or accumulate or gnb is not None) \
-            else None
-        if self.split and k == 3 and stride == 1 and pad == 1 and gnb is None and \
+        epi = ops.epilogue(alpha=alpha, accumulate=accumulate) if (alpha != 1.0 or accumulate) else None
+        if self.split and k == 3 and stride == 1 and pad == 1 and \
                 ops.conv3x3_wino_wanted(dy.shape[-1], 0, dy.shape[0], ih, iw, cin):
             ops.conv3x3_wino(dy, None, self.net._wfrag(conv, True), cin, out, epi)      # Winograd F(2x2, 3x3)
             return
@@ -478,7 +570,6 @@ class _Exec:
                 ops.conv3x3_split_supported(dy.shape[-1], 0, dy.shape[0], ih, iw, cin):
             ops.conv3x3_split(dy, None, self.net._frag(conv, True), cin, out, epi)
             return
-        assert gnb is None, "GroupNorm-backward by-product needs the limb data-gradient kernel"
         wd = self.net._packed(conv, dgrad=True)
         ops.conv2d_nhwc(dy, None, wd, cin, k, k, 1, k - 1 - pad, stride, ih, iw, out, epi)
 
@@ -523,7 +614,9 @@ class _Exec:
             ops.gemm_raw(0, 1, b, total, wcat.shape[1], st.v, wcat.shape[1], 0, wcat, wcat.shape[1], 0, self.tp_all,
                          total, 0, 1, ops.epilogue(bias=bcat))
             if self.record:
-                self.dtp_all = torch.empty((b, total), device=t.device, dtype=torch.float32)
+                # persistent (same address every step: the batched reduction tables hold pointers into it); written and
+                # read inside ONE backward pass, so forward passes whose backward is still pending can share it
+                self.dtp_all = net._persist("dtp_all", (b, total))
         tp_all, dtp_all = self.tp_all, self.dtp_all
 
         def bwd():
@@ -567,6 +660,8 @@ class _Exec:
         xb: Optional[_Node] = None
         if isinstance(x, _CatNode):
             x, xb = x.a, x.b
+        first_x = self.use(x)
+        first_xb = self.use(xb) if xb is not None else False
         b, h, w, c1 = x.v.shape
         cin = c1 + (xb.v.shape[-1] if xb is not None else 0)
         cout = mod.out_ch
@@ -657,7 +752,7 @@ class _Exec:
             ops.conv3x3_wino_gn(h1, st1, None, None, True, net._wfrag(mod.Conv_1, False), cout, out, epi1)
         else:
             self.conv3(a1, mod.Conv_1, out, epi1)
-        on = _Node(out, outp)
+        on = _Node(out, outp, want_gsum=True)       # Conv_1.bias (and Conv_2.bias) = s * column sums of its gradient
         if not self.record:
             return on
         temb_act = self.temb_act
@@ -668,38 +763,40 @@ class _Exec:
         def bwd():
             dout = on.g
             on.g = None
+            # Conv_1 / Conv_2 bias: s * column sums of dout - left behind by the last writer of dout where that was a
+            # one-pass GroupNorm backward, else a pass over dout on the side stream
+            have_bias = self.bias_from(on, dout, mod.Conv_1.bias, s, mod.Conv_2.bias if mod.has_shortcut else None)
+
             # Conv_1 (the 1/sqrt(2) of skip_rescale is folded into alpha); parameter gradients on the side stream
             def side1():
                 self.wgrad(dout, a1, mod.Conv_1, 3, 1, 1, alpha=s)
-                self.bias_grad(dout, self.g(mod.Conv_1.bias), alpha=s)
+                if not have_bias:
+                    self.bias_grad(dout, self.g(mod.Conv_1.bias), alpha=s)
                 if mod.has_shortcut:
                     self.wgrad(dout, xr_saved, mod.Conv_2, 1, 1, 0, alpha=s, x2=xb_v)
-                    # Conv_2.bias sees the same output gradient as Conv_1.bias: copy the sum just computed
-                    ops.axpby(self.g(mod.Conv_1.bias), 1.0, None, 0.0, self.g(mod.Conv_2.bias))
+                    if not have_bias:
+                        # Conv_2.bias sees the same output gradient as Conv_1.bias: copy the sum just computed
+                        ops.axpby(self.g(mod.Conv_1.bias), 1.0, None, 0.0, self.g(mod.Conv_2.bias))
 
             self.on_side(side1, dout, a1, xr_saved, xb_v)
             da1 = torch.empty_like(h1)
-            limb1 = self.split and ops.conv3x3_split_supported(cout, 0, b, ho, wo, cout)
-            gnb1 = self.gnb_for(h1, st1, gn1, True, drop_p, seed, seed_dev) if limb1 else None
-            self.dgrad(dout, mod.Conv_1, 3, 1, 1, ho, wo, da1, alpha=s, gnb=gnb1)
+            self.dgrad(dout, mod.Conv_1, 3, 1, 1, ho, wo, da1, alpha=s)
             dh1 = torch.empty_like(h1)
             # Conv_0's bias gradient and the per-image sums of dh1 (the time-embedding gradient) as a by-product of the
             # GroupNorm backward that writes dh1 (no pass over dh1), where its one-pass kernels take the shape
-            csum = gnb1 is None and self.gn_bwd_colsum and ops.gn_bwd_colsum_supported(b, ho * wo, cout)
-            dtp_pre = None
+            csum = self.gn_bwd_colsum and ops.gn_bwd_colsum_supported(b, ho * wo, cout)
+            per_img, ldp = None, 0
             if csum:
-                if temb_act is None:
-                    per_img, ldp = None, 0
-                elif tp_off is not None and dtp_all is not None:
+                if temb_act is not None and tp_off is not None and dtp_all is not None:
                     per_img, ldp = dtp_all[:, tp_off:tp_off + cout], dtp_all.shape[1]
                 else:
-                    per_img, ldp = torch.empty((b, cout), device=dout.device, dtype=torch.float32), cout
-                dtp_pre = per_img
-                ops.gn_bwd_colsum(da1, h1, st1, gn1.weight, gn1.bias, True, dh1, self.g(gn1.weight), self.g(gn1.bias),
-                                  self.g(mod.Conv_0.bias), 1.0, per_img, ldp, drop_p=drop_p, seed=seed, seed_dev=seed_dev)
-            else:
-                ops.gn_bwd(da1, h1, st1, gn1.weight, gn1.bias, True, dh1, self.g(gn1.weight), self.g(gn1.bias),
-                           drop_p=drop_p, seed=seed, seed_dev=seed_dev, part=gnb1["part"] if gnb1 is not None else None)
+                    per_img, ldp = net._param_arena().floats(b, cout), cout
+            self.gn_backward(da1, h1, st1, gn1.weight, gn1.bias, self.g(gn1.weight), self.g(gn1.bias), True, dh1,
+                             drop_p=drop_p, seed=seed, seed_dev=seed_dev, colsum_img=per_img, ld_img=ldp)
+            if csum:        # Conv_0.bias = sum over the batch of the per-image sums = Dense_0.bias
+                self.defer_param(per_img, b, ldp, cout, self.g(mod.Conv_0.bias),
+                                 self.g(mod.Dense_0.bias) if temb_act is not None else None)
+            dtp_pre = per_img
             del da1
 
             # Conv_0 + time-embedding bias
@@ -729,17 +826,16 @@ class _Exec:
                     gb, acc = _gbuf(temb_act)
                     ops.gemm_raw(0, 0, b, kd, cout, dtp, cout, 0, d0.weight, kd, 0, gb, kd, 0,
                                  epi=ops.epilogue(accumulate=True) if acc else None)
-                # d Dense_0.bias = sum over the batch of dtp = the conv bias gradient just computed
-                ops.axpby(self.g(mod.Conv_0.bias), 1.0, None, 0.0, self.g(d0.bias))
+                if not csum:
+                    # d Dense_0.bias = sum over the batch of dtp = the conv bias gradient just computed
+                    ops.axpby(self.g(mod.Conv_0.bias), 1.0, None, 0.0, self.g(d0.bias))
 
             self.on_side(side0, dh1, a0r, a0b)
             if xb is not None:
-                self._resblock_cat_bwd(mod, x, xb, dout, dh1, st0, st0b, g1, g2)
+                self._resblock_cat_bwd(mod, x, xb, dout, dh1, st0, st0b, g1, g2, first_x, first_xb)
                 return
             da0r = torch.empty((b, ho, wo, cin), device=dout.device, dtype=torch.float32)
-            limb0 = self.split and not (up or down) and ops.conv3x3_split_supported(cout, 0, b, ho, wo, cin)
-            gnb0 = self.gnb_for(x.v, st0, gn0, True) if limb0 else None
-            self.dgrad(dh1, mod.Conv_0, 3, 1, 1, ho, wo, da0r, gnb=gnb0)
+            self.dgrad(dh1, mod.Conv_0, 3, 1, 1, ho, wo, da0r)
             # (no `del dh1`: side0 above may still be waiting for its fork and looks the name up when it runs)
             xg, acc = _gbuf(x)
             identity = False
@@ -767,14 +863,16 @@ class _Exec:
                 self.resample_bwd(da0r, up, (h, w), da0, False)
             else:
                 da0 = da0r
-            ops.gn_bwd(da0, x.v, st0, gn0.weight, gn0.bias, True, xg, self.g(gn0.weight), self.g(gn0.bias),
-                       accumulate_dx=not identity or acc, add=dout if identity else None, add_scale=s,
-                       part=gnb0["part"] if gnb0 is not None else None)
+            # this block read x first (forward order): its GroupNorm_0 backward writes x's gradient last
+            self.gn_backward(da0, x.v, st0, gn0.weight, gn0.bias, self.g(gn0.weight), self.g(gn0.bias), True, xg,
+                             accumulate_dx=not identity or acc, add=dout if identity else None, add_scale=s,
+                             last_writer_of=x if first_x else None)
 
         self.push(bwd, mod)
         return on
 
-    def _resblock_cat_bwd(self, mod, xa: _Node, xb: _Node, dout: Tensor, dh1: Tensor, sta, stb, g1: int, g2: int):
+    def _resblock_cat_bwd(self, mod, xa: _Node, xb: _Node, dout: Tensor, dh1: Tensor, sta, stb, g1: int, g2: int,
+                          first_a: bool, first_b: bool):
         """Input side of the backward of a residual block fed by an unmaterialised concatenation: the data gradients
         of Conv_0 and of the 1x1 shortcut are computed per source (the fragments of a data gradient are ordered by
         output-channel tile, so each source's share is a contiguous slice) and GroupNorm_0's backward runs per source
@@ -785,7 +883,7 @@ class _Exec:
         m = b * h * w
         c1 = xa.v.shape[-1]
         cin = c1 + xb.v.shape[-1]
-        wino = self.split and not self.fuse_gn_bwd and ops.conv3x3_wino_wanted(cout, 0, b, h, w, c1) and \
+        wino = self.split and ops.conv3x3_wino_wanted(cout, 0, b, h, w, c1) and \
             ops.conv3x3_wino_wanted(cout, 0, b, h, w, cin - c1)
         # [cin/128 tiles][...]: data gradient of the 3x3 (Winograd fragments carry 16 KB of read-ahead padding at the end)
         f3 = net._wfrag(mod.Conv_0, True) if wino else net._frag(mod.Conv_0, True)
@@ -793,19 +891,18 @@ class _Exec:
         cut3, cut1 = (f3.numel() - (16384 if wino else 0)) * c1 // cin, f1.numel() * c1 // cin
         gam, bet = gn0.weight.detach(), gn0.bias.detach()
         dgam, dbet = self.g(gn0.weight), self.g(gn0.bias)
-        for node, lo, hi, fr3, fr1, st, g in ((xa, 0, c1, f3[:cut3], f1[:cut1], sta, g1),
-                                             (xb, c1, cin, f3[cut3:], f1[cut1:], stb, g2)):
+        for node, lo, hi, fr3, fr1, st, g, first in ((xa, 0, c1, f3[:cut3], f1[:cut1], sta, g1, first_a),
+                                                    (xb, c1, cin, f3[cut3:], f1[cut1:], stb, g2, first_b)):
             c = hi - lo
             xg, acc = _gbuf(node)
             ops.gemm_split(dout, None, m, fr1, c, xg, ops.epilogue(alpha=s, accumulate=acc))
             da0 = torch.empty_like(node.v)
-            gnb = None if wino else self.gnb_for(node.v, st, gn0, True, gamma=gam[lo:hi], beta=bet[lo:hi], groups=g)
             if wino:
                 ops.conv3x3_wino(dh1, None, fr3, c, da0)
             else:
-                ops.conv3x3_split(dh1, None, fr3, c, da0, ops.epilogue(gnb=gnb) if gnb is not None else None)
-            ops.gn_bwd(da0, node.v, st, gam[lo:hi], bet[lo:hi], True, xg, dgam[lo:hi], dbet[lo:hi], accumulate_dx=True,
-                       groups=g, part=gnb["part"] if gnb is not None else None)
+                ops.conv3x3_split(dh1, None, fr3, c, da0)
+            self.gn_backward(da0, node.v, st, gam[lo:hi], bet[lo:hi], dgam[lo:hi], dbet[lo:hi], True, xg,
+                             accumulate_dx=True, groups=g, last_writer_of=node if first else None)
 
     # -- AttnBlockpp.forward (layerspp.py:75-91) -----------------------------------------------------
     def attn(self, x: _Node, mod: AttnBlockpp) -> _Node:
@@ -815,6 +912,7 @@ class _Exec:
         m = b * hw
         dev = x.v.device
         gn = mod.GroupNorm_0
+        first_x = self.use(x)
         st = self.node_stats(x, gn.weight, gn.bias)
         hn = ops.gn_apply(x.v, st, False)
         n0, n1, n2, n3 = mod.NIN_0, mod.NIN_1, mod.NIN_2, mod.NIN_3
@@ -844,7 +942,7 @@ class _Exec:
             q, k, v = qkv
             ld = c
         ho = torch.empty((b, hw, c), device=dev, dtype=torch.float32)
-        if self.split and (self.fused_attn in (1, 2) or (self.fused_attn == 3 and hw <= 64)) and ops.attn_fwd_supported(hw, c):
+        if self.split and self.fused_attn and ops.attn_fwd_supported(hw, c):
             # QK^T -> softmax -> PV in ONE kernel: the [B, HW, HW] scores never reach HBM; the probabilities are written
             # only when a backward pass will read them
             p = torch.empty((b, hw, hw), device=dev, dtype=torch.float32) if self.record else None
@@ -862,27 +960,29 @@ class _Exec:
             ops.gemm_split(ho, None, m, f_o, c, out, epi_out)
         else:
             ops.gemm_raw(0, 0, m, c, c, ho, c, 0, n3.W, c, 0, out, c, 0, epi=epi_out)
-        on = _Node(out)
+        on = _Node(out, want_gsum=True)             # NIN_3.b = s * column sums of its gradient
         if not self.record:
             return on
 
-        def nin_wgrad(a_in: Tensor, dy: Tensor, nin: NIN, alpha: float, ldd: int):
+        def nin_wgrad(a_in: Tensor, dy: Tensor, nin: NIN, alpha: float, ldd: int, bias: bool = True):
             # dW[in,out] = a_in^T dy  (K = B*HW -> split-K slabs); dy may be a column slice (row stride ldd)
             if self.split and ops.gemm_tn_split_supported(c, c, m):
                 nsplit = self._tn_split(c, c, m)
-                slabs = ops.workspace(4 * c * c * nsplit, dev)
+                slabs = self.slabs_for(4 * c * c * nsplit, dev)
                 ops.gemm_tn_split(c, c, m, a_in, c, dy, ldd, slabs, c, nsplit)
             else:
                 nsplit = _pick_nsplit(((c + 127) // 128) ** 2, m)
-                slabs = ops.workspace(4 * c * c * nsplit, dev)
+                slabs = self.slabs_for(4 * c * c * nsplit, dev)
                 ops.gemm_tn_splitk(c, c, m, a_in, c, dy, ldd, slabs, nsplit)
-            ops.reduce_slabs(slabs, nsplit, c * c, self.g(nin.W), alpha=alpha)
-            self.bias_grad(dy.view(b, hw, 1, c) if ldd == c else dy, self.g(nin.b), alpha=alpha, ld=ldd)
+            self.reduce_slabs(slabs, nsplit, c * c, self.g(nin.W), alpha=alpha)
+            if bias:
+                self.bias_grad(dy.view(b, hw, 1, c) if ldd == c else dy, self.g(nin.b), alpha=alpha, ld=ldd)
 
         def bwd():
             dout = on.g
             on.g = None
-            self.on_side(lambda: nin_wgrad(ho, dout, n3, s, c), ho, dout)
+            have_b3 = self.bias_from(on, dout, n3.b, s)
+            self.on_side(lambda: nin_wgrad(ho, dout, n3, s, c, bias=not have_b3), ho, dout)
             dho = torch.empty_like(ho)
             if fused:
                 f_od = net._pfrag(n3.W, "dgrad", c, c, c, 1)
@@ -903,11 +1003,14 @@ class _Exec:
             self.bmm(0, 0, hw, c, hw, ds, hw, hw * hw, k, ld, hw * ld, dq, ld, hw * ld, b, scale)
             self.bmm(1, 0, hw, c, hw, ds, hw, hw * hw, q, ld, hw * ld, dk, ld, hw * ld, b, scale)
             dhn = torch.empty_like(hn)
+            # q / k / v bias gradients: ONE column-sum pass over the [m, 3c] gradient buffer, written to the three parameters
+            seg = fused and 3 * c <= 1024
+            if seg:
+                self.on_side(lambda: ops.bias_grad_seg(dqkv, 3 * c, b, hw, (self.g(n0.b), self.g(n1.b), self.g(n2.b)), c), dqkv)
             for nin, d in ((n0, dq), (n1, dk), (n2, dv)):
-                self.on_side(lambda nin=nin, d=d: nin_wgrad(hn, d, nin, 1.0, ld), hn, d)
-            gnb_a = self.gnb_for(x.v, st, gn, False) if fused else None
+                self.on_side(lambda nin=nin, d=d: nin_wgrad(hn, d, nin, 1.0, ld, bias=not seg), hn, d)
             if fused:
-                ops.gemm_split(dqkv, None, m, f_qkv_d, c, dhn, ops.epilogue(gnb=gnb_a) if gnb_a is not None else None)
+                ops.gemm_split(dqkv, None, m, f_qkv_d, c, dhn)
             else:
                 first = True
                 for nin, d in ((n0, dq), (n1, dk), (n2, dv)):
@@ -915,8 +1018,8 @@ class _Exec:
                                  epi=None if first else ops.epilogue(accumulate=True))
                     first = False
             xg, acc = _gbuf(x)
-            ops.gn_bwd(dhn, x.v, st, gn.weight, gn.bias, False, xg, self.g(gn.weight), self.g(gn.bias),
-                       accumulate_dx=acc, add=dout, add_scale=s, part=gnb_a["part"] if gnb_a is not None else None)
+            self.gn_backward(dhn, x.v, st, gn.weight, gn.bias, self.g(gn.weight), self.g(gn.bias), False, xg,
+                             accumulate_dx=acc, add=dout, add_scale=s, last_writer_of=x if first_x else None)
 
         self.push(bwd, mod)
         return on
@@ -927,6 +1030,9 @@ class _Exec:
         s = self.s
         conv = mod.conv
         cout = mod.out_ch
+        self.use(h)
+        if not first:
+            self.use(pyr)
         if mod.fir:
             k = _fir_kernel(self.net.sf.fir_kernel)
             pad = (2, 2)  # up_or_down_sampling.py:173-176: p = (4-2) + (3-1)
@@ -957,13 +1063,14 @@ class _Exec:
             del patches
         else:
             ops.conv2d_nhwc(xf, None, self.net._packed(conv), cout, 3, 3, 2, 0, 1, oh, ow, out, epi)
-        on = _Node(out)
+        on = _Node(out, want_gsum=True)             # conv.bias = s * column sums of its gradient
         if not self.record:
             return on
 
         def bwd():
             dout = on.g
             on.g = None
+            have_bias = self.bias_from(on, dout, conv.bias, s)
             hg, acc = _gbuf(h)
             ops.axpby(dout, s, None, 0.0, hg, accumulate=acc)
             def side():
@@ -971,7 +1078,8 @@ class _Exec:
                     self.small_in_wgrad(dout, cols, conv, alpha=s)
                 else:
                     self.wgrad(dout, xf, conv, 3, 2, 0, alpha=s)
-                self.bias_grad(dout, self.g(conv.bias), alpha=s)
+                if not have_bias:
+                    self.bias_grad(dout, self.g(conv.bias), alpha=s)
 
             self.on_side(side, dout, xf)
             if not first:
@@ -1022,6 +1130,8 @@ class _Exec:
         """torch.cat([h, hs.pop()], dim=1) (ncsnpp.py:374) in NHWC; not materialised when ``consumer`` reads two sources."""
         if consumer is not None and self._cat_ok(a, bnode, consumer):
             return _CatNode(a, bnode)
+        self.use(a)
+        self.use(bnode)
         b, h, w, c1 = a.v.shape
         c2 = bnode.v.shape[-1]
         rows = b * h * w
@@ -1069,18 +1179,20 @@ class _Exec:
         else:
             ops.conv2d_nhwc(x_nhwc, None, net._packed(stem), stem.weight.shape[0], 3, 3, 1, 1, 1, hh, ww, h0,
                             ops.epilogue(bias=stem.bias))
-        n0 = _Node(h0)
+        n0 = _Node(h0, want_gsum=True)              # stem.bias = column sums of its gradient
         if self.record:
             def stem_bwd():
                 g0 = n0.g
                 n0.g = None
+                have_bias = self.bias_from(n0, g0, stem.bias)
 
                 def side():
                     if stem_small:
                         self.small_in_wgrad(g0, stem_cols, stem)
                     else:
                         self.wgrad(g0, x_nhwc, stem, 3, 1, 1)
-                    self.bias_grad(g0, self.g(stem.bias))
+                    if not have_bias:
+                        self.bias_grad(g0, self.g(stem.bias))
 
                 self.on_side(side, g0, x_nhwc)
                 if self.want_dx:
@@ -1133,6 +1245,7 @@ class _Exec:
         assert not hs
         gnf, head = mods[mi], mods[mi + 1]
         assert mi + 2 == len(mods)
+        first_last = self.use(hnode)
         stf = self.node_stats(hnode, gnf.weight, gnf.bias)
         af = ops.gn_apply(hnode.v, stf, True)
         oc = head.weight.shape[0]
@@ -1160,14 +1273,15 @@ class _Exec:
                     self.on_side(side, dy, af)
                     self.dgrad(dy, head, 3, 1, 1, hh, ww, daf)
                 xg, acc = _gbuf(last)
-                ops.gn_bwd(daf, last.v, stf, gnf.weight, gnf.bias, True, xg, self.g(gnf.weight), self.g(gnf.bias),
-                           accumulate_dx=acc)
+                self.gn_backward(daf, last.v, stf, gnf.weight, gnf.bias, self.g(gnf.weight), self.g(gnf.bias), True, xg,
+                                 accumulate_dx=acc, last_writer_of=last if first_last else None)
 
             self.push(head_bwd, gnf)
         return ops.nhwc_to_nchw(y)
 
     # -- NCSNppClassifier head (ncsnpp_clf.py:277-283): flatten in NCHW order + Linear(bias=False) ------------------
     def clf_head(self, hnode: _Node, lin: nn.Linear) -> Tensor:
+        self.use(hnode)
         b, h, w, c = hnode.v.shape
         flat = ops.nhwc_to_nchw(hnode.v).view(b, c * h * w)
         n_cls, k = lin.weight.shape
@@ -1195,11 +1309,19 @@ class _Exec:
         net = self.net
         g_out = grad_out_nchw.contiguous()
         self.head_grad.g = g_out if net.is_classifier else ops.nchw_to_nhwc(g_out)
+        if self.defer:
+            net._param_arena().reset()
+        red = net._reducer
         for fn, module in reversed(self.tape):
             fn()
             if module is not None and self.watermark is not None:
+                off = net._module_offset(module)
+                if self.defer and red is not None and red.would_launch(off):
+                    self.flush_deferred()       # a bucket is about to be exchanged: its parked reductions first
                 self.flush_side()       # the reducer may launch a bucket now: its gradients must at least be enqueued
-                self.watermark(net._module_offset(module))
+                self.watermark(off)
+        if self.defer:
+            self.flush_deferred()
         self.join_side()
         self.tape = None
 
@@ -1384,11 +1506,17 @@ class NCSNpp(nn.Module):
         self._posfreq = None
         self._module_offs = None
         # parameter-gradient kernels on a side stream: None = automatic (small batches, see _Exec._run); True / False or
-        # PSLD_OVERLAP_WGRAD=1 / 0 force it.  side_group: calls per fork (PSLD_SIDE_GROUP)
+        # PSLD_OVERLAP_WGRAD=1 / 0 force it
         import os as _os
         _ow = _os.environ.get("PSLD_OVERLAP_WGRAD")
         self.overlap_wgrad = None if _ow is None else _ow == "1"
-        self.side_group = max(1, int(_os.environ.get("PSLD_SIDE_GROUP", "32")))
+        self.side_group = 32        # side-stream calls per fork: one event + one stream wait per group (tools/graph_cross.py)
+        # dgamma / dbeta / bias gradients / split-K slab reductions of a backward pass in batched launches (_Exec.defer_param,
+        # _Exec.reduce_slabs); False: one launch per layer, right where the reference's autograd would compute them
+        self.defer_param_grads = True
+        self._tables = ops.TableCache()
+        self._parena = self._sarena = None
+        self._persistent = {}
         # None (auto): parameters become inputs of the autograd node (gradients delivered through AccumulateGrad, so
         # torch DDP / Lightning's ddp strategy can reduce them) when a multi-rank process group exists and no
         # BucketReducer is attached; True / False (or PSLD_AUTOGRAD_PARAMS=1 / 0) force it.
@@ -1408,6 +1536,27 @@ class NCSNpp(nn.Module):
         self._graphs = {}
         self._conv_by_weight = {}
         self._side = None
+
+    def _param_arena(self) -> "ops.Arena":
+        dev = self._params()[0].device
+        if self._parena is None or self._parena.device != dev:
+            self._parena = ops.Arena(dev, 64 << 20)
+        return self._parena
+
+    def _slab_arena(self) -> "ops.Arena":
+        dev = self._params()[0].device
+        if self._sarena is None or self._sarena.device != dev:
+            self._sarena = ops.Arena(dev, _SLAB_FLUSH_BYTES + (256 << 20))
+        return self._sarena
+
+    def _persist(self, name: str, shape) -> Tensor:
+        """A float32 buffer that keeps its address for this network, name and shape."""
+        dev = self._params()[0].device
+        key = (name, tuple(shape), dev)
+        t = self._persistent.get(key)
+        if t is None:
+            t = self._persistent[key] = torch.empty(tuple(shape), device=dev, dtype=torch.float32)
+        return t
 
     def _side_stream(self):
         dev = next(self.parameters()).device
@@ -1861,13 +2010,16 @@ class NCSNpp(nn.Module):
         cls = self.__class__
         new = cls.__new__(cls)
         memo[id(self)] = new
-        skip = {"_flat", "_flat_grad", "_pack_cache", "_frag_table", "_wfrag_table", "_temb_plan_cache", "_anchor", "_reducer", "_offsets", "_module_offs", "_posfreq",
+        skip = {"_tables", "_parena", "_sarena", "_persistent", "_flat", "_flat_grad", "_pack_cache", "_frag_table", "_wfrag_table", "_temb_plan_cache", "_anchor", "_reducer", "_offsets", "_module_offs", "_posfreq",
                 "_side", "_plist", "_tlist", "_gviews", "_dropout_seed_dev", "_graphs", "_conv_by_weight", "_scratch_grad", "_sviews"}
         for k, v in self.__dict__.items():
             if k in skip:
                 continue
             new.__dict__[k] = copy.deepcopy(v, memo)
         new._flat = new._flat_grad = new._offsets = new._anchor = new._reducer = new._posfreq = new._side = None
+        new._tables = ops.TableCache()
+        new._parena = new._sarena = None
+        new._persistent = {}
         new._module_offs = None
         new._plist = new._tlist = new._gviews = None
         new._graphs = {}

@@ -13,7 +13,6 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from . import tape as _tape
 from .optim import FusedAdam
 from .registry import register_module
 
@@ -89,7 +88,7 @@ class SDEWrapper(_Base):
         pass
 
     # ---- hipGraph-captured training step (launch-bound regime: small per-GPU batches) ---------------------------------
-    def enable_graphs(self, flag: bool = True, warmup_steps: int = 2, tape: bool = False):
+    def enable_graphs(self, flag: bool = True, warmup_steps: int = 2):
         """Capture the whole training step - perturb, forward, loss, backward tape, norm + clip + Adam - into a HIP
         graph per batch shape and replay it: one graph launch instead of ~2700 kernel launches issued from Python (the
         reference's per-GPU batch of 16, scripts_psld/.../train_uncond_psld.sh:25-30; measured in profiles/: worth a few
@@ -101,15 +100,9 @@ class SDEWrapper(_Base):
         device buffer written before each replay.  The first ``warmup_steps`` steps of a shape run eagerly (they size
         workspaces and weight caches).  The NaN check of the perturbation coefficients (a host read) stays outside the
         graph, on the early stream of ``_draw_times``.  Not captured: gradient exchange (``set_reducer``), foreign
-        optimizers.
-
-        ``tape=True``: the step is recorded while it is captured (psld_amd/tape.py) and what is replayed is the launch
-        TAPE, not the graph: the same ~2700 launches issued from C as ordinary stream launches (psld_tape_replay,
-        include/psld_hip.h), the weight-gradient kernels really overlapping on the side stream.  The graph object only
-        keeps the step's buffers at their addresses."""
+        optimizers."""
         self._graphs_on = bool(flag)
         self._graph_warmup = int(warmup_steps)
-        self._tape_on = bool(flag and tape)
         if not flag:
             self._graph_steps = {}
 
@@ -179,12 +172,11 @@ class SDEWrapper(_Base):
             net.flat_grad()
             check_nan, sde.check_nan = getattr(sde, "check_nan", False), False
             graph = torch.cuda.CUDAGraph()
-            tape = _tape.LaunchTape() if getattr(self, "_tape_on", False) else None
             # the dropout seed word is baked into the graph as a pointer: the attribute is set for the capture only
             # (an eager step that found it set would skip its own seed draw and repeat the static word's mask)
             net._dropout_seed_dev = ent["seed"]
             try:
-                with torch.cuda.graph(graph), (_tape.record(tape) if tape is not None else contextlib.nullcontext()):
+                with torch.cuda.graph(graph):
                     t = ent["t_"] * (sde.T - self.train_eps) + self.train_eps
                     loss = self.criterion(ent["x0"], t, net, eps=ent["eps"], m_draw=ent["m_draw"])
                     net.mark_grads_stale()
@@ -194,16 +186,9 @@ class SDEWrapper(_Base):
             finally:
                 sde.check_nan = check_nan
                 net._dropout_seed_dev = None
-            ent["graph"], ent["loss"], ent["tape"] = graph, loss.detach(), tape
+            ent["graph"], ent["loss"] = graph, loss.detach()
         optim._step += 1                    # after a successful capture: a failed one leaves the step count alone
-        if ent["tape"] is not None:
-            cur, rec = torch.cuda.current_stream(), ent["tape"].stream
-            rec.wait_stream(cur)            # the draws and scalars above were queued on the caller's stream
-            with torch.cuda.stream(rec), torch.no_grad():
-                ent["tape"].replay()
-            cur.wait_stream(rec)
-        else:
-            ent["graph"].replay()
+        ent["graph"].replay()
         optim._after_step()
         optim._opt_called = True          # what LambdaLR's step-order check looks at (optimizer.step() ran)
         self.lr_schedulers().step()

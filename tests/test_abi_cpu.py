@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
         assert s in _lib.SIGNATURES, f"{s} declared in the header but not bound in psld_amd/_lib.py"
     for s in _lib.SIGNATURES:
         assert s in syms, f"{s} bound in Python but not declared in include/psld_hip.h"
-    assert lib.psld_version() == _lib.ABI_VERSION == 12
+    assert lib.psld_version() == _lib.ABI_VERSION == 13
 
 
 def test_error_reporting_without_gpu():
@@ -60,75 +60,38 @@ def test_graft_entry_build_runs():
     g.build()
 
 
-def test_launch_tape_stubs_are_current_and_cover_the_launching_entry_points():
-    """tape_stubs.inc is generated from _lib.SIGNATURES (tools/gen_tape_stubs.py): the committed file is current; the
-    rule that picks the launching entry points (status-returning, stream last) agrees with the header's parameter names;
-    the built library has a stub for each of them and for nothing else."""
-    import subprocess
-    import sys
-    assert subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_tape_stubs.py"), "--check"]).returncode == 0, \
-        "psld_amd/csrc/tape_stubs.inc is stale: run python tools/gen_tape_stubs.py and rebuild"
+def test_launching_entry_points_take_the_stream_last():
+    """Every entry point that enqueues work returns a status and takes `hipStream_t stream` as its last parameter - the
+    rule _lib.is_launch applies to the bound signatures agrees with the header's parameter names."""
     text = open(os.path.join(ROOT, "include", "psld_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    lib = _lib.load()
     n = 0
     for m in re.finditer(r"\b(?:int|void|long long|const char\*|void\*)\s+(psld_[a-z0-9_]+)\s*\(([^;{]*)\)\s*;", text):
         name, params = m.group(1), m.group(2)
         takes_stream = bool(re.search(r"hipStream_t\s+stream\s*$", params.strip()))
         assert _lib.is_launch(name) == takes_stream, name
-        assert (lib.psld_tape_fn_index(name.encode()) >= 0) == takes_stream, name
         n += takes_stream
     assert n >= 70
 
 
-def test_launch_tape_packs_arguments_and_replay_validates_entries():
-    """Host side of the tape without a GPU: argument words (negative ints, floats and doubles as bit patterns,
-    structures copied), and psld_tape_replay rejecting a malformed entry / forwarding a launcher's own status."""
-    import ctypes as C
-    import struct
-    import numpy as np
-    from psld_amd import tape as T
-    lib = _lib.load()
-    tp = T.LaunchTape()
-    epi = _lib.Epilogue()
-    epi.alpha = 0.5
-    name = "psld_gemm_f32"
-    args = (0, 1, -3, 4, 5, 1 << 40, 7, 8, None, 9, 10, 12345, 11, -12, 1, C.byref(epi), None)
-    words = tp._convert(name, args)
-    assert words[2] == 0xFFFFFFFD and words[5] == 1 << 40 and words[8] == 0 and words[13] == (1 << 64) - 12
-    epi.alpha = 2.0                                         # the tape holds a COPY of the structure
-    assert C.cast(words[15], C.POINTER(_lib.Epilogue)).contents.alpha == 0.5
-    w = tp._convert("psld_axpby_f32", (1, 1.5, 2, -0.25, 3, 4, 0, None))
-    assert w[1] == struct.unpack("<I", struct.pack("<f", 1.5))[0] and w[3] == struct.unpack("<I", struct.pack("<f", -0.25))[0]
-    w = tp._convert("psld_ema_f32", (1, 2, 3, 0.9999, None))
-    assert w[3] == struct.unpack("<Q", struct.pack("<d", 0.9999))[0]
-    # replay: a launcher's argument check fires from inside the tape (no launch happens: null pointers)
-    tp.add_launch(lib.psld_tape_fn_index(b"psld_axpby_f32"), "psld_axpby_f32", (None, 1.0, None, 0.0, None, 4, 0, None))
-    tp.finish()
-    kind, arr, ptr, n = tp.segments[0]
-    assert kind == "c" and n == 1 and arr.dtype.itemsize == 8 + 8 * T.MAX_ARGS
-    failed = C.c_int(-1)
-    assert lib.psld_tape_replay(ptr, n, C.byref(failed)) != 0 and failed.value == 0
-    assert b"psld_axpby_f32" in lib.psld_last_error()
-    # a recording tape refuses launches on a stream the step never forked to (ADVICE r03: another thread's launches)
-    class _S:
-        cuda_stream = 0x1000
-    t2 = T.LaunchTape()
-    t2.stream = _S()
-    idx = lib.psld_tape_fn_index(b"psld_axpby_f32")
-    t2.add_launch(idx, "psld_axpby_f32", (None, 1.0, None, 0.0, None, 4, 0, C.c_void_p(0x1000)))
-    t2._streams.update((0x1000, 0x2000))
-    t2.add_launch(idx, "psld_axpby_f32", (None, 1.0, None, 0.0, None, 4, 0, C.c_void_p(0x2000)))
-    try:
-        t2.add_launch(idx, "psld_axpby_f32", (None, 1.0, None, 0.0, None, 4, 0, C.c_void_p(0x3000)))
-        raise AssertionError("a launch on a foreign stream was recorded")
-    except RuntimeError as e:
-        assert "neither the recorded compute stream" in str(e)
-    bad = np.zeros(2, dtype=T.ENTRY)
-    bad["fn"][:] = (lib.psld_tape_fn_index(b"psld_axpby_f32"), 10 ** 6)
-    bad["nargs"][0] = 3                                     # wrong argument count for that function
-    assert lib.psld_tape_replay(bad.ctypes.data, 1, C.byref(failed)) == 1 and b"arguments" in lib.psld_last_error()
-    assert lib.psld_tape_replay(bad.ctypes.data + bad.dtype.itemsize, 1, C.byref(failed)) == 1
+def test_product_switches_are_the_documented_ones():
+    """the product reads a short, documented list of PSLD_* switches - every getenv of the kernel sources
+    and every os.environ read of the package is in INTEGRATION.md's table, and nothing else is."""
+    import glob
+    found = set()
+    for f in glob.glob(os.path.join(ROOT, "psld_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "psld_amd", "csrc", "*.h")):
+        text = open(f).read()
+        text = re.sub(r"#ifdef PSLD_ABLATIONS.*?#endif", "", text, flags=re.S)       # the ablation library's own switches
+        found |= set(re.findall(r'getenv\("(PSLD_[A-Z0-9_]+)"\)', text))
+    for f in glob.glob(os.path.join(ROOT, "psld_amd", "*.py")):
+        found |= set(re.findall(r'environ(?:\.get)?[\[(]\s*"(PSLD_[A-Z0-9_]+)"', open(f).read()))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    listed = set(re.findall(r"^\| `(PSLD_[A-Z0-9_]+)`", doc, flags=re.M))
+    assert found == listed, (sorted(found - listed), sorted(listed - found))
+    kernel_or_policy = found - {"PSLD_HIP_LIB", "PSLD_DIST_TIMEOUT_S", "PSLD_GRAPHS"}
+    assert len(kernel_or_policy) <= 10, sorted(kernel_or_policy)
+    n_getenv = sum(open(f).read().count("getenv(") for f in glob.glob(os.path.join(ROOT, "psld_amd", "csrc", "*.hip")))
+    assert n_getenv <= 12, n_getenv
 
 
 def test_product_library_has_no_ablation_modes():

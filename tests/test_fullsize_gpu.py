@@ -217,11 +217,12 @@ def test_headline_configuration_with_dropout_is_repeatable_and_linear_in_the_bat
     assert e < 5e-6
 
 
-def test_taped_training_step_on_c10_sota_is_bitwise_the_eager_step():
-    """configs[1]'s network at the reference's per-GPU batch of 16 (train_uncond_psld.sh:25-30): the launch-tape step
-    (SDEWrapper.enable_graphs(tape=True): ~1700 launches + the side-stream edges replayed by psld_tape_replay) against
-    the eager step on a twin, dropout 0.15 and EMA on: same losses, parameters, Adam state and EMA bitwise after 5 steps
-    (2 eager, the capture + 2 replays)."""
+def test_graph_captured_training_step_on_c10_sota_is_bitwise_the_eager_step():
+    """configs[1]'s network at the reference's per-GPU batch of 16 (train_uncond_psld.sh:25-30): the hipGraph-captured
+    step (SDEWrapper.enable_graphs: ~1400 launches incl. the weight-gradient side stream and the batched parameter-
+    gradient reductions, whose pointer tables must be the ones of the eager warm-up steps) against the eager step on a
+    twin, dropout 0.15 and EMA on: same losses, parameters, Adam state and EMA bitwise after 5 steps (2 eager, the
+    capture + 2 replays)."""
     import copy
     import psld_amd
     from psld_amd import config as C
@@ -236,14 +237,14 @@ def test_taped_training_step_on_c10_sota_is_bitwise_the_eager_step():
     sde = get_module("sde", "psld")(cfg)
     data = [torch.rand(16, 3, 32, 32, device=DEV, generator=torch.Generator(device=DEV).manual_seed(i)) * 2 - 1 for i in range(5)]
     runs = []
-    for net, tape in ((net_a, False), (net_b, True)):
+    for net, graphs in ((net_a, False), (net_b, True)):
         ema = copy.deepcopy(net)
         for p in ema.parameters():
             p.requires_grad = False
         crit = get_module("losses", "psld_score_loss")(cfg, sde)
         wr = get_module("pl_modules", "sde_wrapper")(cfg, sde, net, ema_score_fn=ema, criterion=crit)
-        if tape:
-            wr.enable_graphs(True, warmup_steps=2, tape=True)
+        if graphs:
+            wr.enable_graphs(True, warmup_steps=2)
         cb = EMAWeightUpdate(cfg.training.ema_decay)
         torch.manual_seed(21)
         losses = []
@@ -252,9 +253,8 @@ def test_taped_training_step_on_c10_sota_is_bitwise_the_eager_step():
             cb.on_train_batch_end(None, wr)
         opt = wr.optimizers()
         runs.append((losses, net.flatten_parameters().clone(), opt._m.clone(), opt._v.clone(), ema.flatten_parameters().clone()))
-        if tape:
-            tp = next(iter(wr._graph_steps.values()))["tape"]
-            assert tp is not None and tp.n_launches > 1000 and tp.n_edges > 10
+        if graphs:
+            assert "graph" in next(iter(wr._graph_steps.values()))
     (la, pa, ma, va, ea), (lb, pb, mb, vb, eb) = runs
     assert la == lb
     assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb) and torch.equal(ea, eb)

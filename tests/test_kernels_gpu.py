@@ -462,55 +462,6 @@ def test_conv3x3_split_dgrad_and_wgrad(ops, cfg):
     assert torch.count_nonzero(slabs[:, :, :, :col0]) == 0
 
 
-@pytest.mark.parametrize("act,drop_p", [(True, 0.0), (True, 0.15), (False, 0.0)])
-def test_gn_backward_pass1_from_the_conv_epilogue(ops, act, drop_p):
-    """psld_epilogue_t.gnb_part: the data-gradient kernel whose output is dy of a GroupNorm(+SiLU, dropout) also emits
-    pass 1 of that GroupNorm's backward (per image / 64-row run / channel: sum dz, sum dz*xhat); psld_gn_bwd_nhwc_f32
-    fed with it (part_in) must reproduce the two-pass result: dx, dgamma, dbeta.  48 images of 32x32: 384 tiles, the
-    smallest grid the by-product is offered on (smaller grids split K and finish in another kernel)."""
-    b, s_, c = 48, 32, 128
-    g = torch.Generator().manual_seed(21)
-    x = torch.randn(b, s_, s_, c, generator=g).to(DEV)                    # the GroupNorm's input
-    gy = torch.randn(b, s_, s_, c, generator=g).to(DEV)                   # upstream gradient fed to the data-gradient conv
-    w = (torch.randn(c, c, 3, 3, generator=g) * 0.05).to(DEV)
-    gamma = (1 + 0.2 * torch.randn(c, generator=g)).to(DEV)
-    beta = (0.1 * torch.randn(c, generator=g)).to(DEV)
-    st = ops.gn_stats(x, gamma, beta)
-    assert ops.gn_bwd_part_supported(b, s_ * s_, c)
-    frag = ops.conv3x3_frag(w, True)
-    seed_dev = torch.tensor([77], device=DEV)
-    # two-pass reference
-    dy0 = torch.empty_like(x)
-    ops.conv3x3_split(gy, None, frag, c, dy0, ops.epilogue(alpha=0.7))
-    dx0, dg0, db0 = torch.empty_like(x), torch.empty(c, device=DEV), torch.empty(c, device=DEV)
-    ops.gn_bwd(dy0, x, st, gamma, beta, act, dx0, dg0, db0, drop_p=drop_p, seed=5, seed_dev=seed_dev)
-    # by-product
-    gnb = ops.gn_bwd_part(x, st, gamma, beta, act, drop_p, 5, seed_dev)
-    gnb["part"].fill_(float("nan"))
-    dy1 = torch.empty_like(x)
-    ops.conv3x3_split(gy, None, frag, c, dy1, ops.epilogue(alpha=0.7, gnb=gnb))
-    assert torch.equal(dy1, dy0) and bool(torch.isfinite(gnb["part"]).all())
-    dx1, dg1, db1 = torch.empty_like(x), torch.empty(c, device=DEV), torch.empty(c, device=DEV)
-    ops.gn_bwd(dy1, x, st, gamma, beta, act, dx1, dg1, db1, drop_p=drop_p, seed=5, seed_dev=seed_dev, part=gnb["part"])
-    e = (rel_l2(dx1, dx0), rel_l2(dg1, dg0), rel_l2(db1, db0))
-    print("gn_bwd from the epilogue's pass 1 vs two passes: dx %.2e dgamma %.2e dbeta %.2e" % e)
-    assert max(e) < 2e-6
-    # the sums themselves against fp64
-    xd, dyd = x.double().cpu(), dy0.double().cpu()
-    mean = xd.view(b, s_ * s_, 32, c // 32).mean(dim=(1, 3))
-    var = xd.view(b, s_ * s_, 32, c // 32).var(dim=(1, 3), unbiased=False)
-    xh = (xd.view(b, s_ * s_, 32, c // 32) - mean[:, None, :, None]) / torch.sqrt(var[:, None, :, None] + 1e-6)
-    xh = xh.reshape(b, s_ * s_, c)
-    if drop_p == 0.0:
-        z = xh * gamma.double().cpu() + beta.double().cpu()
-        sg = torch.sigmoid(z)
-        dz = dyd.view(b, s_ * s_, c) * (sg * (1 + z * (1 - sg)) if act else 1.0)
-        s1 = dz.view(b, 16, 64, c).sum(2)
-        s2 = (dz * xh).view(b, 16, 64, c).sum(2)
-        part = gnb["part"].double().cpu()
-        assert rel_l2(part[:, :, 0], s1) < 2e-6 and rel_l2(part[:, :, 1], s2) < 2e-6
-
-
 @pytest.mark.parametrize("cfg", [
     dict(b=2, ci=128, co=64, h=8, w=8),
     dict(b=3, ci=128, co=128, h=16, w=16),
@@ -925,7 +876,7 @@ def test_groupnorm_fwd_bwd(ops, b, c, s, act):
 def test_groupnorm_backward_lds_image_kernel(ops, b, s, c, variant):
     """gn_bwd_pipe_kernel (resident workgroups, the next slab's x landing in LDS by global_load_lds while the current one is
     reduced and stored) against the register-resident one-slab kernel, selected through psld_set_gn_bwd_kernel: dx,
-    dgamma, dbeta bit for bit; the last image against an fp64 reference.  (Small batches and the variants with a third
+    dgamma, dbeta (sums over the batch of the per-image sums) bit for bit; the last image against an fp64 reference.  (Small batches and the variants with a third
     operand stay on the one-slab kernel either way: they check its batched loads of that operand.)"""
     x = (gen(b, s, s, c, seed=60) * 1.5 + 0.3).to(DEV)
     dy = gen(b, s, s, c, seed=61).to(DEV)
@@ -974,37 +925,92 @@ def test_groupnorm_backward_lds_image_kernel(ops, b, s, c, variant):
 
 
 @pytest.mark.parametrize("b,s,c", [(64, 32, 256), (128, 16, 256), (16, 32, 256), (5, 16, 128), (3, 8, 256), (2, 4, 512), (4, 16, 384)])
-@pytest.mark.parametrize("variant", ["plain", "dropout", "no_act"])
+@pytest.mark.parametrize("variant", ["plain", "dropout", "no_act", "branch", "accumulate", "branch_accumulate"])
 def test_groupnorm_backward_column_sums_of_dx(ops, b, s, c, variant):
-    """psld_gn_bwd_colsum_nhwc_f32: dx, dgamma, dbeta bit for bit those of psld_gn_bwd_nhwc_f32; the per-image column sums of
-    dx (written into a wider buffer) and alpha x their batch total against fp64 sums of the dx it wrote - on every one-pass
-    kernel (1 / 2 / 4 / 16 items per thread, resident workgroups)."""
+    """psld_gn_bwd_nhwc_f32 with colsum_img: dx and the per-image sums bit for bit those of the call without it; the
+    per-image column sums of the dx values it STORED (written into a wider buffer) against fp64 sums of that dx - on every
+    one-pass kernel (1 / 2 / 4 / 16 items per thread, resident workgroups), without a third operand (closed form of the
+    channel sums) and with one (identity branch / previous dx: the stored values summed).  The batch total through both
+    reducers (psld_param_reduce2_f32, psld_param_reduce_batch_f32): bitwise each other, fp64-close."""
     assert ops.gn_bwd_colsum_supported(b, s * s, c)
     x = (gen(b, s, s, c, seed=70) * 1.5 + 0.3).to(DEV)
     dy = gen(b, s, s, c, seed=71).to(DEV)
     gamma, beta = (1 + 0.2 * gen(c, seed=72)).to(DEV), (0.1 * gen(c, seed=73)).to(DEV)
     act = variant != "no_act"
     kw = {"drop_p": 0.15, "seed": 99} if variant == "dropout" else {}
+    if "branch" in variant:
+        kw.update(add=gen(b, s, s, c, seed=74).to(DEV), add_scale=0.5)
+    if "accumulate" in variant:
+        kw["accumulate_dx"] = True
+    base = gen(b, s, s, c, seed=75).to(DEV) if "accumulate" in variant else torch.full_like(x, float("nan"))
     st = ops.gn_stats(x, gamma, beta)
-    dx0 = torch.full_like(x, float("nan"))
+    dx0 = base.clone()
     dg0, db0 = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
-    ops.gn_bwd(dy, x, st, gamma, beta, act, dx0, dg0, db0, **kw)
-    dx1 = torch.full_like(x, float("nan"))
-    dg1, db1 = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    sums0 = ops.gn_bwd(dy, x, st, gamma, beta, act, dx0, dg0, db0, **kw)
+    dx1 = base.clone()
     wide = torch.full((b, c + 24), float("nan"), device=DEV)
     per_image = wide[:, 8:8 + c]
-    total = torch.full((c,), float("nan"), device=DEV)
-    ops.gn_bwd_colsum(dy, x, st, gamma, beta, act, dx1, dg1, db1, total, 0.5, per_image, c + 24, **kw)
-    assert torch.equal(dx1, dx0) and torch.equal(dg1, dg0) and torch.equal(db1, db0)
+    sums1 = ops.gn_bwd(dy, x, st, gamma, beta, act, dx1, colsum_img=per_image, ld_img=c + 24, **kw)
+    assert torch.equal(dx1, dx0) and torch.equal(sums1, sums0)
     assert torch.isnan(wide[:, :8]).all() and torch.isnan(wide[:, 8 + c:]).all()
     want_img = dx0.double().sum(dim=(1, 2))
     scale = dx0.double().abs().sum(dim=(1, 2)).clamp_min(1e-30)       # a column sum cancels: compare against the sum of magnitudes
     assert ((per_image.double() - want_img).abs() / scale).max().item() < 2e-6
+    # dgamma / dbeta / the bias gradient = sums over the batch: two-job launch vs the table-driven one, and fp64
+    total = torch.full((c,), float("nan"), device=DEV)
+    ops.param_reduce2(per_image, None, b, c + 24, c, total, None, 0.5)
     assert ((total.double() - 0.5 * want_img.sum(0)).abs() / (0.5 * scale.sum(0))).max().item() < 2e-6
-    # the total alone (the per-image sums in the workspace)
-    total2 = torch.full((c,), float("nan"), device=DEV)
-    ops.gn_bwd_colsum(dy, x, st, gamma, beta, act, dx1, dg1, db1, total2, 0.5, None, 0, **kw)
-    assert torch.equal(total2, total)
+    dg1, db1, tot1, tot2 = (torch.full((c,), float("nan"), device=DEV) for _ in range(4))
+    jobs = [ops.param_job(sums1, b, 2 * c, c, db1), ops.param_job(sums1, b, 2 * c, c, dg1, src_off=c),
+            ops.param_job(per_image, b, c + 24, c, tot1, tot2, 0.5)]
+    rows, blocks = [], 0
+    for j in jobs:
+        rows += list(j) + [blocks]
+        blocks += (c + 63) // 64
+    ops.param_reduce_batch(torch.tensor(rows, dtype=torch.int64, device=DEV), len(jobs), blocks)
+    assert torch.equal(dg1, dg0) and torch.equal(db1, db0) and torch.equal(tot1, total) and torch.equal(tot2, total)
+    assert rel_l2(db0, sums0[:, 0].double().sum(0)) < 1e-6 and rel_l2(dg0, sums0[:, 1].double().sum(0)) < 1e-6
+
+
+def test_split_k_slab_reductions_in_one_launch(ops):
+    """psld_reduce_slabs_batch_f32: many weight gradients' split-K slabs reduced by one launch, bit for bit the per-layer
+    psld_reduce_slabs_f32 calls - plain and OIHW-scattering layouts, slab counts 1 / 3 / 6 / 11, job boundaries that fall
+    inside a workgroup's range of items."""
+    shapes = [(64, 9, 64, 6, 1, 0.7), (128, 1, 128, 3, 0, 1.0), (64, 9, 128, 11, 1, 1.0), (32, 1, 36, 1, 0, 0.5),
+              (128, 9, 64, 3, 1, 2.0), (256, 1, 256, 6, 0, 1.0)]
+    jobs, want, outs, keep = [], [], [], []
+    for i, (co, taps, ci, ns, layout, alpha) in enumerate(shapes):
+        n = co * taps * ci
+        slabs = gen(ns, n, seed=300 + i).to(DEV)
+        ref = torch.full((n,), float("nan"), device=DEV)
+        ops.reduce_slabs(slabs, ns, n, ref, layout=layout, cout=co, taps=taps, cin=ci, alpha=alpha)
+        out = torch.full((n,), float("nan"), device=DEV)
+        jobs.append(ops.slab_job(slabs, ns, n, out, layout, taps, ci, alpha))
+        want.append(ref)
+        outs.append(out)
+        keep.append(slabs)
+    rows, items = [], 0
+    for j in jobs:
+        rows += list(j) + [items, 0]
+        items += j[2] // 4
+    ops.reduce_slabs_batch(torch.tensor(rows, dtype=torch.int64, device=DEV), len(jobs), items)
+    for got, ref in zip(outs, want):
+        assert torch.equal(got, ref)
+    assert rel_l2(want[1], keep[1].double().sum(0)) < 1e-6
+
+
+def test_bias_gradients_of_three_projections_in_one_pass(ops):
+    """psld_bias_grad_seg_f32: the q | k | v bias gradients from one pass over the [rows][3c] gradient buffer, bitwise the
+    three psld_bias_grad_f32 calls on its column slices."""
+    b, hw, c = 6, 64, 256
+    d = gen(b, hw, 3 * c, seed=310).to(DEV)
+    outs = [torch.full((c,), float("nan"), device=DEV) for _ in range(3)]
+    ops.bias_grad_seg(d, 3 * c, b, hw, outs, c, 0.5)
+    for k in range(3):
+        ref = torch.full((c,), float("nan"), device=DEV)
+        ops.bias_grad(d[..., k * c:], 3 * c, b, hw, c, ref, 0.5)
+        assert torch.equal(outs[k], ref)
+        assert rel_l2(ref, 0.5 * d[..., k * c:(k + 1) * c].double().sum(dim=(0, 1))) < 1e-6
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -1139,9 +1139,8 @@ def test_vpsde_score_loss_weightings_match_reference(golden, tag):
         get_module("losses", "score_loss")(cfg, sde)
 
 
-@pytest.mark.parametrize("tape", [False, True], ids=["graph", "tape"])
 @pytest.mark.parametrize("dropout", [0.0, 0.15])
-def test_graph_captured_training_step_is_bitwise_the_eager_step(dropout, tape):
+def test_graph_captured_training_step_is_bitwise_the_eager_step(dropout):
     """SDEWrapper.enable_graphs: the hipGraph-captured training step (perturb + forward + loss + backward tape + norm +
     clip + Adam, replayed as one launch) against the eager step on a twin network: same seeds -> the same random draws
     in the same order (they are made outside the graph) -> bitwise equal losses, parameters, Adam state and EMA after
@@ -1167,7 +1166,7 @@ def test_graph_captured_training_step_is_bitwise_the_eager_step(dropout, tape):
         crit = get_module("losses", "psld_score_loss")(cfg, sde)
         wr = get_module("pl_modules", "sde_wrapper")(cfg, sde, net, ema_score_fn=ema, criterion=crit)
         if graphs:
-            wr.enable_graphs(True, warmup_steps=2, tape=tape)
+            wr.enable_graphs(True, warmup_steps=2)
         cb = EMAWeightUpdate(cfg.training.ema_decay)
         torch.manual_seed(11)
         losses = []
@@ -1180,13 +1179,6 @@ def test_graph_captured_training_step_is_bitwise_the_eager_step(dropout, tape):
         if graphs:
             ent = next(iter(wr._graph_steps.values()))
             assert "graph" in ent                                            # the captured path really ran
-            if tape:    # ... and what was replayed is the launch tape: launches, side-stream edges, few ATen segments
-                tp = ent["tape"]
-                print("tape:", tp.n_launches, "launches,", tp.n_edges, "edges,", len(tp.segments), "segments; ATen:", tp.aten_ops)
-                assert tp.n_launches > 100 and len(tp.aten_ops) < 40
-                assert tp.n_edges >= 2 if net._side is not None else tp.n_edges == 0      # PSLD_OVERLAP_WGRAD=0: one stream
-            else:
-                assert ent["tape"] is None
     (la, pa, ma, va, ea, sa, lra), (lb, pb, mb, vb, eb, sb, lrb) = runs
     print("eager  losses", la)
     print("graph  losses", lb)
@@ -1199,43 +1191,7 @@ def test_graph_captured_training_step_is_bitwise_the_eager_step(dropout, tape):
         assert torch.equal(net_a(x, tt), net_b(x, tt))
 
 
-def test_launch_tape_stubs_issue_the_eager_step_bitwise():
-    """Every launching entry point through its generated C stub (psld_tape_replay on one entry, tape.through_stubs)
-    instead of the ctypes call: an eager training step issued that way equals the plain eager twin bitwise - argument
-    packing (negative ints, float / double bit patterns, copied structures, the FIR taps' host pointer) for every entry
-    point the step uses."""
-    import psld_amd
-    psld_amd.import_modules_into_registry()
-    from psld_amd import tape as T
-    from psld_amd.registry import get_module
-    cfg = C.tiny(nf=128, ch_mult=(1, 1), attn_resolutions=(16,))
-    cfg.model.score_fn.dropout = 0.15
-    torch.manual_seed(3)
-    net_a = get_module("score_fn", "ncsnpp")(cfg).to(DEV).train()
-    net_b = copy.deepcopy(net_a)
-    sde = get_module("sde", "psld")(cfg)
-    data = [torch.rand(4, 3, 16, 16, device=DEV, generator=torch.Generator(device=DEV).manual_seed(i)) * 2 - 1 for i in range(3)]
-    runs = []
-    for net, stubs in ((net_a, False), (net_b, True)):
-        crit = get_module("losses", "psld_score_loss")(cfg, sde)
-        wr = get_module("pl_modules", "sde_wrapper")(cfg, sde, net, criterion=crit)
-        torch.manual_seed(11)
-        losses = []
-        for i in range(3):
-            if stubs:
-                tp = T.LaunchTape()
-                tp.through_stubs = True
-                with T.record(tp):
-                    losses.append(wr.training_step(data[i], i).item())
-                assert tp.n_launches > 100
-            else:
-                losses.append(wr.training_step(data[i], i).item())
-        runs.append((losses, net.flatten_parameters().clone()))
-    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
-
-
-@pytest.mark.parametrize("tape", [False, True], ids=["graph", "tape"])
-def test_graph_replays_without_host_syncs_track_the_lr_schedule(tape):
+def test_graph_replays_without_host_syncs_track_the_lr_schedule():
     """with no host read per step the host runs many replays ahead of the GPU; the step-dependent Adam
     scalars (LR warm-up, bias corrections) must still be the ones of THEIR step.  14 steps (2 eager, 12 captured), the
     losses read back only at the end, LR changing on every step, an eager step after the replays (its dropout masks
@@ -1256,7 +1212,7 @@ def test_graph_replays_without_host_syncs_track_the_lr_schedule(tape):
         crit = get_module("losses", "psld_score_loss")(cfg, sde)
         wr = get_module("pl_modules", "sde_wrapper")(cfg, sde, net, criterion=crit)
         if graphs:
-            wr.enable_graphs(True, warmup_steps=2, tape=tape)
+            wr.enable_graphs(True, warmup_steps=2)
         torch.manual_seed(13)
         losses = [wr.training_step(data[i], i).clone() for i in range(14)]        # no .item(): nothing syncs per step
         if graphs:
@@ -1335,8 +1291,9 @@ def test_input_gradient_matches_oracle():
 @pytest.mark.parametrize("name", ["tiny", "tiny_ablation"])
 def test_side_stream_weight_gradients_are_bitwise_the_single_stream_ones(name):
     """Parameter-gradient kernels on the side stream (the default below 64k pixels per batch), forked one call at a
-    time, in groups, or all at the end: every kernel is deterministic, so the flat gradient must not change by a bit;
-    a stale or early read on the side stream would."""
+    time, in groups, or all at the end; dgamma / dbeta / bias gradients / split-K slab reductions parked and reduced by
+    one launch per kind (the default) or per layer: every kernel is deterministic, so the flat gradient must not change
+    by a bit; a stale or early read on the side stream - or a parked slab overwritten before its reduction - would."""
     net, cfg, _ = _build(name, train=True)
     size = cfg.data.image_size
     g = torch.Generator().manual_seed(23)
@@ -1344,8 +1301,10 @@ def test_side_stream_weight_gradients_are_bitwise_the_single_stream_ones(name):
     t = (torch.rand(3, generator=g) * 0.9 + 0.05).to(DEV)
     gy = torch.randn(3, 6, size, size, generator=g)
     grads = {}
-    for tag, overlap, group in (("off", False, 1), ("each", True, 1), ("grouped", True, 4), ("at the end", True, 10 ** 6)):
-        net.overlap_wgrad, net.side_group = overlap, group
+    for tag, overlap, group, defer in (("off", False, 1, True), ("each", True, 1, True), ("grouped", True, 4, True),
+                                       ("at the end", True, 10 ** 6, True), ("off, reductions per layer", False, 1, False),
+                                       ("grouped, reductions per layer", True, 4, False)):
+        net.overlap_wgrad, net.side_group, net.defer_param_grads = overlap, group, defer
         for p in net.parameters():
             p.grad = None
         y = net(x, t)
@@ -1353,9 +1312,9 @@ def test_side_stream_weight_gradients_are_bitwise_the_single_stream_ones(name):
         torch.cuda.synchronize()
         grads[tag] = net.flat_grad().clone()
         assert bool(torch.isfinite(grads[tag]).all())
-    for tag in ("each", "grouped", "at the end"):
+    for tag in grads:       # ... and the batched dgamma / dbeta / bias / split-K reductions are those of the per-layer launches
         assert torch.equal(grads[tag], grads["off"]), tag
-    net.overlap_wgrad = None
+    net.overlap_wgrad, net.side_group, net.defer_param_grads = None, 32, True
 
 
 def test_nan_check_runs_early_and_still_raises():
