@@ -364,6 +364,12 @@ class _Exec:
         self.on_side(self.flush_slabs)
         self.flush_params()
 
+    def finish_backward(self):
+        """After the last entry of the backward tape: the parked reductions, then the side stream joins."""
+        if self.defer:
+            self.flush_deferred()
+        self.join_side()
+
     def gn_backward(self, dy: Tensor, x: Tensor, st, gamma: Tensor, beta: Tensor, dgamma: Tensor, dbeta: Tensor, act: bool,
                     dx: Tensor, accumulate_dx: bool = False, add: Optional[Tensor] = None, add_scale: float = 1.0,
                     drop_p: float = 0.0, seed: int = 0, seed_dev=None, groups: Optional[int] = None,
@@ -1320,9 +1326,7 @@ class _Exec:
                     self.flush_deferred()       # a bucket is about to be exchanged: its parked reductions first
                 self.flush_side()       # the reducer may launch a bucket now: its gradients must at least be enqueued
                 self.watermark(off)
-        if self.defer:
-            self.flush_deferred()
-        self.join_side()
+        self.finish_backward()
         self.tape = None
 
 

@@ -70,9 +70,11 @@ class Harness:
         net._begin_backward()
         out_node.g = gy_nhwc.contiguous()
         with self.ops.stream_scope():
+            if ex.defer:
+                net._param_arena().reset()
             for fn, _ in reversed(ex.tape):
                 fn()
-            ex.join_side()
+            ex.finish_backward()
         ex.tape = None
         net._end_backward()
         torch.cuda.synchronize()
