@@ -409,6 +409,9 @@ def parse_args():
     ap.add_argument("--launch-check", action="store_true",
                     help="form the process group, all-reduce ones, print the JSON line and exit (no model work; runs on "
                          "CPU with gloo: how the self-launch path is tested without a GPU)")
+    ap.add_argument("--per-layer-reductions", action="store_true",
+                    help="A/B: dgamma / dbeta / bias / split-K slab reductions launched per layer (NCSNpp.defer_param_grads = "
+                         "False) instead of one batched launch per pass; recorded in the JSON line")
     ap.add_argument("--no-partial-sample", action="store_true",
                     help="skip the second sampling run (the last, partial batch of a GPU's shard of the 50 000 samples)")
     ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("PSLD_LAUNCH_TIMEOUT_S", "1500")),
@@ -579,6 +582,8 @@ def main():
     size = cfg.data.image_size
     torch.manual_seed(cfg.training.seed)                      # same seed on every rank (train_sde.py:29)
     net = get_module("score_fn", "ncsnpp")(cfg).to(dev).train()
+    if args.per_layer_reductions:
+        net.defer_param_grads = False
     ema = copy.deepcopy(net)
     for p in ema.parameters():
         p.requires_grad = False
@@ -784,6 +789,7 @@ def main():
             out["sampling"] = sampling
         out["cpu_baseline"] = cpu_base
         out["env"] = psld_env()
+        out["options"] = {"per_layer_reductions": bool(args.per_layer_reductions), "graphs": bool(args.graphs)}
         import ctypes
         ctypes.CDLL(None).fflush(None)
         sys.stdout.flush()

@@ -315,8 +315,7 @@ class _Exec:
         """dst1 (and dst2) [c] = alpha * sum over ``rows`` rows of ``src`` (row stride ld): now, or with every other such
         reduction of the pass in one launch (flush_params)."""
         if not self.defer:
-            flat = src.reshape(-1)[src_off:]
-            ops.param_reduce2(flat, None, rows, ld, c, dst1, None, alpha)
+            ops.param_reduce2(src if src_off == 0 else src.view(-1)[src_off:], None, rows, ld, c, dst1, None, alpha)
             if dst2 is not None:
                 ops.axpby(dst1, 1.0, None, 0.0, dst2)
             return

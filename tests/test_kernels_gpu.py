@@ -1000,8 +1000,9 @@ def test_split_k_slab_reductions_in_one_launch(ops):
 
 
 def test_bias_gradients_of_three_projections_in_one_pass(ops):
-    """psld_bias_grad_seg_f32: the q | k | v bias gradients from one pass over the [rows][3c] gradient buffer, bitwise the
-    three psld_bias_grad_f32 calls on its column slices."""
+    """psld_bias_grad_seg_f32: the q | k | v bias gradients from one pass over the [rows][3c] gradient buffer against fp64
+    column sums and the three psld_bias_grad_f32 calls on its column slices (the pixel lanes per thread differ with the
+    width of the pass, so the fp32 partial sums round differently: compared relative to the sum of magnitudes)."""
     b, hw, c = 6, 64, 256
     d = gen(b, hw, 3 * c, seed=310).to(DEV)
     outs = [torch.full((c,), float("nan"), device=DEV) for _ in range(3)]
@@ -1009,8 +1010,10 @@ def test_bias_gradients_of_three_projections_in_one_pass(ops):
     for k in range(3):
         ref = torch.full((c,), float("nan"), device=DEV)
         ops.bias_grad(d[..., k * c:], 3 * c, b, hw, c, ref, 0.5)
-        assert torch.equal(outs[k], ref)
-        assert rel_l2(ref, 0.5 * d[..., k * c:(k + 1) * c].double().sum(dim=(0, 1))) < 1e-6
+        sl = d[..., k * c:(k + 1) * c].double()
+        want, scale = 0.5 * sl.sum(dim=(0, 1)), 0.5 * sl.abs().sum(dim=(0, 1))
+        assert ((outs[k].double() - want).abs() / scale).max().item() < 1e-6
+        assert ((ref.double() - want).abs() / scale).max().item() < 1e-6
 
 
 # ---------------------------------------------------------------------------------------------------
