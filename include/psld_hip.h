@@ -332,10 +332,13 @@ int psld_gn_bwd_colsum_supported(int batch, int hw, int c, int groups);
 int psld_param_reduce2_f32(const float* src_a, const float* src_b, int rows, int ld, int c, float* dst_a, float* dst_b,
                            float alpha, hipStream_t stream);
 int psld_param_reduce_batch_f32(const long long* table_dev, int jobs, int blocks, hipStream_t stream);
-/* Split-K slab reductions of MANY weight gradients in one launch (psld_reduce_slabs_f32 per job): rows of a DEVICE table of
- * 10 int64 [slabs pointer, nsplit, n, out pointer, layout, taps, cin, bit pattern of (float) alpha, first float4 item, 0];
- * every job needs n and cin multiples of 4 and 16-byte aligned slabs; items = sum of n / 4. */
-int psld_reduce_slabs_batch_f32(const long long* table_dev, int jobs, long long items, hipStream_t stream);
+/* Split-K slab reductions of MANY weight gradients in one launch (psld_reduce_slabs_f32 per job, bitwise the same sums): rows of
+ * a DEVICE table of 10 int64 [slabs pointer, nsplit, n, out pointer, layout, taps, cin, bit pattern of (float) alpha, first
+ * unit, units]; a job has psld_reduce_slabs_batch_units(n, layout, taps, cin) units (0: the job does not qualify - n and cin
+ * must be multiples of 4, taps <= 9; slabs 16-byte aligned); units = their sum.  With layout 1 the OIHW scatter goes through
+ * LDS and leaves as contiguous 16-byte stores. */
+int psld_reduce_slabs_batch_units(long long n, int layout, int taps, int cin);
+int psld_reduce_slabs_batch_f32(const long long* table_dev, int jobs, long long units, hipStream_t stream);
 
 
 /* ---- FIR resampling: the replacement of the pybind op upfirdn2d_op.upfirdn2d

@@ -124,6 +124,7 @@ SIGNATURES = {
     "psld_gn_bwd_colsum_supported": (I, [I, I, I, I]),
     "psld_param_reduce2_f32": (I, [P, P, I, I, I, P, P, F, P]),
     "psld_param_reduce_batch_f32": (I, [P, I, I, P]),
+    "psld_reduce_slabs_batch_units": (I, [LL, I, I, I]),
     "psld_reduce_slabs_batch_f32": (I, [P, I, LL, P]),
     "psld_upfirdn2d_f32": (I, [P, P, I, I, I, I, P, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "psld_fused_bias_act_f32": (I, [P, P, P, LL, I, I, I, F, F, P]),

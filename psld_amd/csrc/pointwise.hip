@@ -112,60 +112,76 @@ __global__ void reduce_slabs4_kernel(const float* __restrict__ slabs, int nsplit
 }
 
 // The same reduction for MANY weight gradients in one launch: rows of a device table
-// [slabs, nsplit, n, out, layout, taps, cin, alpha bits, first float4 item, 0].  A workgroup owns 2048 consecutive float4
-// items (eight per thread, 256 apart), so it looks its job up once (binary search on the first items) and afterwards only
-// steps to the next row when its items run past the current one; within an item the slabs are added in slab order exactly
-// like reduce_slabs4_kernel (bitwise the per-layer launches).
-__global__ void __launch_bounds__(256) reduce_slabs_batch_kernel(const long long* __restrict__ table, int jobs, long long items) {
-    const long long chunk0 = (long long)blockIdx.x * 2048;
-    int lo = 0, hi = jobs - 1;                 // last job whose first item <= chunk0 (uniform: scalar loads)
+// [slabs, nsplit, n, out, layout, taps, cin, alpha bits, first unit, units].  A workgroup owns one UNIT of one job, found by
+// binary search on the first units (block-uniform: scalar loads):
+//   layout 0:  1024 consecutive float4 of the [n] vector (four per thread, 256 apart);
+//   layout 1:  one output channel x up to 256 input channels x all taps.  The slabs hold [co][tap][ci]; the gradient wants
+//              OIHW = [co][ci][tap].  The per-thread scatter of reduce_slabs4_kernel writes single floats `taps` apart -
+//              32-byte memory transactions for 4 useful bytes - so here the summed [tap][ci] tile goes through LDS and
+//              leaves as the contiguous [ci][tap] run it is in the output (16-byte stores).
+// Within a float4 the slabs are added in slab order exactly like reduce_slabs4_kernel: bitwise the per-layer launches.
+__device__ __forceinline__ f32x4 sum_slabs4(const f32x4* __restrict__ p, int nsplit, long long n4) {
+    f32x4 acc = p[0];
+    int s = 1;
+    for (; s + 3 < nsplit; s += 4) {            // four independent loads in flight; the sum stays in slab order
+        const f32x4 v0 = p[(long long)s * n4], v1 = p[(long long)(s + 1) * n4];
+        const f32x4 v2 = p[(long long)(s + 2) * n4], v3 = p[(long long)(s + 3) * n4];
+        acc += v0;
+        acc += v1;
+        acc += v2;
+        acc += v3;
+    }
+    for (; s < nsplit; ++s) acc += p[(long long)s * n4];
+    return acc;
+}
+
+constexpr int RSB_FLAT4 = 1024;     // float4 per unit of a layout-0 job
+constexpr int RSB_CI = 256;         // input channels per unit of a layout-1 job
+constexpr int RSB_MAXTAPS = 9;
+
+__global__ void __launch_bounds__(256) reduce_slabs_batch_kernel(const long long* __restrict__ table, int jobs) {
+    __shared__ __attribute__((aligned(16))) float tile[RSB_CI * RSB_MAXTAPS];      // [ci][tap]
+    int lo = 0, hi = jobs - 1;                 // last job whose first unit <= blockIdx.x
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if (table[(long long)mid * 10 + 8] <= chunk0) lo = mid; else hi = mid - 1;
+        if (table[(long long)mid * 10 + 8] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
     }
-    int j = lo;
-    long long first = table[(long long)j * 10 + 8];
-    long long n4 = table[(long long)j * 10 + 2] >> 2;
-#pragma unroll 1
-    for (int k = 0; k < 8; ++k) {
-        const long long item = chunk0 + k * 256 + threadIdx.x;
-        if (item >= items) break;
-        while (item >= first + n4) {
-            ++j;
-            first = table[(long long)j * 10 + 8];
-            n4 = table[(long long)j * 10 + 2] >> 2;
-        }
-        const long long* row = table + (long long)j * 10;
-        const long long q = item - first;
-        const int nsplit = (int)row[1];
-        const f32x4* p = reinterpret_cast<const f32x4*>(row[0]) + q;
-        f32x4 acc = p[0];
-        int sidx = 1;
-        for (; sidx + 3 < nsplit; sidx += 4) {
-            const f32x4 v0 = p[(long long)sidx * n4], v1 = p[(long long)(sidx + 1) * n4];
-            const f32x4 v2 = p[(long long)(sidx + 2) * n4], v3 = p[(long long)(sidx + 3) * n4];
-            acc += v0;
-            acc += v1;
-            acc += v2;
-            acc += v3;
-        }
-        for (; sidx < nsplit; ++sidx) acc += p[(long long)sidx * n4];
-        acc *= __builtin_bit_cast(float, (unsigned)row[7]);
-        float* out = reinterpret_cast<float*>(row[3]);
-        const long long i = q << 2;
-        if (row[4] == 1) {  // [co][tap][ci] -> [co][ci][tap]
-            const int taps = (int)row[5], cin = (int)row[6];
-            const int ci = (int)(i % cin);
-            const long long t = i / cin;
-            const int tap = (int)(t % taps);
-            const long long co = t / taps;
-            float* o = out + (co * cin + ci) * taps + tap;
+    const long long* row = table + (long long)lo * 10;
+    const int unit = (int)((long long)blockIdx.x - row[8]);
+    const int nsplit = (int)row[1];
+    const long long n4 = row[2] >> 2;
+    const f32x4* slabs = reinterpret_cast<const f32x4*>(row[0]);
+    float* out = reinterpret_cast<float*>(row[3]);
+    const float alpha = __builtin_bit_cast(float, (unsigned)row[7]);
+    const int tid = threadIdx.x;
+    if (row[4] != 1) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[(long long)e * taps] = acc[e];
-        } else {
-            reinterpret_cast<f32x4*>(out)[q] = acc;
+        for (int k = 0; k < RSB_FLAT4 / 256; ++k) {
+            const long long q = (long long)unit * RSB_FLAT4 + k * 256 + tid;
+            if (q < n4) {
+                f32x4 acc = sum_slabs4(slabs + q, nsplit, n4);
+                acc *= alpha;
+                reinterpret_cast<f32x4*>(out)[q] = acc;
+            }
         }
+        return;
     }
+    const int taps = (int)row[5], cin = (int)row[6];
+    const int chunks = (cin + RSB_CI - 1) / RSB_CI;
+    const int co = unit / chunks, c0 = (unit - co * chunks) * RSB_CI;
+    const int cw = min(RSB_CI, cin - c0), cw4 = cw >> 2;             // cin % 4 == 0
+    const f32x4* src = slabs + (((long long)co * taps) * cin + c0) / 4;
+    for (int j = tid; j < taps * cw4; j += 256) {
+        const int tap = j / cw4, q = j - tap * cw4;
+        f32x4 acc = sum_slabs4(src + (long long)tap * (cin >> 2) + q, nsplit, n4);
+        acc *= alpha;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[(q * 4 + e) * taps + tap] = acc[e];
+    }
+    __syncthreads();
+    // out[(co*cin + c0 + ci)*taps + tap]: cw*taps contiguous floats starting at (co*cin + c0)*taps (a multiple of 4)
+    f32x4* dst = reinterpret_cast<f32x4*>(out + ((long long)co * cin + c0) * taps);
+    for (int j = tid; j < (cw * taps) >> 2; j += 256) dst[j] = *reinterpret_cast<const f32x4*>(tile + 4 * j);
 }
 
 // dst[col] = alpha * sum_r src[r * ld + col]: parameter gradients that are sums over the batch (GroupNorm dgamma / dbeta from
@@ -743,10 +759,18 @@ extern "C" int psld_reduce_slabs_f32(const float* slabs, int nsplit, long long n
     return PSLD_OK;
 }
 
-extern "C" int psld_reduce_slabs_batch_f32(const long long* table_dev, int jobs, long long items, hipStream_t stream) {
-    PSLD_CHECK_ARG(table_dev && jobs > 0 && items > 0, "psld_reduce_slabs_batch_f32: bad args");
-    hipLaunchKernelGGL(reduce_slabs_batch_kernel, dim3((unsigned)((items + 2047) / 2048)), dim3(256), 0, stream, table_dev, jobs,
-                       items);
+extern "C" int psld_reduce_slabs_batch_units(long long n, int layout, int taps, int cin) {
+    if (n <= 0 || n % 4) return 0;
+    if (layout == 1) {
+        if (taps < 1 || taps > RSB_MAXTAPS || cin < 4 || cin % 4 || n % ((long long)taps * cin)) return 0;
+        return (int)(n / ((long long)taps * cin)) * ((cin + RSB_CI - 1) / RSB_CI);
+    }
+    return (int)((n / 4 + RSB_FLAT4 - 1) / RSB_FLAT4);
+}
+
+extern "C" int psld_reduce_slabs_batch_f32(const long long* table_dev, int jobs, long long units, hipStream_t stream) {
+    PSLD_CHECK_ARG(table_dev && jobs > 0 && units > 0 && units < (1ll << 31), "psld_reduce_slabs_batch_f32: bad args");
+    hipLaunchKernelGGL(reduce_slabs_batch_kernel, dim3((unsigned)units), dim3(256), 0, stream, table_dev, jobs);
     PSLD_CHECK_LAUNCH("psld_reduce_slabs_batch_f32");
     return PSLD_OK;
 }

@@ -615,16 +615,22 @@ def param_reduce_batch(table: Tensor, jobs: int, blocks: int):
     check(lib().psld_param_reduce_batch_f32(table.data_ptr(), jobs, blocks, _stream()), "psld_param_reduce_batch_f32")
 
 
+@functools.lru_cache(maxsize=None)
+def slab_units(n: int, layout: int, taps: int, cin: int) -> int:
+    """Work units of a job of ``reduce_slabs_batch`` (0: the job does not qualify for the batched kernel)."""
+    return int(lib().psld_reduce_slabs_batch_units(n, layout, taps, cin))
+
+
 def slab_job(slabs: Tensor, nsplit: int, n: int, out: Tensor, layout: int = 0, taps: int = 1, cin: int = 1,
              alpha: float = 1.0):
-    """Table row (without the running item index) of ``reduce_slabs_batch`` equivalent to reduce_slabs(...)."""
-    assert n % 4 == 0 and (layout == 0 or cin % 4 == 0) and slabs.data_ptr() % 16 == 0
+    """Table row (without the running unit index and the unit count) of ``reduce_slabs_batch`` equivalent to reduce_slabs(...)."""
+    assert slab_units(n, layout, taps, cin) > 0 and slabs.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0
     return (slabs.data_ptr(), nsplit, n, out.data_ptr(), layout, taps, cin, _f32_bits(alpha))
 
 
-def reduce_slabs_batch(table: Tensor, jobs: int, items: int):
-    """table rows: slab_job(...) + (first float4 item, 0); a job has n / 4 items."""
-    check(lib().psld_reduce_slabs_batch_f32(table.data_ptr(), jobs, items, _stream()), "psld_reduce_slabs_batch_f32")
+def reduce_slabs_batch(table: Tensor, jobs: int, units: int):
+    """table rows: slab_job(...) + (first unit, units of the job = slab_units(...))."""
+    check(lib().psld_reduce_slabs_batch_f32(table.data_ptr(), jobs, units, _stream()), "psld_reduce_slabs_batch_f32")
 
 
 class Arena:

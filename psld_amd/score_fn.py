@@ -339,11 +339,12 @@ class _Exec:
 
     def reduce_slabs(self, slabs: Tensor, nsplit: int, n: int, out: Tensor, layout: int = 0, cout: int = 1, taps: int = 1,
                      cin: int = 1, alpha: float = 1.0):
-        if not self.defer or n % 4 or (layout == 1 and cin % 4):
+        units = ops.slab_units(n, layout, taps, cin) if self.defer else 0
+        if units == 0 or out.data_ptr() % 16:
             ops.reduce_slabs(slabs, nsplit, n, out, layout=layout, cout=cout, taps=taps, cin=cin, alpha=alpha)
             return
-        self.sjobs.append(ops.slab_job(slabs, nsplit, n, out, layout, taps, cin, alpha) + (self.sitems, 0))
-        self.sitems += n // 4
+        self.sjobs.append(ops.slab_job(slabs, nsplit, n, out, layout, taps, cin, alpha) + (self.sitems, units))
+        self.sitems += units
         self.sbytes += 4 * n * nsplit
         if self.sbytes >= _SLAB_FLUSH_BYTES:
             self.flush_slabs()

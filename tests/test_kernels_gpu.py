@@ -974,10 +974,10 @@ def test_groupnorm_backward_column_sums_of_dx(ops, b, s, c, variant):
 
 def test_split_k_slab_reductions_in_one_launch(ops):
     """psld_reduce_slabs_batch_f32: many weight gradients' split-K slabs reduced by one launch, bit for bit the per-layer
-    psld_reduce_slabs_f32 calls - plain and OIHW-scattering layouts, slab counts 1 / 3 / 6 / 11, job boundaries that fall
-    inside a workgroup's range of items."""
+    psld_reduce_slabs_f32 calls - plain and OIHW-scattering layouts (through LDS: whole and partial 256-channel chunks, 1 and 9
+    taps), slab counts 1 ... 11."""
     shapes = [(64, 9, 64, 6, 1, 0.7), (128, 1, 128, 3, 0, 1.0), (64, 9, 128, 11, 1, 1.0), (32, 1, 36, 1, 0, 0.5),
-              (128, 9, 64, 3, 1, 2.0), (256, 1, 256, 6, 0, 1.0)]
+              (128, 9, 64, 3, 1, 2.0), (256, 1, 256, 6, 0, 1.0), (16, 9, 512, 5, 1, 1.0), (8, 9, 36, 2, 1, 1.0), (130, 1, 96, 4, 1, 1.0)]
     jobs, want, outs, keep = [], [], [], []
     for i, (co, taps, ci, ns, layout, alpha) in enumerate(shapes):
         n = co * taps * ci
@@ -989,11 +989,13 @@ def test_split_k_slab_reductions_in_one_launch(ops):
         want.append(ref)
         outs.append(out)
         keep.append(slabs)
-    rows, items = [], 0
+    rows, units = [], 0
     for j in jobs:
-        rows += list(j) + [items, 0]
-        items += j[2] // 4
-    ops.reduce_slabs_batch(torch.tensor(rows, dtype=torch.int64, device=DEV), len(jobs), items)
+        u = ops.slab_units(j[2], j[4], j[5], j[6])
+        assert u > 0
+        rows += list(j) + [units, u]
+        units += u
+    ops.reduce_slabs_batch(torch.tensor(rows, dtype=torch.int64, device=DEV), len(jobs), units)
     for got, ref in zip(outs, want):
         assert torch.equal(got, ref)
     assert rel_l2(want[1], keep[1].double().sum(0)) < 1e-6
