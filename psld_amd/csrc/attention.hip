@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(64 * QW, 2) attn_fwd_kernel(const AttnArgs a) 
 template <int HW, int C, int QW>
 int launch_attn(const AttnArgs& a, int batch, hipStream_t stream) {
     constexpr size_t PH1 = (size_t)3 * (HW + 16 * QW) * ROWB, PH3 = (size_t)3 * 32 * (C * 2 + 32), LDS = PH1 > PH3 ? PH1 : PH3;
-    static bool configured = false;
+    static PsldPerDeviceFlag configured_; bool& configured = configured_.here();
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<HW, C, QW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);

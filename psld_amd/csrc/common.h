@@ -32,6 +32,19 @@ void psld_set_error(const char* fmt, ...);
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// One-time set-up that is PER DEVICE (hipFuncSetAttribute, occupancy and CU-count queries): a slot per device of the process,
+// so that a second GPU driven from the same process is configured too instead of inheriting the first one's "done" flag.
+constexpr int PSLD_MAX_DEVICES = 32;
+static inline int psld_device_slot() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= PSLD_MAX_DEVICES) d = 0;
+    return d;
+}
+struct PsldPerDeviceFlag {
+    bool done[PSLD_MAX_DEVICES] = {};
+    bool& here() { return done[psld_device_slot()]; }
+};
+
 // wave64 reductions (CDNA wavefront = 64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -1090,7 +1090,7 @@ __global__ void __launch_bounds__(512) dwgrad_ws_kernel(const DWgradArgs a) {
 
 int launch_dwgrad_ws(const DWgradArgs& a, int nsplit, hipStream_t stream) {
     constexpr size_t LDS = (size_t)2 * 3 * (WG_AROWS * (64 * 4 + 32) + WG_BLIMB);
-    static bool configured = false;
+    static PsldPerDeviceFlag configured_; bool& configured = configured_.here();
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dwgrad_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         if (e != hipSuccess) {
@@ -1387,7 +1387,7 @@ __global__ void __launch_bounds__(256, 2) bgemm_kernel(const BGemmArgs a) {
 template <bool AT, bool BT>
 int launch_bgemm(const BGemmArgs& a, int batch, hipStream_t stream) {
     constexpr size_t LDS = (size_t)3 * ((AT ? 32 * 288 : 128 * ROWB) + (BT ? 128 * ROWB : 32 * 288));
-    static bool configured = false;
+    static PsldPerDeviceFlag configured_; bool& configured = configured_.here();
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bgemm_kernel<AT, BT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
@@ -1574,7 +1574,7 @@ __global__ void __launch_bounds__(512) pw8_kernel(const DConvArgs a) {
 template <int ABL = 0>
 int launch_pw8(const DConvArgs& a, hipStream_t stream, const char* name) {
     constexpr size_t LDS = (size_t)2 * PW8_IMG;
-    static bool configured = false;
+    static PsldPerDeviceFlag configured_; bool& configured = configured_.here();
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw8_kernel<ABL>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)LDS);
@@ -1593,7 +1593,7 @@ int launch_pw8(const DConvArgs& a, hipStream_t stream, const char* name) {
 template <int CB, bool XLP, int ABL = 0>
 int launch_dwgrad(const DWgradArgs& a, int nsplit, hipStream_t stream) {
     constexpr size_t LDS = (size_t)3 * (WG_AROWS * (64 * CB + 32) + WG_BLIMB);
-    static bool configured = false;
+    static PsldPerDeviceFlag configured_; bool& configured = configured_.here();
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dwgrad_kernel<CB, XLP, ABL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
@@ -1612,7 +1612,7 @@ int launch_dwgrad(const DWgradArgs& a, int nsplit, hipStream_t stream) {
 template <int NH, int TAPS, bool PW, int MT = 128>
 int launch_dconv(const DConvArgs& a, int nsplit, hipStream_t stream, const char* name) {
     constexpr size_t LDS = (size_t)3 * NH * 32 * ROWB;
-    static bool configured = false;
+    static PsldPerDeviceFlag configured_; bool& configured = configured_.here();
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv_kernel<NH, TAPS, PW, MT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
@@ -1631,7 +1631,7 @@ int launch_dconv(const DConvArgs& a, int nsplit, hipStream_t stream, const char*
 template <int RG, bool DB, int MT = 128>
 int launch_dconv_lp(const DConvArgs& a, int nsplit, hipStream_t stream, const char* name) {
     constexpr size_t LDS = (size_t)(DB ? 2 : 1) * 3 * RG * 16 * ROWB;
-    static bool configured = false;
+    static PsldPerDeviceFlag configured_; bool& configured = configured_.here();
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv_lp_kernel<RG, DB, MT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
@@ -1953,7 +1953,7 @@ extern "C" int psld_gemm_tn_split_f32(int m, int n, int k, const float* a, int l
     p.slabs = slabs; p.ldc = ldc;
     p.slab_stride = (long long)m * ldc;
     constexpr size_t LDS = (size_t)2 * 3 * 32 * 288;
-    static bool configured = false;
+    static PsldPerDeviceFlag configured_; bool& configured = configured_.here();
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pwgrad_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);

@@ -494,7 +494,7 @@ template <int ABL = 0, bool GNF = false, bool ERAW = false, int LA = 2>
 int launch_wino8s(const WinoArgs& a, hipStream_t stream, const char* name) {
     constexpr size_t LDS = (size_t)VBYTES + 2 * (size_t)4 * 64 * 128;
     static_assert(LDS <= 163840, "LDS budget");
-    static bool configured = false;
+    static PsldPerDeviceFlag configured_; bool& configured = configured_.here();
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv8s_kernel<ABL, GNF, ERAW, LA>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
@@ -511,14 +511,15 @@ int launch_wino8s(const WinoArgs& a, hipStream_t stream, const char* name) {
 }
 
 int wino_cu_count() {
-    static const int n = [] {
-        int dev = 0, cu = 0;
+    static int n[PSLD_MAX_DEVICES] = {};      // per device (0 = not asked yet)
+    int& cu = n[psld_device_slot()];
+    if (cu <= 0) {
+        int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
             cu <= 0)
             cu = 256;
-        return cu;
-    }();
-    return n;
+    }
+    return cu;
 }
 
 bool wino_geometry(int h, int w, int* nseg, int* rps, int* halo_px) {

@@ -430,6 +430,10 @@ __device__ int g_gnb_mode = 0;                          // bit 0 delay odd workg
 #define GNP_STAMP(k)
 #endif
 
+// workgroup barrier that orders LDS accesses only: a __syncthreads also waits for every outstanding global load (vmcnt(0)),
+// which would drain loads that are meant to fly across it
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---- backward in ONE pass over (dy, x) ----------------------------------------------------------------------------
 // A block owns image n and a slab of `gb` whole groups (cw = gb * cpg <= 32 channels); its threads keep the slab's dy and
 // x values in REGISTERS (ITEMS float4 of each per thread): pass 1 turns them into dz and xhat in place and reduces the
@@ -441,8 +445,12 @@ __device__ int g_gnb_mode = 0;                          // bit 0 delay odd workg
 // gradient dx is.  Without a third operand from a closed form of the sums the kernel reduces anyway; with one (add /
 // accumulate_dx: this block is the last writer of a residual stream's gradient) by summing the written values: per-thread
 // fp32 over its items, fp64 across the pixel lanes, like every other reduction here.
+// EARLY (launched only with a third operand): the parallel branch's gradient (or, without one, the previous dx) is asked for
+// as soon as pass 1 has consumed the raw values - a third register set - and lands while the workgroup sits in the barriers
+// and the reduction, the quarter of a workgroup's life in which its CU's memory pipe used to be idle (gnb_stamps.md); the
+// barriers then wait for LDS only.  Same arithmetic, same order: bitwise the plain form.
 // Thread -> (channel quad q = tid % cq, pixel lane l = tid / cq), pixels l, l + pl, ...
-template <int ITEMS>
+template <int ITEMS, bool EARLY = false>
 __global__ void __launch_bounds__(512) gn_bwd_fused_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -532,7 +540,18 @@ __global__ void __launch_bounds__(512) gn_bwd_fused_kernel(const float* __restri
 #pragma unroll
         for (int e = 0; e < 4; ++e) red3[((long long)l * cq + q) * 4 + e] = s3[e];
     }
-    __syncthreads();
+    [[maybe_unused]] f32x4 tv[EARLY ? ITEMS : 1];
+    if constexpr (EARLY) {
+        const float* third_src = add ? add : dx;
+#pragma unroll
+        for (int i = 0; i < ITEMS; ++i) {
+            const int p = l + i * pl;
+            tv[i] = p < hw ? *at(third_src, i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        lds_barrier();
+    } else {
+        __syncthreads();
+    }
     GNB_STAMP(3);
     if (!(GNB_MODE & 2))
     for (int i = tid; i < cq * 8; i += blockDim.x) {
@@ -551,14 +570,14 @@ __global__ void __launch_bounds__(512) gn_bwd_fused_kernel(const float* __restri
         for (int ll = 0; ll < pl; ++ll) acc += (double)red3[(long long)ll * cq * 4 + j];
         cs3[j] = (float)acc;
     }
-    __syncthreads();
+    if constexpr (EARLY) lds_barrier(); else __syncthreads();
     if (tid < gb * 2) {
         const int gg = tid >> 1, w = tid & 1;
         double t = 0;
         for (int i = 0; i < cpg; ++i) t += chs[(gg * cpg + i) * 2 + w];
         grp[gg * 2 + w] = t;
     }
-    __syncthreads();
+    if constexpr (EARLY) lds_barrier(); else __syncthreads();
     GNB_STAMP(4);
     const int gl = (q * 4) / cpg;
     const double cnt = (double)cpg * hw;
@@ -581,24 +600,33 @@ __global__ void __launch_bounds__(512) gn_bwd_fused_kernel(const float* __restri
 #pragma unroll
         for (int e = 0; e < 4; ++e) gv[i][e] = gn_dx(k0[e], gv[i][e], k1, xv[i][e], k2);
     if (add) {
+        if constexpr (!EARLY) {
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            const int p = l + i * pl;
-            if (p < hw) xv[i] = *at(add, i);
+            for (int i = 0; i < ITEMS; ++i) {
+                const int p = l + i * pl;
+                if (p < hw) xv[i] = *at(add, i);
+            }
         }
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) gv[i][e] += add_scale * xv[i][e];
+            for (int e = 0; e < 4; ++e) gv[i][e] += add_scale * (EARLY ? tv[i][e] : xv[i][e]);
     }
     if (accumulate) {
+        if (!EARLY || add) {             // (EARLY without a parallel branch: the previous dx is what came early)
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) {
-            const int p = l + i * pl;
-            if (p < hw) xv[i] = *at(dx, i);
+            for (int i = 0; i < ITEMS; ++i) {
+                const int p = l + i * pl;
+                if (p < hw) xv[i] = *at(dx, i);
+            }
         }
+        if (EARLY && !add) {
 #pragma unroll
-        for (int i = 0; i < ITEMS; ++i) gv[i] += xv[i];
+            for (int i = 0; i < ITEMS; ++i) gv[i] += tv[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) gv[i] += xv[i];
+        }
     }
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
@@ -652,7 +680,6 @@ __device__ __forceinline__ void glds16(const float* base, unsigned byte_off, uns
                  : "v"(byte_off), "s"(base), "s"(lds_dst)
                  : "memory");
 }
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int ITEMS>
 __global__ void __launch_bounds__(512) gn_bwd_pipe_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -719,7 +746,7 @@ __global__ void __launch_bounds__(512) gn_bwd_pipe_kernel(const float* __restric
         f32x4 xv[ITEMS], gv[ITEMS];
 #pragma unroll
         for (int i = 0; i < ITEMS; ++i)
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(gv[i]) : "v"(o + i * istride), "s"(dy) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(gv[i]) : "v"(o + i * istride), "s"(dy) : "memory");
         GNP_STAMP(1);
         // the x image of this slab: everything older than the ITEMS dy loads has landed
         asm volatile("s_waitcnt vmcnt(%0)" ::"i"(ITEMS) : "memory");
@@ -839,21 +866,27 @@ inline int& gn_bwd_kind() {
 // shares) or false.  items in {4, 16} with hw == items * pl exactly (no guarded items: the counted vmcnt needs them all).
 template <int ITEMS>
 inline bool gn_bwd_pipe_setup(size_t lds, int threads, int* per_cu) {
-    static int blocks = -1;
-    static size_t configured = 0;
-    if (lds > configured) {
+    // per device and per (threads, lds) of the last query: hipFuncSetAttribute and the occupancy belong to ONE device, and
+    // the occupancy to one launch shape (510 vs 512 threads, LDS sizes differ by shape)
+    struct Slot { size_t configured = 0; int blocks = -1; int threads = 0; size_t lds = 0; };
+    static Slot slots[PSLD_MAX_DEVICES];
+    Slot& s = slots[psld_device_slot()];
+    if (lds > s.configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_bwd_pipe_kernel<ITEMS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return false;
-        configured = lds;
-        blocks = -1;
+        s.configured = lds;
+        s.blocks = -1;
     }
-    if (blocks < 0 &&
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, reinterpret_cast<const void*>(&gn_bwd_pipe_kernel<ITEMS>), threads,
-                                                     lds) != hipSuccess)
-        blocks = 0;
-    *per_cu = blocks;
-    return blocks > 0;
+    if (s.blocks < 0 || s.threads != threads || s.lds != lds) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&s.blocks, reinterpret_cast<const void*>(&gn_bwd_pipe_kernel<ITEMS>),
+                                                         threads, lds) != hipSuccess)
+            s.blocks = 0;
+        s.threads = threads;
+        s.lds = lds;
+    }
+    *per_cu = s.blocks;
+    return s.blocks > 0;
 }
 
 inline bool gn_bwd_pipe_plan(int batch, int hw, int c, int slabs, int gb, int threads, int pl, int items, size_t fused_lds,
@@ -866,11 +899,14 @@ inline bool gn_bwd_pipe_plan(int batch, int hw, int c, int slabs, int gb, int th
     int per_cu = 0;
     const bool ok = items == 4 ? gn_bwd_pipe_setup<4>(lds, threads, &per_cu) : gn_bwd_pipe_setup<16>(lds, threads, &per_cu);
     if (!ok) return false;
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-        return n;
-    }();
+    static int cu_count[PSLD_MAX_DEVICES] = {};       // per device (0 = not asked yet, -1 = the query failed)
+    int& cus = cu_count[psld_device_slot()];
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            cus <= 0)
+            cus = -1;
+    }
     if (cus <= 0) return false;
     // whole images per round: the grid is a multiple of the slabs per image (a workgroup keeps its channels), everything resident
     const int images_per_round = cus * per_cu / slabs;
@@ -978,14 +1014,17 @@ extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float
             PSLD_CHECK_LAUNCH("gn_bwd_pipe_kernel");
             return PSLD_OK;
         }
-#define PSLD_GN_FUSED(IT)                                                                                              \
-    hipLaunchKernelGGL((gn_bwd_fused_kernel<IT>), grid, block, flds, stream, dy, x, mean, rstd, gamma, beta, hw, c, groups, \
-                       gb, fpl, act, drop_p, seed, seed_dev, accumulate_dx, add, add_scale, dx, sums, colsum_img, ld_img)
+#define PSLD_GN_FUSED(IT, EARLY)                                                                                       \
+    hipLaunchKernelGGL((gn_bwd_fused_kernel<IT, EARLY>), grid, block, flds, stream, dy, x, mean, rstd, gamma, beta, hw, c, \
+                       groups, gb, fpl, act, drop_p, seed, seed_dev, accumulate_dx, add, add_scale, dx, sums, colsum_img,  \
+                       ld_img)
+        // a third operand on the larger slabs: asked for before the reduction (gn_bwd_fused_kernel<., EARLY>)
+        const bool early = (add || accumulate_dx) && gn_bwd_kind() == PSLD_GN_BWD_AUTO;
         switch (items) {
-            case 1: PSLD_GN_FUSED(1); break;
-            case 2: PSLD_GN_FUSED(2); break;
-            case 4: PSLD_GN_FUSED(4); break;
-            default: PSLD_GN_FUSED(16); break;
+            case 1: PSLD_GN_FUSED(1, false); break;
+            case 2: PSLD_GN_FUSED(2, false); break;
+            case 4: if (early) PSLD_GN_FUSED(4, true); else PSLD_GN_FUSED(4, false); break;
+            default: if (early) PSLD_GN_FUSED(16, true); else PSLD_GN_FUSED(16, false); break;
         }
 #undef PSLD_GN_FUSED
         PSLD_CHECK_LAUNCH("gn_bwd_fused_kernel");

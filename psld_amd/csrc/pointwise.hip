@@ -843,7 +843,7 @@ extern "C" int psld_conv3x3_fewout_f32(const float* x, const float* w_ohwi, cons
     long long blocks = (groups + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     if (cout == 6) {
-        static bool configured = false;
+        static PsldPerDeviceFlag configured_; bool& configured = configured_.here();
         if (!configured) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_fewout_kernel<6>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
@@ -852,7 +852,7 @@ extern "C" int psld_conv3x3_fewout_f32(const float* x, const float* w_ohwi, cons
         hipLaunchKernelGGL(conv3x3_fewout_kernel<6>, dim3((unsigned)blocks), dim3(256), lds, stream, x, w_ohwi, bias, y, batch,
                            h, w, cin);
     } else {
-        static bool configured = false;
+        static PsldPerDeviceFlag configured_; bool& configured = configured_.here();
         if (!configured) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_fewout_kernel<3>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);

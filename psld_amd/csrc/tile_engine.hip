@@ -705,7 +705,7 @@ int launch_fast_impl(const TileArgs& a, FastGeom fg, int nz, hipStream_t stream,
     constexpr int A_SZ = A_KC ? TBM * KC_LD : BK * MC_LD;
     constexpr int B_SZ = B_KC ? TBN * KC_LD : BK * MC_LD;
     constexpr size_t LDS = (size_t)NBUF * (A_SZ + B_SZ) * sizeof(float);
-    static bool configured = false;
+    static PsldPerDeviceFlag configured_; bool& configured = configured_.here();
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_kernel_fast<AMODE, BMODE, TBM, NBUF, TBN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);

@@ -610,8 +610,13 @@ def param_job(src: Tensor, rows: int, ld: int, c: int, dst1: Tensor, dst2: Optio
             _f32_bits(alpha))
 
 
-def param_reduce_batch(table: Tensor, jobs: int, blocks: int):
+byte_hook = None      # callable(family, algorithmic bytes): set by tools/hbm_in_situ.py for the table-driven launches
+
+
+def param_reduce_batch(table: Tensor, jobs: int, blocks: int, nbytes: int = 0):
     """table rows: param_job(...) + (first 64-column block,); a job has ceil(c / 64) blocks."""
+    if byte_hook is not None:
+        byte_hook("param_reduce", nbytes)
     check(lib().psld_param_reduce_batch_f32(table.data_ptr(), jobs, blocks, _stream()), "psld_param_reduce_batch_f32")
 
 
@@ -628,8 +633,11 @@ def slab_job(slabs: Tensor, nsplit: int, n: int, out: Tensor, layout: int = 0, t
     return (slabs.data_ptr(), nsplit, n, out.data_ptr(), layout, taps, cin, _f32_bits(alpha))
 
 
-def reduce_slabs_batch(table: Tensor, jobs: int, units: int):
-    """table rows: slab_job(...) + (first unit, units of the job = slab_units(...))."""
+def reduce_slabs_batch(table: Tensor, jobs: int, units: int, nbytes: int = 0):
+    """table rows: slab_job(...) + (first unit, units of the job = slab_units(...)).  ``nbytes``: algorithmic bytes of the
+    jobs (sum of 4 n (nsplit + 1)), for a measurement hook (tools/hbm_in_situ.py) - the table itself lives on the device."""
+    if byte_hook is not None:
+        byte_hook("reduce_slabs", nbytes)
     check(lib().psld_reduce_slabs_batch_f32(table.data_ptr(), jobs, units, _stream()), "psld_reduce_slabs_batch_f32")
 
 

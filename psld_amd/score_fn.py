@@ -328,7 +328,7 @@ class _Exec:
             self.pjobs, self.pblocks = [], 0
             rows = [v for job in jobs for v in job]
             table = self.net._tables.get(rows, self.net._params()[0].device)
-            ops.param_reduce_batch(table, len(jobs), blocks)
+            ops.param_reduce_batch(table, len(jobs), blocks, sum(4 * (j[1] + 1) * j[3] for j in jobs))
 
     def slabs_for(self, nbytes: int, device) -> Tensor:
         """Split-K slab storage: the stream's workspace when the reduction follows at once, else a slice of the slab arena
@@ -357,7 +357,7 @@ class _Exec:
             self.sjobs, self.sitems, self.sbytes = [], 0, 0
             rows = [v for job in jobs for v in job]
             table = self.net._tables.get(rows, self.net._params()[0].device)
-            ops.reduce_slabs_batch(table, len(jobs), items)
+            ops.reduce_slabs_batch(table, len(jobs), items, sum(4 * j[2] * (j[1] + 1) for j in jobs))
             self.net._slab_arena().reset()
 
     def flush_deferred(self):

@@ -107,3 +107,26 @@ def test_product_library_has_no_ablation_modes():
     env = dict(os.environ, PSLD_WINO_ABL="2")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], env=env, capture_output=True, text=True)
     assert r.returncode == 2 and "PSLD_WINO_ABL" in r.stderr
+
+
+def test_hand_scheduled_groupnorm_backward_has_no_scratch():
+    """gn_bwd_pipe_kernel orders its asm loads with hand-counted `s_waitcnt vmcnt(N)`; a compiler-inserted vector
+    memory operation (a scratch spill or reload) would shift those counts.  The build must report zero scratch and zero
+    spills for every instance of that kernel (and of the one-slab kernel with the early third operand, which sits at 238
+    of 256 registers)."""
+    import subprocess
+    src = os.path.join(ROOT, "psld_amd", "csrc")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "--offload-arch=gfx950", "-std=c++17", "-I../../include", "-I.",
+                        "-Rpass-analysis=kernel-resource-usage", "-c", "norm_act.hip", "-o", "/dev/null"],
+                       cwd=src, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    blocks = re.split(r"remark: Function Name: ", r.stderr)[1:]
+    seen = 0
+    for b in blocks:
+        name = b.split()[0]
+        if "gn_bwd_pipe_kernel" in name or "gn_bwd_fused_kernelILi16ELb1" in name or "gn_bwd_fused_kernelILi4ELb1" in name:
+            seen += 1
+            scratch = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1))
+            spills = [int(v) for v in re.findall(r"[SV]GPRs Spill: (\d+)", b)]
+            assert scratch == 0 and not any(spills), (name, scratch, spills)
+    assert seen >= 4

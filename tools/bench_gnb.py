@@ -1,5 +1,6 @@
-"""GroupNorm backward at the step's shapes and variants: us per call (one-pass kernel + parameter-gradient finalize).
-    python tools/bench_gnb.py            (PSLD_GN_BWD_PIPE=0: the one-slab kernel for every shape)"""
+"""GroupNorm backward at the step's shapes and variants: us per call of psld_gn_bwd_nhwc_f32 (dx + per-image sums; dgamma /
+dbeta are a batched reduction elsewhere).
+    python tools/bench_gnb.py            (PSLD_GN_BWD_PIPE=0: the one-slab kernel without the early third operand for every shape)"""
 import os
 import sys
 
@@ -19,11 +20,13 @@ for B, S, C in ((128, 32, 256), (128, 16, 256), (128, 8, 256), (64, 32, 256), (1
     gamma = torch.rand(C, device="cuda") + 0.5
     beta = torch.randn(C, device="cuda") * 0.1
     st = ops.gn_stats(x, gamma, beta)
-    dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    sums = torch.empty(B, 2, C, device="cuda")
     for name, kw, nb in (("SiLU", {}, 12), ("SiLU + branch gradient", {"add": other, "add_scale": 0.7}, 16),
                          ("SiLU + dropout 0.15", {"drop_p": 0.15, "seed": 11}, 12),
-                         ("SiLU, accumulating", {"accumulate_dx": True}, 16), ("no activation", {"act": False}, 12)):
+                         ("SiLU, accumulating", {"accumulate_dx": True}, 16),
+                         ("SiLU + branch, accumulating", {"add": other, "add_scale": 0.7, "accumulate_dx": True}, 20),
+                         ("no activation", {"act": False}, 12)):
         kw = dict(kw)
         act = kw.pop("act", True)
-        t = timeit(lambda: ops.gn_bwd(dy, x, st, gamma, beta, act, dx, dg, db, **kw), 30)
+        t = timeit(lambda: ops.gn_bwd(dy, x, st, gamma, beta, act, dx, sums=sums, **kw), 30)
         print(f"{B}x{S}x{S}x{C:<10d} {name:28s} {t * 1e6:8.1f} {nb * x.numel() / t / 1e9:20.0f}")

@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 
 PEAK = 8.0e12
 SOURCES = ["psld_amd/csrc/norm_act.hip", "psld_amd/csrc/resample.hip", "psld_amd/csrc/pointwise.hip", "psld_amd/csrc/optim.hip",
-           "psld_amd/csrc/sde.hip", "psld_amd/csrc/common.h"]
+           "psld_amd/csrc/sde.hip", "psld_amd/csrc/common.h", "psld_amd/score_fn.py"]
 
 # entry point -> (family, bytes(args))
 def _b(fam, fn):
@@ -36,8 +36,9 @@ BYTES = {
     "psld_gn_stats_from_partials_f32": _b("gn_stats", lambda a: a[1] * max(1, a[2] // 64) * (a[3] // 8) * 16),
     "psld_gn_apply_nhwc_f32": _b("gn_apply", lambda a: 8 * a[4] * a[5] * a[6]),
     "psld_gn_apply_limb_nhwc": _b("gn_apply_limb", lambda a: 10 * a[4] * a[5] * a[6]),
-    "psld_gn_bwd_nhwc_f32": _b("gn_bwd", lambda a: (12 + (4 if a[17] else 0) + (4 if a[18] else 0)) * a[6] * a[7] * a[8]),
-    "psld_gn_bwd_colsum_nhwc_f32": _b("gn_bwd", lambda a: 12 * a[6] * a[7] * a[8]),
+    "psld_gn_bwd_nhwc_f32": _b("gn_bwd", lambda a: (12 + (4 if a[15] else 0) + (4 if a[16] else 0)) * a[6] * a[7] * a[8]),
+    "psld_param_reduce2_f32": _b("param_reduce", lambda a: 4 * (a[2] + 1) * a[4] * (2 if a[1] else 1)),
+    "psld_bias_grad_seg_f32": _b("bias_grad", lambda a: 4 * a[2] * a[3] * 3 * a[4]),
     "psld_upfirdn2d_f32": _b("fir", lambda a: 4 * a[2] * a[3] * (a[4] * a[5] + _fir_out(a) * (2 if a[18] else 1))),
     "psld_axpby_f32": _b("axpby", lambda a: 4 * a[5] * (2 + (1 if a[2] else 0) + (1 if a[6] else 0))),
     "psld_silu_f32": _b("silu", lambda a: 8 * a[2]),
@@ -63,7 +64,7 @@ BYTES = {
 KERNELS = [
     ("gn_apply_limb_kernel", "gn_apply_limb"), ("gn_apply_kernel", "gn_apply"), ("gn_partial_kernel", "gn_stats"),
     ("gn_finalize_kernel", "gn_stats"), ("gn_bwd_", "gn_bwd"), ("upfirdn", "fir"), ("axpby_kernel", "axpby"),
-    ("silu_", "silu"), ("colsum", "bias_grad"), ("bias_grad", "bias_grad"), ("reduce_slabs", "reduce_slabs"),
+    ("silu_", "silu"), ("colsum", "bias_grad"), ("bias_grad", "bias_grad"), ("reduce_slabs", "reduce_slabs"), ("param_reduce", "param_reduce"),
     ("scale_copy2d", "copy2d"), ("copy2d_kernel", "copy2d"), ("softmax_rows", "softmax"), ("nchw_to_nhwc", "layout"),
     ("nhwc_to_nchw", "layout"), ("perturb_kernel", "perturb"), ("perturb_coeffs", "perturb"), ("sqerr", "sqerr"),
     ("adam_ema_kernel", "adam"), ("ema_kernel", "ema"), ("sumsq", "grad_norm"), ("f32_to_limb", "limb_convert"),
@@ -106,6 +107,17 @@ class _Log:
         return logged
 
 
+def _hook_tables(log):
+    """The table-driven launches (psld_param_reduce_batch_f32, psld_reduce_slabs_batch_f32) carry their jobs in device memory:
+    the executor reports their algorithmic bytes through ops.byte_hook."""
+    from psld_amd import ops
+
+    def hook(fam, nbytes):
+        log.bytes[fam] += int(nbytes)
+        log.calls[fam] += 1
+    ops.byte_hook = hook
+
+
 def run(out_path, steps=8, warmup=2):
     import copy
     import torch
@@ -115,6 +127,7 @@ def run(out_path, steps=8, warmup=2):
     from psld_amd.registry import get_module
     log = _Log(_lib.load_real())
     _lib.set_proxy(log)                                  # from here on every launch of the process is sized
+    _hook_tables(log)
     psld_amd.import_modules_into_registry()
     cfg = C.c10_sota()
     dev = torch.device("cuda")
@@ -149,6 +162,7 @@ def run_forward(out_path, steps=20, warmup=3, batch=128):
     from psld_amd.registry import get_module
     log = _Log(_lib.load_real())
     _lib.set_proxy(log)
+    _hook_tables(log)
     psld_amd.import_modules_into_registry()
     cfg = C.c10_sota()
     dev = torch.device("cuda")
