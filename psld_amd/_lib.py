@@ -122,6 +122,9 @@ SIGNATURES = {
     "psld_gn_apply_nhwc_f32": (I, [P, P, P, P, I, I, I, I, F, C.c_ulonglong, P, P]),
     "psld_gn_bwd_nhwc_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, F, C.c_ulonglong, P, P, I, P, F, P, P, I, P, P]),
     "psld_gn_bwd_colsum_supported": (I, [I, I, I, I]),
+    "psld_gn_bwd_team_rows": (I, [I, I, I, I]),
+    "psld_gn_bwd_team_sync_bytes": (LL, []),
+    "psld_gn_bwd_team_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, F, C.c_ulonglong, P, P, I, P, F, P, P, I, P, P]),
     "psld_param_reduce2_f32": (I, [P, P, I, I, I, P, P, F, P]),
     "psld_param_reduce_batch_f32": (I, [P, I, I, P]),
     "psld_reduce_slabs_batch_units": (I, [LL, I, I, I]),

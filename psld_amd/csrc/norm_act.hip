@@ -839,6 +839,230 @@ __global__ void __launch_bounds__(512) gn_bwd_pipe_kernel(const float* __restric
     }
 }
 
+// ---- the one-pass backward on WHOLE ROWS: teams of resident workgroups -----------------------------------------------------
+// Round 5 (profiles/r05/gnb_rows.md): the one-slab kernels read a 128-byte segment (32 channels) out of every 1 KB NHWC row
+// and reach 4.3-4.6 TB/s on 128x32x32x256; the elementwise apply pass of the three-pass form, which reads whole rows, moves
+// the same bytes at 5.9-6.4 TB/s.  The slab shape was forced by the reduction - all pixels of an (image, group) in one
+// workgroup's registers.  Here a workgroup owns 64 pixels x 128 channels of an image (512-byte segments of consecutive rows:
+// 256 threads = 32 channel quads x 8 pixel lanes, 8 items per thread), and the K = hw / 64 workgroups of an (image, 128-
+// channel block) form a TEAM that exchanges its per-group partial sums through memory:
+//   pass 1 as ever (dz, xhat in place; per-thread fp32 sums, fp64 across the 8 pixel lanes) -> the block's per-channel sums
+//   go to part[image][k][2][c] (dgamma / dbeta are sums over images AND team members: psld_param_reduce*_f32 takes rows);
+//   their gamma-weighted group sums are PUBLISHED as 64-bit slots {fp32 value, 32-bit tag} by relaxed agent-scope atomic
+//   stores; every member polls the K x (2 x groups-in-block) slots of its team until they carry this set's tag, adds them in
+//   member order (fp64) - every member gets bitwise the same group terms - and writes dx from its registers.
+// A slot is one atomic object that carries its own validity: no fence, no counter, nothing to reset.  Slots are double-
+// buffered by set parity: a member overwrites set s's slots only when it publishes s + 2, i.e. after it has read every
+// member's s + 1 slots, which they published after reading all of set s.  Tags rise with every set of every launch: the
+// launch's first tag is a counter in the slot buffer (word 1) that the LAST workgroup to finish advances (word 2 counts the
+// finished ones) - nothing for the host to hand out, and a hipGraph replay of the launch gets fresh tags like any other.
+// The buffer is zeroed once, when it is allocated, and belongs to one stream at a time.
+// The grid is RESIDENT (teams x K workgroups <= what the device holds at once, teams walk their sets in lock step), so a
+// member only ever waits for workgroups that are running or will run without anything finishing first.  The poll loop is
+// bounded all the same: on a timeout (another process hogging the device for seconds) the workgroup raises an error word in
+// the slot buffer and carries on with garbage rather than hang the queue.
+constexpr int TEAM_PX = 64;          // pixels per workgroup and set
+constexpr int TEAM_CH = 128;         // channels per workgroup
+constexpr int TEAM_ITEMS = 8;
+constexpr int TEAM_MAXK = 16;        // hw <= 1024
+constexpr int TEAM_SLOTS = 64;       // 2 sums x up to 32 groups in a 128-channel block
+constexpr long long TEAM_SYNC_BYTES = 256 + (long long)2048 * 2 * TEAM_MAXK * TEAM_SLOTS * 8;     // error word + up to 2048 teams
+
+template <bool THIRD>
+__global__ void __launch_bounds__(256) gn_bwd_team_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          int hw, int c, int groups, int act, float drop_p,
+                                                          unsigned long long seed, const unsigned long long* __restrict__ seed_dev,
+                                                          int accumulate, const float* __restrict__ add, float add_scale,
+                                                          float* __restrict__ dx, float* __restrict__ part,
+                                                          float* __restrict__ colsum_rows, int ld_rows,
+                                                          unsigned long long* __restrict__ sync, int rounds, int K, int sets,
+                                                          int teams) {
+    __shared__ float red[8 * 32 * 8];            // [pixel lane][quad][s1 x4 | s2 x4]; later [lane][quad][4] column sums
+    __shared__ double chs[TEAM_CH * 2];          // gamma-weighted channel sums of this block
+    __shared__ float gp[TEAM_MAXK * TEAM_SLOTS]; // the team's group partials [member][slot]
+    __shared__ double grp[TEAM_SLOTS];           // the image's group terms [group in block][2]
+    if (seed_dev) seed += seed_dev[0];
+    const int tid = threadIdx.x;
+    const int q = tid & 31, l = tid >> 5;        // channel quad of the block, pixel lane
+    const int team = blockIdx.x / K, k = blockIdx.x - team * K;
+    // first tag of this launch (the counter moves only after every workgroup of the launch has finished, see the end)
+    const unsigned tag0 = (unsigned)__hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    const int cblocks = c / TEAM_CH;
+    const int cpg = c / groups, gpb = TEAM_CH / cpg, nslot = 2 * gpb;
+    const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    const double cnt = (double)cpg * hw;
+    unsigned long long* slots = sync + 32 + (long long)team * 2 * TEAM_MAXK * TEAM_SLOTS;
+    for (int s = team, it = 0; s < sets; s += teams, ++it) {
+        const int n = s / cblocks, cb = s - n * cblocks;
+        const int c0 = cb * TEAM_CH, ch0 = c0 + q * 4;
+        const int g = ch0 / cpg;                 // cpg % 4 == 0: a quad lies in one group
+        const float mu = mean[n * groups + g], rs = rstd[n * groups + g];
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + ch0), be = *reinterpret_cast<const f32x4*>(beta + ch0);
+        // pixels k*64 + l + 8 i: a wave (2 pixel lanes x 32 quads) reads two 512-byte runs
+        const long long e0 = (((long long)n * hw + k * TEAM_PX + l) * c + ch0);
+        const long long istride = (long long)8 * c;
+        f32x4 xv[TEAM_ITEMS], gv[TEAM_ITEMS];
+#pragma unroll
+        for (int i = 0; i < TEAM_ITEMS; ++i) {
+            xv[i] = *reinterpret_cast<const f32x4*>(x + e0 + i * istride);
+            gv[i] = *reinterpret_cast<const f32x4*>(dy + e0 + i * istride);
+        }
+        float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < TEAM_ITEMS; ++i) {
+            const long long idx = e0 + i * istride;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (xv[i][e] - mu) * rs;
+                float dz = gv[i][e];
+                if (drop_p > 0.f) dz = psld_dropout_keep(seed, (unsigned long long)(idx + e), drop_p) ? dz * keep_scale : 0.f;
+                if (act) dz *= dsilu_f(xh * ga[e] + be[e]);
+                s1[e] += dz;
+                s2[e] += dz * xh;
+                xv[i][e] = xh;
+                gv[i][e] = dz;
+            }
+        }
+        float* my = red + (l * 32 + q) * 8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            my[e] = s1[e];
+            my[4 + e] = s2[e];
+        }
+        __syncthreads();
+        {   // 256 threads = 128 channels x 2 sums: the eight pixel lanes in lane order
+            const int chl = tid >> 1, w = tid & 1;
+            double acc = 0;
+#pragma unroll
+            for (int ll = 0; ll < 8; ++ll) acc += (double)red[(ll * 32 + (chl >> 2)) * 8 + w * 4 + (chl & 3)];
+            const float rounded = (float)acc;
+            part[(((long long)n * K + k) * 2 + w) * c + c0 + chl] = rounded;
+            chs[chl * 2 + w] = (double)rounded * (double)gamma[c0 + chl];
+        }
+        __syncthreads();
+        const unsigned tag = tag0 + (unsigned)it;
+        unsigned long long* buf = slots + (long long)(it & 1) * TEAM_MAXK * TEAM_SLOTS;
+        if (tid < nslot) {
+            const int gg = tid >> 1, w = tid & 1;
+            double t = 0;
+            for (int i = 0; i < cpg; ++i) t += chs[(gg * cpg + i) * 2 + w];
+            const unsigned long long word = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint((float)t);
+            __hip_atomic_store(buf + k * TEAM_SLOTS + tid, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // every member's slots of this set
+        for (int j = tid; j < K * nslot; j += 256) {
+            const int kk = j / nslot, sl = j - kk * nslot;
+            const unsigned long long* ptr = buf + kk * TEAM_SLOTS + sl;
+            unsigned long long word = __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            while ((unsigned)(word >> 32) != tag) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1 << 22)) {       // seconds: give up rather than hang the queue
+                    __hip_atomic_store(sync, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                word = __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            gp[kk * TEAM_SLOTS + sl] = __uint_as_float((unsigned)word);
+        }
+        __syncthreads();
+        if (tid < nslot) {
+            double t = 0;
+            for (int kk = 0; kk < K; ++kk) t += (double)gp[kk * TEAM_SLOTS + tid];
+            grp[tid] = t;
+        }
+        __syncthreads();
+        const int gl = (q * 4) / cpg;
+        const float k1 = (float)((double)rs * grp[gl * 2 + 0] / cnt), k2 = (float)((double)rs * grp[gl * 2 + 1] / cnt);
+        f32x4 k0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) k0[e] = rs * ga[e];
+#pragma unroll
+        for (int i = 0; i < TEAM_ITEMS; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gv[i][e] = gn_dx(k0[e], gv[i][e], k1, xv[i][e], k2);
+        if constexpr (THIRD) {
+            if (add) {
+#pragma unroll
+                for (int i = 0; i < TEAM_ITEMS; ++i) xv[i] = *reinterpret_cast<const f32x4*>(add + e0 + i * istride);
+#pragma unroll
+                for (int i = 0; i < TEAM_ITEMS; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gv[i][e] += add_scale * xv[i][e];
+            }
+            if (accumulate) {
+#pragma unroll
+                for (int i = 0; i < TEAM_ITEMS; ++i) xv[i] = *reinterpret_cast<const f32x4*>(dx + e0 + i * istride);
+#pragma unroll
+                for (int i = 0; i < TEAM_ITEMS; ++i) gv[i] += xv[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TEAM_ITEMS; ++i) *reinterpret_cast<f32x4*>(dx + e0 + i * istride) = gv[i];
+        if (colsum_rows) {       // column sums of the values just written, over this block's 64 pixels (red: free since the barrier above)
+            float s4[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < TEAM_ITEMS; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s4[e] += gv[i][e];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[(l * 32 + q) * 4 + e] = s4[e];
+            __syncthreads();
+            if (tid < TEAM_CH) {
+                double acc = 0;
+#pragma unroll
+                for (int ll = 0; ll < 8; ++ll) acc += (double)red[ll * TEAM_CH + tid];
+                colsum_rows[((long long)n * K + k) * ld_rows + c0 + tid] = (float)acc;
+            }
+        }
+        __syncthreads();         // red / chs / gp / grp are rewritten by the next set
+    }
+    if (tid == 0) {              // the last workgroup out advances the tag counter for the next launch
+        const unsigned long long done = __hip_atomic_fetch_add(sync + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+        if (done == (unsigned long long)gridDim.x) {
+            __hip_atomic_store(sync + 2, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(sync + 1, (unsigned long long)rounds, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// team size (= rows per image of `part`), or 0 when the team form does not take the shape
+inline int gn_bwd_team_k(int batch, int hw, int c, int groups) {
+    if (batch <= 0 || groups <= 0 || c % groups) return 0;
+    const int cpg = c / groups;
+    if (c % TEAM_CH || cpg % 4 || TEAM_CH % cpg || 2 * (TEAM_CH / cpg) > TEAM_SLOTS) return 0;
+    if (hw % TEAM_PX || hw / TEAM_PX < 2 || hw / TEAM_PX > TEAM_MAXK) return 0;
+    return hw / TEAM_PX;
+}
+
+// resident grid: teams (each K workgroups) and the sets every team walks
+inline bool gn_bwd_team_grid(int batch, int c, int K, bool third, int* teams, int* rounds) {
+    struct Slot { int per_cu[2] = {-1, -1}; int cus = 0; };
+    static Slot slots[PSLD_MAX_DEVICES];
+    Slot& sl = slots[psld_device_slot()];
+    int& per_cu = sl.per_cu[third ? 1 : 0];
+    if (per_cu < 0) {
+        const void* fn = third ? reinterpret_cast<const void*>(&gn_bwd_team_kernel<true>) : reinterpret_cast<const void*>(&gn_bwd_team_kernel<false>);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess) per_cu = 0;
+    }
+    if (sl.cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&sl.cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            sl.cus <= 0)
+            sl.cus = -1;
+    }
+    if (per_cu <= 0 || sl.cus <= 0) return false;
+    const int sets = batch * (c / TEAM_CH);
+    int max_teams = (int)((long long)per_cu * sl.cus / K);
+    if (max_teams > 2048) max_teams = 2048;
+    if (max_teams < 1) return false;
+    *rounds = cdiv(sets, max_teams);
+    *teams = cdiv(sets, *rounds);            // equal shares: every team walks `rounds` sets (the last ones one fewer)
+    return true;
+}
+
 // groups per block / pixel lanes / items per thread of the fused backward, or false when the slab does not fit registers
 inline bool gn_bwd_fused_plan(int batch, int hw, int c, int groups, int* gb, int* pl, int* items) {
     const int cpg = c / groups;
@@ -1049,6 +1273,45 @@ extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float
                        gamma, beta, coef, hw, c, groups, ma.cq, ma.pl, ma.chunk_px, act, drop_p, seed, seed_dev, accumulate_dx, add, add_scale,
                        dx);
     PSLD_CHECK_LAUNCH("gn_bwd_apply_kernel");
+    return PSLD_OK;
+}
+
+extern "C" int psld_gn_bwd_team_rows(int batch, int hw, int c, int groups) {
+    if (gn_bwd_kind() != PSLD_GN_BWD_AUTO || (long long)batch * hw * c >= (1ll << 40)) return 0;
+    const int K = gn_bwd_team_k(batch, hw, c, groups);
+    int teams = 0, rounds = 0;
+    return K > 0 && gn_bwd_team_grid(batch, c, K, true, &teams, &rounds) ? K : 0;
+}
+
+extern "C" long long psld_gn_bwd_team_sync_bytes(void) { return TEAM_SYNC_BYTES; }
+
+extern "C" int psld_gn_bwd_team_f32(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                    const float* beta, int batch, int hw, int c, int groups, int act, float drop_p,
+                                    unsigned long long seed, const unsigned long long* seed_dev, float* dx, int accumulate_dx,
+                                    const float* add, float add_scale, float* sums, float* colsum_rows, int ld_rows, void* sync,
+                                    hipStream_t stream) {
+    PSLD_CHECK_ARG(dy && x && mean && rstd && gamma && beta && dx && sums && sync, "psld_gn_bwd_team: null pointer");
+    const int K = gn_bwd_team_k(batch, hw, c, groups);
+    PSLD_CHECK_ARG(K > 0, "psld_gn_bwd_team: unsupported shape B=%d hw=%d C=%d groups=%d (psld_gn_bwd_team_rows)", batch, hw, c, groups);
+    PSLD_CHECK_ARG(!colsum_rows || ld_rows >= c, "psld_gn_bwd_team: ld_rows < c");
+    PSLD_CHECK_ARG((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx) |
+                    reinterpret_cast<uintptr_t>(add) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) % 16 == 0 &&
+                       reinterpret_cast<uintptr_t>(sync) % 8 == 0,
+                   "psld_gn_bwd_team: unaligned pointer");
+    const bool third = add != nullptr || accumulate_dx != 0;
+    int teams = 0, rounds = 0;
+    PSLD_CHECK_ARG(gn_bwd_team_grid(batch, c, K, true, &teams, &rounds), "psld_gn_bwd_team: no resident grid");
+    const int sets = batch * (c / TEAM_CH);
+    unsigned long long* sy = reinterpret_cast<unsigned long long*>(sync);
+    if (third)
+        hipLaunchKernelGGL(gn_bwd_team_kernel<true>, dim3(teams * K), dim3(256), 0, stream, dy, x, mean, rstd, gamma, beta, hw, c,
+                           groups, act, drop_p, seed, seed_dev, accumulate_dx, add, add_scale, dx, sums, colsum_rows, ld_rows, sy, rounds, K,
+                           sets, teams);
+    else
+        hipLaunchKernelGGL(gn_bwd_team_kernel<false>, dim3(teams * K), dim3(256), 0, stream, dy, x, mean, rstd, gamma, beta, hw, c,
+                           groups, act, drop_p, seed, seed_dev, accumulate_dx, add, add_scale, dx, sums, colsum_rows, ld_rows, sy, rounds, K,
+                           sets, teams);
+    PSLD_CHECK_LAUNCH("gn_bwd_team_kernel");
     return PSLD_OK;
 }
 

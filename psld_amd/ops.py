@@ -591,6 +591,48 @@ def gn_bwd_colsum_supported(b: int, hw: int, c: int, groups: Optional[int] = Non
     return bool(lib().psld_gn_bwd_colsum_supported(b, hw, c, groups if groups is not None else gn_groups(c)))
 
 
+def gn_bwd_team_rows(b: int, hw: int, c: int, groups: Optional[int] = None) -> int:
+    """Team size K (= rows per image of the sums) when the whole-row GroupNorm backward takes the shape, else 0 (not
+    cached: the answer follows psld_set_gn_bwd_kernel)."""
+    return int(lib().psld_gn_bwd_team_rows(b, hw, c, groups if groups is not None else gn_groups(c)))
+
+
+_team_sync = {}      # device index -> zero-initialised slot buffer of the team kernels (one stream at a time uses it)
+
+
+def gn_team_sync(device) -> Tensor:
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    t = _team_sync.get(key)
+    if t is None:
+        t = _team_sync[key] = torch.zeros(int(lib().psld_gn_bwd_team_sync_bytes()), device=device, dtype=torch.uint8)
+    return t
+
+
+def gn_team_errors(device) -> int:
+    """Error word of the team kernels' slot buffer (non-zero: a workgroup gave up waiting for its team); a host read."""
+    return int(gn_team_sync(device)[:8].view(torch.int64).item())
+
+
+def gn_bwd_team(dy: Tensor, x: Tensor, st: GNStats, gamma: Tensor, beta: Tensor, act: bool, dx: Tensor,
+                accumulate_dx: bool = False, drop_p: float = 0.0, seed: int = 0, groups: Optional[int] = None,
+                add: Optional[Tensor] = None, add_scale: float = 1.0, seed_dev: Optional[Tensor] = None,
+                sums: Optional[Tensor] = None, colsum_rows: Optional[Tensor] = None, ld_rows: int = 0) -> Tensor:
+    """gn_bwd on whole rows by teams of resident workgroups (psld_gn_bwd_team_f32; shapes: gn_bwd_team_rows > 0).  Returns
+    ``sums`` [b * K][2][c]; ``colsum_rows`` [b * K] rows: column sums of the stored dx per team member."""
+    b, h, w, c = x.shape
+    g = groups if groups is not None else gn_groups(c)
+    k = gn_bwd_team_rows(b, h * w, c, g)
+    assert k > 0
+    if sums is None:
+        sums = torch.empty((b * k, 2, c), device=x.device, dtype=torch.float32)
+    check(lib().psld_gn_bwd_team_f32(dy.data_ptr(), x.data_ptr(), st.mean.data_ptr(), st.rstd.data_ptr(), gamma.data_ptr(),
+                                     beta.data_ptr(), b, h * w, c, g, 1 if act else 0, drop_p, seed, _p(seed_dev), dx.data_ptr(),
+                                     1 if accumulate_dx else 0, _p(add), add_scale, sums.data_ptr(), _p(colsum_rows),
+                                     (ld_rows or c) if colsum_rows is not None else 0, gn_team_sync(x.device).data_ptr(),
+                                     _stream()), "psld_gn_bwd_team_f32")
+    return sums
+
+
 def param_reduce2(src_a: Tensor, src_b: Optional[Tensor], rows: int, ld: int, c: int, dst_a: Tensor,
                   dst_b: Optional[Tensor], alpha: float = 1.0):
     """dst[col] = alpha * sum over rows of src[r * ld + col] for one or two sources of the same shape (one launch)."""

@@ -972,6 +972,58 @@ def test_groupnorm_backward_column_sums_of_dx(ops, b, s, c, variant):
     assert rel_l2(db0, sums0[:, 0].double().sum(0)) < 1e-6 and rel_l2(dg0, sums0[:, 1].double().sum(0)) < 1e-6
 
 
+@pytest.mark.parametrize("b,s,c", [(128, 32, 256), (128, 16, 256), (16, 32, 256), (5, 16, 128), (3, 32, 128), (7, 16, 512)])
+@pytest.mark.parametrize("variant", ["plain", "branch", "dropout", "accumulate", "branch_accumulate", "no_act"])
+def test_groupnorm_backward_on_whole_rows_by_teams(ops, b, s, c, variant):
+    """psld_gn_bwd_team_f32 (64 pixels x 128 channels per workgroup, the hw / 64 workgroups of an image exchanging their
+    group partial sums through tagged slots) against the one-slab kernel: dx to fp32 rounding (the group terms are formed
+    from fp32-rounded member sums), dgamma / dbeta = sums over all batch x K rows, the per-member column sums of the stored
+    dx against fp64; three launches in a row (tag counter, slot parity) bitwise equal; no member timed out."""
+    k = ops.gn_bwd_team_rows(b, s * s, c)
+    assert k == s * s // 64
+    x = (gen(b, s, s, c, seed=80) * 1.5 + 0.3).to(DEV)
+    dy = gen(b, s, s, c, seed=81).to(DEV)
+    gamma, beta = (1 + 0.2 * gen(c, seed=82)).to(DEV), (0.1 * gen(c, seed=83)).to(DEV)
+    act = variant != "no_act"
+    kw = {}
+    if "branch" in variant:
+        kw = {"add": gen(b, s, s, c, seed=84).to(DEV), "add_scale": 0.5}
+    if "accumulate" in variant:
+        kw["accumulate_dx"] = True
+    if variant == "dropout":
+        kw.update(drop_p=0.15, seed=1234)
+    st = ops.gn_stats(x, gamma, beta)
+    base = gen(b, s, s, c, seed=85).to(DEV) if "accumulate" in variant else torch.full_like(x, float("nan"))
+    dx0 = base.clone()
+    dg0, db0 = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    initial = ops.get_gn_bwd_kernel()
+    try:
+        ops.set_gn_bwd_kernel("one_slab")
+        assert ops.gn_bwd_team_rows(b, s * s, c) == 0            # the selector switches the team form off
+        ops.gn_bwd(dy, x, st, gamma, beta, act, dx0, dg0, db0, **kw)
+    finally:
+        ops.set_gn_bwd_kernel(initial)
+    outs = []
+    for _ in range(3):
+        dx = base.clone()
+        rows = torch.full((b * k, c + 8), float("nan"), device=DEV)
+        sums = ops.gn_bwd_team(dy, x, st, gamma, beta, act, dx, colsum_rows=rows, ld_rows=c + 8, **kw)
+        outs.append((dx, sums.clone(), rows))
+    assert ops.gn_team_errors(x.device) == 0
+    for dx, sums, rows in outs[1:]:
+        assert torch.equal(dx, outs[0][0]) and torch.equal(sums, outs[0][1]) and torch.equal(rows[:, :c], outs[0][2][:, :c])
+    dx, sums, rows = outs[0]
+    assert torch.isnan(rows[:, c:]).all()
+    scale = dx0.abs().max().item()
+    assert (dx - dx0).abs().max().item() < 3e-6 * scale and rel_l2(dx, dx0) < 1e-6
+    dg, db = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    ops.param_reduce2(sums, sums.view(-1)[c:], b * k, 2 * c, c, db, dg)
+    assert rel_l2(dg, dg0) < 2e-6 and rel_l2(db, db0) < 2e-6
+    want = dx.double().view(b, k, 64, c).sum(2).view(b * k, c)
+    mag = dx.double().abs().view(b, k, 64, c).sum(2).view(b * k, c).clamp_min(1e-30)
+    assert ((rows[:, :c].double() - want).abs() / mag).max().item() < 2e-6
+
+
 def test_split_k_slab_reductions_in_one_launch(ops):
     """psld_reduce_slabs_batch_f32: many weight gradients' split-K slabs reduced by one launch, bit for bit the per-layer
     psld_reduce_slabs_f32 calls - plain and OIHW-scattering layouts (through LDS: whole and partial 256-channel chunks, 1 and 9

@@ -2,7 +2,8 @@
     python tools/bench_reduce.py [jobs]"""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from psld_amd import ops
 
 dev = torch.device("cuda")
