@@ -379,16 +379,25 @@ class _Exec:
         the column sums of that gradient (a bias gradient) and a one-pass kernel takes the shape, they are formed here."""
         b, h, w, c = x.shape
         pa = self.net._param_arena()
-        sums = pa.floats(b, 2, c)
         node = last_writer_of
         fold = node is not None and node.want_gsum and colsum_img is None and self.gn_bwd_colsum and \
             ops.gn_bwd_colsum_supported(b, h * w, c, groups)
+        # with a third operand (and no per-IMAGE column sums asked for) large maps go through the whole-row team kernel:
+        # its sums / column sums come per (image, team member): k rows per image
+        k = ops.gn_bwd_team_wanted(b, h * w, c, groups) if (add is not None or accumulate_dx) and colsum_img is None else 0
+        rows = b * max(k, 1)
+        sums = pa.floats(rows, 2, c)
         if fold:
-            colsum_img, ld_img = pa.floats(b, c), c
-        ops.gn_bwd(dy, x, st, gamma, beta, act, dx, accumulate_dx=accumulate_dx, drop_p=drop_p, seed=seed, groups=groups,
-                   add=add, add_scale=add_scale, seed_dev=seed_dev, sums=sums, colsum_img=colsum_img, ld_img=ld_img)
-        self.defer_param(sums, b, 2 * c, c, dbeta)
-        self.defer_param(sums, b, 2 * c, c, dgamma, src_off=c)
+            colsum_img, ld_img = pa.floats(rows, c), c
+        if k:
+            ops.gn_bwd_team(dy, x, st, gamma, beta, act, dx, accumulate_dx=accumulate_dx, drop_p=drop_p, seed=seed,
+                            groups=groups, add=add, add_scale=add_scale, seed_dev=seed_dev, sums=sums, colsum_rows=colsum_img,
+                            ld_rows=ld_img)
+        else:
+            ops.gn_bwd(dy, x, st, gamma, beta, act, dx, accumulate_dx=accumulate_dx, drop_p=drop_p, seed=seed, groups=groups,
+                       add=add, add_scale=add_scale, seed_dev=seed_dev, sums=sums, colsum_img=colsum_img, ld_img=ld_img)
+        self.defer_param(sums, rows, 2 * c, c, dbeta)
+        self.defer_param(sums, rows, 2 * c, c, dgamma, src_off=c)
         if fold:
             node.gsum = colsum_img
 
