@@ -356,7 +356,10 @@ int psld_param_reduce_batch_f32(const long long* table_dev, int jobs, int blocks
  * a DEVICE table of 10 int64 [slabs pointer, nsplit, n, out pointer, layout, taps, cin, bit pattern of (float) alpha, first
  * unit, units]; a job has psld_reduce_slabs_batch_units(n, layout, taps, cin) units (0: the job does not qualify - n and cin
  * must be multiples of 4, taps <= 9; slabs 16-byte aligned); units = their sum.  With layout 1 the OIHW scatter goes through
- * LDS and leaves as contiguous 16-byte stores. */
+ * LDS and leaves as contiguous 16-byte stores.  layout 2: a column block of wider slabs - element (r, j) of the
+ * [n / cols][cols] result is the sum over slabs of slabs[s][r * ld + j] with cols passed as `taps`, ld as `cin`, a slab
+ * (n / cols) * ld floats long and the slabs pointer at the block's first column (the q | k | v weight gradients of
+ * AttnBlockpp from ONE [c][3c] GEMM, layerspp.py:78-80). */
 int psld_reduce_slabs_batch_units(long long n, int layout, int taps, int cin);
 int psld_reduce_slabs_batch_f32(const long long* table_dev, int jobs, long long units, hipStream_t stream);
 

@@ -115,6 +115,9 @@ __global__ void reduce_slabs4_kernel(const float* __restrict__ slabs, int nsplit
 // [slabs, nsplit, n, out, layout, taps, cin, alpha bits, first unit, units].  A workgroup owns one UNIT of one job, found by
 // binary search on the first units (block-uniform: scalar loads):
 //   layout 0:  1024 consecutive float4 of the [n] vector (four per thread, 256 apart);
+//   layout 2:  the same over a column block of wider slabs: slab element (r, j) of [n / cols][cols] sits at r * ld + j
+//              (cols = the `taps` field, ld = the `cin` field; the slabs pointer already points at the block's first column) -
+//              the three [c][c] gradients of one [c][3c] slab set (q | k | v projections computed by one GEMM);
 //   layout 1:  one output channel x up to 256 input channels x all taps.  The slabs hold [co][tap][ci]; the gradient wants
 //              OIHW = [co][ci][tap].  The per-thread scatter of reduce_slabs4_kernel writes single floats `taps` apart -
 //              32-byte memory transactions for 4 useful bytes - so here the summed [tap][ci] tile goes through LDS and
@@ -155,11 +158,15 @@ __global__ void __launch_bounds__(256) reduce_slabs_batch_kernel(const long long
     const float alpha = __builtin_bit_cast(float, (unsigned)row[7]);
     const int tid = threadIdx.x;
     if (row[4] != 1) {
+        const bool block2d = row[4] == 2;
+        const long long cols4 = block2d ? row[5] >> 2 : n4, ld4 = block2d ? row[6] >> 2 : n4;
+        const long long stride4 = block2d ? (n4 / cols4) * ld4 : n4;                 // float4 from a slab to the next
 #pragma unroll
         for (int k = 0; k < RSB_FLAT4 / 256; ++k) {
             const long long q = (long long)unit * RSB_FLAT4 + k * 256 + tid;
             if (q < n4) {
-                f32x4 acc = sum_slabs4(slabs + q, nsplit, n4);
+                const long long r = q / cols4, j = q - r * cols4;
+                f32x4 acc = sum_slabs4(slabs + r * ld4 + j, nsplit, stride4);
                 acc *= alpha;
                 reinterpret_cast<f32x4*>(out)[q] = acc;
             }
@@ -765,6 +772,7 @@ extern "C" int psld_reduce_slabs_batch_units(long long n, int layout, int taps, 
         if (taps < 1 || taps > RSB_MAXTAPS || cin < 4 || cin % 4 || n % ((long long)taps * cin)) return 0;
         return (int)(n / ((long long)taps * cin)) * ((cin + RSB_CI - 1) / RSB_CI);
     }
+    if (layout == 2 && (taps < 4 || taps % 4 || cin < taps || cin % 4 || n % taps)) return 0;      // taps = cols, cin = ld
     return (int)((n / 4 + RSB_FLAT4 - 1) / RSB_FLAT4);
 }
 

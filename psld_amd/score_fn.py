@@ -338,7 +338,8 @@ class _Exec:
         return self.net._slab_arena().alloc(nbytes)
 
     def reduce_slabs(self, slabs: Tensor, nsplit: int, n: int, out: Tensor, layout: int = 0, cout: int = 1, taps: int = 1,
-                     cin: int = 1, alpha: float = 1.0):
+                     cin: int = 1, alpha: float = 1.0, more: bool = False):
+        """``more``: further jobs on the SAME slab allocation follow (no flush - which rewinds the arena - in between)."""
         units = ops.slab_units(n, layout, taps, cin) if self.defer else 0
         if units == 0 or out.data_ptr() % 16:
             ops.reduce_slabs(slabs, nsplit, n, out, layout=layout, cout=cout, taps=taps, cin=cin, alpha=alpha)
@@ -346,7 +347,7 @@ class _Exec:
         self.sjobs.append(ops.slab_job(slabs, nsplit, n, out, layout, taps, cin, alpha) + (self.sitems, units))
         self.sitems += units
         self.sbytes += 4 * n * nsplit
-        if self.sbytes >= _SLAB_FLUSH_BYTES:
+        if self.sbytes >= _SLAB_FLUSH_BYTES and not more:
             self.flush_slabs()
 
     def flush_slabs(self):
@@ -975,7 +976,7 @@ class _Exec:
             ops.gemm_split(ho, None, m, f_o, c, out, epi_out)
         else:
             ops.gemm_raw(0, 0, m, c, c, ho, c, 0, n3.W, c, 0, out, c, 0, epi=epi_out)
-        on = _Node(out, want_gsum=True)             # NIN_3.b = s * column sums of its gradient
+        on = _Node(out, outp, want_gsum=True)       # NIN_3.b = s * column sums of its gradient
         if not self.record:
             return on
 
@@ -1022,8 +1023,26 @@ class _Exec:
             seg = fused and 3 * c <= 1024
             if seg:
                 self.on_side(lambda: ops.bias_grad_seg(dqkv, 3 * c, b, hw, (self.g(n0.b), self.g(n1.b), self.g(n2.b)), c), dqkv)
-            for nin, d in ((n0, dq), (n1, dk), (n2, dv)):
-                self.on_side(lambda nin=nin, d=d: nin_wgrad(hn, d, nin, 1.0, ld, bias=not seg), hn, d)
+            # ... and their weight gradients from ONE GEMM hn^T [dq | dk | dv] (N = 3c: hn is staged and split once instead
+            # of three times); the batched slab reduction cuts the [c][3c] result into the three parameters
+            one_gemm = fused and self.defer and self.split and ops.gemm_tn_split_supported(c, 3 * c, m) and \
+                ops.slab_units(c * c, 2, c, 3 * c) > 0
+
+            def qkv_wgrad():
+                nsplit = self._tn_split(c, 3 * c, m)
+                slabs = self.slabs_for(4 * 3 * c * c * nsplit, dev).view(torch.float32)
+                ops.gemm_tn_split(c, 3 * c, m, hn, c, dqkv, 3 * c, slabs, 3 * c, nsplit)
+                for i, nin in enumerate((n0, n1, n2)):
+                    self.reduce_slabs(slabs[i * c:], nsplit, c * c, self.g(nin.W), layout=2, taps=c, cin=3 * c, more=i < 2)
+
+            if one_gemm:
+                self.on_side(qkv_wgrad, hn, dqkv)
+                if not seg:
+                    for nin, d in ((n0, dq), (n1, dk), (n2, dv)):
+                        self.on_side(lambda nin=nin, d=d: self.bias_grad(d, self.g(nin.b), ld=ld), d)
+            else:
+                for nin, d in ((n0, dq), (n1, dk), (n2, dv)):
+                    self.on_side(lambda nin=nin, d=d: nin_wgrad(hn, d, nin, 1.0, ld, bias=not seg), hn, d)
             if fused:
                 ops.gemm_split(dqkv, None, m, f_qkv_d, c, dhn)
             else:

@@ -1041,6 +1041,18 @@ def test_split_k_slab_reductions_in_one_launch(ops):
         want.append(ref)
         outs.append(out)
         keep.append(slabs)
+    # three column blocks of one [c][3c] slab set (layout 2): the q | k | v weight gradients of one GEMM
+    cq, nsq = 64, 5
+    wide = gen(nsq, cq, 3 * cq, seed=330).to(DEV)
+    for kblk in range(3):
+        out = torch.full((cq * cq,), float("nan"), device=DEV)
+        jobs.append(ops.slab_job(wide.view(-1)[kblk * cq:], nsq, cq * cq, out, 2, cq, 3 * cq, 0.5))
+        ref = wide[0, :, kblk * cq:(kblk + 1) * cq].clone()
+        for s_ in range(1, nsq):
+            ref += wide[s_, :, kblk * cq:(kblk + 1) * cq]
+        want.append((ref * 0.5).reshape(-1))
+        outs.append(out)
+    keep.append(wide)
     rows, units = [], 0
     for j in jobs:
         u = ops.slab_units(j[2], j[4], j[5], j[6])
