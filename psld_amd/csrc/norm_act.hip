@@ -214,21 +214,19 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, const float* __rest
     if (seed_dev) seed += seed_dev[0];        // per-step seed kept in device memory (graph-captured training)
     const int q = threadIdx.x % cq, l = threadIdx.x / cq;
     const int p0 = chunk * chunk_px, p1 = min(hw, p0 + chunk_px);
-    const long long off = ((long long)n * hw) * c + q * 4;
-    f32x4 sc, sh, pre[4];
-    if (fp.part) {      // the first four pixels of this thread are asked for BEFORE the prologue: both latencies overlap
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int p = p0 + l + i * pl;
-            if (p < p1) pre[i] = *reinterpret_cast<const f32x4*>(x + off + (long long)p * c);
-        }
+    f32x4 sc, sh;
+    if (fp.part) {
         gn_own_scale_shift(fp, n, chunk, hw, c, q, sc, sh);
     } else {
         sc = *reinterpret_cast<const f32x4*>(scale + (long long)n * c + q * 4);
         sh = *reinterpret_cast<const f32x4*>(shift + (long long)n * c + q * 4);
     }
+    const long long off = ((long long)n * hw) * c + q * 4;
     const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
-    auto emit = [&](long long idx, const f32x4& v) {
+#pragma unroll 4
+    for (int p = p0 + l; p < p1; p += pl) {
+        const long long idx = off + (long long)p * c;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + idx);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -238,17 +236,6 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, const float* __rest
             o[e] = a;
         }
         *reinterpret_cast<f32x4*>(y + idx) = o;
-    };
-    int p = p0 + l;
-    if (fp.part) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i, p += pl)
-            if (p < p1) emit(off + (long long)p * c, pre[i]);
-    }
-#pragma unroll 4
-    for (; p < p1; p += pl) {
-        const long long idx = off + (long long)p * c;
-        emit(idx, *reinterpret_cast<const f32x4*>(x + idx));
     }
 }
 
@@ -276,23 +263,20 @@ __global__ void gn_apply_limb_kernel(const float* __restrict__ x, const float* _
     if (seed_dev) seed += seed_dev[0];        // per-step seed kept in device memory (graph-captured training)
     const int q = threadIdx.x % cq, l = threadIdx.x / cq;
     const int p0 = chunk * chunk_px, p1 = min(hw, p0 + chunk_px);
-    const long long off = ((long long)n * hw) * c + q * 4;
-    f32x4 sc, sh, pre[4];
-    if (fp.part) {      // (see gn_apply_kernel)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int p = p0 + l + i * pl;
-            if (p < p1) pre[i] = *reinterpret_cast<const f32x4*>(x + off + (long long)p * c);
-        }
+    f32x4 sc, sh;
+    if (fp.part) {
         gn_own_scale_shift(fp, n, chunk, hw, c, q, sc, sh);
     } else {
         sc = *reinterpret_cast<const f32x4*>(scale + (long long)n * c + q * 4);
         sh = *reinterpret_cast<const f32x4*>(shift + (long long)n * c + q * 4);
     }
+    const long long off = ((long long)n * hw) * c + q * 4;
     const long long yoff = ((long long)n * hw) * c * 6 + (q >> 3) * 192 + (q & 7) * 8;
     const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
-    auto emit = [&](int p, const f32x4& v) {
+#pragma unroll 4
+    for (int p = p0 + l; p < p1; p += pl) {
         const long long idx = off + (long long)p * c;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + idx);
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -308,15 +292,7 @@ __global__ void gn_apply_limb_kernel(const float* __restrict__ x, const float* _
         *reinterpret_cast<u32x2_t*>(d) = u32x2_t{h0, h1};
         *reinterpret_cast<u32x2_t*>(d + 64) = u32x2_t{m0, m1};
         *reinterpret_cast<u32x2_t*>(d + 128) = u32x2_t{l0, l1};
-    };
-    int p = p0 + l;
-    if (fp.part) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i, p += pl)
-            if (p < p1) emit(p, pre[i]);
     }
-#pragma unroll 4
-    for (; p < p1; p += pl) emit(p, *reinterpret_cast<const f32x4*>(x + off + (long long)p * c));
 }
 
 // ---- backward -------------------------------------------------------------------------------
