@@ -93,10 +93,6 @@ __global__ void gn_partial_kernel(const float* __restrict__ x, int hw, int c, in
     }
 }
 
-// shift = beta - mean * scale in ONE spelled-out form (a fused multiply-add): the finalize kernel and the apply kernels that
-// finalize for themselves must agree bit for bit, and left to itself hipcc contracts the expression differently per kernel
-__device__ __forceinline__ float gn_shift(float beta, float mean, float scale) { return __builtin_fmaf(-mean, scale, beta); }
-
 // Statistics of image n from its partial sums, by a 256-thread block: chunk lane kl adds chunks kl, kl + 8, ... of group g
 // (independent loads in flight: a single thread walking all chunks pays one memory latency per chunk), the 8 lanes are then
 // combined in lane order.  ONE definition for the finalize kernel and for the apply kernels that finalize for themselves:
@@ -157,7 +153,7 @@ __global__ void gn_finalize_kernel(const double* __restrict__ part, int hw, int 
         const int g = ch / cpg;
         const float sc = srstd[g] * gamma[ch];
         scale[(long long)n * c + ch] = sc;
-        shift[(long long)n * c + ch] = gn_shift(beta[ch], smean[g], sc);
+        shift[(long long)n * c + ch] = beta[ch] - smean[g] * sc;
     }
 }
 
@@ -189,7 +185,7 @@ __device__ __forceinline__ void gn_own_scale_shift(const GnFromPart& fp, int n, 
     for (int e = 0; e < 4; ++e) {
         const int g = (q * 4 + e) / cpg;
         sc[e] = srstd[g] * ga[e];
-        sh[e] = gn_shift(be[e], smean[g], sc[e]);
+        sh[e] = be[e] - smean[g] * sc[e];
     }
     if (chunk == 0) {
         const int tid = threadIdx.x;
@@ -201,7 +197,7 @@ __device__ __forceinline__ void gn_own_scale_shift(const GnFromPart& fp, int n, 
             const int g = ch / cpg;
             const float s_ = srstd[g] * fp.gamma[ch];
             fp.scale_out[(long long)n * c + ch] = s_;
-            fp.shift_out[(long long)n * c + ch] = gn_shift(fp.beta[ch], smean[g], s_);
+            fp.shift_out[(long long)n * c + ch] = fp.beta[ch] - smean[g] * s_;
         }
     }
 }
