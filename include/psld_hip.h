@@ -66,8 +66,7 @@ typedef struct psld_epilogue {
      * (layerspp.py:258,264 GroupNorm_0/1; :77 of the attention block).  gn_part[((img*chunks + chunk)*(N/8) + f)*2 + {0,1}]
      * = sum / sum of squares of the 8 channels 8f..8f+7 over the chunk-th run of 64 rows of image img
      * (chunks = gn_hw / 64, gn_hw = rows per image, a multiple of 64; N a multiple of 128).
-     * psld_gn_stats_from_partials_f32 (chunks = gn_hw / 64, fine = channels per group / 8) turns them into the statistics of
-     * any group size that is a multiple of 8. */
+     * psld_gn_stats_from_partials_f32 turns them into the statistics of any group size that is a multiple of 8. */
     double* gn_part;
     int gn_hw;
 } psld_epilogue_t;
@@ -269,25 +268,11 @@ int psld_gn_stats_nhwc_f32(const float* x, int batch, int hw, int c, int groups,
                            const float* gamma, const float* beta,
                            float* mean, float* rstd, float* scale, float* shift,
                            void* workspace, hipStream_t stream);
-/* First half of psld_gn_stats_nhwc_f32 alone: part[batch][chunks][groups][2] doubles (sum, sum of squares),
- * chunks = psld_gn_partial_chunks(batch, hw, c). */
-int psld_gn_partial_chunks(int batch, int hw, int c);
-int psld_gn_partials_nhwc_f32(const float* x, int batch, int hw, int c, int groups, double* part, hipStream_t stream);
-/* Second half of psld_gn_stats_nhwc_f32 on partial sums [batch][chunks][groups][fine][2]: those of psld_gn_partials_nhwc_f32
- * (fine = 1) or those a limb kernel's epilogue produced (psld_epilogue_t.gn_part: chunks = hw / 64, fine = channels per group / 8). */
-int psld_gn_stats_from_partials_f32(const double* gn_part, int batch, int hw, int c, int groups, int chunks, int fine, float eps,
+/* Second half of psld_gn_stats_nhwc_f32 on partial sums a limb kernel's epilogue produced (psld_epilogue_t.gn_part):
+ * fine = channels per group / 8. */
+int psld_gn_stats_from_partials_f32(const double* gn_part, int batch, int hw, int c, int groups, float eps,
                                     const float* gamma, const float* beta, float* mean, float* rstd,
                                     float* scale, float* shift, hipStream_t stream);
-/* psld_gn_apply_nhwc_f32 / psld_gn_apply_limb_nhwc (limb = 1) with the second half of the statistics done BY THE APPLY KERNEL:
- * every workgroup finalizes its image's statistics from the partial sums (bit for bit psld_gn_stats_from_partials_f32) and
- * the workgroup of an image's first pixels also writes mean / rstd (read by the backward pass) and the scale / shift rows.
- * One launch per GroupNorm instead of two (151 five-microsecond launches per C10-SOTA forward).  Shapes:
- * psld_gn_apply_part_supported (channel quads x pixel lanes = 256 threads). */
-int psld_gn_apply_part_supported(int batch, int hw, int c, int groups);
-int psld_gn_apply_part_nhwc_f32(const float* x, const double* part, int chunks, int fine, int groups, float eps,
-                                const float* gamma, const float* beta, float* mean, float* rstd, float* scale, float* shift,
-                                void* y, int limb, int batch, int hw, int c, int act, float drop_p, unsigned long long seed,
-                                const unsigned long long* seed_dev, hipStream_t stream);
 /* y = dropout(act(x*scale[n,c] + shift[n,c])); act: 0 = identity, 1 = SiLU.  Dropout
  * (nn.Dropout, layerspp.py:265): element i of the NHWC tensor is kept iff
  * psld_dropout_keep(seed, i, p) (counter-based hash, reproducible in the backward pass, no mask

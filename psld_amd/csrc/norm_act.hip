@@ -93,17 +93,22 @@ __global__ void gn_partial_kernel(const float* __restrict__ x, int hw, int c, in
     }
 }
 
-// Statistics of image n from its partial sums, by a 256-thread block: chunk lane kl adds chunks kl, kl + 8, ... of group g
-// (independent loads in flight: a single thread walking all chunks pays one memory latency per chunk), the 8 lanes are then
-// combined in lane order.  ONE definition for the finalize kernel and for the apply kernels that finalize for themselves:
-// the same sums in the same order, bit for bit.
-__device__ __forceinline__ void gn_block_stats(const double* __restrict__ part, int n, int hw, int cpg, int groups, int chunks,
-                                               int fine, float eps, double (*ps)[MAXG][2], float* smean, float* srstd) {
-    const int tid = threadIdx.x;
+// fine: partial sums per group in `part` (1 from gn_partial_kernel; channels-per-group / 8 for the 8-channel sums a
+// limb kernel's epilogue wrote), added in index order
+__global__ void gn_finalize_kernel(const double* __restrict__ part, int hw, int c, int groups, int chunks, int fine,
+                                   float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ mean, float* __restrict__ rstd,
+                                   float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ float smean[MAXG], srstd[MAXG];
+    __shared__ double ps[8][MAXG][2];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int cpg = c / groups;
+    // chunk lane kl adds chunks kl, kl + 8, ... of group g (independent loads in flight: a single thread walking all
+    // chunks pays one memory latency per chunk, 9 us per launch); the 8 lanes are then combined in lane order
     {
         const int g = tid & 31, kl = tid >> 5;
         double s = 0, ss = 0;
-        if (g < groups && kl < 8)
+        if (g < groups)
             for (int k = kl; k < chunks; k += 8) {
                 const double* pp = part + (((long long)n * chunks + k) * groups + g) * fine * 2;
                 for (int f = 0; f < fine; ++f) {
@@ -111,10 +116,8 @@ __device__ __forceinline__ void gn_block_stats(const double* __restrict__ part, 
                     ss += pp[2 * f + 1];
                 }
             }
-        if (kl < 8) {
-            ps[kl][g][0] = s;
-            ps[kl][g][1] = ss;
-        }
+        ps[kl][g][0] = s;
+        ps[kl][g][1] = ss;
     }
     __syncthreads();
     if (tid < groups) {
@@ -128,27 +131,13 @@ __device__ __forceinline__ void gn_block_stats(const double* __restrict__ part, 
         const double mu = s / cnt;
         double var = ss / cnt - mu * mu;
         if (var < 0) var = 0;
-        smean[tid] = (float)mu;
-        srstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+        const float m = (float)mu, r = (float)(1.0 / sqrt(var + (double)eps));
+        smean[tid] = m;
+        srstd[tid] = r;
+        mean[n * groups + tid] = m;
+        rstd[n * groups + tid] = r;
     }
     __syncthreads();
-}
-
-// fine: partial sums per group in `part` (1 from gn_partial_kernel; channels-per-group / 8 for the 8-channel sums a
-// limb kernel's epilogue wrote), added in index order
-__global__ void gn_finalize_kernel(const double* __restrict__ part, int hw, int c, int groups, int chunks, int fine,
-                                   float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ mean, float* __restrict__ rstd,
-                                   float* __restrict__ scale, float* __restrict__ shift) {
-    __shared__ float smean[MAXG], srstd[MAXG];
-    __shared__ double ps[8][MAXG][2];
-    const int n = blockIdx.x, tid = threadIdx.x;
-    const int cpg = c / groups;
-    gn_block_stats(part, n, hw, cpg, groups, chunks, fine, eps, ps, smean, srstd);
-    if (tid < groups) {
-        mean[n * groups + tid] = smean[tid];
-        rstd[n * groups + tid] = srstd[tid];
-    }
     for (int ch = tid; ch < c; ch += blockDim.x) {
         const int g = ch / cpg;
         const float sc = srstd[g] * gamma[ch];
@@ -157,66 +146,16 @@ __global__ void gn_finalize_kernel(const double* __restrict__ part, int hw, int 
     }
 }
 
-// What an apply kernel needs to finalize the statistics ITSELF (round 5): the partial sums of the tensor (from the producing
-// limb kernel's epilogue or from gn_partial_kernel) and the affine parameters.  Every block recomputes its image's group
-// statistics (8 KB of L2-resident partial sums; gn_block_stats: bit for bit gn_finalize_kernel) instead of reading the
-// scale / shift rows a separate 5 us launch used to write - 151 launches per forward; the block of chunk 0 writes mean /
-// rstd (the backward pass reads them) and the scale / shift rows (the C ABI's contract for psld_gn_stats_*).
-struct GnFromPart {
-    const double* part;      // null: scale / shift are given
-    const float* gamma;
-    const float* beta;
-    float* mean;
-    float* rstd;
-    float* scale_out;
-    float* shift_out;
-    int groups, chunks, fine;
-    float eps;
-};
-
-__device__ __forceinline__ void gn_own_scale_shift(const GnFromPart& fp, int n, int chunk, int hw, int c, int q, f32x4& sc,
-                                                   f32x4& sh) {
-    __shared__ float smean[MAXG], srstd[MAXG];
-    __shared__ double ps[8][MAXG][2];
-    const int cpg = c / fp.groups;
-    gn_block_stats(fp.part, n, hw, cpg, fp.groups, fp.chunks, fp.fine, fp.eps, ps, smean, srstd);
-    const f32x4 ga = *reinterpret_cast<const f32x4*>(fp.gamma + q * 4), be = *reinterpret_cast<const f32x4*>(fp.beta + q * 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int g = (q * 4 + e) / cpg;
-        sc[e] = srstd[g] * ga[e];
-        sh[e] = be[e] - smean[g] * sc[e];
-    }
-    if (chunk == 0) {
-        const int tid = threadIdx.x;
-        if (tid < fp.groups) {
-            fp.mean[n * fp.groups + tid] = smean[tid];
-            fp.rstd[n * fp.groups + tid] = srstd[tid];
-        }
-        for (int ch = tid; ch < c; ch += blockDim.x) {
-            const int g = ch / cpg;
-            const float s_ = srstd[g] * fp.gamma[ch];
-            fp.scale_out[(long long)n * c + ch] = s_;
-            fp.shift_out[(long long)n * c + ch] = fp.beta[ch] - smean[g] * s_;
-        }
-    }
-}
-
 __global__ void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                 const float* __restrict__ shift, float* __restrict__ y, int hw, int c, int cq,
                                 int pl, int chunk_px, int act, float drop_p, unsigned long long seed,
-                                const unsigned long long* __restrict__ seed_dev, const GnFromPart fp) {
+                                const unsigned long long* __restrict__ seed_dev) {
     const int n = blockIdx.y, chunk = blockIdx.x;
     if (seed_dev) seed += seed_dev[0];        // per-step seed kept in device memory (graph-captured training)
     const int q = threadIdx.x % cq, l = threadIdx.x / cq;
     const int p0 = chunk * chunk_px, p1 = min(hw, p0 + chunk_px);
-    f32x4 sc, sh;
-    if (fp.part) {
-        gn_own_scale_shift(fp, n, chunk, hw, c, q, sc, sh);
-    } else {
-        sc = *reinterpret_cast<const f32x4*>(scale + (long long)n * c + q * 4);
-        sh = *reinterpret_cast<const f32x4*>(shift + (long long)n * c + q * 4);
-    }
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + (long long)n * c + q * 4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + (long long)n * c + q * 4);
     const long long off = ((long long)n * hw) * c + q * 4;
     const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
 #pragma unroll 4
@@ -253,19 +192,14 @@ __device__ __forceinline__ void gn_split3(float x0, float x1, unsigned& hi, unsi
 __global__ void gn_apply_limb_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                      const float* __restrict__ shift, unsigned char* __restrict__ y, int hw, int c, int cq,
                                      int pl, int chunk_px, int act, float drop_p, unsigned long long seed,
-                                const unsigned long long* __restrict__ seed_dev, const GnFromPart fp) {
+                                const unsigned long long* __restrict__ seed_dev) {
     typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
     const int n = blockIdx.y, chunk = blockIdx.x;
     if (seed_dev) seed += seed_dev[0];        // per-step seed kept in device memory (graph-captured training)
     const int q = threadIdx.x % cq, l = threadIdx.x / cq;
     const int p0 = chunk * chunk_px, p1 = min(hw, p0 + chunk_px);
-    f32x4 sc, sh;
-    if (fp.part) {
-        gn_own_scale_shift(fp, n, chunk, hw, c, q, sc, sh);
-    } else {
-        sc = *reinterpret_cast<const f32x4*>(scale + (long long)n * c + q * 4);
-        sh = *reinterpret_cast<const f32x4*>(shift + (long long)n * c + q * 4);
-    }
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + (long long)n * c + q * 4);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + (long long)n * c + q * 4);
     const long long off = ((long long)n * hw) * c + q * 4;
     const long long yoff = ((long long)n * hw) * c * 6 + (q >> 3) * 192 + (q & 7) * 8;
     const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
@@ -1222,24 +1156,6 @@ extern "C" long long psld_gn_workspace_bytes(int batch, int hw, int c, int group
     return (long long)(fwd > bwd ? fwd : bwd);
 }
 
-// Partial sums only (psld_gn_stats_nhwc_f32 without its finalize launch): part[batch][chunks][groups][2] doubles with
-// chunks = psld_gn_partial_chunks(batch, hw, c); psld_gn_apply_part_* / psld_gn_stats_from_partials_f32 (fine = 1) take them.
-extern "C" int psld_gn_partial_chunks(int batch, int hw, int c) {
-    if (batch <= 0 || hw <= 0 || c <= 0 || c % 4 || c / 4 > MAXT) return 0;
-    return make_map(batch, hw, c).chunks;
-}
-
-extern "C" int psld_gn_partials_nhwc_f32(const float* x, int batch, int hw, int c, int groups, double* part, hipStream_t stream) {
-    PSLD_CHECK_ARG(x && part, "psld_gn_partials: null pointer");
-    PSLD_CHECK_ARG(c % 4 == 0 && c / 4 <= MAXT && groups <= MAXG && c % groups == 0,
-                   "psld_gn_partials: unsupported C=%d groups=%d", c, groups);
-    const Map m = make_map(batch, hw, c);
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(m.chunks, batch), dim3(m.threads), 0, stream, x, hw, c, groups, m.cq,
-                       m.pl, m.chunk_px, m.chunks, part);
-    PSLD_CHECK_LAUNCH("gn_partial_kernel");
-    return PSLD_OK;
-}
-
 extern "C" int psld_gn_stats_nhwc_f32(const float* x, int batch, int hw, int c, int groups, float eps,
                                       const float* gamma, const float* beta, float* mean, float* rstd,
                                       float* scale, float* shift, void* workspace, hipStream_t stream) {
@@ -1257,59 +1173,15 @@ extern "C" int psld_gn_stats_nhwc_f32(const float* x, int batch, int hw, int c, 
     return PSLD_OK;
 }
 
-extern "C" int psld_gn_stats_from_partials_f32(const double* gn_part, int batch, int hw, int c, int groups, int chunks, int fine,
-                                               float eps, const float* gamma, const float* beta, float* mean, float* rstd,
+extern "C" int psld_gn_stats_from_partials_f32(const double* gn_part, int batch, int hw, int c, int groups, float eps,
+                                               const float* gamma, const float* beta, float* mean, float* rstd,
                                                float* scale, float* shift, hipStream_t stream) {
     PSLD_CHECK_ARG(gn_part && gamma && beta && mean && rstd && scale && shift, "psld_gn_stats_from_partials: null pointer");
-    PSLD_CHECK_ARG(groups > 0 && groups <= MAXG && c % groups == 0 && chunks > 0 && fine > 0 && hw > 0,
-                   "psld_gn_stats_from_partials: unsupported C=%d groups=%d chunks=%d fine=%d", c, groups, chunks, fine);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, stream, gn_part, hw, c, groups, chunks, fine, eps,
-                       gamma, beta, mean, rstd, scale, shift);
+    PSLD_CHECK_ARG(groups > 0 && groups <= MAXG && c % groups == 0 && (c / groups) % 8 == 0 && hw % 64 == 0 && hw > 0,
+                   "psld_gn_stats_from_partials: unsupported C=%d groups=%d hw=%d", c, groups, hw);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, stream, gn_part, hw, c, groups, hw / 64,
+                       (c / groups) / 8, eps, gamma, beta, mean, rstd, scale, shift);
     PSLD_CHECK_LAUNCH("gn_finalize_kernel");
-    return PSLD_OK;
-}
-
-namespace {
-// map of the apply kernels that finalize for themselves: 256 threads (gn_block_stats' thread roles) and at least 16 pixels
-// per block (the 8 KB prologue is paid per block)
-inline bool apply_part_map(int batch, int hw, int c, Map* out) {
-    if (c % 4 || c / 4 > MAXT) return false;
-    Map m = make_map(batch, hw, c, true);
-    if (m.threads != 256) return false;
-    const int min_px = 16;
-    if (m.chunk_px < min_px) {
-        m.chunk_px = min_px < hw ? min_px : hw;
-        m.chunks = cdiv(hw, m.chunk_px);
-    }
-    *out = m;
-    return true;
-}
-}  // namespace
-
-extern "C" int psld_gn_apply_part_supported(int batch, int hw, int c, int groups) {
-    Map m;
-    return batch > 0 && hw > 0 && c > 0 && groups > 0 && groups <= MAXG && c % groups == 0 && apply_part_map(batch, hw, c, &m);
-}
-
-// y = dropout(act(GN(x))) with the statistics finalized by the kernel itself from partial sums (limb = 1: y as limb planes)
-extern "C" int psld_gn_apply_part_nhwc_f32(const float* x, const double* part, int chunks, int fine, int groups, float eps,
-                                           const float* gamma, const float* beta, float* mean, float* rstd, float* scale,
-                                           float* shift, void* y, int limb, int batch, int hw, int c, int act, float drop_p,
-                                           unsigned long long seed, const unsigned long long* seed_dev, hipStream_t stream) {
-    PSLD_CHECK_ARG(x && part && gamma && beta && mean && rstd && scale && shift && y, "psld_gn_apply_part: null pointer");
-    Map m;
-    PSLD_CHECK_ARG(psld_gn_apply_part_supported(batch, hw, c, groups) && apply_part_map(batch, hw, c, &m) && chunks > 0 && fine > 0,
-                   "psld_gn_apply_part: unsupported B=%d hw=%d C=%d groups=%d", batch, hw, c, groups);
-    PSLD_CHECK_ARG(!limb || c % 32 == 0, "psld_gn_apply_part: limb planes need C %% 32 == 0 (C=%d)", c);
-    PSLD_CHECK_ARG((reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) % 16 == 0, "psld_gn_apply_part: unaligned gamma / beta");
-    const GnFromPart fp{part, gamma, beta, mean, rstd, scale, shift, groups, chunks, fine, eps};
-    if (limb)
-        hipLaunchKernelGGL(gn_apply_limb_kernel, dim3(m.chunks, batch), dim3(m.threads), 0, stream, x, nullptr, nullptr,
-                           reinterpret_cast<unsigned char*>(y), hw, c, m.cq, m.pl, m.chunk_px, act, drop_p, seed, seed_dev, fp);
-    else
-        hipLaunchKernelGGL(gn_apply_kernel, dim3(m.chunks, batch), dim3(m.threads), 0, stream, x, nullptr, nullptr,
-                           reinterpret_cast<float*>(y), hw, c, m.cq, m.pl, m.chunk_px, act, drop_p, seed, seed_dev, fp);
-    PSLD_CHECK_LAUNCH("gn_apply_kernel (own statistics)");
     return PSLD_OK;
 }
 
@@ -1320,7 +1192,7 @@ extern "C" int psld_gn_apply_nhwc_f32(const float* x, const float* scale, const 
     PSLD_CHECK_ARG(c % 4 == 0 && c / 4 <= MAXT, "psld_gn_apply: unsupported C=%d", c);
     const Map m = make_map(batch, hw, c, true);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(m.chunks, batch), dim3(m.threads), 0, stream, x, scale, shift, y, hw, c,
-                       m.cq, m.pl, m.chunk_px, act, drop_p, seed, seed_dev, GnFromPart{});
+                       m.cq, m.pl, m.chunk_px, act, drop_p, seed, seed_dev);
     PSLD_CHECK_LAUNCH("gn_apply_kernel");
     return PSLD_OK;
 }
@@ -1332,8 +1204,7 @@ extern "C" int psld_gn_apply_limb_nhwc(const float* x, const float* scale, const
     PSLD_CHECK_ARG(c % 32 == 0 && c / 4 <= MAXT, "psld_gn_apply_limb: unsupported C=%d (needs a multiple of 32, <= 1024)", c);
     const Map m = make_map(batch, hw, c, true);
     hipLaunchKernelGGL(gn_apply_limb_kernel, dim3(m.chunks, batch), dim3(m.threads), 0, stream, x, scale, shift,
-                       reinterpret_cast<unsigned char*>(y_limb), hw, c, m.cq, m.pl, m.chunk_px, act, drop_p, seed, seed_dev,
-                       GnFromPart{});
+                       reinterpret_cast<unsigned char*>(y_limb), hw, c, m.cq, m.pl, m.chunk_px, act, drop_p, seed, seed_dev);
     PSLD_CHECK_LAUNCH("gn_apply_limb_kernel");
     return PSLD_OK;
 }

@@ -474,35 +474,13 @@ def workspace(nbytes: int, device) -> Tensor:
 
 
 class GNStats:
-    """GroupNorm statistics of a [b, h, w, c] tensor: mean / rstd [b][groups], scale / shift [b][c].  They may be PENDING: the
-    partial sums exist (``pending`` = (part, chunks, fine, gamma, beta, eps, hw)) and the second half runs either inside the
-    apply kernel that consumes them (gn_apply / gn_apply_limb: no launch of its own) or, for any other reader of the four
-    tensors, as a finalize launch on first access."""
-    __slots__ = ("_mean", "_rstd", "_scale", "_shift", "pending", "groups")
+    __slots__ = ("mean", "rstd", "scale", "shift")
 
     def __init__(self, b, g, c, device):
-        self._mean = torch.empty((b, g), device=device, dtype=torch.float32)
-        self._rstd = torch.empty((b, g), device=device, dtype=torch.float32)
-        self._scale = torch.empty((b, c), device=device, dtype=torch.float32)
-        self._shift = torch.empty((b, c), device=device, dtype=torch.float32)
-        self.pending = None
-        self.groups = g
-
-    def materialize(self):
-        if self.pending is not None:
-            part, chunks, fine, gamma, beta, eps, hw = self.pending
-            self.pending = None
-            b, c = self._scale.shape
-            check(lib().psld_gn_stats_from_partials_f32(part.data_ptr(), b, hw, c, self.groups, chunks, fine, eps,
-                                                        gamma.data_ptr(), beta.data_ptr(), self._mean.data_ptr(),
-                                                        self._rstd.data_ptr(), self._scale.data_ptr(), self._shift.data_ptr(),
-                                                        _stream()), "psld_gn_stats_from_partials_f32")
-        return self
-
-    mean = property(lambda self: self.materialize()._mean)
-    rstd = property(lambda self: self.materialize()._rstd)
-    scale = property(lambda self: self.materialize()._scale)
-    shift = property(lambda self: self.materialize()._shift)
+        self.mean = torch.empty((b, g), device=device, dtype=torch.float32)
+        self.rstd = torch.empty((b, g), device=device, dtype=torch.float32)
+        self.scale = torch.empty((b, c), device=device, dtype=torch.float32)
+        self.shift = torch.empty((b, c), device=device, dtype=torch.float32)
 
 
 @functools.lru_cache(maxsize=None)
@@ -511,15 +489,14 @@ def gn_groups(c: int) -> int:
 
 
 def gn_stats(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-6, groups: Optional[int] = None) -> GNStats:
-    """``groups``: override for a tensor that is one source of a concatenation (its share of the groups).  One pass over x
-    for the partial sums; the second half is pending (see GNStats)."""
+    """``groups``: override for a tensor that is one source of a concatenation (its share of the groups)."""
     b, h, w, c = x.shape
     g = groups if groups is not None else gn_groups(c)
     st = GNStats(b, g, c, x.device)
-    chunks = int(lib().psld_gn_partial_chunks(b, h * w, c))
-    part = torch.empty((b, chunks, g, 2), device=x.device, dtype=torch.float64)
-    check(lib().psld_gn_partials_nhwc_f32(x.data_ptr(), b, h * w, c, g, part.data_ptr(), _stream()), "psld_gn_partials_nhwc_f32")
-    st.pending = (part, chunks, 1, gamma, beta, eps, h * w)
+    ws = workspace(lib().psld_gn_workspace_bytes(b, h * w, c, g), x.device)
+    check(lib().psld_gn_stats_nhwc_f32(x.data_ptr(), b, h * w, c, g, eps, gamma.data_ptr(), beta.data_ptr(),
+                                       st.mean.data_ptr(), st.rstd.data_ptr(), st.scale.data_ptr(),
+                                       st.shift.data_ptr(), ws.data_ptr(), _stream()), "psld_gn_stats_nhwc_f32")
     return st
 
 
@@ -538,36 +515,14 @@ def gn_part_buffer(b: int, hw: int, c: int, device) -> Tensor:
 
 def gn_stats_from_part(part: Tensor, shape, gamma: Tensor, beta: Tensor, eps: float = 1e-6,
                        groups: Optional[int] = None) -> GNStats:
-    """gn_stats of a tensor of ``shape`` = (b, h, w, c) whose producer left the partial sums in ``part`` (pending: GNStats)."""
+    """gn_stats of a tensor of ``shape`` = (b, h, w, c) whose producer left the partial sums in ``part``."""
     b, h, w, c = shape
     g = groups if groups is not None else gn_groups(c)
     st = GNStats(b, g, c, part.device)
-    st.pending = (part, (h * w) // 64, (c // g) // 8, gamma, beta, eps, h * w)
+    check(lib().psld_gn_stats_from_partials_f32(part.data_ptr(), b, h * w, c, g, eps, gamma.data_ptr(), beta.data_ptr(),
+                                                st.mean.data_ptr(), st.rstd.data_ptr(), st.scale.data_ptr(),
+                                                st.shift.data_ptr(), _stream()), "psld_gn_stats_from_partials_f32")
     return st
-
-
-@functools.lru_cache(maxsize=None)
-def gn_apply_part_supported(b: int, hw: int, c: int, groups: int) -> bool:
-    return bool(lib().psld_gn_apply_part_supported(b, hw, c, groups))
-
-
-_APPLY_PART_MIN_PIXELS = 32768      # batch x hw from which the apply kernels finalize the statistics themselves (B = 32 at 32x32)
-
-
-def _apply_from_part(x: Tensor, st: GNStats, act: bool, out_ptr: int, limb: bool, drop_p: float, seed: int, seed_dev) -> bool:
-    """The apply pass with the pending second half of the statistics inside it; False: not applicable (materialize first)."""
-    b, h, w, c = x.shape
-    if st.pending is None or b * h * w < _APPLY_PART_MIN_PIXELS or not gn_apply_part_supported(b, h * w, c, st.groups):
-        return False
-    part, chunks, fine, gamma, beta, eps, hw = st.pending
-    if gamma.data_ptr() % 16 or beta.data_ptr() % 16:
-        return False
-    st.pending = None
-    check(lib().psld_gn_apply_part_nhwc_f32(x.data_ptr(), part.data_ptr(), chunks, fine, st.groups, eps, gamma.data_ptr(),
-                                            beta.data_ptr(), st._mean.data_ptr(), st._rstd.data_ptr(), st._scale.data_ptr(),
-                                            st._shift.data_ptr(), out_ptr, 1 if limb else 0, b, hw, c, 1 if act else 0, drop_p,
-                                            seed, _p(seed_dev), _stream()), "psld_gn_apply_part_nhwc_f32")
-    return True
 
 
 def gn_apply(x: Tensor, st: GNStats, act: bool, out: Optional[Tensor] = None, drop_p: float = 0.0,
@@ -576,8 +531,6 @@ def gn_apply(x: Tensor, st: GNStats, act: bool, out: Optional[Tensor] = None, dr
     b, h, w, c = x.shape
     if out is None:
         out = torch.empty_like(x)
-    if _apply_from_part(x, st, act, out.data_ptr(), False, drop_p, seed, seed_dev):
-        return out
     check(lib().psld_gn_apply_nhwc_f32(x.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), out.data_ptr(), b,
                                        h * w, c, 1 if act else 0, drop_p, seed, _p(seed_dev), _stream()),
           "psld_gn_apply_nhwc_f32")
@@ -589,8 +542,6 @@ def gn_apply_limb(x: Tensor, st: GNStats, act: bool, drop_p: float = 0.0, seed: 
     """GroupNorm apply (+SiLU, dropout) writing bf16 limb planes for a 3x3 convolution to stage by LDS-DMA."""
     b, h, w, c = x.shape
     out = LimbPlanes(x.shape, x.device)
-    if _apply_from_part(x, st, act, out.data_ptr(), True, drop_p, seed, seed_dev):
-        return out
     check(lib().psld_gn_apply_limb_nhwc(x.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), out.data_ptr(), b,
                                         h * w, c, 1 if act else 0, drop_p, seed, _p(seed_dev), _stream()),
           "psld_gn_apply_limb_nhwc")

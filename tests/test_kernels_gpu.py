@@ -972,51 +972,6 @@ def test_groupnorm_backward_column_sums_of_dx(ops, b, s, c, variant):
     assert rel_l2(db0, sums0[:, 0].double().sum(0)) < 1e-6 and rel_l2(dg0, sums0[:, 1].double().sum(0)) < 1e-6
 
 
-@pytest.mark.parametrize("b,s,c", [(64, 32, 256), (128, 16, 256), (32, 32, 128), (128, 8, 256), (33, 32, 512), (40, 32, 64)])
-@pytest.mark.parametrize("source", ["tensor pass", "epilogue sums"])
-def test_groupnorm_apply_finalizes_its_own_statistics(ops, b, s, c, source):
-    """psld_gn_apply_part_nhwc_f32: the apply pass (fp32 and limb-plane output, SiLU + dropout) with the second half of the
-    statistics inside it, from the partial sums of the tensor pass (psld_gn_partials_nhwc_f32) or in the layout a limb kernel's
-    epilogue leaves ([b][hw/64][c/8][2]): output, mean, rstd, scale and shift bit for bit those of the finalize launch +
-    plain apply."""
-    x = (gen(b, s, s, c, seed=90) * 1.3 - 0.2).to(DEV)
-    gamma, beta = (1 + 0.2 * gen(c, seed=91)).to(DEV), (0.1 * gen(c, seed=92)).to(DEV)
-    hw = s * s
-
-    def stats():
-        if source == "tensor pass":
-            return ops.gn_stats(x, gamma, beta)
-        if (c // ops.gn_groups(c)) % 8 or hw % 64:
-            pytest.skip("the epilogue's 8-channel / 64-row sums do not tile this shape")
-        xd = x.double().view(b, hw // 64, 64, c // 8, 8)
-        part = torch.stack([xd.sum(dim=(2, 4)), (xd * xd).sum(dim=(2, 4))], dim=-1).contiguous()
-        return ops.gn_stats_from_part(part, x.shape, gamma, beta)
-
-    assert ops.gn_apply_part_supported(b, hw, c, ops.gn_groups(c))
-    for limb in (False, True):
-        if limb and c % 32:
-            continue
-        apply = ops.gn_apply_limb if limb else ops.gn_apply
-        kw = dict(drop_p=0.15, seed=77)
-        st_a = stats()
-        assert st_a.pending is not None
-        ya = apply(x, st_a, True, **kw)                      # own statistics
-        assert st_a.pending is None
-        st_b = stats().materialize()                         # finalize launch, then the plain apply
-        yb = apply(x, st_b, True, **kw)
-        if limb:
-            assert torch.equal(ya.t, yb.t)
-        else:
-            assert torch.equal(ya, yb)
-        for f in ("_mean", "_rstd", "_scale", "_shift"):
-            assert torch.equal(getattr(st_a, f), getattr(st_b, f)), f
-    # against fp64
-    xr = x[:2].permute(0, 3, 1, 2).double().cpu()
-    want = F.silu(F.group_norm(xr, ops.gn_groups(c), gamma.double().cpu(), beta.double().cpu(), 1e-6)).permute(0, 2, 3, 1)
-    got = ops.gn_apply(x, stats(), True)[:2]
-    assert rel_l2(got, want) < 2e-6
-
-
 @pytest.mark.parametrize("b,s,c", [(128, 32, 256), (128, 16, 256), (16, 32, 256), (5, 16, 128), (3, 32, 128), (7, 16, 512)])
 @pytest.mark.parametrize("variant", ["plain", "branch", "dropout", "accumulate", "branch_accumulate", "no_act"])
 def test_groupnorm_backward_on_whole_rows_by_teams(ops, b, s, c, variant):

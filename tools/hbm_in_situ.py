@@ -33,12 +33,7 @@ def _b(fam, fn):
 
 BYTES = {
     "psld_gn_stats_nhwc_f32": _b("gn_stats", lambda a: 4 * a[1] * a[2] * a[3]),
-    "psld_gn_partials_nhwc_f32": _b("gn_stats", lambda a: 4 * a[1] * a[2] * a[3]),
-    "psld_gn_stats_from_partials_f32": _b("gn_stats", lambda a: a[1] * a[5] * a[4] * a[6] * 16),
-    # the apply kernels that finalize the statistics themselves: 8 (10 into limb planes) B / element + the partial sums once
-    "psld_gn_apply_part_nhwc_f32": _b("gn_apply", lambda a: ("gn_apply_limb" if a[13] else "gn_apply",
-                                                              (10 if a[13] else 8) * a[14] * a[15] * a[16] + a[14] * a[2] * a[4] * a[3] * 16)),
-    "psld_gn_bwd_team_f32": _b("gn_bwd", lambda a: (12 + (4 if a[15] else 0) + (4 if a[16] else 0)) * a[6] * a[7] * a[8]),
+    "psld_gn_stats_from_partials_f32": _b("gn_stats", lambda a: a[1] * max(1, a[2] // 64) * (a[3] // 8) * 16),
     "psld_gn_apply_nhwc_f32": _b("gn_apply", lambda a: 8 * a[4] * a[5] * a[6]),
     "psld_gn_apply_limb_nhwc": _b("gn_apply_limb", lambda a: 10 * a[4] * a[5] * a[6]),
     "psld_gn_bwd_nhwc_f32": _b("gn_bwd", lambda a: (12 + (4 if a[15] else 0) + (4 if a[16] else 0)) * a[6] * a[7] * a[8]),
@@ -104,10 +99,8 @@ class _Log:
             vals = [int(v.value if hasattr(v, "value") and v.value is not None else 0) if hasattr(v, "value") else (v if v is not None else 0)
                     for v in args]
             try:
-                got = calc(vals)
-                f2, nb = got if isinstance(got, tuple) else (fam, got)
-                self.bytes[f2] += int(nb)
-                self.calls[f2] += 1
+                self.bytes[fam] += int(calc(vals))
+                self.calls[fam] += 1
             except Exception as e:  # noqa: BLE001
                 print("hbm_in_situ: cannot size", name, e, file=sys.stderr)
             return fn(*args)
