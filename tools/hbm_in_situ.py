@@ -36,6 +36,7 @@ BYTES = {
     "psld_gn_stats_from_partials_f32": _b("gn_stats", lambda a: a[1] * max(1, a[2] // 64) * (a[3] // 8) * 16),
     "psld_gn_apply_nhwc_f32": _b("gn_apply", lambda a: 8 * a[4] * a[5] * a[6]),
     "psld_gn_apply_limb_nhwc": _b("gn_apply_limb", lambda a: 10 * a[4] * a[5] * a[6]),
+    "psld_gn_bwd_team_f32": _b("gn_bwd", lambda a: (12 + (4 if a[15] else 0) + (4 if a[16] else 0)) * a[6] * a[7] * a[8]),
     "psld_gn_bwd_nhwc_f32": _b("gn_bwd", lambda a: (12 + (4 if a[15] else 0) + (4 if a[16] else 0)) * a[6] * a[7] * a[8]),
     "psld_param_reduce2_f32": _b("param_reduce", lambda a: 4 * (a[2] + 1) * a[4] * (2 if a[1] else 1)),
     "psld_bias_grad_seg_f32": _b("bias_grad", lambda a: 4 * a[2] * a[3] * 3 * a[4]),
