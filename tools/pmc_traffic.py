@@ -1,4 +1,4 @@
-"""HBM traffic per launch of the dominant convolution from rocprofv3 PMC passes -> profiles/r04/pmc_traffic.json
+"""HBM traffic per launch of the dominant convolution from rocprofv3 PMC passes -> profiles/r05/pmc_traffic.json
 (read by bench.py for roofline.traffic, which refuses it once the kernel sources change).  Round 3: the dominant launch
 is the Winograd kernel (wino_conv8s_kernel); the direct kernel and the weight gradient are recorded next to it.
 
@@ -67,14 +67,21 @@ def main():
         "sources": SOURCES, "sources_sha256": sources_sha(),
         "note": f"HBM bytes/launch of the conv3x3 256->256 @32x32 B=128 Winograd launch (PMC FETCH_SIZE x2 + WRITE_SIZE, "
                 f"this build): {(fetch_b + write_b) / 1e6:.1f} MB vs {algo / 1e6:.1f} MB algorithmic "
-                f"(input 134.2 + residual 134.2 + output 134.2 + Winograd limb fragments 6.3)",
+                f"(input 134.2 + residual 134.2 + output 134.2 + Winograd limb fragments 6.3).  STRUCTURAL for this kernel's "
+                f"128-channel accumulator tile, and closed as such (VERDICT r04 #6b): the input is fetched once per 128-channel "
+                f"output tile (2 of them) x 6/4 halo rows = 3 x 134.2 = 402.6 MB, + residual 134.2 + the transformed weights "
+                f"streamed once per XCD (~25 MB) = 562 MB of the {fetch_b / 1e6:.0f} MB fetched (the rest: 34-pixel halo rows "
+                f"over-fetching partial lines).  The two channel tiles of a pixel tile run on DIFFERENT XCDs (channel-tile-major "
+                f"order: an XCD streams ONE 3.1 MB slice of U, which stays in its 4 MB L2); putting them on the same XCD "
+                f"(pixel-tile-major) was measured in round 3: 690 MB fetched (both slices of U no longer fit the L2) and 1-2 % "
+                f"slower.  At {(fetch_b + write_b) / 1e6 / 0.44:.0f} GB/s over the launch's ~440 us this is 0.2 of the HBM rate: not the bound.",
     }
     for tag, label in (("dconv", "dconv_lp_kernel (direct, limb-plane input, same shape and epilogue)"),
                        ("dconv_f32", "dconv_kernel<7,9> (direct, fp32 input, same shape and epilogue)"),
                        ("dwgrad", "dwgrad_kernel<4> 256->256 @32x32 B=128")):
         if tag in fetch and tag in write:
             rec[label] = {"fetch_bytes_corrected": fetch[tag][0] * 2048, "write_bytes": write[tag][0] * 1024}
-    path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r04", "pmc_traffic.json")
+    path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r05", "pmc_traffic.json")
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "w") as fh:
         json.dump(rec, fh, indent=1)
