@@ -544,6 +544,10 @@ def main():
             sh = sampling_shard(rank, world, 0, batch=max(1, args.sample_batch))
             fake = {"measured_batch_s": 1.0 + rank, "sampler_s": 0.5 + rank, "finite": True, "n_discrete_steps": 1000,
                     "network_evals_per_s": 1.0, "fwd_tflops": 1.0}
+            own = -(-50000 // world)
+            if own % max(1, args.sample_batch):          # the shard's last batch is partial: it is measured too
+                fake["partial_batch"] = {"batch": own % max(1, args.sample_batch), "measured_batch_s": 0.25 + rank,
+                                         "finite": True, "ms_per_em_step": 0.25 + rank}
             samp = reduce_sampling(fake, rank, world, backend_name == "nccl", torch.device("cuda", local) if backend_name == "nccl" else None, sh)
             lohi = torch.zeros(2 * world, dtype=torch.float64, device=torch.device("cuda", local) if backend_name == "nccl" else "cpu")
             lohi[2 * rank], lohi[2 * rank + 1] = sh["lo"], sh["hi"]

@@ -161,16 +161,34 @@ __global__ void __launch_bounds__(256) reduce_slabs_batch_kernel(const long long
         const bool block2d = row[4] == 2;
         const long long cols4 = block2d ? row[5] >> 2 : n4, ld4 = block2d ? row[6] >> 2 : n4;
         const long long stride4 = block2d ? (n4 / cols4) * ld4 : n4;                 // float4 from a slab to the next
+        // the thread's four items advance through the slabs TOGETHER (their loads of a slab are independent: 4 - 16 in
+        // flight per thread); per item the slabs are still added in slab order
+        constexpr int NI = RSB_FLAT4 / 256;
+        const f32x4* ptr[NI];
+        f32x4 acc[NI];
+        bool on[NI];
 #pragma unroll
-        for (int k = 0; k < RSB_FLAT4 / 256; ++k) {
+        for (int k = 0; k < NI; ++k) {
             const long long q = (long long)unit * RSB_FLAT4 + k * 256 + tid;
-            if (q < n4) {
-                const long long r = q / cols4, j = q - r * cols4;
-                f32x4 acc = sum_slabs4(slabs + r * ld4 + j, nsplit, stride4);
-                acc *= alpha;
-                reinterpret_cast<f32x4*>(out)[q] = acc;
-            }
+            on[k] = q < n4;
+            const long long qq = on[k] ? q : 0, r = qq / cols4, j = qq - r * cols4;
+            ptr[k] = slabs + r * ld4 + j;
+            acc[k] = ptr[k][0];
         }
+#pragma unroll 4
+        for (int sidx = 1; sidx < nsplit; ++sidx) {
+            f32x4 v[NI];
+#pragma unroll
+            for (int k = 0; k < NI; ++k) v[k] = ptr[k][(long long)sidx * stride4];
+#pragma unroll
+            for (int k = 0; k < NI; ++k) acc[k] += v[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NI; ++k)
+            if (on[k]) {
+                acc[k] *= alpha;
+                reinterpret_cast<f32x4*>(out)[(long long)unit * RSB_FLAT4 + k * 256 + tid] = acc[k];
+            }
         return;
     }
     const int taps = (int)row[5], cin = (int)row[6];
@@ -178,12 +196,35 @@ __global__ void __launch_bounds__(256) reduce_slabs_batch_kernel(const long long
     const int co = unit / chunks, c0 = (unit - co * chunks) * RSB_CI;
     const int cw = min(RSB_CI, cin - c0), cw4 = cw >> 2;             // cin % 4 == 0
     const f32x4* src = slabs + (((long long)co * taps) * cin + c0) / 4;
-    for (int j = tid; j < taps * cw4; j += 256) {
-        const int tap = j / cw4, q = j - tap * cw4;
-        f32x4 acc = sum_slabs4(src + (long long)tap * (cin >> 2) + q, nsplit, n4);
-        acc *= alpha;
+    {   // up to three items per thread (9 taps x 64 quads = 576 = 2.25 x 256), advancing through the slabs together
+        constexpr int NI = (RSB_MAXTAPS * (RSB_CI / 4) + 255) / 256;
+        const int total = taps * cw4;
+        const f32x4* ptr[NI];
+        f32x4 acc[NI];
+        int dst[NI];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) tile[(q * 4 + e) * taps + tap] = acc[e];
+        for (int i = 0; i < NI; ++i) {
+            const int j = min(tid + i * 256, total - 1);             // (clamped: loads stay in range; stored only when on)
+            const int tap = j / cw4, q = j - tap * cw4;
+            ptr[i] = src + (long long)tap * (cin >> 2) + q;
+            dst[i] = (tid + i * 256 < total) ? (q * 4) * taps + tap : -1;
+            acc[i] = ptr[i][0];
+        }
+#pragma unroll 4
+        for (int sidx = 1; sidx < nsplit; ++sidx) {
+            f32x4 v[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) v[i] = ptr[i][(long long)sidx * n4];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) acc[i] += v[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            if (dst[i] >= 0) {
+                acc[i] *= alpha;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tile[dst[i] + e * taps] = acc[i][e];
+            }
     }
     __syncthreads();
     // out[(co*cin + c0 + ci)*taps + tap]: cw*taps contiguous floats starting at (co*cin + c0)*taps (a multiple of 4)

@@ -139,7 +139,9 @@ def test_bench_self_launches_its_ranks():
     sc = out["sampling_check"]
     assert sc["n_gpus"] == 2 and sc["rank_seeds"] == [0, 1] and sc["shards"] == [[0, 25000], [25000, 50000]]
     assert sc["measured_batch_s"] == 2.0 and sc["measured_batch_s_min_over_ranks"] == 1.0      # fake timings 1 + rank
-    assert sc["batches_per_rank"] == 49 and sc["wallclock_50k_samples_s"] == 98.0               # ceil(25000 / 512) x max
+    # 25000 = 48 x 512 + 424: 48 full batches at the slowest rank's 2.0 s + the measured partial batch's slowest 1.25 s
+    assert sc["batches_per_rank"] == 49 and sc["wallclock_50k_samples_s"] == 48 * 2.0 + 1.25
+    assert sc["partial_batch"]["batch"] == 424 and sc["partial_batch"]["measured_batch_s"] == 1.25
 
 
 def test_bench_refuses_a_world_that_is_not_gpus():
