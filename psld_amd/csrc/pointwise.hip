@@ -122,22 +122,8 @@ __global__ void reduce_slabs4_kernel(const float* __restrict__ slabs, int nsplit
 //              OIHW = [co][ci][tap].  The per-thread scatter of reduce_slabs4_kernel writes single floats `taps` apart -
 //              32-byte memory transactions for 4 useful bytes - so here the summed [tap][ci] tile goes through LDS and
 //              leaves as the contiguous [ci][tap] run it is in the output (16-byte stores).
-// Within a float4 the slabs are added in slab order exactly like reduce_slabs4_kernel: bitwise the per-layer launches.
-__device__ __forceinline__ f32x4 sum_slabs4(const f32x4* __restrict__ p, int nsplit, long long n4) {
-    f32x4 acc = p[0];
-    int s = 1;
-    for (; s + 3 < nsplit; s += 4) {            // four independent loads in flight; the sum stays in slab order
-        const f32x4 v0 = p[(long long)s * n4], v1 = p[(long long)(s + 1) * n4];
-        const f32x4 v2 = p[(long long)(s + 2) * n4], v3 = p[(long long)(s + 3) * n4];
-        acc += v0;
-        acc += v1;
-        acc += v2;
-        acc += v3;
-    }
-    for (; s < nsplit; ++s) acc += p[(long long)s * n4];
-    return acc;
-}
-
+// Within a float4 the slabs are added in slab order exactly like reduce_slabs4_kernel: bitwise the per-layer launches.  A
+// thread's items advance through the slabs together, so 3 - 16 independent 16-byte loads are in flight per thread.
 constexpr int RSB_FLAT4 = 1024;     // float4 per unit of a layout-0 job
 constexpr int RSB_CI = 256;         // input channels per unit of a layout-1 job
 constexpr int RSB_MAXTAPS = 9;
