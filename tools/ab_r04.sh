@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE (round 5): kept as the record of how profiles of that round were produced; switches it names that lost their A/B
+# (PSLD_FUSED_ATTN=3, PSLD_DWGRAD_WS outside the ablation library, --tape, ...) were removed in round 5 - see git history.
 # Round-4 same-box A/Bs (run on the GPU box through gpurun; results in profiles/r04/).  The kernel variants and timing-only
 # ablations live in libpsld_hip_abl.so (make -C psld_amd/csrc abl); bench.py refuses that library by name, so the two
 # step-level A/Bs of product-equivalent kernels load a copy under a neutral name.

@@ -20,7 +20,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--tape", action="store_true")
     ap.add_argument("--graphs", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -35,8 +34,8 @@ def main():
     crit = get_module("losses", "psld_score_loss")(cfg, sde)
     wrapper = get_module("pl_modules", "sde_wrapper")(cfg, sde, net, ema_score_fn=ema, criterion=crit)
     cb = EMAWeightUpdate(cfg.training.ema_decay)
-    if args.tape or args.graphs:
-        wrapper.enable_graphs(True, tape=args.tape)
+    if args.graphs:
+        wrapper.enable_graphs(True)
     x = torch.rand(args.batch, 3, 32, 32, device=dev) * 2 - 1
     for i in range(5):
         wrapper.training_step(x, i)
@@ -60,7 +59,7 @@ def main():
         t_one += time.perf_counter() - t1
     torch.cuda.synchronize()
     print(f"batch {args.batch}: host cost of one step issued into an empty queue {t_one / 10 * 1e3:.2f} ms")
-    print(f"batch {args.batch}{' tape' if args.tape else ' graph' if args.graphs else ''}: host enqueue {t_host / args.steps * 1e3:.2f} ms/step, finished {t_all / args.steps * 1e3:.2f} ms/step "
+    print(f"batch {args.batch}{' graph' if args.graphs else ''}: host enqueue {t_host / args.steps * 1e3:.2f} ms/step, finished {t_all / args.steps * 1e3:.2f} ms/step "
           f"-> {'host' if t_host > 0.9 * t_all else 'GPU'}-bound")
 
 

@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE (round 5): kept as the record of how profiles of that round were produced; switches it names that lost their A/B
+# (PSLD_FUSED_ATTN=3, PSLD_DWGRAD_WS outside the ablation library, --tape, ...) were removed in round 5 - see git history.
 # Round-3 measurement pass (run on the GPU box through gpurun):  bash tools/profile_r03.sh
 # Everything lands under gpurun_out/r03/; the files that are cited are then copied into profiles/r03/.
 set -u
