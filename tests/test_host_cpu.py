@@ -187,3 +187,53 @@ def test_checkpoint_resume_restores_scheduler_and_adopts_torch_adam_state(tmp_pa
     with pytest.warns(RuntimeWarning, match="restart from"):
         cli.load_checkpoint(bare, net, ema, opt3, None)
     assert opt3._step == 0
+
+
+def test_arena_and_table_cache_keep_addresses_stable():
+    """Host logic of the batched parameter-gradient reductions (psld_amd/ops.py): the bump allocator hands out the SAME
+    addresses after every reset (device tables hold raw pointers and are cached by content), keeps an outgrown buffer alive
+    until the next reset (parked jobs point into it), and the table cache uploads a table once per distinct content."""
+    from psld_amd import ops
+    dev = torch.device("cpu")
+    a = ops.Arena(dev, 4096)
+    first = [a.alloc(1000).data_ptr(), a.floats(10, 3).data_ptr()]
+    assert first[1] - first[0] == 1024 and first[0] % 256 == 0            # 256-byte granules
+    a.reset()
+    assert [a.alloc(1000).data_ptr(), a.floats(10, 3).data_ptr()] == first
+    old = a.buf
+    big = a.alloc(8192)                                                     # outgrows the 4 KB buffer
+    assert a.buf is not old and a.retired and a.retired[0] is old and big.numel() == 8192
+    a.reset()
+    assert not a.retired and a.buf.numel() >= 8192
+    p1 = a.alloc(1000).data_ptr()
+    a.reset()
+    assert a.alloc(1000).data_ptr() == p1                                   # stable again after the growth
+    t = ops.TableCache(limit=2)
+    rows = [1, 2, 3, 4]
+    t1 = t.get(rows, dev)
+    assert t.get(list(rows), dev) is t1 and t1.dtype == torch.int64 and t1.tolist() == rows
+    t2 = t.get([5, 6], dev)
+    t.get([7, 8], dev)                                                      # evicts the oldest entry
+    assert len(t.tabs) == 2 and t.get([5, 6], dev) is t2 and t.get(rows, dev) is not t1
+    # job rows: pointer arithmetic and the float bit pattern of alpha
+    src = torch.zeros(8, 6)
+    dst = torch.zeros(6)
+    job = ops.param_job(src, 8, 6, 4, dst, None, 0.5, src_off=2)
+    assert job[0] == src.data_ptr() + 8 and job[1:4] == (8, 6, 4) and job[4] == dst.data_ptr() and job[5] == 0
+    import struct
+    assert job[6] == struct.unpack("<I", struct.pack("<f", 0.5))[0]
+
+
+def test_bucket_reducer_announces_a_launch_before_it_happens():
+    """BucketReducer.would_launch(offset) is what lets the network reduce its parked parameter gradients BEFORE a bucket is
+    exchanged: it must say yes exactly when ready_from(offset) launches something."""
+    from psld_amd.ddp import BucketReducer
+    red = BucketReducer(bucket_bytes=4 * 256)
+    red.begin(torch.zeros(1000))
+    launched = 0
+    for off in (990, 900, 736, 700, 480, 300, 100, 32, 0):
+        will = red.would_launch(off)
+        red.ready_from(off)
+        assert will == (len(red.launched) > launched), off
+        launched = len(red.launched)
+    assert launched == 6 and not red.would_launch(0)
