@@ -1032,6 +1032,62 @@ def _team_kernel_case(ops, b, s, c, variant):
     assert ((rows[:, :c].double() - want).abs() / mag).max().item() < 2e-6
 
 
+def test_integration_md_groupnorm_binding(ops):
+    """The GroupNorm + SiLU binding INTEGRATION.md shows a maintainer (raw ctypes calls of psld_gn_stats_nhwc_f32,
+    psld_gn_apply_nhwc_f32, psld_gn_bwd_nhwc_f32 and psld_param_reduce2_f32 inside a torch.autograd.Function), run as written,
+    against autograd of F.silu(F.group_norm(.)) in fp64."""
+    from psld_amd import _lib as L
+    lib = L.load()
+
+    class GroupNormSiLU(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, gamma, beta, groups):
+            b, h, w, c = x.shape
+            s = torch.cuda.current_stream().cuda_stream
+            mean, rstd = x.new_empty(b, groups), x.new_empty(b, groups)
+            scale, shift = x.new_empty(b, c), x.new_empty(b, c)
+            ws = x.new_empty(lib.psld_gn_workspace_bytes(b, h * w, c, groups), dtype=torch.uint8)
+            assert lib.psld_gn_stats_nhwc_f32(x.data_ptr(), b, h * w, c, groups, 1e-6, gamma.data_ptr(), beta.data_ptr(),
+                                              mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                              ws.data_ptr(), s) == 0
+            y = torch.empty_like(x)
+            assert lib.psld_gn_apply_nhwc_f32(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), b, h * w, c, 1,
+                                              0.0, 0, None, s) == 0
+            ctx.save_for_backward(x, gamma, beta, mean, rstd)
+            ctx.groups = groups
+            return y
+
+        @staticmethod
+        def backward(ctx, dy):
+            x, gamma, beta, mean, rstd = ctx.saved_tensors
+            b, h, w, c = x.shape
+            s = torch.cuda.current_stream().cuda_stream
+            dx, sums = torch.empty_like(x), x.new_empty(b, 2, c)
+            dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+            ws = x.new_empty(lib.psld_gn_workspace_bytes(b, h * w, c, ctx.groups), dtype=torch.uint8)
+            assert lib.psld_gn_bwd_nhwc_f32(dy.contiguous().data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                            gamma.data_ptr(), beta.data_ptr(), b, h * w, c, ctx.groups, 1, 0.0, 0, None,
+                                            dx.data_ptr(), 0, None, 1.0, sums.data_ptr(), None, 0, ws.data_ptr(), s) == 0
+            assert lib.psld_param_reduce2_f32(sums.data_ptr(), sums.data_ptr() + 4 * c, b, 2 * c, c, dbeta.data_ptr(),
+                                              dgamma.data_ptr(), 1.0, s) == 0
+            return dx, dgamma, dbeta, None
+
+    b, hh, c, groups = 6, 16, 128, 32
+    x = (gen(b, hh, hh, c, seed=340) * 1.4 + 0.2).to(DEV).requires_grad_(True)
+    gamma = (1 + 0.2 * gen(c, seed=341)).to(DEV).requires_grad_(True)
+    beta = (0.1 * gen(c, seed=342)).to(DEV).requires_grad_(True)
+    gy = gen(b, hh, hh, c, seed=343).to(DEV)
+    y = GroupNormSiLU.apply(x, gamma, beta, groups)
+    y.backward(gy)
+    xr = x.detach().double().cpu().permute(0, 3, 1, 2).requires_grad_(True)
+    gr, br = gamma.detach().double().cpu().requires_grad_(True), beta.detach().double().cpu().requires_grad_(True)
+    yr = F.silu(F.group_norm(xr, groups, gr, br, 1e-6))
+    yr.backward(gy.double().cpu().permute(0, 3, 1, 2))
+    assert rel_l2(y.permute(0, 3, 1, 2), yr) < 2e-6
+    assert rel_l2(x.grad.permute(0, 3, 1, 2), xr.grad) < 1e-5
+    assert rel_l2(gamma.grad, gr.grad) < 1e-5 and rel_l2(beta.grad, br.grad) < 1e-5
+
+
 def test_split_k_slab_reductions_in_one_launch(ops):
     """psld_reduce_slabs_batch_f32: many weight gradients' split-K slabs reduced by one launch, bit for bit the per-layer
     psld_reduce_slabs_f32 calls - plain and OIHW-scattering layouts (through LDS: whole and partial 256-channel chunks, 1 and 9
