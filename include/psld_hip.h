@@ -322,12 +322,14 @@ int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float* mean, con
 int psld_gn_bwd_colsum_supported(int batch, int hw, int c, int groups);
 /* The same backward on WHOLE NHWC ROWS (round 5): a workgroup owns 64 pixels x 128 channels, the K = hw / 64 workgroups of an
  * (image, 128-channel block) exchange their per-group partial sums through `sync` and write dx from their registers - the
- * reads are 512-byte runs of consecutive rows instead of one 128-byte segment per row (5.9-6.4 against 4.3-4.6 TB/s).
+ * reads are 512-byte runs of consecutive rows instead of one 128-byte segment per row (5.9-6.4 against 4.3-4.6 TB/s).  Maps
+ * above 32x32 take 128 pixels per workgroup (K = hw / 128): there the alternative is the three-pass form.
  *   psld_gn_bwd_team_rows: K (> 1) when the form takes the shape - c a multiple of 128, groups of 4 | cpg | 128 channels,
- *        128 <= hw <= 1024 a multiple of 64 - and the kernel selector is PSLD_GN_BWD_AUTO; else 0.
+ *        128 <= hw <= 1024 a multiple of 64 or 1024 < hw <= 4096 a multiple of 128 - and the kernel selector is
+ *        PSLD_GN_BWD_AUTO; else 0.
  *   sums [batch * K][2][c]: sum_p dz and sum_p dz * xhat per (image, team member, channel): dbeta / dgamma are the sums over
  *        ALL batch * K rows (psld_param_reduce*_f32 with rows = batch * K).
- *   colsum_rows (may be NULL): [batch * K] rows of ld_rows floats: column sums of the stored dx over the member's 64 pixels
+ *   colsum_rows (may be NULL): [batch * K] rows of ld_rows floats: column sums of the stored dx over the member's pixels
  *        (a bias gradient is alpha * the sum over all rows; per-IMAGE sums - the time-embedding gradient - need the one-slab
  *        kernels, psld_gn_bwd_nhwc_f32).
  *   sync: psld_gn_bwd_team_sync_bytes() of device memory, zeroed ONCE by the caller and then left to the kernels (slots,

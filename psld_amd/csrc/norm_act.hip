@@ -861,15 +861,17 @@ __global__ void __launch_bounds__(512) gn_bwd_pipe_kernel(const float* __restric
 // member only ever waits for workgroups that are running or will run without anything finishing first.  The poll loop is
 // bounded all the same: on a timeout (another process hogging the device for seconds) the workgroup raises an error word in
 // the slot buffer and carries on with garbage rather than hang the queue.
-constexpr int TEAM_PX = 64;          // pixels per workgroup and set
+// LANES = pixel lanes of a workgroup: 8 (256 threads, 64 pixels per set: maps up to 32x32) or 16 (512 threads, 128 pixels:
+// 64x64 maps, where the alternative is the three-pass form at 20+ bytes per element; the exchange is half as large).
 constexpr int TEAM_CH = 128;         // channels per workgroup
 constexpr int TEAM_ITEMS = 8;
-constexpr int TEAM_MAXK = 16;        // hw <= 1024
+constexpr int TEAM_MAXK = 32;        // team members: hw <= 1024 at 64 pixels, hw <= 4096 at 128 pixels per member
 constexpr int TEAM_SLOTS = 64;       // 2 sums x up to 32 groups in a 128-channel block
-constexpr long long TEAM_SYNC_BYTES = 256 + (long long)2048 * 2 * TEAM_MAXK * TEAM_SLOTS * 8;     // error word + up to 2048 teams
+constexpr int TEAM_MAXTEAMS = 512;
+constexpr long long TEAM_SYNC_BYTES = 256 + (long long)TEAM_MAXTEAMS * 2 * TEAM_MAXK * TEAM_SLOTS * 8;     // error word, tag counter + slots
 
-template <bool THIRD>
-__global__ void __launch_bounds__(256) gn_bwd_team_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <bool THIRD, int LANES>
+__global__ void __launch_bounds__(LANES * 32) gn_bwd_team_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           int hw, int c, int groups, int act, float drop_p,
@@ -879,7 +881,8 @@ __global__ void __launch_bounds__(256) gn_bwd_team_kernel(const float* __restric
                                                           float* __restrict__ colsum_rows, int ld_rows,
                                                           unsigned long long* __restrict__ sync, int rounds, int K, int sets,
                                                           int teams) {
-    __shared__ float red[8 * 32 * 8];            // [pixel lane][quad][s1 x4 | s2 x4]; later [lane][quad][4] column sums
+    constexpr int TEAM_PX = LANES * TEAM_ITEMS, THREADS = LANES * 32;
+    __shared__ float red[LANES * 32 * 8];        // [pixel lane][quad][s1 x4 | s2 x4]; later [lane][quad][4] column sums
     __shared__ double chs[TEAM_CH * 2];          // gamma-weighted channel sums of this block
     __shared__ float gp[TEAM_MAXK * TEAM_SLOTS]; // the team's group partials [member][slot]
     __shared__ double grp[TEAM_SLOTS];           // the image's group terms [group in block][2]
@@ -900,9 +903,9 @@ __global__ void __launch_bounds__(256) gn_bwd_team_kernel(const float* __restric
         const int g = ch0 / cpg;                 // cpg % 4 == 0: a quad lies in one group
         const float mu = mean[n * groups + g], rs = rstd[n * groups + g];
         const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + ch0), be = *reinterpret_cast<const f32x4*>(beta + ch0);
-        // pixels k*64 + l + 8 i: a wave (2 pixel lanes x 32 quads) reads two 512-byte runs
+        // pixels k*TEAM_PX + l + LANES i: a wave (2 pixel lanes x 32 quads) reads two 512-byte runs
         const long long e0 = (((long long)n * hw + k * TEAM_PX + l) * c + ch0);
-        const long long istride = (long long)8 * c;
+        const long long istride = (long long)LANES * c;
         f32x4 xv[TEAM_ITEMS], gv[TEAM_ITEMS];
 #pragma unroll
         for (int i = 0; i < TEAM_ITEMS; ++i) {
@@ -932,11 +935,11 @@ __global__ void __launch_bounds__(256) gn_bwd_team_kernel(const float* __restric
             my[4 + e] = s2[e];
         }
         __syncthreads();
-        {   // 256 threads = 128 channels x 2 sums: the eight pixel lanes in lane order
+        if (tid < 2 * TEAM_CH) {   // 128 channels x 2 sums: the pixel lanes in lane order
             const int chl = tid >> 1, w = tid & 1;
             double acc = 0;
 #pragma unroll
-            for (int ll = 0; ll < 8; ++ll) acc += (double)red[(ll * 32 + (chl >> 2)) * 8 + w * 4 + (chl & 3)];
+            for (int ll = 0; ll < LANES; ++ll) acc += (double)red[(ll * 32 + (chl >> 2)) * 8 + w * 4 + (chl & 3)];
             const float rounded = (float)acc;
             part[(((long long)n * K + k) * 2 + w) * c + c0 + chl] = rounded;
             chs[chl * 2 + w] = (double)rounded * (double)gamma[c0 + chl];
@@ -952,7 +955,7 @@ __global__ void __launch_bounds__(256) gn_bwd_team_kernel(const float* __restric
             __hip_atomic_store(buf + k * TEAM_SLOTS + tid, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // every member's slots of this set
-        for (int j = tid; j < K * nslot; j += 256) {
+        for (int j = tid; j < K * nslot; j += THREADS) {
             const int kk = j / nslot, sl = j - kk * nslot;
             const unsigned long long* ptr = buf + kk * TEAM_SLOTS + sl;
             unsigned long long word = __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1001,7 +1004,7 @@ __global__ void __launch_bounds__(256) gn_bwd_team_kernel(const float* __restric
         }
 #pragma unroll
         for (int i = 0; i < TEAM_ITEMS; ++i) *reinterpret_cast<f32x4*>(dx + e0 + i * istride) = gv[i];
-        if (colsum_rows) {       // column sums of the values just written, over this block's 64 pixels (red: free since the barrier above)
+        if (colsum_rows) {       // column sums of the values just written, over this block's pixels (red: free since the barrier above)
             float s4[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int i = 0; i < TEAM_ITEMS; ++i)
@@ -1013,7 +1016,7 @@ __global__ void __launch_bounds__(256) gn_bwd_team_kernel(const float* __restric
             if (tid < TEAM_CH) {
                 double acc = 0;
 #pragma unroll
-                for (int ll = 0; ll < 8; ++ll) acc += (double)red[ll * TEAM_CH + tid];
+                for (int ll = 0; ll < LANES; ++ll) acc += (double)red[ll * TEAM_CH + tid];
                 colsum_rows[((long long)n * K + k) * ld_rows + c0 + tid] = (float)acc;
             }
         }
@@ -1028,24 +1031,29 @@ __global__ void __launch_bounds__(256) gn_bwd_team_kernel(const float* __restric
     }
 }
 
-// team size (= rows per image of `part`), or 0 when the team form does not take the shape
-inline int gn_bwd_team_k(int batch, int hw, int c, int groups) {
+// team size (= rows per image of `part`) and pixel lanes per member, or 0 when the team form does not take the shape
+inline int gn_bwd_team_k(int batch, int hw, int c, int groups, int* lanes) {
     if (batch <= 0 || groups <= 0 || c % groups) return 0;
     const int cpg = c / groups;
     if (c % TEAM_CH || cpg % 4 || TEAM_CH % cpg || 2 * (TEAM_CH / cpg) > TEAM_SLOTS) return 0;
-    if (hw % TEAM_PX || hw / TEAM_PX < 2 || hw / TEAM_PX > TEAM_MAXK) return 0;
-    return hw / TEAM_PX;
+    const int ln = hw > 1024 ? 16 : 8, px = ln * TEAM_ITEMS;
+    if (hw % px || hw / px < 2 || hw / px > TEAM_MAXK) return 0;
+    *lanes = ln;
+    return hw / px;
 }
 
 // resident grid: teams (each K workgroups) and the sets every team walks
-inline bool gn_bwd_team_grid(int batch, int c, int K, bool third, int* teams, int* rounds) {
-    struct Slot { int per_cu[2] = {-1, -1}; int cus = 0; };
+inline bool gn_bwd_team_grid(int batch, int c, int K, int lanes, bool third, int* teams, int* rounds) {
+    struct Slot { int per_cu[4] = {-1, -1, -1, -1}; int cus = 0; };
     static Slot slots[PSLD_MAX_DEVICES];
     Slot& sl = slots[psld_device_slot()];
-    int& per_cu = sl.per_cu[third ? 1 : 0];
+    int& per_cu = sl.per_cu[(third ? 1 : 0) + (lanes == 16 ? 2 : 0)];
     if (per_cu < 0) {
-        const void* fn = third ? reinterpret_cast<const void*>(&gn_bwd_team_kernel<true>) : reinterpret_cast<const void*>(&gn_bwd_team_kernel<false>);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess) per_cu = 0;
+        const void* fn = lanes == 16 ? (third ? reinterpret_cast<const void*>(&gn_bwd_team_kernel<true, 16>)
+                                              : reinterpret_cast<const void*>(&gn_bwd_team_kernel<false, 16>))
+                                     : (third ? reinterpret_cast<const void*>(&gn_bwd_team_kernel<true, 8>)
+                                              : reinterpret_cast<const void*>(&gn_bwd_team_kernel<false, 8>));
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, lanes * 32, 0) != hipSuccess) per_cu = 0;
     }
     if (sl.cus == 0) {
         int dev = 0;
@@ -1056,7 +1064,7 @@ inline bool gn_bwd_team_grid(int batch, int c, int K, bool third, int* teams, in
     if (per_cu <= 0 || sl.cus <= 0) return false;
     const int sets = batch * (c / TEAM_CH);
     int max_teams = (int)((long long)per_cu * sl.cus / K);
-    if (max_teams > 2048) max_teams = 2048;
+    if (max_teams > TEAM_MAXTEAMS) max_teams = TEAM_MAXTEAMS;
     if (max_teams < 1) return false;
     *rounds = cdiv(sets, max_teams);
     *teams = cdiv(sets, *rounds);            // equal shares: every team walks `rounds` sets (the last ones one fewer)
@@ -1278,9 +1286,10 @@ extern "C" int psld_gn_bwd_nhwc_f32(const float* dy, const float* x, const float
 
 extern "C" int psld_gn_bwd_team_rows(int batch, int hw, int c, int groups) {
     if (gn_bwd_kind() != PSLD_GN_BWD_AUTO || (long long)batch * hw * c >= (1ll << 40)) return 0;
-    const int K = gn_bwd_team_k(batch, hw, c, groups);
+    int lanes = 0;
+    const int K = gn_bwd_team_k(batch, hw, c, groups, &lanes);
     int teams = 0, rounds = 0;
-    return K > 0 && gn_bwd_team_grid(batch, c, K, true, &teams, &rounds) ? K : 0;
+    return K > 0 && gn_bwd_team_grid(batch, c, K, lanes, true, &teams, &rounds) && gn_bwd_team_grid(batch, c, K, lanes, false, &teams, &rounds) ? K : 0;
 }
 
 extern "C" long long psld_gn_bwd_team_sync_bytes(void) { return TEAM_SYNC_BYTES; }
@@ -1291,7 +1300,8 @@ extern "C" int psld_gn_bwd_team_f32(const float* dy, const float* x, const float
                                     const float* add, float add_scale, float* sums, float* colsum_rows, int ld_rows, void* sync,
                                     hipStream_t stream) {
     PSLD_CHECK_ARG(dy && x && mean && rstd && gamma && beta && dx && sums && sync, "psld_gn_bwd_team: null pointer");
-    const int K = gn_bwd_team_k(batch, hw, c, groups);
+    int lanes = 0;
+    const int K = gn_bwd_team_k(batch, hw, c, groups, &lanes);
     PSLD_CHECK_ARG(K > 0, "psld_gn_bwd_team: unsupported shape B=%d hw=%d C=%d groups=%d (psld_gn_bwd_team_rows)", batch, hw, c, groups);
     PSLD_CHECK_ARG(!colsum_rows || ld_rows >= c, "psld_gn_bwd_team: ld_rows < c");
     PSLD_CHECK_ARG((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx) |
@@ -1300,17 +1310,19 @@ extern "C" int psld_gn_bwd_team_f32(const float* dy, const float* x, const float
                    "psld_gn_bwd_team: unaligned pointer");
     const bool third = add != nullptr || accumulate_dx != 0;
     int teams = 0, rounds = 0;
-    PSLD_CHECK_ARG(gn_bwd_team_grid(batch, c, K, true, &teams, &rounds), "psld_gn_bwd_team: no resident grid");
+    PSLD_CHECK_ARG(gn_bwd_team_grid(batch, c, K, lanes, third, &teams, &rounds), "psld_gn_bwd_team: no resident grid");
     const int sets = batch * (c / TEAM_CH);
     unsigned long long* sy = reinterpret_cast<unsigned long long*>(sync);
-    if (third)
-        hipLaunchKernelGGL(gn_bwd_team_kernel<true>, dim3(teams * K), dim3(256), 0, stream, dy, x, mean, rstd, gamma, beta, hw, c,
-                           groups, act, drop_p, seed, seed_dev, accumulate_dx, add, add_scale, dx, sums, colsum_rows, ld_rows, sy, rounds, K,
-                           sets, teams);
-    else
-        hipLaunchKernelGGL(gn_bwd_team_kernel<false>, dim3(teams * K), dim3(256), 0, stream, dy, x, mean, rstd, gamma, beta, hw, c,
-                           groups, act, drop_p, seed, seed_dev, accumulate_dx, add, add_scale, dx, sums, colsum_rows, ld_rows, sy, rounds, K,
-                           sets, teams);
+#define PSLD_GN_TEAM(THIRD, LANES)                                                                                     \
+    hipLaunchKernelGGL((gn_bwd_team_kernel<THIRD, LANES>), dim3(teams * K), dim3(LANES * 32), 0, stream, dy, x, mean, rstd,  \
+                       gamma, beta, hw, c, groups, act, drop_p, seed, seed_dev, accumulate_dx, add, add_scale, dx, sums,     \
+                       colsum_rows, ld_rows, sy, rounds, K, sets, teams)
+    if (lanes == 16) {
+        if (third) PSLD_GN_TEAM(true, 16); else PSLD_GN_TEAM(false, 16);
+    } else {
+        if (third) PSLD_GN_TEAM(true, 8); else PSLD_GN_TEAM(false, 8);
+    }
+#undef PSLD_GN_TEAM
     PSLD_CHECK_LAUNCH("gn_bwd_team_kernel");
     return PSLD_OK;
 }

@@ -597,12 +597,13 @@ def gn_bwd_team_rows(b: int, hw: int, c: int, groups: Optional[int] = None) -> i
     return int(lib().psld_gn_bwd_team_rows(b, hw, c, groups if groups is not None else gn_groups(c)))
 
 
-def gn_bwd_team_wanted(b: int, hw: int, c: int, groups: Optional[int] = None) -> int:
+def gn_bwd_team_wanted(b: int, hw: int, c: int, groups: Optional[int] = None, third: bool = True) -> int:
     """Policy: the team size when the whole-row kernel is the faster one, else 0.  Measured on MI355X (tools/bench_gnb_team.py,
     profiles/r05/ab_gnb_team.txt): with a third operand 102 / 100 / 129 against 117 / 112 / 148 us on 128x32x32x256 (4 sets
     per team); on smaller problems (fewer than two rounds of resident teams, or K = 4) the exchange costs more than the
-    access pattern saves."""
-    if b * hw * c < (1 << 25) or hw < 1024:
+    access pattern saves.  Maps above 32x32 (CelebA-64's first level) have no one-slab kernel - the alternative there is the
+    three-pass form at 20+ bytes per element - so the team kernel also takes the calls without a third operand."""
+    if b * hw * c < (1 << 25) or hw < 1024 or (hw == 1024 and not third):
         return 0
     return gn_bwd_team_rows(b, hw, c, groups)
 

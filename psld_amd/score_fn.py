@@ -383,9 +383,9 @@ class _Exec:
         node = last_writer_of
         fold = node is not None and node.want_gsum and colsum_img is None and self.gn_bwd_colsum and \
             ops.gn_bwd_colsum_supported(b, h * w, c, groups)
-        # with a third operand (and no per-IMAGE column sums asked for) large maps go through the whole-row team kernel:
-        # its sums / column sums come per (image, team member): k rows per image
-        k = ops.gn_bwd_team_wanted(b, h * w, c, groups) if (add is not None or accumulate_dx) and colsum_img is None else 0
+        # large maps with a third operand - and maps above 32x32 in any case - go through the whole-row team kernel unless
+        # per-IMAGE column sums are asked for: its sums / column sums come per (image, team member), k rows per image
+        k = ops.gn_bwd_team_wanted(b, h * w, c, groups, add is not None or accumulate_dx) if colsum_img is None else 0
         rows = b * max(k, 1)
         sums = pa.floats(rows, 2, c)
         if fold:

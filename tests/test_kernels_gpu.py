@@ -972,10 +972,12 @@ def test_groupnorm_backward_column_sums_of_dx(ops, b, s, c, variant):
     assert rel_l2(db0, sums0[:, 0].double().sum(0)) < 1e-6 and rel_l2(dg0, sums0[:, 1].double().sum(0)) < 1e-6
 
 
-@pytest.mark.parametrize("b,s,c", [(128, 32, 256), (128, 16, 256), (16, 32, 256), (5, 16, 128), (3, 32, 128), (7, 16, 512)])
+@pytest.mark.parametrize("b,s,c", [(128, 32, 256), (128, 16, 256), (16, 32, 256), (5, 16, 128), (3, 32, 128), (7, 16, 512),
+                                   (9, 64, 128), (2, 64, 256)])
 @pytest.mark.parametrize("variant", ["plain", "branch", "dropout", "accumulate", "branch_accumulate", "no_act"])
 def test_groupnorm_backward_on_whole_rows_by_teams(ops, b, s, c, variant):
-    """psld_gn_bwd_team_f32 (64 pixels x 128 channels per workgroup, the hw / 64 workgroups of an image exchanging their
+    """psld_gn_bwd_team_f32 (64 pixels x 128 channels per workgroup - 128 pixels on 64x64 maps, against the three-pass form
+    there -, the workgroups of an image exchanging their
     group partial sums through tagged slots) against the one-slab kernel: dx to fp32 rounding (the group terms are formed
     from fp32-rounded member sums), dgamma / dbeta = sums over all batch x K rows, the per-member column sums of the stored
     dx against fp64; three launches in a row (tag counter, slot parity) bitwise equal; no member timed out."""
@@ -989,7 +991,8 @@ def test_groupnorm_backward_on_whole_rows_by_teams(ops, b, s, c, variant):
 
 def _team_kernel_case(ops, b, s, c, variant):
     k = ops.gn_bwd_team_rows(b, s * s, c)
-    assert k == s * s // 64
+    px = 128 if s * s > 1024 else 64
+    assert k == s * s // px
     x = (gen(b, s, s, c, seed=80) * 1.5 + 0.3).to(DEV)
     dy = gen(b, s, s, c, seed=81).to(DEV)
     gamma, beta = (1 + 0.2 * gen(c, seed=82)).to(DEV), (0.1 * gen(c, seed=83)).to(DEV)
@@ -1027,8 +1030,8 @@ def _team_kernel_case(ops, b, s, c, variant):
     dg, db = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
     ops.param_reduce2(sums, sums.view(-1)[c:], b * k, 2 * c, c, db, dg)
     assert rel_l2(dg, dg0) < 2e-6 and rel_l2(db, db0) < 2e-6
-    want = dx.double().view(b, k, 64, c).sum(2).view(b * k, c)
-    mag = dx.double().abs().view(b, k, 64, c).sum(2).view(b * k, c).clamp_min(1e-30)
+    want = dx.double().view(b, k, px, c).sum(2).view(b * k, c)
+    mag = dx.double().abs().view(b, k, px, c).sum(2).view(b * k, c).clamp_min(1e-30)
     assert ((rows[:, :c].double() - want).abs() / mag).max().item() < 2e-6
 
 

@@ -10,7 +10,7 @@ from tools.bench_tile import timeit  # noqa: E402
 
 ops.lib()
 print(f"{'shape':20s} {'variant':30s} {'slab us':>9s} {'TB/s':>6s} {'team us':>9s} {'TB/s':>6s}")
-for B, S, C in ((128, 32, 256), (128, 16, 256), (128, 32, 128), (64, 32, 256), (16, 32, 256), (16, 16, 256)):
+for B, S, C in ((128, 32, 256), (128, 64, 128), (64, 64, 128), (128, 16, 256), (128, 32, 128), (64, 32, 256), (16, 32, 256), (16, 16, 256)):
     x = torch.randn(B, S, S, C, device="cuda")
     dy = torch.randn_like(x)
     dx = torch.zeros_like(x)
