@@ -65,10 +65,13 @@ typedef struct psld_epilogue {
      * range): GroupNorm statistics of the OUTPUT as a by-product, for the GroupNorm that reads it next
      * (layerspp.py:258,264 GroupNorm_0/1; :77 of the attention block).  gn_part[((img*chunks + chunk)*(N/8) + f)*2 + {0,1}]
      * = sum / sum of squares of the 8 channels 8f..8f+7 over the chunk-th run of 64 rows of image img
-     * (chunks = gn_hw / 64, gn_hw = rows per image, a multiple of 64; N a multiple of 128).
+     * (chunks = gn_hw / 64, gn_hw = rows per image, a multiple of 64; N a multiple of 128).  gn_fine = 4: sums of FOUR
+     * channels 4f..4f+3 instead ((N/4) entries per run: tensors whose groups are 4 channels wide - 128 channels in 32
+     * groups, CelebA-64's first level); 0 or 8: eight.
      * psld_gn_stats_from_partials_f32 turns them into the statistics of any group size that is a multiple of 8. */
     double* gn_part;
     int gn_hw;
+    int gn_fine;
 } psld_epilogue_t;
 
 /* C[b] = epilogue(op(A[b]) * op(B[b])), fp32 MFMA (v_mfma_f32_32x32x2_f32), batched.
@@ -268,9 +271,9 @@ int psld_gn_stats_nhwc_f32(const float* x, int batch, int hw, int c, int groups,
                            const float* gamma, const float* beta,
                            float* mean, float* rstd, float* scale, float* shift,
                            void* workspace, hipStream_t stream);
-/* Second half of psld_gn_stats_nhwc_f32 on partial sums a limb kernel's epilogue produced (psld_epilogue_t.gn_part):
- * fine = channels per group / 8. */
-int psld_gn_stats_from_partials_f32(const double* gn_part, int batch, int hw, int c, int groups, float eps,
+/* Second half of psld_gn_stats_nhwc_f32 on partial sums a limb kernel's epilogue produced (psld_epilogue_t.gn_part,
+ * fine_width = its gn_fine: 8 or 4 channels per sum; channels per group must be a multiple of it). */
+int psld_gn_stats_from_partials_f32(const double* gn_part, int fine_width, int batch, int hw, int c, int groups, float eps,
                                     const float* gamma, const float* beta, float* mean, float* rstd,
                                     float* scale, float* shift, hipStream_t stream);
 /* y = dropout(act(x*scale[n,c] + shift[n,c])); act: 0 = identity, 1 = SiLU.  Dropout

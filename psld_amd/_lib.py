@@ -35,6 +35,7 @@ class Epilogue(C.Structure):
         ("accumulate", C.c_int),
         ("gn_part", C.c_void_p),
         ("gn_hw", C.c_int),
+        ("gn_fine", C.c_int),
     ]
 
 
@@ -118,7 +119,7 @@ SIGNATURES = {
     "psld_nhwc_to_nchw_f32": (I, [P, P, I, I, I, P]),
     "psld_gn_workspace_bytes": (LL, [I, I, I, I]),
     "psld_gn_stats_nhwc_f32": (I, [P, I, I, I, I, F, P, P, P, P, P, P, P, P]),
-    "psld_gn_stats_from_partials_f32": (I, [P, I, I, I, I, F, P, P, P, P, P, P, P]),
+    "psld_gn_stats_from_partials_f32": (I, [P, I, I, I, I, I, F, P, P, P, P, P, P, P]),
     "psld_gn_apply_nhwc_f32": (I, [P, P, P, P, I, I, I, I, F, C.c_ulonglong, P, P]),
     "psld_gn_bwd_nhwc_f32": (I, [P, P, P, P, P, P, I, I, I, I, I, F, C.c_ulonglong, P, P, I, P, F, P, P, I, P, P]),
     "psld_gn_bwd_colsum_supported": (I, [I, I, I, I]),

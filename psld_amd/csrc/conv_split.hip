@@ -244,7 +244,10 @@ __device__ __forceinline__ void dconv_epilogue_n32(const DConvArgs& a, f32x4v (&
         for (int mb = 0; mb < MBK; ++mb) row_store(mb, z2, z2, z2);
     }
     if (e.gn_part) {
-        const int fine = a.N >> 3, chunks = e.gn_hw >> 6;
+        // a lane holds 4 channels of a block column (quad kq = lane >> 4), its 16-lane row the 16 pixels of a block row: the
+        // butterfly over sft = 1..8 sums the pixels (four-channel sums, gn_fine = 4), sft = 16 adds the partner quad (eight)
+        const bool fine4 = e.gn_fine == 4;
+        const int fine = fine4 ? a.N >> 2 : a.N >> 3, chunks = e.gn_hw >> 6;
 #pragma unroll
         for (int r = 0; r < RUNS; ++r) {
             const int row0 = m0 + r * 64;
@@ -254,10 +257,21 @@ __device__ __forceinline__ void dconv_epilogue_n32(const DConvArgs& a, f32x4v (&
             for (int nb = 0; nb < 2; ++nb) {
                 float s1 = gs[r][nb], s2 = gss[r][nb];
 #pragma unroll
-                for (int sft = 1; sft <= 16; sft <<= 1) {
+                for (int sft = 1; sft <= 8; sft <<= 1) {
                     s1 += __shfl_xor(s1, sft, 64);
                     s2 += __shfl_xor(s2, sft, 64);
                 }
+                if (fine4) {
+                    if ((lane & 0xf) == 0) {
+                        const int f = ((nw0 + nb * 16) >> 2) + (lane >> 4);
+                        double* pp = e.gn_part + (((long long)img * chunks + chunk) * fine + f) * 2;
+                        pp[0] = (double)s1;
+                        pp[1] = (double)s2;
+                    }
+                    continue;
+                }
+                s1 += __shfl_xor(s1, 16, 64);
+                s2 += __shfl_xor(s2, 16, 64);
                 if ((lane & 0x1f) == 0) {
                     const int f = ((nw0 + nb * 16) >> 3) + (lane >> 5);
                     double* pp = e.gn_part + (((long long)img * chunks + chunk) * fine + f) * 2;

@@ -469,14 +469,24 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArg
         if (e.gn_part) {
             float s1 = gs, s2 = gss;
 #pragma unroll
-            for (int sft = 1; sft <= 16; sft <<= 1) {
+            for (int sft = 1; sft <= 8; sft <<= 1) {
                 s1 += __shfl_xor(s1, sft, 64);
                 s2 += __shfl_xor(s2, sft, 64);
             }
+            const float q1 = s1, q2 = s2;                // four-channel sums of this lane's quad (gn_fine = 4)
+            s1 += __shfl_xor(s1, 16, 64);
+            s2 += __shfl_xor(s2, 16, 64);
             // tile block tb = 64 pixels of one image = one run of the partial-sum table (any fixed partition of an image
             // into hw/64 runs serves: the consumer sums all of them): run 2 reg + tb, or image img0 + tb of a two-image region
             const int img = a.nseg == 1 ? img0 : img0 + tb, chunk = a.nseg == 1 ? 2 * reg + tb : 0, chunks = e.gn_hw >> 6;
-            if ((lane & 0x1f) == 0 && img < a.B) {
+            if (e.gn_fine == 4) {
+                if ((lane & 0xf) == 0 && img < a.B) {
+                    const int f = ((n0 + wave * 16) >> 2) + (lane >> 4);
+                    double* pp = e.gn_part + (((long long)img * chunks + chunk) * (a.N >> 2) + f) * 2;
+                    pp[0] = (double)q1;
+                    pp[1] = (double)q2;
+                }
+            } else if ((lane & 0x1f) == 0 && img < a.B) {
                 const int f = ((n0 + wave * 16) >> 3) + (lane >> 5);
                 double* pp = e.gn_part + (((long long)img * chunks + chunk) * (a.N >> 3) + f) * 2;
                 pp[0] = (double)s1;

@@ -1181,14 +1181,15 @@ extern "C" int psld_gn_stats_nhwc_f32(const float* x, int batch, int hw, int c, 
     return PSLD_OK;
 }
 
-extern "C" int psld_gn_stats_from_partials_f32(const double* gn_part, int batch, int hw, int c, int groups, float eps,
-                                               const float* gamma, const float* beta, float* mean, float* rstd,
+extern "C" int psld_gn_stats_from_partials_f32(const double* gn_part, int fine_width, int batch, int hw, int c, int groups,
+                                               float eps, const float* gamma, const float* beta, float* mean, float* rstd,
                                                float* scale, float* shift, hipStream_t stream) {
     PSLD_CHECK_ARG(gn_part && gamma && beta && mean && rstd && scale && shift, "psld_gn_stats_from_partials: null pointer");
-    PSLD_CHECK_ARG(groups > 0 && groups <= MAXG && c % groups == 0 && (c / groups) % 8 == 0 && hw % 64 == 0 && hw > 0,
-                   "psld_gn_stats_from_partials: unsupported C=%d groups=%d hw=%d", c, groups, hw);
+    PSLD_CHECK_ARG((fine_width == 8 || fine_width == 4) && groups > 0 && groups <= MAXG && c % groups == 0 &&
+                       (c / groups) % fine_width == 0 && hw % 64 == 0 && hw > 0,
+                   "psld_gn_stats_from_partials: unsupported C=%d groups=%d hw=%d fine_width=%d", c, groups, hw, fine_width);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, stream, gn_part, hw, c, groups, hw / 64,
-                       (c / groups) / 8, eps, gamma, beta, mean, rstd, scale, shift);
+                       (c / groups) / fine_width, eps, gamma, beta, mean, rstd, scale, shift);
     PSLD_CHECK_LAUNCH("gn_finalize_kernel");
     return PSLD_OK;
 }

@@ -17,19 +17,20 @@ struct PsldEpilogue {
     int accumulate;         // C += result
     double* gn_part;        // limb kernels only: GroupNorm partial sums of the output (psld_epilogue_t.gn_part)
     int gn_hw;
+    int gn_fine;            // channels per partial sum: 8, or 4 (psld_epilogue_t.gn_fine)
 };
 
 static inline PsldEpilogue make_epilogue(const psld_epilogue_t* e) {
     PsldEpilogue o;
     o.alpha = 1.f; o.bias = nullptr; o.rowbias = nullptr; o.ld_rowbias = 0; o.rows_per_img = 1;
     o.res = nullptr; o.ldres = 0; o.res_stride_z = 0; o.out_scale = 1.f; o.accumulate = 0;
-    o.gn_part = nullptr; o.gn_hw = 0;
+    o.gn_part = nullptr; o.gn_hw = 0; o.gn_fine = 8;
     if (e) {
         o.alpha = e->alpha; o.bias = e->bias; o.rowbias = e->rowbias; o.ld_rowbias = e->ld_rowbias;
         o.rows_per_img = e->rows_per_img > 0 ? e->rows_per_img : 1;
         o.res = e->residual; o.ldres = e->ld_residual; o.res_stride_z = e->residual_stride_batch;
         o.out_scale = e->out_scale; o.accumulate = e->accumulate;
-        o.gn_part = e->gn_part; o.gn_hw = e->gn_hw;
+        o.gn_part = e->gn_part; o.gn_hw = e->gn_hw; o.gn_fine = e->gn_fine == 4 ? 4 : 8;
     }
     return o;
 }

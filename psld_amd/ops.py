@@ -78,6 +78,7 @@ def epilogue(alpha: float = 1.0, bias: Optional[Tensor] = None, rowbias: Optiona
     e.accumulate = 1 if accumulate else 0
     e.gn_part = _p(gn_part)
     e.gn_hw = gn_hw if gn_part is not None else 0
+    e.gn_fine = getattr(gn_part, "fine_width", 8) if gn_part is not None else 0
     e._keep = (bias, rowbias, residual, gn_part)  # the struct holds raw pointers: keep the tensors alive
     return e
 
@@ -500,17 +501,27 @@ def gn_stats(x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-6, groups: 
     return st
 
 
+def gn_part_width(c: int) -> int:
+    """Channels per partial sum a limb kernel's epilogue leaves for a [.., c] output: 8, or 4 when the tensor's own groups
+    are narrower (128 channels in 32 groups)."""
+    return 8 if (c // gn_groups(c)) % 8 == 0 else 4
+
+
 @functools.lru_cache(maxsize=None)
 def gn_part_supported(b: int, hw: int, c: int) -> bool:
     """Can a limb kernel's epilogue produce the GroupNorm partial sums of its [b, hw, c] output?  (Whole 64-row
-    runs per image, groups made of 8-channel fine groups, and a grid large enough that the kernel does not split
+    runs per image, groups made of 4- or 8-channel fine groups, and a grid large enough that the kernel does not split
     its K range.)"""
-    return hw % 64 == 0 and c % 128 == 0 and (c // gn_groups(c)) % 8 == 0 and ((b * hw + 127) // 128) * (c // 128) >= 384
+    return hw % 64 == 0 and c % 128 == 0 and (c // gn_groups(c)) % 4 == 0 and ((b * hw + 127) // 128) * (c // 128) >= 384
 
 
 def gn_part_buffer(b: int, hw: int, c: int, device) -> Tensor:
-    """[b][hw/64][c/8][2] float64: sum / sum of squares per 64-row run and 8-channel fine group."""
-    return torch.empty((b, hw // 64, c // 8, 2), device=device, dtype=torch.float64)
+    """[b][hw/64][c/w][2] float64: sum / sum of squares per 64-row run and w-channel fine group, w = gn_part_width(c)
+    (carried as the tensor's ``fine_width`` attribute)."""
+    w = gn_part_width(c)
+    buf = torch.empty((b, hw // 64, c // w, 2), device=device, dtype=torch.float64)
+    buf.fine_width = w
+    return buf
 
 
 def gn_stats_from_part(part: Tensor, shape, gamma: Tensor, beta: Tensor, eps: float = 1e-6,
@@ -519,9 +530,10 @@ def gn_stats_from_part(part: Tensor, shape, gamma: Tensor, beta: Tensor, eps: fl
     b, h, w, c = shape
     g = groups if groups is not None else gn_groups(c)
     st = GNStats(b, g, c, part.device)
-    check(lib().psld_gn_stats_from_partials_f32(part.data_ptr(), b, h * w, c, g, eps, gamma.data_ptr(), beta.data_ptr(),
-                                                st.mean.data_ptr(), st.rstd.data_ptr(), st.scale.data_ptr(),
-                                                st.shift.data_ptr(), _stream()), "psld_gn_stats_from_partials_f32")
+    check(lib().psld_gn_stats_from_partials_f32(part.data_ptr(), getattr(part, "fine_width", 8), b, h * w, c, g, eps,
+                                                gamma.data_ptr(), beta.data_ptr(), st.mean.data_ptr(), st.rstd.data_ptr(),
+                                                st.scale.data_ptr(), st.shift.data_ptr(), _stream()),
+          "psld_gn_stats_from_partials_f32")
     return st
 
 

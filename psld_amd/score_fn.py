@@ -460,7 +460,7 @@ class _Exec:
         multiple of their 8 channels, else by a pass over the tensor."""
         c = node.v.shape[-1]
         g = groups if groups is not None else ops.gn_groups(c)
-        if node.gp is not None and (c // g) % 8 == 0:
+        if node.gp is not None and (c // g) % getattr(node.gp, "fine_width", 8) == 0:
             return ops.gn_stats_from_part(node.gp, node.v.shape, gamma, beta, groups=groups)
         return ops.gn_stats(node.v, gamma, beta, groups=groups)
 

@@ -395,10 +395,11 @@ def test_conv3x3_wino_wide_dynamic_range(ops):
     assert rel_l2(y.permute(0, 3, 1, 2), ref) < 4.0 * max(rel_l2(ref32, ref), 2e-7)
 
 
-@pytest.mark.parametrize("b,c,co,h", [(24, 128, 256, 32), (96, 128, 256, 16), (6, 32, 128, 64)])
+@pytest.mark.parametrize("b,c,co,h", [(24, 128, 256, 32), (96, 128, 256, 16), (6, 32, 128, 64), (48, 128, 128, 32)])
 def test_gn_partials_from_wino_epilogue(ops, b, c, co, h):
     """psld_epilogue_t.gn_part from the Winograd kernel's epilogue: GroupNorm statistics of its output, for every group
-    size that is a multiple of the 8-channel fine groups, against a statistics pass over the written tensor."""
+    size that is a multiple of the fine groups (8 channels; 4 for a 128-channel output, whose own groups are 4 wide:
+    gn_fine), against a statistics pass over the written tensor."""
     x = gen(b, h, h, c, seed=70).to(DEV)
     w = gen(co, c, 3, 3, seed=71, scale=0.05).to(DEV)
     bias = gen(co, seed=72).to(DEV)
@@ -408,7 +409,8 @@ def test_gn_partials_from_wino_epilogue(ops, b, c, co, h):
     y = torch.empty(b, h, h, co, device=DEV)
     ops.conv3x3_wino(x, None, ops.conv3x3_wino_frag(w, False), co, y, ops.epilogue(bias=bias, gn_part=part, gn_hw=h * h))
     assert bool(torch.isfinite(part).all())
-    for groups in (co // 8, co // 16):
+    assert part.fine_width == (4 if co == 128 else 8)
+    for groups in (co // part.fine_width, co // 8, co // 16):
         st = ops.gn_stats_from_part(part, y.shape, gamma, beta, groups=groups)
         ref = ops.gn_stats(y, gamma, beta, groups=groups)
         assert rel_l2(st.mean, ref.mean) < 1e-5 and rel_l2(st.rstd, ref.rstd) < 1e-5
@@ -570,7 +572,8 @@ def test_conv3x3_fewout(ops, b, c, co, h, w_):
     assert not ops.conv3x3_fewout_supported(512, 6) and not ops.conv3x3_fewout_supported(256, 8)
 
 
-@pytest.mark.parametrize("b,c,co,h", [(24, 128, 256, 32), (96, 128, 256, 16), (40, 128, 256, 32)])   # last: eight-wave pointwise kernel
+@pytest.mark.parametrize("b,c,co,h", [(24, 128, 256, 32), (96, 128, 256, 16), (40, 128, 256, 32),      # third: eight-wave pointwise kernel
+                                      (48, 128, 128, 32)])                                             # four-channel sums
 def test_gn_partials_from_conv_epilogue(ops, b, c, co, h):
     """GroupNorm statistics of a limb convolution's output as a by-product of its epilogue == gn_stats of the output,
     for the consumer's own group size and for the coarser groups of a concatenation source; same for the pointwise form."""
@@ -589,7 +592,7 @@ def test_gn_partials_from_conv_epilogue(ops, b, c, co, h):
     ops.conv3x3_split(xd, None, ops.conv3x3_frag(w.to(DEV), False), co, y_ref,
                       ops.epilogue(bias=bias.to(DEV), residual=res.to(DEV), ld_residual=co, out_scale=0.7))
     assert torch.equal(y, y_ref)
-    assert not ops.gn_part_supported(b, h * h, 128)              # 32 groups of 4 channels: finer than the 8-channel sums
+    assert part.fine_width == (4 if co == 128 else 8)            # 128 channels: 32 groups of 4 -> four-channel sums
     for groups in (None, ops.gn_groups(2 * co) // 2):            # own GroupNorm / as one half of a concatenation
         ref = ops.gn_stats(y, gamma, beta, groups=groups)
         got = ops.gn_stats_from_part(part, y.shape, gamma, beta, groups=groups)

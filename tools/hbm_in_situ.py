@@ -33,7 +33,7 @@ def _b(fam, fn):
 
 BYTES = {
     "psld_gn_stats_nhwc_f32": _b("gn_stats", lambda a: 4 * a[1] * a[2] * a[3]),
-    "psld_gn_stats_from_partials_f32": _b("gn_stats", lambda a: a[1] * max(1, a[2] // 64) * (a[3] // 8) * 16),
+    "psld_gn_stats_from_partials_f32": _b("gn_stats", lambda a: a[2] * max(1, a[3] // 64) * (a[4] // max(1, a[1])) * 16),
     "psld_gn_apply_nhwc_f32": _b("gn_apply", lambda a: 8 * a[4] * a[5] * a[6]),
     "psld_gn_apply_limb_nhwc": _b("gn_apply_limb", lambda a: 10 * a[4] * a[5] * a[6]),
     "psld_gn_bwd_team_f32": _b("gn_bwd", lambda a: (12 + (4 if a[15] else 0) + (4 if a[16] else 0)) * a[6] * a[7] * a[8]),
