@@ -381,11 +381,11 @@ class _Exec:
         b, h, w, c = x.shape
         pa = self.net._param_arena()
         node = last_writer_of
-        fold = node is not None and node.want_gsum and colsum_img is None and self.gn_bwd_colsum and \
-            ops.gn_bwd_colsum_supported(b, h * w, c, groups)
         # large maps with a third operand - and maps above 32x32 in any case - go through the whole-row team kernel unless
         # per-IMAGE column sums are asked for: its sums / column sums come per (image, team member), k rows per image
         k = ops.gn_bwd_team_wanted(b, h * w, c, groups, add is not None or accumulate_dx) if colsum_img is None else 0
+        fold = node is not None and node.want_gsum and colsum_img is None and self.gn_bwd_colsum and \
+            (k > 0 or ops.gn_bwd_colsum_supported(b, h * w, c, groups))
         rows = b * max(k, 1)
         sums = pa.floats(rows, 2, c)
         if fold:
