@@ -255,6 +255,7 @@ class _Exec:
         # by ONE launch per kind at the end of the pass (net.defer_param_grads; earlier when a gradient bucket is about to
         # be exchanged, or when the parked slabs pass _SLAB_FLUSH_BYTES)
         self.defer = bool(net.defer_param_grads) and record
+        self.dense_batched = False
         self.pjobs, self.pblocks = [], 0
         self.sjobs, self.sitems, self.sbytes = [], 0, 0
 
@@ -634,9 +635,25 @@ class _Exec:
                 # read inside ONE backward pass, so forward passes whose backward is still pending can share it
                 self.dtp_all = net._persist("dtp_all", (b, total))
         tp_all, dtp_all = self.tp_all, self.dtp_all
+        # Dense_0's weight gradients of ALL blocks as one GEMM dtp_all^T act(temb) at the end of the pass (57 eight-workgroup
+        # launches of ~10 us otherwise) - unless a bucket reducer needs each block's gradients final at its own watermark
+        self.dense_batched = self.dtp_all is not None and self.defer and net._reducer is None and self.split and \
+            ops.gemm_tn_split_supported(plan["total"], plan["wcat"].shape[1], b)
+        dense_batched = self.dense_batched
 
         def bwd():
             self.join_side()            # every block wrote its slice of dtp_all / accumulated into st.g
+            if dense_batched:
+                total, kd = plan["total"], plan["wcat"].shape[1]
+                dwcat = net._persist("dwcat", (total, kd))
+                ops.gemm_tn_split(total, kd, b, dtp_all, total, st.v, kd, dwcat, kd, 1)
+                rows, first = [], 0
+                for m_ in plan["blocks"]:
+                    o, w_ = plan["offsets"][id(m_)], m_.Dense_0.weight
+                    n4 = w_.numel() // 4
+                    rows += [dwcat.data_ptr() + 4 * o * kd, self.g(w_).data_ptr(), n4, first]
+                    first += n4
+                ops.copy_batch(net._tables.get(rows, dwcat.device), len(plan["blocks"]), first)
             if dtp_all is not None:     # d act(temb) = sum over blocks dtp_i W_i = dtp_all Wcat: one GEMM
                 wcat = plan["wcat"]
                 gb, acc = _gbuf(st)
@@ -831,7 +848,9 @@ class _Exec:
                     dtp = dtp_all[:, tp_off:tp_off + cout]
                     if not csum:
                         self.bias_grad(dh1, self.g(mod.Conv_0.bias), per_image=dtp, ld_per_image=ldt)
-                    if self.split and ops.gemm_tn_split_supported(cout, kd, b) and dtp.data_ptr() % 16 == 0:
+                    if self.dense_batched:
+                        pass                # one GEMM over all blocks at the end (time_embedding.bwd)
+                    elif self.split and ops.gemm_tn_split_supported(cout, kd, b) and dtp.data_ptr() % 16 == 0:
                         # one "slab" = the gradient itself: K = batch is short enough for a single range
                         ops.gemm_tn_split(cout, kd, b, dtp, ldt, temb_act.v, kd, self.g(d0.weight), kd, 1)
                     else:
@@ -1822,7 +1841,7 @@ class NCSNpp(nn.Module):
             kd = blocks[0].Dense_0.weight.shape[1]
             plan = {"wcat": torch.empty((total, kd), device=dev, dtype=torch.float32),
                     "bcat": torch.empty((total,), device=dev, dtype=torch.float32), "total": total, "offsets": {},
-                    "table": None, "sig": None}
+                    "table": None, "sig": None, "blocks": blocks}
             off = 0
             for m in blocks:
                 plan["offsets"][id(m)] = off
