@@ -650,6 +650,7 @@ def main():
         dt_probed, _ = timed_pass(args.warmup + args.steps)
         probe.enabled = False
     loss_val = float(last.item())
+    ops.check_device_errors(dev)      # a device-side timeout (team GroupNorm backward) voids the run: raise on the rank that saw it
     # replicas stay identical: same seed, same averaged gradient -> same parameters on every rank
     in_sync = None
     if world > 1:

@@ -228,6 +228,7 @@ def train(args, overrides):
                 print(f"epoch {epoch} step {step} loss {loss.item():.4f} ({step * bs * world / dt:.1f} img/s)", flush=True)
             if args.max_steps and step >= args.max_steps:
                 break
+        ops.check_device_errors(dev)        # every rank, once per epoch, before anything is written
         if rank == 0 and ((epoch + 1) % cfg.training.chkpt_interval == 0 or (args.max_steps and step >= args.max_steps)):
             name = f"{cfg.model.sde.name}-{cfg.training.chkpt_prefix}-epoch={epoch:02d}-loss={loss.item():.4f}.ckpt"
             save_checkpoint(os.path.join(ckdir, name), wrapper, optim, step, epoch + 1, sched)

@@ -631,6 +631,21 @@ def gn_team_sync(device) -> Tensor:
     return t
 
 
+def check_device_errors(device=None) -> None:
+    """Raise if a device-side error word is set (today: a workgroup of the team GroupNorm backward gave up waiting for its
+    team and wrote garbage rather than hang the queue).  A host read: call it where the host already waits for the device
+    (the training loop's log line, before a checkpoint, after a timed region) - never per launch.  Allocates nothing."""
+    if device is None:
+        keys = list(_team_sync)
+    else:
+        keys = [device.index if device.index is not None else torch.cuda.current_device()]
+    for key in keys:
+        t = _team_sync.get(key)
+        if t is not None and int(t[:8].view(torch.int64).item()) != 0:
+            raise RuntimeError(f"psld_amd: gn_bwd_team_kernel on cuda:{key} timed out waiting for a team member - the "
+                               "gradients of this step are invalid (set PSLD_GN_BWD_PIPE=0 to take the one-slab kernels)")
+
+
 def gn_team_errors(device) -> int:
     """Error word of the team kernels' slot buffer (non-zero: a workgroup gave up waiting for its team); a host read."""
     return int(gn_team_sync(device)[:8].view(torch.int64).item())

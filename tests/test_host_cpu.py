@@ -237,3 +237,8 @@ def test_bucket_reducer_announces_a_launch_before_it_happens():
         assert will == (len(red.launched) > launched), off
         launched = len(red.launched)
     assert launched == 6 and not red.would_launch(0)
+
+
+def test_device_error_check_is_a_no_op_before_any_team_launch():
+    from psld_amd import ops
+    ops.check_device_errors()               # no slot buffer was ever allocated here: nothing to read, nothing raised

@@ -1024,6 +1024,7 @@ def _team_kernel_case(ops, b, s, c, variant):
         sums = ops.gn_bwd_team(dy, x, st, gamma, beta, act, dx, colsum_rows=rows, ld_rows=c + 8, **kw)
         outs.append((dx, sums.clone(), rows))
     assert ops.gn_team_errors(x.device) == 0
+    ops.check_device_errors(x.device)                            # nothing raised: no workgroup gave up
     for dx, sums, rows in outs[1:]:
         assert torch.equal(dx, outs[0][0]) and torch.equal(sums, outs[0][1]) and torch.equal(rows[:, :c], outs[0][2][:, :c])
     dx, sums, rows = outs[0]
@@ -1389,3 +1390,21 @@ def test_writer_and_loader_edges(ops, golden):
     ref[0], ref[2] = ref[0].flip(-1), ref[2].flip(-1)
     assert torch.equal(tf.cpu(), ref)
     assert torch.equal(ops.uint8_to_images(img.to(DEV), norm=False).cpu(), O.images_to_tensor(img.numpy(), False))
+
+
+def test_a_team_kernel_timeout_is_raised_on_the_host():
+    """The team kernel's poll loop is bounded: a workgroup that gives up raises the error word of the slot buffer
+    (norm_act.hip).  The word reaches the user: ops.check_device_errors - called by the training loop once per epoch and by
+    bench.py after the timed region - raises while it is set."""
+    sync = ops.gn_team_sync(DEV)
+    torch.cuda.synchronize()
+    ops.check_device_errors(DEV)
+    sync[:8].view(torch.int64).fill_(1)                          # what the kernel stores on a timeout
+    try:
+        with pytest.raises(RuntimeError, match="gn_bwd_team_kernel"):
+            ops.check_device_errors(DEV)
+        with pytest.raises(RuntimeError, match="gn_bwd_team_kernel"):
+            ops.check_device_errors()                            # all devices this process drove
+    finally:
+        sync[:8].view(torch.int64).fill_(0)
+    ops.check_device_errors(DEV)
