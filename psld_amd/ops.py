@@ -624,6 +624,7 @@ _team_sync = {}      # device index -> zero-initialised slot buffer of the team 
 
 
 def gn_team_sync(device) -> Tensor:
+    device = torch.device(device)
     key = device.index if device.index is not None else torch.cuda.current_device()
     t = _team_sync.get(key)
     if t is None:
@@ -638,6 +639,7 @@ def check_device_errors(device=None) -> None:
     if device is None:
         keys = list(_team_sync)
     else:
+        device = torch.device(device)
         keys = [device.index if device.index is not None else torch.cuda.current_device()]
     for key in keys:
         t = _team_sync.get(key)
