@@ -1392,7 +1392,7 @@ def test_writer_and_loader_edges(ops, golden):
     assert torch.equal(ops.uint8_to_images(img.to(DEV), norm=False).cpu(), O.images_to_tensor(img.numpy(), False))
 
 
-def test_a_team_kernel_timeout_is_raised_on_the_host():
+def test_a_team_kernel_timeout_is_raised_on_the_host(ops):
     """The team kernel's poll loop is bounded: a workgroup that gives up raises the error word of the slot buffer
     (norm_act.hip).  The word reaches the user: ops.check_device_errors - called by the training loop once per epoch and by
     bench.py after the timed region - raises while it is set."""
