@@ -256,6 +256,8 @@ class _Exec:
         # be exchanged, or when the parked slabs pass _SLAB_FLUSH_BYTES)
         self.defer = bool(net.defer_param_grads) and record
         self.dense_batched = False
+        self.dense_ok = False
+        self.dense_pending = []         # (first column of dtp_all, C_out, Dense_0) of blocks whose Dense_0 gradient is parked
         self.pjobs, self.pblocks = [], 0
         self.sjobs, self.sitems, self.sbytes = [], 0, 0
 
@@ -362,9 +364,33 @@ class _Exec:
             ops.reduce_slabs_batch(table, len(jobs), items, sum(4 * j[2] * (j[1] + 1) for j in jobs))
             self.net._slab_arena().reset()
 
+    def flush_dense(self):
+        """Dense_0 weight gradients of the blocks finished since the last flush: ONE GEMM over their (contiguous) columns of
+        dtp_all and one scatter into the flat gradient - the per-bucket form of time_embedding.bwd's batched GEMM."""
+        pend, self.dense_pending = self.dense_pending, []
+        if not pend:
+            return
+        net, dtp_all, act = self.net, self.dtp_all, self.temb_act.v
+        b, total = dtp_all.shape
+        kd = act.shape[1]
+        lo, hi = min(o for o, _, _ in pend), max(o + c for o, c, _ in pend)
+        if hi - lo == sum(c for _, c, _ in pend) and lo % 4 == 0 and ops.gemm_tn_split_supported(hi - lo, kd, b):
+            dwcat = net._persist("dwcat", (total, kd))
+            ops.gemm_tn_split(hi - lo, kd, b, dtp_all[:, lo:hi], total, act, kd, dwcat[lo:hi], kd, 1)
+            rows, first = [], 0
+            for o, c, d0 in pend:
+                n4 = c * kd // 4
+                rows += [dwcat.data_ptr() + 4 * o * kd, self.g(d0.weight).data_ptr(), n4, first]
+                first += n4
+            ops.copy_batch(net._tables.get(rows, dwcat.device), len(pend), first)
+        else:
+            for o, c, d0 in pend:
+                ops.gemm_tn_split(c, kd, b, dtp_all[:, o:o + c], total, act, kd, self.g(d0.weight), kd, 1)
+
     def flush_deferred(self):
         self.on_side(self.flush_slabs)
         self.flush_params()
+        self.flush_dense()
 
     def finish_backward(self):
         """After the last entry of the backward tape: the parked reductions, then the side stream joins."""
@@ -637,8 +663,11 @@ class _Exec:
         tp_all, dtp_all = self.tp_all, self.dtp_all
         # Dense_0's weight gradients of ALL blocks as one GEMM dtp_all^T act(temb) at the end of the pass (57 eight-workgroup
         # launches of ~10 us otherwise) - unless a bucket reducer needs each block's gradients final at its own watermark
-        self.dense_batched = self.dtp_all is not None and self.defer and net._reducer is None and self.split and \
+        # With a reducer (and no side stream) the same GEMM runs once per BUCKET, over the columns of the blocks finished since
+        # the last one (flush_dense, called with the other parked reductions before a bucket is exchanged).
+        self.dense_ok = self.dtp_all is not None and self.defer and self.split and \
             ops.gemm_tn_split_supported(plan["total"], plan["wcat"].shape[1], b)
+        self.dense_batched = self.dense_ok and net._reducer is None
         dense_batched = self.dense_batched
 
         def bwd():
@@ -850,6 +879,8 @@ class _Exec:
                         self.bias_grad(dh1, self.g(mod.Conv_0.bias), per_image=dtp, ld_per_image=ldt)
                     if self.dense_batched:
                         pass                # one GEMM over all blocks at the end (time_embedding.bwd)
+                    elif self.dense_ok and self.side is None and ops.gemm_tn_split_supported(cout, kd, b):
+                        self.dense_pending.append((tp_off, cout, d0))       # one GEMM per gradient bucket (flush_dense)
                     elif self.split and ops.gemm_tn_split_supported(cout, kd, b) and dtp.data_ptr() % 16 == 0:
                         # one "slab" = the gradient itself: K = batch is short enough for a single range
                         ops.gemm_tn_split(cout, kd, b, dtp, ldt, temb_act.v, kd, self.g(d0.weight), kd, 1)

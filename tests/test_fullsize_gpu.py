@@ -200,6 +200,17 @@ def test_headline_configuration_with_dropout_is_repeatable_and_linear_in_the_bat
     y2, g2 = run(w)
     assert bool(torch.isfinite(y1).all()) and bool(torch.isfinite(g1).all())
     assert torch.equal(y1, y2) and torch.equal(g1, g2)
+    # with a gradient reducer attached the parked reductions - and the batched Dense_0 weight gradients - run once per
+    # BUCKET instead of once per pass (a world of one: the buckets are formed, nothing is exchanged): bitwise the same
+    from psld_amd.ddp import BucketReducer
+    red = BucketReducer()
+    net.set_reducer(red)
+    try:
+        y3, g3 = run(w)
+    finally:
+        net.set_reducer(None)
+    assert len(red.launched) >= 6 and red.launched[-1][0] == 0
+    assert torch.equal(y1, y3) and torch.equal(g1, g3)
     # dropout really is on: the eval forward differs
     net.eval()
     with torch.no_grad():
