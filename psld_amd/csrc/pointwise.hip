@@ -259,8 +259,22 @@ __global__ void __launch_bounds__(1024) param_reduce_kernel(const long long* __r
     const int col = local * 64 + (tid & 63);
     const int lane = tid >> 6;
     double acc = 0.0;
-    if (col < job.c)
-        for (int r = lane; r < job.rows; r += 16) acc += (double)job.src[(long long)r * job.ld + col];
+    if (col < job.c) {
+        // eight rows asked for before the first is added (a lane of a team-kernel job walks 128 rows: one memory latency
+        // each otherwise); the adds stay in row order
+        const float* p = job.src + col;
+        const long long step = 16ll * job.ld;
+        int r = lane;
+        for (; r + 7 * 16 < job.rows; r += 8 * 16) {
+            float v[8];
+            const float* q = p + (long long)r * job.ld;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = q[u * step];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += (double)v[u];
+        }
+        for (; r < job.rows; r += 16) acc += (double)p[(long long)r * job.ld];
+    }
     sh[lane * 64 + (tid & 63)] = acc;
     __syncthreads();
     if (lane == 0 && col < job.c) {
