@@ -93,6 +93,9 @@ def init_distributed(backend: Optional[str] = None, force: bool = False,
         store, timeout = _rendezvous(rank, world, timeout_s)       # before any HIP call: a missing rank costs no GPU state
         if backend == "nccl":
             torch.cuda.set_device(local)
+            # Work._get_duration(): BucketReducer(profile=True) reads the time each collective occupied the process
+            # group's stream from it (start / end events the group records itself)
+            os.environ.setdefault("TORCH_NCCL_ENABLE_TIMING", "1")
         dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout,
                                 store=dist.PrefixStore("psld/pg", store))
     return rank, local, world
@@ -156,7 +159,18 @@ class BucketReducer:
         if self.world == 1 and not self.force:
             return
         view = self._flat[lo:hi]
-        if self._flat.is_cuda and dist.get_backend(self.pg) == "nccl":
+        if self._flat.is_cuda and dist.get_backend(self.pg) == "nccl" and not self.producer_streams:
+            # Every gradient of the bucket was enqueued on the CURRENT stream: issue the collective from it.  The process
+            # group makes its own stream wait for this point and runs the collective there, beside the rest of backward;
+            # finish() joins.  One foreign queue with a pending wait instead of two (a side stream of ours in front of the
+            # group's): measured on MI355X, every queue that holds an unsatisfied wait while the compute stream
+            # dispatches costs the step ~0.5-1 ms (profiles/r05/rccl_occupancy.txt).
+            op = dist.ReduceOp.AVG if self.average else dist.ReduceOp.SUM
+            w = dist.all_reduce(view, op=op, group=self.pg, async_op=True)
+            self._works.append(w)
+            if self._cur is not None:
+                self._cur.append(w)
+        elif self._flat.is_cuda and dist.get_backend(self.pg) == "nccl":
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self._side.wait_event(ev)
@@ -214,7 +228,11 @@ class BucketReducer:
             if self._cur is not None:
                 j0 = torch.cuda.Event(enable_timing=True)
                 j0.record(cur)
-            cur.wait_stream(self._side)
+            if self.producer_streams:
+                cur.wait_stream(self._side)
+            else:
+                for w in self._works:
+                    w.wait()             # stream-level: the compute stream waits for the collective's end event
             if self._cur is not None:
                 j1 = torch.cuda.Event(enable_timing=True)
                 j1.record(cur)
@@ -240,13 +258,27 @@ class BucketReducer:
                 comm += c
                 exposed += c
             else:
-                comm += sum(a.elapsed_time(b) for a, b in evs)
+                comm += sum(_bucket_ms(e) for e in evs)
                 exposed += join[0].elapsed_time(join[1])
         if reset:
             self._prof.clear()
+        if comm != comm:            # a collective whose length could not be read (no timing in the process group)
+            return {"steps": steps, "buckets_per_step": buckets / steps, "bucket_mb": self.bucket_elems * 4 / 2 ** 20,
+                    "comm_ms_per_step": None, "exposed_ms_per_step": exposed / steps, "hidden_ms_per_step": None}
         return {"steps": steps, "buckets_per_step": buckets / steps, "bucket_mb": self.bucket_elems * 4 / 2 ** 20,
                 "comm_ms_per_step": comm / steps, "exposed_ms_per_step": exposed / steps,
                 "hidden_ms_per_step": max(0.0, comm - exposed) / steps}
+
+
+def _bucket_ms(entry) -> float:
+    """Time one collective occupied its stream: a pair of HIP events of ours (side-stream form) or the process group's own
+    start / end events (Work._get_duration, needs TORCH_NCCL_ENABLE_TIMING=1 - init_distributed sets it)."""
+    if isinstance(entry, tuple):
+        return entry[0].elapsed_time(entry[1])
+    try:
+        return float(entry._get_duration())
+    except Exception:       # noqa: BLE001 - timing not enabled in this process group: the exchange ran, its length is unknown
+        return float("nan")
 
 
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:

@@ -1445,7 +1445,7 @@ class _NCSNppFn(torch.autograd.Function):
         if ex is None:
             raise RuntimeError("psld_amd.NCSNpp: backward through the same forward pass twice is not supported")
         ctx.ex = None
-        net._begin_backward()
+        net._begin_backward(side=ex.side)
         ex.backward(gy)
         net._end_backward()
         ctx.pending.release()
@@ -1475,7 +1475,7 @@ class _NCSNppParamFn(torch.autograd.Function):
         if ex is None:
             raise RuntimeError("psld_amd.NCSNpp: backward through the same forward pass twice is not supported")
         ctx.ex = None
-        net._begin_backward(visible=True)
+        net._begin_backward(visible=True, side=ex.side)
         ex.backward(gy)
         grads = net._end_backward_visible()
         ctx.pending.release()
@@ -1931,7 +1931,8 @@ class NCSNpp(nn.Module):
         import torch.distributed as dist
         return self._reducer is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
-    def _begin_backward(self, visible: bool = False):
+    def _begin_backward(self, visible: bool = False, side=None):
+        """``side``: the stream THIS pass runs its parameter-gradient kernels on (None: everything on one stream)."""
         self.flat_grad()
         # torch semantics: a populated .grad is accumulated into.  Kernels WRITE their results, so in that
         # case this pass goes to a scratch buffer that is added afterwards (one extra 0.4 GB pass).
@@ -1952,7 +1953,7 @@ class NCSNpp(nn.Module):
             target = self._scratch_grad
         if self._reducer is not None:
             self._reducer.begin(target)
-            self._reducer.producer_streams = [self._side] if self._side is not None else []
+            self._reducer.producer_streams = [side] if side is not None else []
 
     def _watermark_hook(self, offset: int):
         if self._reducer is not None:

@@ -552,7 +552,7 @@ def test_rccl_bucket_reducer_single_rank():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TORCH_NCCL_ENABLE_TIMING="1")
     dist.init_process_group("nccl", rank=0, world_size=1)
     try:
         net, cfg, _ = _build("tiny", train=True)
@@ -564,14 +564,26 @@ def test_rccl_bucket_reducer_single_rank():
         ref = net.flat_grad().clone()
         for p in net.parameters():
             p.grad = None
-        red = BucketReducer(bucket_bytes=1 << 18, force_collective=True)
-        net.set_reducer(red)
-        crit(x0, t, net, eps=eps).backward()
-        torch.cuda.synchronize()
-        assert len(red.launched) >= 8
-        assert red.launched[0][1] == ref.numel() and red.launched[-1][0] == 0     # end of buffer first
-        assert all(red.launched[i][0] == red.launched[i + 1][1] for i in range(len(red.launched) - 1))
-        assert torch.equal(net.flat_grad(), ref)
+        # both forms of the exchange: weight gradients on the network's side stream -> the reducer's own side stream waits
+        # for both producers; everything on one stream -> the collectives are issued from it (the process group's stream
+        # is the only second queue) and joined at the end of backward
+        for overlap in (True, False):
+            for p in net.parameters():
+                p.grad = None
+            net.overlap_wgrad = overlap
+            red = BucketReducer(bucket_bytes=1 << 18, force_collective=True, profile=True)
+            net.set_reducer(red)
+            crit(x0, t, net, eps=eps).backward()
+            torch.cuda.synchronize()
+            assert bool(red.producer_streams) == overlap
+            assert len(red.launched) >= 8
+            assert red.launched[0][1] == ref.numel() and red.launched[-1][0] == 0     # end of buffer first
+            assert all(red.launched[i][0] == red.launched[i + 1][1] for i in range(len(red.launched) - 1))
+            assert torch.equal(net.flat_grad(), ref)
+            st = red.stats()
+            assert st["buckets_per_step"] == len(red.launched) and st["exposed_ms_per_step"] >= 0
+            if os.environ.get("TORCH_NCCL_ENABLE_TIMING") == "1" or overlap:
+                assert st["comm_ms_per_step"] is not None and st["comm_ms_per_step"] > 0
     finally:
         dist.destroy_process_group()
 
