@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--ranks", type=int, default=8)
     ap.add_argument("--touch", type=int, default=1, help="1: the hog walks the bucket's bytes; 0: spins only")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--host-sync", action="store_true", help="the host waits for the bucket's event before it issues the exchange")
     ap.add_argument("--real", action="store_true", help="leave the (1-rank) RCCL collectives in place")
     ap.add_argument("--side-stream", action="store_true", help="force the reducer's side-stream form")
     ap.add_argument("--side-priority", type=int, default=None)
@@ -89,6 +90,8 @@ def main():
         hs = pg_stream.setdefault("s", torch.cuda.Stream(device=tensor.device))
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
+        if args.host_sync:
+            ev.synchronize()        # the host waits for the device to get here: the stream wait below is satisfied at once
         hs.wait_event(ev)
         s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s0.record(hs)
