@@ -6,9 +6,12 @@ mean of the flat fp32 gradient buffer (390.5 MB for the CIFAR-10 net).
 
 The network's backward produces parameter gradients from the END of the flat buffer towards the
 front (reverse module order) and reports a watermark; every bucket that lies entirely above the
-watermark is all-reduced immediately on a side HIP stream while the remaining layers' dgrad/wgrad
-kernels keep the compute stream busy.  ``finish()`` flushes the rest and makes the compute stream
-wait.  xGMI is point-to-point, so buckets are large (default 64 MiB: ~6 collectives per step).
+watermark is all-reduced immediately, off the compute stream, while the remaining layers' dgrad/wgrad
+kernels keep that stream busy: issued from the compute stream itself (the process group runs it on its own
+stream, which waits for that point) when every gradient is produced there, or behind a side stream of the
+reducer's that waits for both producers when the pass runs its weight gradients on a second stream.
+``finish()`` flushes the rest and makes the compute stream wait.  xGMI is point-to-point, so buckets are
+large (default 64 MiB, geometric from the front: 8 collectives per step for the CIFAR-10 net).
 
 The same class runs on CPU tensors with the gloo backend (no streams) — that is how the N>1 path is
 tested in this container (tests/test_ddp_cpu.py).
@@ -244,7 +247,8 @@ class BucketReducer:
 
     def stats(self, reset: bool = True):
         """Exchange timing over the backward passes since the last reset (``profile=True``): per step the number of
-        buckets, the time the collectives occupied the side stream (``comm_ms``), the time the compute stream
+        buckets, the time the collectives occupied their stream (``comm_ms``: the reducer's side stream, or the process
+        group's own when the exchange is issued from the compute stream), the time the compute stream
         stood waiting for them at the join (``exposed_ms``) and the difference (``hidden_ms``: ran under backward).
         Host-synchronous backends (gloo) expose everything.  Call after a device synchronize."""
         steps = len(self._prof)
