@@ -129,7 +129,10 @@ int psld_pack_conv3x3_frag(const float* w_oihw, void* wfrag, int cout, int cin, 
  * table_dev: device array of `entries` x 8 int64: {src pointer, dst pointer, n_out, k_in, taps | flip << 32,
  * stride_n, stride_k, first work item}; an entry has n_out*k_in/8 work items (one per lane slot, all taps and limbs)
  * and produces exactly what psld_pack_conv3x3_frag (taps 9) / psld_pack_gemm_frag (taps 1) would;
- * total_items = sum over entries. */
+ * total_items = sum over entries.  k_in may carry (chunk0 << 20) | (chunks_total << 40) in its upper bits: the entry then
+ * fills the 32-wide K chunks chunk0 .. chunk0 + k_in/32 of a fragment set whose K dimension has chunks_total chunks
+ * (several parameters concatenated along K into one set - the q | k | v projections of an attention block read by ONE
+ * data-gradient GEMM); both zero: the entry is the whole K dimension. */
 int psld_pack_frag_batch(const long long* table_dev, int entries, long long total_items, hipStream_t stream);
 int psld_conv3x3_split_f32(const float* x1, int c1, const float* x2, int c2, int batch, int h, int w,
                            const void* wfrag, int cout, float* y, int ldy, const psld_epilogue_t* epi,

@@ -54,9 +54,13 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, cons
 // One work item = one lane slot (nt, wc, chunk, nb, lane) for ALL taps and limbs: its 8 k-values x taps source
 // elements are neighbours in memory (OIHW keeps the 9 taps of a (co, ci) pair together), and split3 yields the three
 // limbs at once.
+// chunk0 / chunks_total: the tensor fills the 32-wide K chunks chunk0 .. chunk0 + k_in/32 of a fragment set whose K
+// dimension has chunks_total chunks (several parameters concatenated along K: the attention q | k | v data gradient).
 __device__ __forceinline__ void pack_frag_item(const float* __restrict__ w, u32x4* __restrict__ out, long long item,
-                                               int k_in, int taps, long long sn, long long sk, long long st, int flip) {
+                                               int k_in, int taps, long long sn, long long sk, long long st, int flip,
+                                               int chunk0 = 0, int chunks_total = 0) {
     const int chunks = k_in / 32;
+    if (chunks_total == 0) chunks_total = chunks;
     long long t = item;
     const int lane = (int)(t & 63); t >>= 6;
     const int nb = (int)(t & 3); t >>= 2;
@@ -67,7 +71,7 @@ __device__ __forceinline__ void pack_frag_item(const float* __restrict__ w, u32x
     const int k0 = chunk * 32 + (lane >> 4) * 8;
     const float* src = w + n * sn + k0 * sk;
     // uint4 index of (tap, limb) for this slot: ((((nt*2 + wc)*chunks + chunk)*taps + tap)*4 + nb)*3 + limb)*64 + lane
-    const long long base = ((long long)(nt * 2 + wc) * chunks + chunk) * taps;
+    const long long base = ((long long)(nt * 2 + wc) * chunks_total + chunk0 + chunk) * taps;
     for (int tap = 0; tap < taps; ++tap) {
         const float* p = src + (flip ? taps - 1 - tap : tap) * st;
         unsigned hi[4], mid[4], lo[4];
@@ -87,8 +91,9 @@ __global__ void pack_frag_kernel(const float* __restrict__ w, u32x4* __restrict_
         pack_frag_item(w, out, i, k_in, taps, sn, sk, st, flip);
 }
 
-// Many weight tensors in one launch.  tab[8*i ..]: src pointer, dst pointer, n_out, k_in, taps | flip << 32, sn, sk,
-// first work item of tensor i in the launch-wide numbering (st = 1; a tensor has n_out * k_in / 8 items).
+// Many weight tensors in one launch.  tab[8*i ..]: src pointer, dst pointer, n_out, k_in | chunk0 << 20 | chunks_total << 40,
+// taps | flip << 32, sn, sk, first work item of tensor i in the launch-wide numbering (st = 1; a tensor has
+// n_out * k_in / 8 items; chunk0 = chunks_total = 0: the tensor is the whole K dimension of its fragment set).
 __global__ void pack_frag_batch_kernel(const long long* __restrict__ tab, int ntab, long long total) {
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
@@ -98,8 +103,9 @@ __global__ void pack_frag_batch_kernel(const long long* __restrict__ tab, int nt
             if (tab[8 * mid + 7] <= idx) lo = mid; else hi = mid - 1;
         }
         const long long* d = tab + 8 * lo;
-        pack_frag_item(reinterpret_cast<const float*>(d[0]), reinterpret_cast<u32x4*>(d[1]), idx - d[7], (int)d[3],
-                       (int)(d[4] & 0xffffffffLL), d[5], d[6], 1, (int)(d[4] >> 32));
+        pack_frag_item(reinterpret_cast<const float*>(d[0]), reinterpret_cast<u32x4*>(d[1]), idx - d[7], (int)(d[3] & 0xfffff),
+                       (int)(d[4] & 0xffffffffLL), d[5], d[6], 1, (int)(d[4] >> 32), (int)((d[3] >> 20) & 0xfffff),
+                       (int)((d[3] >> 40) & 0xfffff));
     }
 }
 

@@ -331,6 +331,10 @@ def gemm_split_supported(k1: int, k2: int, m: int, n: int) -> bool:
     return bool(lib().psld_gemm_split_supported(k1, k2, m, n))
 
 
+def gemm_frag_bytes(n: int, k: int) -> int:
+    return int(lib().psld_gemm_frag_bytes(n, k))
+
+
 def gemm_frag(b: Tensor, n: int, k: int, stride_n: int, stride_k: int, out: Optional[Tensor] = None) -> Tensor:
     """Limb fragments of the [n][k] matrix whose element (i, j) sits at b.flatten()[i*stride_n + j*stride_k]."""
     if out is None:

@@ -987,14 +987,7 @@ class _Exec:
         fused = self.split and ops.gemm_split_supported(c, 0, m, c)
         net = self.net
         if fused:
-            def build_qkv(prev):
-                wcat = torch.cat([n0.W.detach(), n1.W.detach(), n2.W.detach()], dim=1).contiguous()      # [in][3 out]
-                pf, pd, pb = prev if prev is not None else (None, None, None)
-                bcat = torch.cat([n0.b.detach(), n1.b.detach(), n2.b.detach()])
-                return (ops.gemm_frag(wcat, 3 * c, c, 1, 3 * c, pf),        # forward:  B[n][k] = wcat[k][n]
-                        ops.gemm_frag(wcat, c, 3 * c, 3 * c, 1, pd),        # data gradient: B[n][k] = wcat[n][k]
-                        bcat if pb is None else pb.copy_(bcat))
-            f_qkv, f_qkv_d, b_qkv = net._gfrag(n0.W, "qkv", build_qkv)
+            f_qkv, f_qkv_d, b_qkv = net._qkv_frags(mod)
             qkv = torch.empty((b, hw, 3 * c), device=dev, dtype=torch.float32)
             ops.gemm_split(hn, None, m, f_qkv, 3 * c, qkv, ops.epilogue(bias=b_qkv))
             q, k, v = qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
@@ -1579,6 +1572,8 @@ class NCSNpp(nn.Module):
         self._offsets = None
         self._pack_cache = {}
         self._frag_table = None     # (signature, device table, entries, total work items) of the batched fragment refresh
+        self._qkv_bias_table = None
+        self._qkv_bias_stamp = {}
         self._wfrag_table = None    # the same for the Winograd fragment sets
         self._temb_plan_cache = None
         self._pack_key = None
@@ -1687,6 +1682,8 @@ class NCSNpp(nn.Module):
             self._gviews = None
             self._scratch_grad = self._sviews = None
             self._pack_cache.clear()
+            self._qkv_bias_table = None
+            self._qkv_bias_stamp = {}
             self._epoch += 1
         self._offsets = offs
         self._module_offs = None
@@ -1824,8 +1821,8 @@ class NCSNpp(nn.Module):
                     rows.append(ops.conv3x3_frag_entry(w.detach(), k[1], o) + [total])
                     total += w.shape[0] * w.shape[1] // 8        # work items: one per lane slot
                 else:
-                    n, kk, sn, sk = self._pack_cache[k][3]
-                    rows.append([w.data_ptr(), o.data_ptr(), n, kk, 1, sn, sk, total])
+                    n, kk, sn, sk, c0, ct = self._pack_cache[k][3]
+                    rows.append([w.data_ptr(), o.data_ptr(), n, kk | (c0 << 20) | (ct << 40), 1, sn, sk, total])
                     total += n * kk // 8
             self._frag_table = (sig, torch.tensor(rows, dtype=torch.int64, device=ws[0].device), len(rows), total)
         _, table, n, total = self._frag_table
@@ -1834,22 +1831,76 @@ class NCSNpp(nn.Module):
             self._pack_cache[k] = ((self._epoch, w._version, w.data_ptr()),) + tuple(self._pack_cache[k][1:])
         return True
 
-    def _pfrag(self, owner: nn.Parameter, tag: str, n: int, k: int, sn: int, sk: int) -> Tensor:
+    def _pfrag(self, owner: nn.Parameter, tag: str, n: int, k: int, sn: int, sk: int, into: Optional[Tensor] = None,
+               chunk0: int = 0, chunks_total: int = 0) -> Tensor:
         """Limb fragments (ops.gemm_frag) of the [n][k] view of ONE parameter (element (i, j) at i*sn + j*sk), cached
-        until the weights change and refreshed together with the 3x3 fragments by the batched launch."""
+        until the weights change and refreshed together with the 3x3 fragments by the batched launch.
+        ``into``: the buffer to fill (several parameters that share one fragment set: q | k | v) - then ``chunk0`` /
+        ``chunks_total`` place this parameter's K range inside the set's K dimension (psld_pack_frag_batch)."""
         key = (id(owner), tag, "pfrag")
         ent = self._pack_cache.get(key)
         stamp = (self._epoch, owner._version, owner.data_ptr())
-        if ent is not None and ent[0] == stamp:
+        if ent is not None and ent[0] == stamp and (into is None or ent[1].data_ptr() == into.data_ptr()):
             return ent[1]
-        if ent is not None and ent[1].device == owner.device and self._refresh_frags():
+        if ent is not None and ent[1].device == owner.device and (into is None or ent[1].data_ptr() == into.data_ptr()) and \
+                self._refresh_frags():
             ent = self._pack_cache[key]
             if ent[0] == stamp:
                 return ent[1]
-        out = ops.gemm_frag(owner.detach(), n, k, sn, sk, ent[1] if ent is not None and ent[1].device == owner.device else None)
-        self._pack_cache[key] = (stamp, out, owner, (n, k, sn, sk))
+        if into is None:
+            out = ops.gemm_frag(owner.detach(), n, k, sn, sk, ent[1] if ent is not None and ent[1].device == owner.device else None)
+        else:       # first use: a one-entry table through the batched entry point (the only one that takes a K placement)
+            out = into
+            row = [owner.data_ptr(), out.data_ptr(), n, k | (chunk0 << 20) | (chunks_total << 40), 1, sn, sk, 0]
+            ops.pack_frag_batch(torch.tensor(row, dtype=torch.int64, device=owner.device), 1, n * k // 8)
+        self._pack_cache[key] = (stamp, out, owner, (n, k, sn, sk, chunk0, chunks_total))
         self._frag_table = None
         return out
+
+    def _qkv_frags(self, mod):
+        """Fragments of an attention block's q | k | v projections as ONE GEMM operand each way - forward B[n][k] =
+        [W_q | W_k | W_v][k][n] (N = 3c), data gradient B[n][k] = [W_q | W_k | W_v][n][k] (K = 3c) - and the concatenated
+        bias.  Packed straight from the three parameters into shared buffers by the batched refresh of all fragments (no
+        concatenated copy of the weights, no launch of their own after the first step); the biases of ALL attention blocks
+        are gathered by one batched copy when they change."""
+        n0, n1, n2 = mod.NIN_0, mod.NIN_1, mod.NIN_2
+        c = n0.W.shape[0]
+        key = (id(n0.W), "qkv", "bufs")
+        bufs = self._pack_cache.get(key)
+        dev = n0.W.device
+        if bufs is None or bufs[0].device != dev:
+            fb = ops.gemm_frag_bytes(c, c)
+            bufs = (torch.empty(3 * fb, dtype=torch.uint8, device=dev), torch.empty(3 * fb, dtype=torch.uint8, device=dev),
+                    torch.empty(3 * c, dtype=torch.float32, device=dev), fb, mod)
+            self._pack_cache[key] = bufs
+            self._qkv_bias_table = None
+        pf, pd, bq, fb = bufs[:4]
+        for i, nin in enumerate((n0, n1, n2)):
+            # forward: rows n of the set are output channels -> each projection is a contiguous third of the set
+            self._pfrag(nin.W, "qkv_f", c, c, 1, c, into=pf[i * fb:(i + 1) * fb])
+            # data gradient: the three projections are concatenated along K
+            self._pfrag(nin.W, "qkv_d", c, c, c, 1, into=pd, chunk0=i * (c // 32), chunks_total=3 * (c // 32))
+        stamp = (self._epoch, n0.b._version, n0.b.data_ptr())
+        if self._qkv_bias_stamp.get(id(mod)) != stamp:
+            self._refresh_qkv_biases()
+        return pf, pd, bq
+
+    def _refresh_qkv_biases(self):
+        mods = [m for m in self.all_modules if isinstance(m, AttnBlockpp) and (id(m.NIN_0.W), "qkv", "bufs") in self._pack_cache]
+        sig = tuple((m.NIN_0.b.data_ptr(), self._pack_cache[(id(m.NIN_0.W), "qkv", "bufs")][2].data_ptr()) for m in mods)
+        if self._qkv_bias_table is None or self._qkv_bias_table[0] != sig:
+            rows, first = [], 0
+            for m in mods:
+                bq = self._pack_cache[(id(m.NIN_0.W), "qkv", "bufs")][2]
+                c = m.NIN_0.b.numel()
+                for i, nin in enumerate((m.NIN_0, m.NIN_1, m.NIN_2)):
+                    rows += [nin.b.data_ptr(), bq.data_ptr() + 4 * i * c, c // 4, first]
+                    first += c // 4
+            self._qkv_bias_table = (sig, torch.tensor(rows, dtype=torch.int64, device=mods[0].NIN_0.b.device), 3 * len(mods), first)
+        _, table, jobs, total = self._qkv_bias_table
+        ops.copy_batch(table, jobs, total)
+        for m in mods:
+            self._qkv_bias_stamp[id(m)] = (self._epoch, m.NIN_0.b._version, m.NIN_0.b.data_ptr())
 
     def _temb_offset(self, mod) -> Optional[int]:
         plan = self._temb_plan_cache
@@ -2072,8 +2123,14 @@ class NCSNpp(nn.Module):
                 if ck[-1] == "gfrag":
                     self._gfrag(cv[2], ck[1], cv[3])
                 elif ck[-1] == "pfrag":
-                    if ck[1] == "fwd":
-                        self._pfrag(cv[2], ck[1], *cv[3])
+                    if ck[1] in ("fwd", "qkv_f"):
+                        n_, k_, sn_, sk_, c0_, ct_ = cv[3]
+                        self._pfrag(cv[2], ck[1], n_, k_, sn_, sk_, into=cv[1] if ck[1] == "qkv_f" else None, chunk0=c0_,
+                                    chunks_total=ct_)
+                elif ck[-1] == "bufs":                          # an attention block's gathered q | k | v bias
+                    m_ = cv[4]
+                    if self._qkv_bias_stamp.get(id(m_)) != (self._epoch, m_.NIN_0.b._version, m_.NIN_0.b.data_ptr()):
+                        self._refresh_qkv_biases()
                 elif ck[-1] == "wfrag":                         # Winograd fragments the captured forward reads
                     if not ck[1]:
                         self._wfrag(self._conv_by_weight[ck[0]], False)
@@ -2093,7 +2150,7 @@ class NCSNpp(nn.Module):
         cls = self.__class__
         new = cls.__new__(cls)
         memo[id(self)] = new
-        skip = {"_tables", "_parena", "_sarena", "_persistent", "_flat", "_flat_grad", "_pack_cache", "_frag_table", "_wfrag_table", "_temb_plan_cache", "_anchor", "_reducer", "_offsets", "_module_offs", "_posfreq",
+        skip = {"_tables", "_parena", "_sarena", "_persistent", "_flat", "_flat_grad", "_pack_cache", "_frag_table", "_wfrag_table", "_qkv_bias_table", "_qkv_bias_stamp", "_temb_plan_cache", "_anchor", "_reducer", "_offsets", "_module_offs", "_posfreq",
                 "_side", "_plist", "_tlist", "_gviews", "_dropout_seed_dev", "_graphs", "_conv_by_weight", "_scratch_grad", "_sviews"}
         for k, v in self.__dict__.items():
             if k in skip:
@@ -2115,6 +2172,8 @@ class NCSNpp(nn.Module):
         new._pack_cache = {}
         new._frag_table = None
         new._wfrag_table = None
+        new._qkv_bias_table = None
+        new._qkv_bias_stamp = {}
         new._temb_plan_cache = None
         new._pack_key = None
         new._epoch = 0
