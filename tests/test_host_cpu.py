@@ -242,3 +242,38 @@ def test_bucket_reducer_announces_a_launch_before_it_happens():
 def test_device_error_check_is_a_no_op_before_any_team_launch():
     from psld_amd import ops
     ops.check_device_errors()               # no slot buffer was ever allocated here: nothing to read, nothing raised
+
+
+def test_bucket_timing_sources_and_missing_timing():
+    """BucketReducer.stats() takes a collective's length from a pair of events of its own (side-stream form) or from the
+    process group's Work (compute-stream form); a group without timing gives comm = None, never a made-up number."""
+    from psld_amd.ddp import BucketReducer, _bucket_ms
+
+    class Ev:
+        def __init__(self, t):
+            self.t = t
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+
+    class Work:
+        def __init__(self, ms):
+            self.ms = ms
+
+        def _get_duration(self):
+            if self.ms is None:
+                raise RuntimeError("timing not enabled")
+            return self.ms
+
+    assert _bucket_ms((Ev(1.0), Ev(3.5))) == 2.5 and _bucket_ms(Work(0.75)) == 0.75
+    assert _bucket_ms(Work(None)) != _bucket_ms(Work(None))          # NaN
+    red = BucketReducer(profile=True)
+    red._prof.append(([Work(0.5), Work(1.5)], (Ev(10.0), Ev(10.25))))
+    red._prof.append(([(Ev(0.0), Ev(1.0)), Work(1.0)], (Ev(20.0), Ev(20.75))))
+    st = red.stats()
+    assert st["steps"] == 2 and st["buckets_per_step"] == 2.0
+    assert abs(st["comm_ms_per_step"] - 2.0) < 1e-12 and abs(st["exposed_ms_per_step"] - 0.5) < 1e-12
+    assert abs(st["hidden_ms_per_step"] - 1.5) < 1e-12
+    red._prof.append(([Work(None)], (Ev(0.0), Ev(0.1))))
+    st = red.stats()
+    assert st["comm_ms_per_step"] is None and st["hidden_ms_per_step"] is None and abs(st["exposed_ms_per_step"] - 0.1) < 1e-12
