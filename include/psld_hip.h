@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 
-#define PSLD_ABI_VERSION 13 /* 2: limb-MFMA convolutions, math mode, bias-gradient / batched-copy entry points; 3: pointwise weight gradient and batched activation GEMM on limb kernels; 4: GroupNorm statistics from the limb kernels' epilogue; 5: per-sample-time reverse SDE, ScoreLoss nll / l1; 6: limb-plane activations; 7: device-resident dropout seed / Adam scalars (captured training step), GroupNorm-backward sums from the producing epilogue; 8: Winograd F(2x2,3x3) limb convolution; 9: launch tape; 10: GroupNorm apply (+SiLU) fused into the Winograd convolution's input staging; 11: GroupNorm backward kernel selector; 12: column sums of dx from the GroupNorm backward; 13: GroupNorm backward returns per-image sums (dgamma / dbeta / bias gradients and split-K slab reductions of a whole backward pass in batched launches), the GroupNorm-backward by-product of the limb epilogue and the launch tape (9) removed */
+#define PSLD_ABI_VERSION 14 /* 2: limb-MFMA convolutions, math mode, bias-gradient / batched-copy entry points; 3: pointwise weight gradient and batched activation GEMM on limb kernels; 4: GroupNorm statistics from the limb kernels' epilogue; 5: per-sample-time reverse SDE, ScoreLoss nll / l1; 6: limb-plane activations; 7: device-resident dropout seed / Adam scalars (captured training step), GroupNorm-backward sums from the producing epilogue; 8: Winograd F(2x2,3x3) limb convolution; 9: launch tape; 10: GroupNorm apply (+SiLU) fused into the Winograd convolution's input staging; 11: GroupNorm backward kernel selector; 12: column sums of dx from the GroupNorm backward; 13: GroupNorm backward returns per-image sums (dgamma / dbeta / bias gradients and split-K slab reductions of a whole backward pass in batched launches), the GroupNorm-backward by-product of the limb epilogue and the launch tape (9) removed; 14: the optimiser kernels take the device error word (a refused step is a no-op + NaN loss) */
 #define PSLD_COEFF_STRIDE 12
 
 int psld_version(void);
@@ -577,11 +577,15 @@ int psld_f32_to_f64(const float* x, double* y, long long n, hipStream_t stream);
 int psld_grad_norm_f32(const float* g, long long n, double* norm_out, void* workspace, hipStream_t stream);
 /* clip_coef = min(max_norm / (norm + 1e-6), 1) computed on device from norm_out (no host sync);
  * g *= clip_coef; Adam (torch.optim.Adam semantics, step is 1-based); optional EMA of p into ema.
- * max_norm <= 0 disables clipping (norm may be NULL). */
+ * max_norm <= 0 disables clipping (norm may be NULL).
+ * err_word (may be NULL): a device error word of this step's backward (first 8 bytes of the team kernels' slot buffer,
+ * psld_gn_bwd_team_f32): when it is non-zero at execution time the launch leaves p / m / v / ema untouched and writes NaN to
+ * poison[0] (may be NULL; the loss scalar the caller logs) - bad gradients never reach the parameters, with no host read. */
 int psld_adam_ema_f32(float* p, const float* g, float* m, float* v, float* ema, long long n,
                       const double* norm, double max_norm, double lr, double beta1, double beta2,
                       double eps, double weight_decay, int step, double ema_tau, int write_clipped_grad,
-                      float* g_mut, const float* hyper_dev, hipStream_t stream);
+                      float* g_mut, const float* hyper_dev, const unsigned long long* err_word, float* poison,
+                      hipStream_t stream);
 /* The two per-step scalars of the kernel above, lr / (1 - beta1^step) and 1 / sqrt(1 - beta2^step), formed in
  * double like the launcher does: what a caller writes into hyper_dev[0..1] (device floats) before replaying a
  * captured training step (then lr / step of the captured call are ignored). */
@@ -589,8 +593,10 @@ void psld_adam_step_scalars(double lr, double beta1, double beta2, int step, flo
 /* The same two scalars written to a 2-float DEVICE buffer by a kernel that takes them by value (captured training step). */
 int psld_adam_step_scalars_dev(double lr, double beta1, double beta2, int step, float* out2_dev, hipStream_t stream);
 /* target = target*tau + src*(1-tau) (callbacks.py:62-64); hyper-parameters are doubles so that
- * (1 - tau), (1 - beta) are formed in double and rounded once, as torch does for python floats. */
-int psld_ema_f32(float* target, const float* src, long long n, double tau, hipStream_t stream);
+ * (1 - tau), (1 - beta) are formed in double and rounded once, as torch does for python floats.
+ * err_word as in psld_adam_ema_f32: non-zero -> no-op. */
+int psld_ema_f32(float* target, const float* src, long long n, double tau, const unsigned long long* err_word,
+                 hipStream_t stream);
 
 #ifdef __cplusplus
 }

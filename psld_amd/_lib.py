@@ -65,7 +65,7 @@ class SscsCoeffs(C.Structure):
 I, F, D, LL, P = C.c_int, C.c_float, C.c_double, C.c_longlong, C.c_void_p
 EP = C.POINTER(Epilogue)
 
-ABI_VERSION = 13   # PSLD_ABI_VERSION of include/psld_hip.h these signatures were written against
+ABI_VERSION = 14   # PSLD_ABI_VERSION of include/psld_hip.h these signatures were written against
 
 # name -> (restype, argtypes): every symbol include/psld_hip.h declares
 SIGNATURES = {
@@ -173,10 +173,10 @@ SIGNATURES = {
     "psld_f64_to_f32": (I, [P, P, LL, P]),
     "psld_f32_to_f64": (I, [P, P, LL, P]),
     "psld_grad_norm_f32": (I, [P, LL, P, P, P]),
-    "psld_adam_ema_f32": (I, [P, P, P, P, P, LL, P, D, D, D, D, D, D, I, D, I, P, P, P]),
+    "psld_adam_ema_f32": (I, [P, P, P, P, P, LL, P, D, D, D, D, D, D, I, D, I, P, P, P, P, P]),
     "psld_adam_step_scalars": (None, [D, D, D, I, P]),
     "psld_adam_step_scalars_dev": (I, [D, D, D, I, P, P]),
-    "psld_ema_f32": (I, [P, P, LL, D, P]),
+    "psld_ema_f32": (I, [P, P, LL, D, P, P]),
 }
 
 

@@ -55,7 +55,15 @@ struct AdamArgs {
 __global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                 float* __restrict__ v, float* __restrict__ ema, long long n,
                                 const double* __restrict__ norm, AdamArgs a, float* __restrict__ g_mut,
-                                const float* __restrict__ hyper_dev) {
+                                const float* __restrict__ hyper_dev, const unsigned long long* __restrict__ err_word,
+                                float* __restrict__ poison) {
+    // A device-side error of this step's backward (today: a team GroupNorm backward that gave up waiting, norm_act.hip) must
+    // not reach the parameters: the step becomes a no-op for p / m / v / ema and the loss scalar the caller logs turns NaN
+    // (psld.py:166-171: fail loudly, never continue on bad numerics).  No host read: works inside a captured step.
+    if (err_word && err_word[0] != 0ull) {
+        if (poison && blockIdx.x == 0 && threadIdx.x == 0) poison[0] = __builtin_nanf("");
+        return;
+    }
     if (hyper_dev) {                 // captured training step: the two step-dependent scalars come from device memory
         a.step_size = hyper_dev[0];
         a.inv_sqrt_bc2 = hyper_dev[1];
@@ -83,7 +91,8 @@ __global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__
 }
 
 __global__ void ema_kernel(float* __restrict__ target, const float* __restrict__ src, long long n, float tau,
-                           float omtau) {
+                           float omtau, const unsigned long long* __restrict__ err_word) {
+    if (err_word && err_word[0] != 0ull) return;      // the step that would have moved src was refused (adam_ema_kernel)
     GRID_STRIDE(i, n) target[i] = target[i] * tau + src[i] * omtau;
 }
 
@@ -105,7 +114,8 @@ extern "C" int psld_grad_norm_f32(const float* g, long long n, double* norm_out,
 extern "C" int psld_adam_ema_f32(float* p, const float* g, float* m, float* v, float* ema, long long n,
                                  const double* norm, double max_norm, double lr, double beta1, double beta2,
                                  double eps, double weight_decay, int step, double ema_tau, int write_clipped_grad,
-                                 float* g_mut, const float* hyper_dev, hipStream_t stream) {
+                                 float* g_mut, const float* hyper_dev, const unsigned long long* err_word, float* poison,
+                                 hipStream_t stream) {
     PSLD_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "psld_adam_ema_f32: bad args");
     PSLD_CHECK_ARG(max_norm <= 0.f || norm, "psld_adam_ema_f32: clipping needs the norm buffer");
     AdamArgs a;
@@ -118,7 +128,7 @@ extern "C" int psld_adam_ema_f32(float* p, const float* g, float* m, float* v, f
     long long b = (n + 1023) / 1024;
     if (b > 256 * 16) b = 256 * 16;
     hipLaunchKernelGGL(adam_ema_kernel, dim3((int)b), dim3(256), 0, stream, p, g, m, v, ema, n, norm, a,
-                       write_clipped_grad ? g_mut : nullptr, hyper_dev);
+                       write_clipped_grad ? g_mut : nullptr, hyper_dev, err_word, poison);
     PSLD_CHECK_LAUNCH("adam_ema_kernel");
     return PSLD_OK;
 }
@@ -144,12 +154,13 @@ extern "C" int psld_adam_step_scalars_dev(double lr, double beta1, double beta2,
     return PSLD_OK;
 }
 
-extern "C" int psld_ema_f32(float* target, const float* src, long long n, double tau, hipStream_t stream) {
+extern "C" int psld_ema_f32(float* target, const float* src, long long n, double tau, const unsigned long long* err_word,
+                            hipStream_t stream) {
     PSLD_CHECK_ARG(target && src && n > 0, "psld_ema_f32: bad args");
     long long b = (n + 1023) / 1024;
     if (b > 256 * 16) b = 256 * 16;
     hipLaunchKernelGGL(ema_kernel, dim3((int)b), dim3(256), 0, stream, target, src, n, (float)tau,
-                       (float)(1.0 - tau));
+                       (float)(1.0 - tau), err_word);
     PSLD_CHECK_LAUNCH("ema_kernel");
     return PSLD_OK;
 }

@@ -1175,13 +1175,18 @@ def grad_norm(g: Tensor, norm_out: Tensor):
 
 def adam_ema(p: Tensor, g: Tensor, m: Tensor, v: Tensor, ema: Optional[Tensor], norm: Optional[Tensor],
              max_norm: float, lr: float, beta1: float, beta2: float, eps: float, weight_decay: float, step: int,
-             ema_tau: float, write_clipped_grad: bool = False, hyper_dev: Optional[Tensor] = None):
+             ema_tau: float, write_clipped_grad: bool = False, hyper_dev: Optional[Tensor] = None,
+             poison: Optional[Tensor] = None):
     """``hyper_dev``: float32[2] device tensor holding (lr / bias_correction1, 1 / sqrt(bias_correction2)) of THIS step
-    (``adam_step_scalars``); then ``lr`` / ``step`` of the call are ignored (captured training step)."""
+    (``adam_step_scalars``); then ``lr`` / ``step`` of the call are ignored (captured training step).
+    The launch is guarded by the device's error word (``gn_team_sync``): while it is set the step is a no-op and
+    ``poison`` (float32 scalar on the device: the loss the caller logs) is overwritten with NaN - no host read."""
+    assert poison is None or (poison.dtype == torch.float32 and poison.is_cuda and poison.numel() == 1)
     check(lib().psld_adam_ema_f32(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(ema), p.numel(),
                                   _p(norm), max_norm, lr, beta1, beta2, eps, weight_decay, step, ema_tau,
                                   1 if write_clipped_grad else 0, g.data_ptr() if write_clipped_grad else None,
-                                  _p(hyper_dev), _stream()), "psld_adam_ema_f32")
+                                  _p(hyper_dev), gn_team_sync(p.device).data_ptr(), _p(poison), _stream()),
+          "psld_adam_ema_f32")
 
 
 def adam_step_scalars(lr: float, beta1: float, beta2: float, step: int, out: Tensor) -> Tensor:
@@ -1202,4 +1207,5 @@ def adam_step_scalars_dev(lr: float, beta1: float, beta2: float, step: int, out:
 
 
 def ema(target: Tensor, src: Tensor, tau: float):
-    check(lib().psld_ema_f32(target.data_ptr(), src.data_ptr(), target.numel(), tau, _stream()), "psld_ema_f32")
+    check(lib().psld_ema_f32(target.data_ptr(), src.data_ptr(), target.numel(), tau, gn_team_sync(target.device).data_ptr(),
+                             _stream()), "psld_ema_f32")

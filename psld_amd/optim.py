@@ -26,6 +26,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._step = 0
         self._m = self._v = self._norm = None
         self._backward_seen = -1     # module._backward_count at the last zero_grad()/step(): step() needs a newer one
+        self.poison = None           # float32 device scalar (the step's loss): turned NaN by the kernel when it refuses the step
 
     def _state_buffers(self):
         flat = self.module.flatten_parameters()
@@ -33,6 +34,7 @@ class FusedAdam(torch.optim.Optimizer):
             self._m = torch.zeros_like(flat)
             self._v = torch.zeros_like(flat)
             self._norm = torch.zeros(1, dtype=torch.float64, device=flat.device)
+            ops.gn_team_sync(flat.device)      # the error word the kernels are guarded by: exists before any capture
         return flat
 
     @property
@@ -51,9 +53,11 @@ class FusedAdam(torch.optim.Optimizer):
                 p.grad = None
         self._backward_seen = self.module._backward_count
 
-    def _launch(self, hyper_dev=None):
+    def _launch(self, hyper_dev=None, poison=None):
         """The kernels of one step (norm, clip + Adam (+ EMA)) against the current ``self._step`` / lr; with
-        ``hyper_dev`` the two step-dependent scalars are read from device memory instead (captured training step)."""
+        ``hyper_dev`` the two step-dependent scalars are read from device memory instead (captured training step).
+        A device error word raised during this step's backward (``ops.gn_team_sync``) turns the launch into a no-op for
+        p / m / v / ema and ``poison`` (the loss scalar) into NaN."""
         group = self.param_groups[0]
         flat = self._state_buffers()
         grad = self.module.flat_grad()
@@ -68,7 +72,8 @@ class FusedAdam(torch.optim.Optimizer):
         kept = [p.detach().clone() for p in frozen]
         ops.adam_ema(flat, grad, self._m, self._v, ema_flat, self._norm if self.grad_clip > 0 else None,
                      self.grad_clip, group["lr"], group["betas"][0], group["betas"][1], group["eps"],
-                     group["weight_decay"], max(1, self._step), self.ema_decay, hyper_dev=hyper_dev)
+                     group["weight_decay"], max(1, self._step), self.ema_decay, hyper_dev=hyper_dev,
+                     poison=poison if poison is not None else self.poison)
         for p, k in zip(frozen, kept):
             p.detach().copy_(k)
 
@@ -90,6 +95,7 @@ class FusedAdam(torch.optim.Optimizer):
         self.module.adopt_foreign_grads()     # a foreign reducer may have replaced .grad (DDP bucket views)
         self._step += 1
         self._launch()
+        self.poison = None
         self._after_step()
 
     def state_dict(self):

@@ -1386,8 +1386,10 @@ class _Exec:
         net = self.net
         g_out = grad_out_nchw.contiguous()
         self.head_grad.g = g_out if net.is_classifier else ops.nchw_to_nhwc(g_out)
-        if self.defer:
-            net._param_arena().reset()
+        # every pass: gn_backward and the resblock column sums allocate from the arena whether or not the reductions are
+        # deferred (with defer off the offset was never rewound and the buffer doubled until OOM); the previous
+        # pass's readers of it are stream-ordered before this pass's writers
+        net._param_arena().reset()
         red = net._reducer
         for fn, module in reversed(self.tape):
             fn()

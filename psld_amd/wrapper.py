@@ -182,7 +182,7 @@ class SDEWrapper(_Base):
                     net.mark_grads_stale()
                     loss.backward()
                     with torch.no_grad():
-                        optim._launch(hyper_dev=ent["hyper"])
+                        optim._launch(hyper_dev=ent["hyper"], poison=loss.detach())
             finally:
                 sde.check_nan = check_nan
                 net._dropout_seed_dev = None
@@ -215,6 +215,8 @@ class SDEWrapper(_Base):
         fused = isinstance(getattr(optim, "optimizer", optim), FusedAdam)
         if gc != 0 and not fused:
             torch.nn.utils.clip_grad_norm_(self.score_fn.parameters(), gc)   # wrapper.py:82-85
+        if fused and loss.is_cuda and loss.dtype == torch.float32:
+            getattr(optim, "optimizer", optim).poison = loss.detach()   # a refused step (device error word) logs NaN
         optim.step()                  # FusedAdam: norm + clip + Adam (+EMA) in two launches
         lr_sched.step()
         self.log("loss", loss, prog_bar=True)

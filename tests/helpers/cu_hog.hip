@@ -1,7 +1,8 @@
-// A stand-in for RCCL's channel kernel on a 1-GPU box (tools/rccl_occupancy.py): `blocks` workgroups of `threads`
+// Test helper (tests/test_fullsize_gpu.py: the co-residency test; tools/rccl_occupancy.py).
+// A stand-in for RCCL's channel kernel on a 1-GPU box: `blocks` workgroups of `threads`
 // threads that hold `lds_bytes` of LDS each and spin for `usec` microseconds - what a ring all-reduce does to the CUs it sits
 // on for the time the bytes are on the wire - and touch `bytes` of memory on the way (the collective's own read + write of the
-// bucket).  NOT part of the product library: built on the box by the tool (hipcc --offload-arch=gfx950 -shared).
+// bucket).  NOT part of the product library: __graft_entry__.build() compiles it to tests/helpers/libcuhog.so.
 #include <hip/hip_runtime.h>
 
 extern "C" __global__ void cu_hog_kernel(float* buf, long long n, long long ticks) {

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
         assert s in _lib.SIGNATURES, f"{s} declared in the header but not bound in psld_amd/_lib.py"
     for s in _lib.SIGNATURES:
         assert s in syms, f"{s} bound in Python but not declared in include/psld_hip.h"
-    assert lib.psld_version() == _lib.ABI_VERSION == 13
+    assert lib.psld_version() == _lib.ABI_VERSION == 14
 
 
 def test_error_reporting_without_gpu():

@@ -24,7 +24,7 @@ def _init(rank, world, port):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.set_num_threads(2)
+    torch.set_num_threads(2 if world <= 2 else 1)
 
 
 def _worker_buckets(rank, world, port, q):
@@ -60,7 +60,8 @@ def _worker_grads(rank, world, port, q):
     keys = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
     sd = synth_state_dict(keys, 5)
     sde = O.PSLDOracle.from_config(cfg)
-    x0, eps, t = synth_inputs(4, 3, 8, seed=9)
+    n = max(4, world)                                   # one sample per rank at world 8
+    x0, eps, t = synth_inputs(n, 3, 8, seed=9)
 
     def grads(sl):
         p = {k: v.clone().requires_grad_(k != "all_modules.0.W") for k, v in sd.items()}
@@ -68,7 +69,7 @@ def _worker_grads(rank, world, port, q):
         loss.backward()
         return {k: v.grad for k, v in p.items() if v.grad is not None}
 
-    lo, hi = shard_range(4, rank, world)
+    lo, hi = shard_range(n, rank, world)
     mine = grads(slice(lo, hi))
     names = list(mine.keys())
     sizes = [mine[k].numel() for k in names]
@@ -80,7 +81,7 @@ def _worker_grads(rank, world, port, q):
         off -= s
         red.ready_from(off)
     red.finish()
-    full = grads(slice(0, 4))
+    full = grads(slice(0, n))
     ref = torch.cat([full[k].reshape(-1) for k in names])
     err = ((flat - ref).norm() / ref.norm()).item()
     q.put((rank, err < 1e-5))
@@ -98,9 +99,13 @@ def test_bucket_sizes_are_geometric_from_the_front():
     assert max(sizes) <= (64 << 20) // 4 * 3 // 2 and min(sizes) >= (8 << 20) // 4 and len(b) == 8
 
 
+@pytest.mark.parametrize("world", [2, 8])
 @pytest.mark.parametrize("worker", [_worker_buckets, _worker_grads])
-def test_two_process_gloo(worker):
-    world, port = 2, _free_port()
+def test_multi_process_gloo(worker, world):
+    """World 2 and world 8 (one thread per rank; the only N = 8 evidence a box without eight GPUs can
+    produce): bucket launch order / mean semantics, and DP gradient (mean over ranks of the per-shard oracle gradients)
+    == the large-batch gradient."""
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
@@ -110,7 +115,7 @@ def test_two_process_gloo(worker):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert sorted(results) == [(0, True), (1, True)]
+    assert sorted(results) == [(r, True) for r in range(world)]
 
 
 def test_shard_range_partitions_samples():
@@ -119,6 +124,23 @@ def test_shard_range_partitions_samples():
     assert spans[0][0] == 0 and spans[-1][1] == n
     assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
     assert shard_range(5, 7, 8) == (5, 5)
+    # BASELINE configs[4]: 50 000 samples, 512 per batch, 8 GPUs -> every rank 6250 = 12 x 512 + 106
+    assert all(hi - lo == 6250 for lo, hi in spans) and divmod(6250, 512) == (12, 106)
+
+
+def test_bucket_bounds_on_the_real_gradient_buffer():
+    """The flat gradient buffer of the C10-SOTA network as the executor lays it out (256-byte aligned parameter slots), cut
+    by the reducer's default sizes: 8 collectives, geometric from the front, the sizes DESIGN 6 states."""
+    from psld_amd import config as C
+    from psld_amd.score_fn import NCSNpp
+    net = NCSNpp(C.c10_sota())
+    n = net.flatten_parameters().numel()
+    assert 97_627_910 <= n < 97_627_910 + 749 * 64            # 749 tensors, each slot padded to a 64-float boundary
+    red = BucketReducer()                                      # the defaults bench.py and the CLI run with
+    b = BucketReducer.make_bounds(n, red.first_elems, red.bucket_elems)
+    mib = [round((hi - lo) * 4 / (1 << 20), 1) for lo, hi in b]
+    assert len(b) == 8 and b[0][0] == 0 and b[-1][1] == n and all(x[1] == y[0] for x, y in zip(b, b[1:]))
+    assert n == 97_627_968 and mib == [8.0, 16.0, 32.0, 64.0, 64.0, 64.0, 64.0, 60.4], (n, mib)
 
 
 def test_bench_self_launches_its_ranks():
@@ -142,6 +164,43 @@ def test_bench_self_launches_its_ranks():
     # 25000 = 48 x 512 + 424: 48 full batches at the slowest rank's 2.0 s + the measured partial batch's slowest 1.25 s
     assert sc["batches_per_rank"] == 49 and sc["wallclock_50k_samples_s"] == 48 * 2.0 + 1.25
     assert sc["partial_batch"]["batch"] == 424 and sc["partial_batch"]["measured_batch_s"] == 1.25
+
+
+def test_bench_self_launches_eight_ranks():
+    """`python bench.py --gpus 8 --launch-check`: the form the driver's SCALE run takes, on gloo: eight ranks come up, an
+    all-reduce of ones returns 8, every rank gets 6250 latents = 12 full batches + 106 and its own seed."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--launch-check"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(next(ln for ln in reversed(r.stdout.strip().splitlines()) if ln.startswith("{")))
+    assert out["n_gpus"] == 8 and out["allreduce_ones_ok"] is True and out["parallelism"] == "dp8" and out["backend"] == "gloo"
+    sc = out["sampling_check"]
+    assert sc["n_gpus"] == 8 and sc["rank_seeds"] == list(range(8))
+    assert sc["shards"] == [[6250 * r, 6250 * (r + 1)] for r in range(8)]
+    assert sc["batches_per_rank"] == 13 and sc["partial_batch"]["batch"] == 106
+    assert sc["measured_batch_s"] == 8.0 and sc["measured_batch_s_min_over_ranks"] == 1.0      # fake timings 1 + rank
+
+
+def test_a_missing_rank_of_eight_is_named():
+    """Rank 5 of 8 asleep before the rendezvous: rank 0 names exactly that rank within the rendezvous timeout and the job
+    exits non-zero well inside a minute."""
+    import subprocess
+    import sys
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(PSLD_DIST_TIMEOUT_S="8", PSLD_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--launch-check",
+                        "--test-hang-rank", "5", "--launch-timeout", "100"],
+                       capture_output=True, text=True, timeout=150, env=env)
+    assert r.returncode not in (0, 124), (r.returncode, r.stderr[-2000:])
+    assert "rank(s) [5] of 8 did not reach the rendezvous" in r.stderr
+    assert time.monotonic() - t0 < 60
 
 
 def test_bench_refuses_a_world_that_is_not_gpus():

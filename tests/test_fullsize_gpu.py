@@ -269,3 +269,66 @@ def test_graph_captured_training_step_on_c10_sota_is_bitwise_the_eager_step():
     (la, pa, ma, va, ea), (lb, pb, mb, vb, eb) = runs
     assert la == lb
     assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb) and torch.equal(ea, eb)
+
+
+def _cu_hog():
+    """tests/helpers/libcuhog.so (built by __graft_entry__.build()): a kernel that holds `blocks` workgroups resident."""
+    import ctypes
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "libcuhog.so")
+    if not os.path.exists(path):
+        import __graft_entry__
+        __graft_entry__.build()
+    hog = ctypes.CDLL(path)
+    hog.cu_hog.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                           ctypes.c_void_p]
+    hog.cu_hog.restype = ctypes.c_int
+    return hog
+
+
+def test_team_groupnorm_backward_beside_a_resident_foreign_kernel():
+    """VERDICT r05 next #3b - the N = 8 hazard rehearsed on one GPU.  gn_bwd_team_kernel sizes its grid to what the device
+    holds when it has the device to itself; RCCL's channel kernels will be resident beside it.  Here 32 workgroups of 512
+    threads and 64 KB of LDS (RCCL's largest kernel shape) sit on a second stream for the whole of a C10-SOTA B=128 forward
+    + backward (24 team launches): no team member may time out (error word 0) and the flat gradient must be bitwise the one
+    of the undisturbed pass - a member that read a slot too early, or gave up, would change it."""
+    from psld_amd import ops
+    net, cfg, _ = _build("c10_sota", train=True)
+    cfg.model.score_fn.dropout = 0.0
+    net.sf.dropout = 0.0
+    B = 128
+    gen = torch.Generator(device=DEV).manual_seed(17)
+    x = torch.randn(B, 6, 32, 32, device=DEV, generator=gen)
+    t = torch.rand(B, device=DEV, generator=gen) * 0.98 + 0.01
+    w = torch.randn(B, 6, 32, 32, device=DEV, generator=gen)
+    assert ops.gn_bwd_team_wanted(B, 32 * 32, 256, None, True) > 0, "the team kernel does not take this shape any more"
+
+    def run():
+        net.mark_grads_stale()
+        y = net(x, t)
+        (y * w).sum().backward()
+        return net.flat_grad()
+
+    run()                                   # sizes workspaces, arenas and weight caches
+    torch.cuda.synchronize()
+    ref = run().clone()
+    torch.cuda.synchronize()
+    assert ops.gn_team_errors(DEV) == 0
+    hog = _cu_hog()
+    side = torch.cuda.Stream(device=DEV)
+    scratch = torch.zeros(1 << 22, device=DEV)
+    for rep in range(3):
+        done_hog, done_pass = torch.cuda.Event(), torch.cuda.Event()
+        torch.cuda.synchronize()
+        rc = hog.cu_hog(scratch.data_ptr(), scratch.numel(), 32, 512, 65536, 400e3, side.cuda_stream)    # resident for 400 ms
+        assert rc == 0, rc
+        done_hog.record(side)
+        got = run()
+        done_pass.record(torch.cuda.current_stream(DEV))
+        done_pass.synchronize()
+        still_there = not done_hog.query()
+        torch.cuda.synchronize()
+        assert still_there, "the foreign kernel left before the pass ended: nothing was rehearsed"
+        assert ops.gn_team_errors(DEV) == 0, "a team member timed out beside the resident kernel"
+        assert torch.equal(got, ref), f"repetition {rep}: the gradient changed beside a resident foreign kernel"
+    ops.check_device_errors(DEV)

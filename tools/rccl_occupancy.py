@@ -4,7 +4,7 @@ The 8-GPU run is the driver's.  What can be measured on a 1-GPU box is the part 
 wire: a collective is a kernel of `blocks` workgroups that sits on CUs for bytes x 2(N-1)/N / bus-bandwidth, can only start
 where a CU drains, and keeps this step's one-workgroup-per-CU kernels off those CUs while it runs.  This tool runs bench.py's
 own training loop with the real BucketReducer (1-rank RCCL group: PSLD_FORCE_PG=1; same buckets, same events, same join) and
-replaces every bucket's all-reduce by `cu_hog` (tools/cu_hog.hip) on a stream of its own that waits for the caller's - what
+replaces every bucket's all-reduce by `cu_hog` (tests/helpers/cu_hog.hip) on a stream of its own that waits for the caller's - what
 ProcessGroupNCCL does -: `blocks` x `threads` threads, `lds` bytes of LDS, spinning for the time the bucket would be on an
 8-rank ring at `--busbw` GB/s while walking the bucket's bytes.  --real leaves the 1-rank RCCL collectives in place;
 --side-stream forces the reducer's side-stream form (its own stream in front of the group's); --schedule-only keeps only the
@@ -30,7 +30,7 @@ def build_hog() -> str:
     out = os.path.join(os.environ.get("TMPDIR", "/tmp"), "libcuhog.so")
     if not os.path.exists(out):
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", out,
-                        os.path.join(ROOT, "tools", "cu_hog.hip")], check=True)
+                        os.path.join(ROOT, "tests", "helpers", "cu_hog.hip")], check=True)
     return out
 
 
