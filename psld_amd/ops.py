@@ -422,6 +422,35 @@ def conv3x3_wgrad_split(dy: Tensor, cout: int, x: Tensor, slabs: Tensor, cin_tot
           "psld_conv3x3_wgrad_split_f32")
 
 
+@functools.lru_cache(maxsize=None)
+def conv3x3_wgrad_wino_supported(cout: int, cin: int, cin2: int, b: int, h: int, w: int) -> bool:
+    return bool(lib().psld_conv3x3_wgrad_wino_supported(cout, cin, cin2, b, h, w))
+
+
+@functools.lru_cache(maxsize=None)
+def conv3x3_wgrad_wino_plan(cout: int, cin_total: int, b: int, h: int, w: int):
+    """(K splits, workspace bytes) of the Winograd-domain weight gradient for this shape."""
+    ns = int(lib().psld_conv3x3_wgrad_wino_nsplit(cout, cin_total, b, h, w))
+    return ns, int(lib().psld_conv3x3_wgrad_wino_ws_bytes(cout, cin_total, ns))
+
+
+def conv3x3_wgrad_wino(dy: Tensor, cout: int, x: Tensor, dw: Tensor, x2: Optional[Tensor] = None, accumulate: bool = False,
+                       slabs: Optional[Tensor] = None, nsplit: Optional[int] = None):
+    """dw[cout][cin (+ cin2)][3][3] (OIHW, contiguous) = (or +=) the weight gradient of the 3x3 stride-1 convolution, formed in
+    the Winograd F(2x2, 3x3) domain (psld_conv3x3_wgrad_wino_f32: 16 limb products per 2x2 tile instead of 36)."""
+    b, h, w, cin = x.shape
+    cin2 = x2.shape[-1] if x2 is not None else 0
+    ns, wsb = conv3x3_wgrad_wino_plan(cout, cin + cin2, b, h, w)
+    if nsplit is not None:
+        ns, wsb = nsplit, int(lib().psld_conv3x3_wgrad_wino_ws_bytes(cout, cin + cin2, nsplit))
+    if slabs is None:
+        slabs = workspace(wsb, x.device)
+    assert slabs.numel() * slabs.element_size() >= wsb and dw.is_contiguous() and dw.numel() == cout * (cin + cin2) * 9
+    check(lib().psld_conv3x3_wgrad_wino_f32(dy.data_ptr(), cout, cout, x.data_ptr(), cin, _p(x2), cin2, b, h, w,
+                                            slabs.data_ptr(), ns, dw.data_ptr(), 1 if accumulate else 0, _stream()),
+          "psld_conv3x3_wgrad_wino_f32")
+
+
 def conv2d_wgrad_nhwc(dy: Tensor, cout: int, x: Tensor, kh: int, kw: int, stride: int, pad: int, oh: int, ow: int,
                       slabs: Tensor, cin_total: int, col0: int, nsplit: int):
     b, ih, iw, cin = x.shape

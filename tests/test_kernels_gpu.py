@@ -514,6 +514,47 @@ def test_wave_specialised_wgrad_on_short_k_ranges(ops, per):
     assert rel_l2(dw, w.grad) < 3e-6
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(b=2, c1=128, c2=0, co=256, h=32, w=32, nsplit=None),      # one K tile = two tile rows of an image
+    dict(b=4, c1=256, c2=0, co=256, h=16, w=16, nsplit=1),         # K tile = half an image; all K tiles in ONE range
+    dict(b=8, c1=128, c2=0, co=256, h=8, w=8, nsplit=2),           # K tile = two images
+    dict(b=1, c1=128, c2=0, co=256, h=64, w=64, nsplit=4),         # K tile = one tile row
+    dict(b=3, c1=256, c2=128, co=256, h=32, w=32, nsplit=3),       # two sources of a concatenation, odd batch
+    dict(b=2, c1=128, c2=128, co=512, h=16, w=16, nsplit=None),    # two c_out tiles
+])
+def test_conv3x3_wgrad_winograd_domain(ops, cfg):
+    """psld_conv3x3_wgrad_wino_f32 (wgrad_wino.hip): dU = sum over 2x2 tiles of (A dY A^T) (x) (B^T d B) on limb MFMAs, dw =
+    G^T dU G - against fp64 autograd of nn.Conv2d (layers.py:103-109) at the forward Winograd kernel's tolerance (3e-6),
+    next to the direct limb weight gradient on the same inputs; image borders (zero padding inside the transform), every
+    K-tile geometry (two tile rows / half an image / two images / one row per tile), accumulate = 1, repeatability."""
+    b, c1, c2, co, h, w_ = (cfg[n] for n in ("b", "c1", "c2", "co", "h", "w"))
+    ci = c1 + c2
+    assert ops.conv3x3_wgrad_wino_supported(co, c1, c2, b, h, w_)
+    xt = gen(b, ci, h, w_, seed=83) + 0.25                 # a mean: the transforms cancel it, the limbs must carry it
+    gyt = gen(b, co, h, w_, seed=84)
+    w = torch.zeros(co, ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xt.double(), w, padding=1).backward(gyt.double())
+    x1 = _nhwc(xt[:, :c1]).to(DEV)
+    x2 = _nhwc(xt[:, c1:]).to(DEV) if c2 else None
+    gy = _nhwc(gyt).to(DEV)
+    dw = torch.full((co, ci, 3, 3), float("nan"), device=DEV)
+    ops.conv3x3_wgrad_wino(gy, co, x1, dw, x2=x2, nsplit=cfg["nsplit"])
+    e = rel_l2(dw, w.grad)
+    # the direct limb kernel on the same inputs
+    ktiles = b * h * w_ // 32
+    slabs = torch.zeros((1, co, 9, ci), device=DEV)
+    ops.conv3x3_wgrad_split(gy, co, x1, slabs, ci, 0, 1, x2=x2)
+    ed = rel_l2(slabs[0].reshape(co, 3, 3, ci).permute(0, 3, 1, 2), w.grad)
+    print(f"winograd-domain wgrad {e:.2e}  direct {ed:.2e}  ({ktiles} pixel K tiles)")
+    assert e < 3e-6 and e < 2.0 * max(ed, 3e-7)
+    again = torch.full_like(dw, float("nan"))
+    ops.conv3x3_wgrad_wino(gy, co, x1, again, x2=x2, nsplit=cfg["nsplit"])
+    assert torch.equal(again, dw)
+    acc = torch.ones_like(dw)
+    ops.conv3x3_wgrad_wino(gy, co, x1, acc, x2=x2, nsplit=cfg["nsplit"], accumulate=True)
+    assert torch.equal(acc, dw + 1.0)
+
+
 def test_conv3x3_wgrad_limb_x_two_sources(ops):
     b, c1, c2, co, s_ = 2, 128, 256, 128, 16
     x = gen(b, c1 + c2, s_, s_, seed=70)
