@@ -228,9 +228,10 @@ int psld_conv3x3_wgrad_xlimb_f32(const float* dy, int lddy, int cout, const void
 /* Weight gradient of the same convolution in the Winograd F(2x2, 3x3) domain (wgrad_wino.hip; replaces the backward of
  * nn.Conv2d, reference main/models/score_fn/song_sde/layers.py:103-109): dU[xi] = sum over 2x2 output tiles of
  * (A dY A^T)[xi] (x) (B^T d B)[xi] for the 16 positions - 16 limb-MFMA products per 4 pixels instead of 36 - then
- * dw = G^T dU G written (accumulate = 0) or added (1) to the OIHW gradient dw_oihw[cout][cin + cin2][3][3].  fp32 in, fp32
+ * alpha * G^T dU G written (accumulate = 0) or added (1) to the OIHW gradient dw_oihw[cout][cin + cin2][3][3].  fp32 in, fp32
  * accumulate, exact three-limb operands like every limb kernel.  slabs: workspace of psld_conv3x3_wgrad_wino_ws_bytes;
- * nsplit: K splits (must divide batch*h*w/128; psld_conv3x3_wgrad_wino_nsplit fills the chip with one round).
+ * nsplit: K splits of ceil(batch*h*w/128 / nsplit) 32-tile K tiles, none empty (psld_conv3x3_wgrad_wino_nsplit fills the chip
+ * with one round of one-workgroup-per-CU tiles).
  * Shapes: cout % 256 == 0, cin % 128 == 0, cin2 % 128 == 0 (second source of a channel concatenation; 0 / null for none),
  * h == w in {8,16,32,64}, batch*h*w % 128 == 0; dy rows of lddy floats. */
 int psld_conv3x3_wgrad_wino_supported(int cout, int cin, int cin2, int batch, int h, int w);
@@ -238,7 +239,7 @@ int psld_conv3x3_wgrad_wino_nsplit(int cout, int cin_total, int batch, int h, in
 long long psld_conv3x3_wgrad_wino_ws_bytes(int cout, int cin_total, int nsplit);
 int psld_conv3x3_wgrad_wino_f32(const float* dy, int lddy, int cout, const float* x, int cin, const float* x2, int cin2,
                                 int batch, int h, int w, float* slabs, int nsplit, float* dw_oihw, int accumulate,
-                                hipStream_t stream);
+                                float alpha, hipStream_t stream);
 /* Pointwise weight gradient on the limb kernels: slabs[s][i][j] (row stride ldc) = sum over the s-th range of
  * ceil(k/32 / nsplit) 32-row tiles of a[p][i] * b[p][j]  (a: [k][m] rows of lda floats, b: [k][n] rows of ldb floats;
  * b2 / ldb2 / n2 (null / 0 / 0 for none): further columns [n, n + n2) of B from a second tensor (concatenation);

@@ -111,7 +111,7 @@ SIGNATURES = {
     "psld_conv3x3_wgrad_wino_supported": (I, [I, I, I, I, I, I]),
     "psld_conv3x3_wgrad_wino_nsplit": (I, [I, I, I, I, I]),
     "psld_conv3x3_wgrad_wino_ws_bytes": (LL, [I, I, I]),
-    "psld_conv3x3_wgrad_wino_f32": (I, [P, I, I, P, I, P, I, I, I, I, P, I, P, I, P]),
+    "psld_conv3x3_wgrad_wino_f32": (I, [P, I, I, P, I, P, I, I, I, I, P, I, P, I, F, P]),
     "psld_gemm_tn_split_supported": (I, [I, I, I]),
     "psld_gemm_tn_split_f32": (I, [I, I, I, P, I, P, I, P, I, I, P, I, I, P]),
     "psld_bgemm_split_supported": (I, [I, I, I, I, I]),

@@ -61,7 +61,7 @@ struct WWgradArgs {
     int lg_tw, th_mask, tw_mask;    // tiles per row = W / 2 = 1 << lg_tw; tile rows per image - 1; tiles per row - 1
     int rows_per_kt;        // tile rows of a K tile = 32 >> lg_tw
     int cout_tiles, cin_tiles;
-    int ktiles_per_split;
+    int ktiles, ktiles_per_split;       // the last split may be shorter (never empty)
     float* slabs;           // [split][16][cout][cin_total]
     int cout, cin_total;
 };
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(512) wwgrad_ws_kernel(const WWgradArgs a) {
     const int pi = pos >> 2, pj = pos & 3;
     const int co0 = co_tile * WW_CO, ci_out = ci_tile * WW_CI;
     const int kt_beg = split * a.ktiles_per_split;
-    const int nkt = a.ktiles_per_split;
+    const int nkt = min(a.ktiles_per_split, a.ktiles - kt_beg);
 
     if (wave >= 4) {
         // ---- producers ------------------------------------------------------------------------------------------------------
@@ -180,14 +180,13 @@ __global__ void __launch_bounds__(512) wwgrad_ws_kernel(const WWgradArgs a) {
                 ww_store(Bs + i * 8 * WW_RSB, WW_BLIMB, v);
             }
         };
-        // dY items of one half (four items): NR x NC loads each, combined, split and stored
-        auto stage_y = [&](auto nr_tag, auto nc_tag, int kt, int half, unsigned char* img) {
+        // dY items of one half (four items): NR x NC loads each ...
+        auto load_y = [&](auto nr_tag, auto nc_tag, int kt, int half, auto& yv) {
             constexpr int NR = decltype(nr_tag)::value, NC = decltype(nc_tag)::value;
             const int R0 = kt * a.rows_per_kt;
             const float* yb = a.dy + ((long long)(2 * R0) * a.W) * a.lddy + co0;
             const __amdgpu_buffer_rsrc_t r00 = brsrc(yb + (long long)(yr1 * a.W + yc1) * a.lddy), r01 = brsrc(yb + (long long)(yr1 * a.W + 1) * a.lddy),
                                          r10 = brsrc(yb + (long long)(a.W + yc1) * a.lddy), r11 = brsrc(yb + (long long)(a.W + 1) * a.lddy);
-            f32x4 yv[4][NR * NC];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const unsigned off = yoff[half * 4 + i];
@@ -198,6 +197,10 @@ __global__ void __launch_bounds__(512) wwgrad_ws_kernel(const WWgradArgs a) {
                     if constexpr (NC == 2) yv[i][NC + 1] = bload(r11, off);
                 }
             }
+        };
+        // ... combined, split and stored
+        auto store_y = [&](auto nr_tag, auto nc_tag, int half, unsigned char* img, const auto& yv) {
+            constexpr int NR = decltype(nr_tag)::value, NC = decltype(nc_tag)::value;
             unsigned char* As = img + lds_y + half * 16 * WW_RSA;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -218,13 +221,18 @@ __global__ void __launch_bounds__(512) wwgrad_ws_kernel(const WWgradArgs a) {
         };
         auto stage_tile = [&](int kt, int buf, bool more) {
             unsigned char* img = smem + buf * WW_IMG;
-            // x values of this tile are in flight since the previous call; dY half 0 is asked for before they are combined,
-            // the next tile's x values before dY half 1 is
+            // Every group of loads has one group's worth of combine + split work to land: the x values of this tile are in
+            // flight since the previous call; dY half 0 is asked for before they are combined, dY half 1 before half 0 is
+            // combined, the next tile's x values before half 1 is.
             auto both = [&](auto nr_tag, auto nc_tag) {
+                constexpr int NL = decltype(nr_tag)::value * decltype(nc_tag)::value;
+                f32x4 ya[4][NL], yb[4][NL];
+                load_y(nr_tag, nc_tag, kt, 0, ya);
                 store_x(img);
-                stage_y(nr_tag, nc_tag, kt, 0, img);
+                load_y(nr_tag, nc_tag, kt, 1, yb);
+                store_y(nr_tag, nc_tag, 0, img, ya);
                 if (more) load_x(kt + 1);
-                stage_y(nr_tag, nc_tag, kt, 1, img);
+                store_y(nr_tag, nc_tag, 1, img, yb);
             };
             using I1 = std::integral_constant<int, 1>;
             using I2 = std::integral_constant<int, 2>;
@@ -308,7 +316,7 @@ __global__ void __launch_bounds__(512) wwgrad_ws_kernel(const WWgradArgs a) {
 // (the -1: the dY-side transform of the positions with i = 3 / j = 3 was formed without A's sign).  One thread per (co, ci):
 // 16 x nsplit coalesced reads, nine values written as one contiguous 36-byte run of the OIHW gradient.
 __global__ void __launch_bounds__(256) wwgrad_reduce_kernel(const float* __restrict__ slabs, int nsplit, long long n, float* __restrict__ dw,
-                                                            int accumulate) {
+                                                            int accumulate, float alpha) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n) return;
     float m[16];
@@ -337,7 +345,7 @@ __global__ void __launch_bounds__(256) wwgrad_reduce_kernel(const float* __restr
     }
     float* out = dw + idx * 9;
 #pragma unroll
-    for (int e = 0; e < 9; ++e) out[e] = accumulate ? out[e] + o[e] : o[e];
+    for (int e = 0; e < 9; ++e) out[e] = accumulate ? out[e] + alpha * o[e] : alpha * o[e];
 }
 
 int ilog2(int v) {
@@ -367,8 +375,9 @@ extern "C" int psld_conv3x3_wgrad_wino_nsplit(int cout, int cin_total, int batch
     }
     int ns = n / units;
     if (ns < 1) ns = 1;
-    while (ns > 1 && ktiles % ns) --ns;
-    return ns;
+    if (ns > ktiles) ns = (int)ktiles;
+    const long long per = (ktiles + ns - 1) / ns;
+    return (int)((ktiles + per - 1) / per);       // every split non-empty
 }
 
 extern "C" long long psld_conv3x3_wgrad_wino_ws_bytes(int cout, int cin_total, int nsplit) {
@@ -377,21 +386,22 @@ extern "C" long long psld_conv3x3_wgrad_wino_ws_bytes(int cout, int cin_total, i
 
 extern "C" int psld_conv3x3_wgrad_wino_f32(const float* dy, int lddy, int cout, const float* x, int cin, const float* x2, int cin2,
                                            int batch, int h, int w, float* slabs, int nsplit, float* dw_oihw, int accumulate,
-                                           hipStream_t stream) {
+                                           float alpha, hipStream_t stream) {
     PSLD_CHECK_ARG(dy && x && slabs && dw_oihw && nsplit >= 1 && (cin2 == 0 || x2), "psld_conv3x3_wgrad_wino_f32: bad args");
     PSLD_CHECK_ARG(psld_conv3x3_wgrad_wino_supported(cout, cin, cin2, batch, h, w),
                    "psld_conv3x3_wgrad_wino_f32: unsupported shape cout=%d cin=%d+%d B=%d %dx%d", cout, cin, cin2, batch, h, w);
     PSLD_CHECK_ARG(aligned16(dy) && aligned16(x) && (cin2 == 0 || aligned16(x2)) && lddy % 4 == 0 && lddy >= cout,
                    "psld_conv3x3_wgrad_wino_f32: unaligned operand");
     const long long ktiles = (long long)batch * h * w / 4 / 32;
-    PSLD_CHECK_ARG(ktiles % nsplit == 0, "psld_conv3x3_wgrad_wino_f32: %lld K tiles do not divide into %d splits", ktiles, nsplit);
+    const long long per_split = (ktiles + nsplit - 1) / nsplit;
+    PSLD_CHECK_ARG((ktiles + per_split - 1) / per_split == nsplit, "psld_conv3x3_wgrad_wino_f32: %d splits of %lld K tiles leave empty slabs", nsplit, ktiles);
     WWgradArgs a{};
     a.dy = dy; a.lddy = lddy; a.x = x; a.cin = cin; a.x2 = x2; a.cin2 = cin2;
     a.H = h; a.W = w;
     a.lg_tw = ilog2(w / 2); a.tw_mask = w / 2 - 1; a.th_mask = h / 2 - 1;
     a.rows_per_kt = 32 >> a.lg_tw;
     a.cout_tiles = cout / WW_CO; a.cin_tiles = (cin + cin2) / WW_CI;
-    a.ktiles_per_split = (int)(ktiles / nsplit);
+    a.ktiles = (int)ktiles; a.ktiles_per_split = (int)per_split;
     a.slabs = slabs; a.cout = cout; a.cin_total = cin + cin2;
     static PsldPerDeviceFlag configured_; bool& configured = configured_.here();
     if (!configured) {
@@ -405,7 +415,7 @@ extern "C" int psld_conv3x3_wgrad_wino_f32(const float* dy, int lddy, int cout, 
     hipLaunchKernelGGL(wwgrad_ws_kernel, dim3((unsigned)(16 * a.cout_tiles * a.cin_tiles * nsplit)), dim3(512), WW_LDS, stream, a);
     PSLD_CHECK_LAUNCH("wwgrad_ws_kernel");
     const long long n = (long long)cout * a.cin_total;
-    hipLaunchKernelGGL(wwgrad_reduce_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, slabs, nsplit, n, dw_oihw, accumulate);
+    hipLaunchKernelGGL(wwgrad_reduce_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, slabs, nsplit, n, dw_oihw, accumulate, alpha);
     PSLD_CHECK_LAUNCH("wwgrad_reduce_kernel");
     return PSLD_OK;
 }

@@ -427,6 +427,32 @@ def conv3x3_wgrad_wino_supported(cout: int, cin: int, cin2: int, b: int, h: int,
     return bool(lib().psld_conv3x3_wgrad_wino_supported(cout, cin, cin2, b, h, w))
 
 
+_WGRAD_WINO_MODE: Optional[int] = None
+
+
+def set_wgrad_winograd(mode: Optional[int]):
+    """Override ``PSLD_WGRAD_WINOGRAD`` for this process (None: back to the environment); see conv3x3_wgrad_wino_wanted."""
+    global _WGRAD_WINO_MODE
+    _WGRAD_WINO_MODE = mode
+    conv3x3_wgrad_wino_wanted.cache_clear()
+
+
+@functools.lru_cache(maxsize=None)
+def conv3x3_wgrad_wino_wanted(cout: int, cin: int, cin2: int, b: int, h: int, w: int) -> bool:
+    """Policy (limb-MFMA math mode, fp32 x - the caller checks both): does the weight gradient of a 3x3 stride-1 convolution
+    run in the Winograd domain (wgrad_wino.hip)?  ``PSLD_WGRAD_WINOGRAD=1`` (default): when the kernel takes the shape and
+    every K split holds at least 16 K tiles (measured on MI355X, tools/bench_wwgrad.py: x1.40-1.47 on the 32x32 level, x1.23-
+    1.37 on the 16x16 level at B=128; short K ranges are prologue + epilogue); ``=0``: the direct limb kernels everywhere;
+    ``=2``: every supported shape (parity tests at small batches)."""
+    mode = _WGRAD_WINO_MODE if _WGRAD_WINO_MODE is not None else int(os.environ.get("PSLD_WGRAD_WINOGRAD", "1"))
+    if mode == 0 or not conv3x3_wgrad_wino_supported(cout, cin, cin2, b, h, w):
+        return False
+    if mode == 2:
+        return True
+    ns, _ = conv3x3_wgrad_wino_plan(cout, cin + cin2, b, h, w)
+    return h >= 16 and (b * h * w // 128) // ns >= 16
+
+
 @functools.lru_cache(maxsize=None)
 def conv3x3_wgrad_wino_plan(cout: int, cin_total: int, b: int, h: int, w: int):
     """(K splits, workspace bytes) of the Winograd-domain weight gradient for this shape."""
@@ -435,7 +461,7 @@ def conv3x3_wgrad_wino_plan(cout: int, cin_total: int, b: int, h: int, w: int):
 
 
 def conv3x3_wgrad_wino(dy: Tensor, cout: int, x: Tensor, dw: Tensor, x2: Optional[Tensor] = None, accumulate: bool = False,
-                       slabs: Optional[Tensor] = None, nsplit: Optional[int] = None):
+                       slabs: Optional[Tensor] = None, nsplit: Optional[int] = None, alpha: float = 1.0):
     """dw[cout][cin (+ cin2)][3][3] (OIHW, contiguous) = (or +=) the weight gradient of the 3x3 stride-1 convolution, formed in
     the Winograd F(2x2, 3x3) domain (psld_conv3x3_wgrad_wino_f32: 16 limb products per 2x2 tile instead of 36)."""
     b, h, w, cin = x.shape
@@ -447,7 +473,7 @@ def conv3x3_wgrad_wino(dy: Tensor, cout: int, x: Tensor, dw: Tensor, x2: Optiona
         slabs = workspace(wsb, x.device)
     assert slabs.numel() * slabs.element_size() >= wsb and dw.is_contiguous() and dw.numel() == cout * (cin + cin2) * 9
     check(lib().psld_conv3x3_wgrad_wino_f32(dy.data_ptr(), cout, cout, x.data_ptr(), cin, _p(x2), cin2, b, h, w,
-                                            slabs.data_ptr(), ns, dw.data_ptr(), 1 if accumulate else 0, _stream()),
+                                            slabs.data_ptr(), ns, dw.data_ptr(), 1 if accumulate else 0, float(alpha), _stream()),
           "psld_conv3x3_wgrad_wino_f32")
 
 

@@ -452,6 +452,13 @@ class _Exec:
         taps = k * k
         n = cout * taps * cin
         assert x2 is None or self.split, "two-source weight gradients exist on the limb kernels only"
+        if self.split and k == 3 and stride == 1 and pad == 1 and not isinstance(x, ops.LimbPlanes) and \
+                ops.conv3x3_wgrad_wino_wanted(cout, c1, c2, b, oh, ow):
+            # Winograd domain (wgrad_wino.hip): 16 limb products per 2x2 tile instead of 36; its own slabs and reduction
+            # (G^T . G over 16 positions), written straight into the flat gradient
+            # (the stream's workspace: the reduction follows at once, nothing is parked in the slab arena)
+            ops.conv3x3_wgrad_wino(dy, cout, x, self.g(conv.weight), x2=x2, alpha=alpha)
+            return
         if self.split and k == 3 and stride == 1 and pad == 1 and \
                 ops.conv3x3_wgrad_split_supported(cout, c1, b, oh, ow) and \
                 (x2 is None or ops.conv3x3_wgrad_split_supported(cout, c2, b, oh, ow)):

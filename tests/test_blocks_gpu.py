@@ -173,6 +173,7 @@ def test_pyramid_downsample_golden_on_the_hip_path(golden, name):
 def test_wide_resblock_against_the_oracle(cin, cout, hw, kw, two, winograd):
     from psld_amd import ops, score_fn as S
     ops.set_winograd(winograd)
+    ops.set_wgrad_winograd(winograd)         # 2: the weight gradients in the Winograd domain too (wgrad_wino.hip), 0: direct
     try:
         b = 2
         mod = S.ResnetBlockBigGANpp(cin, cout, temb_dim=128, dropout=0.0, **kw)
@@ -207,6 +208,7 @@ def test_wide_resblock_against_the_oracle(cin, cout, hw, kw, two, winograd):
             assert rel_l2(h.grad(k), osd[f"m.{k}"].grad) < 2e-5, k
     finally:
         ops.set_winograd(None)
+        ops.set_wgrad_winograd(None)
 
 
 @pytest.mark.parametrize("c,hw", [(256, 16), (256, 8)])

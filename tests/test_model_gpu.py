@@ -885,19 +885,23 @@ def test_fused_adam_refuses_a_consumed_gradient():
         opt.step()
 
 
-@pytest.mark.parametrize("name,winograd", [("c10_sota", 1), ("c10_sota", 2), ("celeba64", 2)])
-def test_full_size_network_gradients_against_live_oracle(name, winograd):
+@pytest.mark.parametrize("name,winograd,wgrad", [("c10_sota", 1, 1), ("c10_sota", 2, 0), ("c10_sota", 2, 2), ("celeba64", 2, 0),
+                                                 ("celeba64", 2, 2)])
+def test_full_size_network_gradients_against_live_oracle(name, winograd, wgrad):
     """North-star scale backward: every parameter gradient of the 97.6 M (C10-SOTA) / 62.8 M (CelebA-64)
     network vs torch autograd through the oracle on this box's CPU (same weights, inputs, t, eps).  ``winograd`` = 2:
     forward and data-gradient convolutions in Winograd F(2x2, 3x3) form wherever the kernel takes the shape (at this
-    batch size the default policy, 1, keeps the direct kernels)."""
+    batch size the default policy, 1, keeps the direct kernels); ``wgrad`` = 2: the weight gradients in the Winograd domain
+    wherever wgrad_wino.hip takes the shape (round 6; the same 2e-5 global gate), 0: the direct limb kernels."""
     from psld_amd import ops
     from psld_amd.registry import get_module
     ops.set_winograd(winograd)
+    ops.set_wgrad_winograd(wgrad)
     try:
         _full_size_gradients(name)
     finally:
         ops.set_winograd(None)
+        ops.set_wgrad_winograd(None)
 
 
 def _full_size_gradients(name):
