@@ -50,7 +50,9 @@ class ConvProbe:
         self.orig_split = ops.conv3x3_split
         self.orig_tile = ops.conv2d_nhwc
         self.orig_wino = ops.conv3x3_wino
-        self.records = {"split": [], "tile": [], "wino": []}
+        self.orig_wgrad = ops.conv3x3_wgrad_split
+        self.orig_wgrad_wino = ops.conv3x3_wgrad_wino
+        self.records = {"split": [], "tile": [], "wino": [], "wgrad": [], "wgrad_wino": []}
         self.enabled = False
 
     def install(self):
@@ -83,9 +85,24 @@ class ConvProbe:
             timed("tile", flops, lambda: probe.orig_tile(x1, x2, w, cout, kh, kw, stride, pad, tstride, oh, ow, y,
                                                          epi, ldy))
 
+        def wgrad(dy, cout, x, slabs, cin_total, col0, nsplit, x2=None):
+            cin = x.shape[-1] + (x2.shape[-1] if x2 is not None else 0)
+            flops = 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * cout * 9 * cin
+            timed("wgrad", flops, lambda: probe.orig_wgrad(dy, cout, x, slabs, cin_total, col0, nsplit, x2))
+
+        def wgrad_wino(dy, cout, x, dw, x2=None, **kw):
+            cin = x.shape[-1] + (x2.shape[-1] if x2 is not None else 0)
+            flops = 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * cout * 9 * cin      # direct-convolution (algorithmic) count
+            timed("wgrad_wino", flops, lambda: probe.orig_wgrad_wino(dy, cout, x, dw, x2=x2, **kw))
+
         self.ops.conv3x3_split = split
         self.ops.conv3x3_wino = wino
         self.ops.conv2d_nhwc = tile
+        self.ops.conv3x3_wgrad_split = wgrad
+        self.ops.conv3x3_wgrad_wino = wgrad_wino
+
+    def reset(self):
+        self.records = {k: [] for k in self.records}
 
     def summary(self, kind):
         recs = self.records[kind] if isinstance(kind, str) else [r for k in kind for r in self.records[k]]
@@ -315,11 +332,11 @@ def reduce_sampling(res, rank: int, world: int, on_dev: bool, dev, shard):
 
 
 def _guarded_record(name):
-    """A committed profile record (the newest of profiles/r05 ... r03/<name>) that carries the hash of the kernel
+    """A committed profile record (the newest of profiles/r06 ... r03/<name>) that carries the hash of the kernel
     sources it was measured on; a record measured on other sources is refused."""
     import hashlib
     rec, path = None, None
-    for rnd in ("r05", "r04", "r03"):
+    for rnd in ("r06", "r05", "r04", "r03"):
         path = os.path.join(ROOT, "profiles", rnd, name)
         try:
             with open(path) as fh:
@@ -328,7 +345,7 @@ def _guarded_record(name):
         except Exception:  # noqa: BLE001
             continue
     if rec is None:
-        return None, f"no record (profiles/r05/{name})"
+        return None, f"no record (profiles/r06/{name})"
     h = hashlib.sha256()
     for f in rec.get("sources", []):
         try:
@@ -360,7 +377,13 @@ def hbm_in_situ_forward_record():
     return _guarded_record("hbm_in_situ_forward.json")
 
 
-def forward_block(net, dev, batch, size, steps=5):
+# algorithmic work of one eval forward per image (measured with torch.utils.flop_counter on the reference) and the
+# fused plan's compulsory activation bytes per image where SURVEY states them (C10-SOTA only); weights are read once per batch
+FORWARD_WORK = {"c10_sota": {"gflop": 76.46, "act_bytes": 173.2e6, "weight_bytes": 390.5e6},
+                "celeba64_sota": {"gflop": 84.17, "act_bytes": None, "weight_bytes": 251.1e6}}
+
+
+def forward_block(net, dev, batch, size, steps=5, config="c10_sota"):
     """SURVEY 8(d) 'Which roofline': the end-to-end eval forward at the training batch on BOTH axes - algorithmic FLOPs
     against the 416.7 TFLOP/s ceiling of the limb algorithm and the fused plan's compulsory bytes (176.3 MB per image at
     B=128) against 8 TB/s - timed with HIP events on the launch stream."""
@@ -381,12 +404,86 @@ def forward_block(net, dev, batch, size, steps=5):
         torch.cuda.synchronize()
     net.train(was_training)
     dt = e0.elapsed_time(e1) * 1e-3 / steps
-    fl, by = 76.46e9 * batch, (173.2e6 + 390.5e6 / batch) * batch
-    return {"batch": batch, "ms": dt * 1e3, "images_per_s": batch / dt, "tflops": fl / dt / 1e12,
+    work = FORWARD_WORK[config]
+    fl = work["gflop"] * 1e9 * batch
+    by = (work["act_bytes"] + work["weight_bytes"] / batch) * batch if work["act_bytes"] is not None else None
+    return {"config": config, "batch": batch, "ms": dt * 1e3, "images_per_s": batch / dt, "tflops": fl / dt / 1e12,
             "frac_of_limb_mfma_ceiling": fl / dt / 1e12 / (PEAK_BF16_MFMA_TFLOPS / LIMB_PRODUCTS),
-            "compulsory_bytes": by, "gb_per_s": by / dt / 1e9, "frac_of_hbm_8tbs": by / dt / 8.0e12,
-            "note": "eval forward, HIP events; 76.46 GFLOP and 173.2 MB + weights / B of compulsory traffic per image (SURVEY 8(d)): "
-                    "the forward is compute-bound (434 FLOP/B), the HBM line is met per bandwidth-bound kernel (roofline.hbm_bound_*)"}
+            "compulsory_bytes": by, "gb_per_s": by / dt / 1e9 if by else None, "frac_of_hbm_8tbs": by / dt / 8.0e12 if by else None,
+            "note": f"eval forward of {config}, HIP events; {work['gflop']} GFLOP per image (SURVEY 8(d))" +
+                    (f" and {work['act_bytes'] / 1e6:.1f} MB + weights / B of compulsory traffic per image: the forward is compute-bound "
+                     "(434 FLOP/B), the HBM line is met per bandwidth-bound kernel (roofline.hbm_bound_*)" if by else
+                     "; SURVEY states no fused-plan byte count for this configuration: FLOP axis only")}
+
+
+def config_block(name, dev, batch, probe, steps=10, warmup=5):
+    """BASELINE configs[3] in the driver's own run: the full HSM train step of another configuration
+    (CelebA-64: 6x64x64, ch_mult [1,2,2,2], 4 blocks per level) at the per-GPU batch, `warmup` + `steps` steps timed like the
+    headline pass (wall clock between device fences, nothing inside), then the same steps with the 3x3 limb convolutions
+    bracketed by HIP events for its own roofline fraction."""
+    cfg = getattr(C, name)()
+    cfg.training.batch_size = batch
+    size = cfg.data.image_size
+    torch.manual_seed(cfg.training.seed)
+    net = get_module("score_fn", "ncsnpp")(cfg).to(dev).train()
+    ema = copy.deepcopy(net)
+    for p in ema.parameters():
+        p.requires_grad = False
+    sde = get_module("sde", "psld")(cfg)
+    sde.check_nan = True
+    crit = get_module("losses", "psld_score_loss")(cfg, sde)
+    wrapper = get_module("pl_modules", "sde_wrapper")(cfg, sde, net, ema_score_fn=ema, criterion=crit)
+    ema_cb = EMAWeightUpdate(cfg.training.ema_decay)
+    g = torch.Generator(device=dev).manual_seed(0)
+    data = [torch.rand(batch, 3, size, size, device=dev, generator=g) * 2 - 1 for _ in range(2)]
+
+    def run(n, first):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        last = None
+        for i in range(n):
+            last = wrapper.training_step(data[(first + i) % len(data)], first + i)
+            ema_cb.on_train_batch_end(None, wrapper)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, last
+
+    run(warmup, 0)
+    dt, last = run(steps, warmup)
+    out = {"config": name, "workload": f"{name} NCSN++ full HSM train step (perturb+fwd+loss+bwd+clip+Adam+EMA), 6x{size}x{size}",
+           "per_gpu_batch": batch, "steps": steps, "warmup": warmup, "images_per_s": batch * steps / dt,
+           "ms_per_step": 1e3 * dt / steps, "final_loss": float(last.item()),
+           "whole_step_tflops": 3 * FORWARD_WORK[name]["gflop"] * 1e9 * batch * steps / dt / 1e12}
+    if probe is not None:
+        probe.reset()
+        probe.enabled = True
+        dtp, _ = run(steps, warmup + steps)
+        probe.enabled = False
+        ps = probe.summary(("split", "wino"))
+        if ps is not None:
+            peak = PEAK_BF16_MFMA_TFLOPS / LIMB_PRODUCTS
+            out["ms_per_step_probed_pass"] = 1e3 * dtp / steps
+            out["roofline"] = {"bound": "mfma", "kernel": "3x3 limb-MFMA convolutions, forward + data gradient (as the headline's)",
+                               "achieved": ps["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": ps["tflops"] / peak,
+                               "launches": ps["launches"], "avg_launch_us": ps["avg_us"],
+                               "share_of_step": ps["total_ms"] / (1e3 * dtp)}
+            out["weight_gradient"] = wgrad_summary(probe, dtp)
+    ops.check_device_errors(dev)
+    del wrapper, net, ema
+    torch.cuda.empty_cache()
+    return out
+
+
+def wgrad_summary(probe, dt_pass):
+    """The 3x3 weight gradients of the probed pass: Winograd-domain launches (kernel + its reduction) and direct limb
+    launches (kernel only; their slabs are reduced in batched launches), direct-equivalent TFLOP/s against the limb ceiling."""
+    peak = PEAK_BF16_MFMA_TFLOPS / LIMB_PRODUCTS
+    out = {}
+    for kind, label in (("wgrad_wino", "winograd_domain"), ("wgrad", "direct")):
+        r = probe.summary(kind)
+        if r is not None:
+            out[label] = {"tflops_direct_equivalent": r["tflops"], "frac_of_limb_ceiling": r["tflops"] / peak,
+                          "launches": r["launches"], "avg_launch_us": r["avg_us"], "share_of_step": r["total_ms"] / (1e3 * dt_pass)}
+    return out or None
 
 
 def parse_args():
@@ -398,6 +495,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--no-forward", action="store_true", help="skip the eval-forward block (kernel-stats profiles of the training steps only)")
+    ap.add_argument("--no-config-block", action="store_true", help="skip the CelebA-64 (BASELINE configs[3]) train-step block of the default run")
     ap.add_argument("--bucket-mb", type=int, default=64)
     ap.add_argument("--config", default="c10_sota", choices=["c10_sota", "celeba64_sota"],
                     help="c10_sota = BASELINE.json configs[0..2] (headline); celeba64_sota = configs[3] (extra data point)")
@@ -650,6 +748,10 @@ def main():
         dt_probed, _ = timed_pass(args.warmup + args.steps)
         probe.enabled = False
     loss_val = float(last.item())
+    # the headline pass's probe summaries now: the configuration block below reuses the probe
+    ps = probe.summary(("split", "wino"))      # every 3x3 limb convolution, forward + data gradient
+    pw, pd, pt = probe.summary("wino"), probe.summary("split"), probe.summary("tile")
+    wg = wgrad_summary(probe, dt_probed) if dt_probed is not None else None
     ops.check_device_errors(dev)      # a device-side timeout (team GroupNorm backward) voids the run: raise on the rank that saw it
     # replicas stay identical: same seed, same averaged gradient -> same parameters on every rank
     in_sync = None
@@ -686,8 +788,13 @@ def main():
             sampling = reduce_sampling(sampling, rank, world, backend_name == "nccl", dev, shard)
         fence()
     fwd_blk = None
-    if rank == 0 and not args.launch_check and not args.no_forward and torch.cuda.is_available() and args.config == "c10_sota":
-        fwd_blk = forward_block(net, dev, args.batch, size)
+    if rank == 0 and not args.launch_check and not args.no_forward and torch.cuda.is_available():
+        fwd_blk = forward_block(net, dev, args.batch, size, config=args.config)
+    fence()
+    # BASELINE configs[3] (CelebA-64) at its per-GPU batch, in the default single-GPU run only
+    other_blk = None
+    if world == 1 and not args.no_config_block and args.config == "c10_sota" and args.batch == 128:
+        other_blk = config_block("celeba64_sota", dev, 128, None if args.no_probe else probe)
     fence()
 
     if rank == 0:
@@ -723,9 +830,6 @@ def main():
                                   "gradient_bytes_per_step": int(net.flat_grad().numel()) * 4,
                                   "shared_gpu_rehearsal": share_gpu}
             out["overlap"] = st if st is not None else {"note": "no collective ran"}
-        ps = probe.summary(("split", "wino"))      # every 3x3 limb convolution, forward + data gradient
-        pw, pd = probe.summary("wino"), probe.summary("split")
-        pt = probe.summary("tile")
         pmc, pmc_err = pmc_traffic_record()
         hbm, hbm_err = hbm_in_situ_record()
         if hbm is not None and (args.batch != hbm.get("batch", 128) or args.config != "c10_sota"):
@@ -761,7 +865,8 @@ def main():
                                    f"the B=128 step ({hbm['bytes_per_step'] / 1e9:.1f} GB algorithmic in {hbm['ms_per_step']:.1f} ms per step)")
                 if hbm else hbm_err,
                 "launches": ps["launches"], "avg_launch_us": ps["avg_us"],
-                "share_of_step": ps["total_ms"] / (1e3 * (dt_probed or dt))}
+                "share_of_step": ps["total_ms"] / (1e3 * (dt_probed or dt)),
+                "weight_gradient": wg}
         elif pt is not None:        # PSLD_MATH=f32: the fp32 MFMA tile engine carries the convolutions
             out["roofline"] = {"bound": "mfma", "kernel": "tile_kernel_fast<IM2COL,KC> (fp32 MFMA convolutions)",
                                "achieved": pt["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -782,14 +887,16 @@ def main():
             out["config"]["image"] = f"6x{size}x{size}"
         if fwd_blk is not None:
             fh_, fh_err = hbm_in_situ_forward_record()
-            if fh_ is not None and args.batch != fh_.get("batch", 128):
-                fh_, fh_err = None, f"the forward in-situ record was measured at B={fh_.get('batch', 128)}, this run is B={args.batch}"
+            if fh_ is not None and (args.batch != fh_.get("batch", 128) or args.config != "c10_sota"):
+                fh_, fh_err = None, f"the forward in-situ record was measured at C10-SOTA B={fh_.get('batch', 128)}, this run is {args.config} B={args.batch}"
             fwd_blk["hbm_bound_aggregate_frac"] = fh_.get("hbm_bound_aggregate_frac") if fh_ else None
             fwd_blk["hbm_bound_under_0.6"] = fh_.get("under_0.6") if fh_ else None
             fwd_blk["hbm_bound_note"] = (f"{fh_['_path']}: {fh_['aggregate_gb_per_s']:.0f} GB/s byte-weighted over the bandwidth-bound "
                                          f"kernels of the B={fh_.get('batch', 128)} eval forward ({fh_['bytes_per_step'] / 1e9:.2f} GB "
                                          f"algorithmic in {fh_['ms_per_step']:.2f} ms per forward)") if fh_ else fh_err
             out["forward"] = fwd_blk
+        if other_blk is not None:
+            out["celeba64"] = other_blk
         if sampling is not None:
             out["sampling"] = sampling
         out["cpu_baseline"] = cpu_base

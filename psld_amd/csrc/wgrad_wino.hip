@@ -151,103 +151,107 @@ __global__ void __launch_bounds__(512) wwgrad_ws_kernel(const WWgradArgs a) {
         }
         const int lds_x = kx0 * WW_RSB + qx * 8, lds_y = ky0 * WW_RSA + qy * 8;
 
-        f32x4 xv[4][4];         // [item][r1c1, r1c2, r2c1, r2c2] of the K tile being staged next
-        auto load_x = [&](int kt) {
-            const int R0 = kt * a.rows_per_kt;                       // global tile row (image * tile rows + ty) of the K tile
-            // pixel row 2 R0 - 1 + r, column -1 + c of the first tile: may lie before the tensor; never dereferenced there
-            const float* xb = xsrc + ((long long)(2 * R0 - 1) * a.W - 1) * xc + ci0;
-            const __amdgpu_buffer_rsrc_t r11 = brsrc(xb + (long long)(xr1 * a.W + xc1) * xc), r12 = brsrc(xb + (long long)(xr1 * a.W + xc2) * xc),
-                                         r21 = brsrc(xb + (long long)(xr2 * a.W + xc1) * xc), r22 = brsrc(xb + (long long)(xr2 * a.W + xc2) * xc);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ty = (R0 + xdr[i]) & a.th_mask;
-                const bool row1 = !(need_top && ty == 0), row2 = !(need_bot && ty == a.th_mask);
-                const bool c1 = (xcol[i] & 1u) != 0, c2 = (xcol[i] & 2u) != 0;
-                xv[i][0] = bload(r11, (row1 && c1) ? xoff[i] : 0xffffffffu);
-                xv[i][1] = bload(r12, (row1 && c2) ? xoff[i] : 0xffffffffu);
-                xv[i][2] = bload(r21, (row2 && c1) ? xoff[i] : 0xffffffffu);
-                xv[i][3] = bload(r22, (row2 && c2) ? xoff[i] : 0xffffffffu);
-            }
-        };
-        auto store_x = [&](unsigned char* img) {
-            unsigned char* Bs = img + 3 * WW_ALIMB + lds_x;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
+        // One register SLOT per item of a K tile (4 x-items of four loads, 8 dY-items of NR x NC loads): an item of tile t is
+        // combined, split and stored from its slot and the slot is refilled at once with the same item of tile t + 1 - every
+        // load has a whole K tile of work (~3,000 cycles) to land, whatever the L2 does under load.  (The first form kept three
+        // groups of four items and gave a group one group's work to land: 486 us on 256->256 @32 B=128 where this runs 404.)
+        auto stage = [&](auto nr_tag, auto nc_tag) {
+            constexpr int NR = decltype(nr_tag)::value, NC = decltype(nc_tag)::value, NL = NR * NC;
+            f32x4 sx[4][4];         // [item][r1c1, r1c2, r2c1, r2c2]
+            f32x4 sy[8][NL];
+            auto load_tile = [&](int kt) {
+                const int R0 = kt * a.rows_per_kt;                   // global tile row (image * tile rows + ty) of the K tile
+                // pixel row 2 R0 - 1 + r, column -1 + c of the first tile: may lie before the tensor; never dereferenced there
+                const float* xb = xsrc + ((long long)(2 * R0 - 1) * a.W - 1) * xc + ci0;
+                const __amdgpu_buffer_rsrc_t r11 = brsrc(xb + (long long)(xr1 * a.W + xc1) * xc), r12 = brsrc(xb + (long long)(xr1 * a.W + xc2) * xc),
+                                             r21 = brsrc(xb + (long long)(xr2 * a.W + xc1) * xc), r22 = brsrc(xb + (long long)(xr2 * a.W + xc2) * xc);
+                const float* yb = a.dy + ((long long)(2 * R0) * a.W) * a.lddy + co0;
+                const __amdgpu_buffer_rsrc_t q00 = brsrc(yb + (long long)(yr1 * a.W + yc1) * a.lddy), q01 = brsrc(yb + (long long)(yr1 * a.W + 1) * a.lddy),
+                                             q10 = brsrc(yb + (long long)(a.W + yc1) * a.lddy), q11 = brsrc(yb + (long long)(a.W + 1) * a.lddy);
+                return [=, &sx, &sy](auto is_x, int i) {
+                    if constexpr (decltype(is_x)::value) {
+                        const int ty = (R0 + xdr[i]) & a.th_mask;
+                        const bool row1 = !(need_top && ty == 0), row2 = !(need_bot && ty == a.th_mask);
+                        const bool c1 = (xcol[i] & 1u) != 0, c2 = (xcol[i] & 2u) != 0;
+                        sx[i][0] = bload(r11, (row1 && c1) ? xoff[i] : 0xffffffffu);
+                        sx[i][1] = bload(r12, (row1 && c2) ? xoff[i] : 0xffffffffu);
+                        sx[i][2] = bload(r21, (row2 && c1) ? xoff[i] : 0xffffffffu);
+                        sx[i][3] = bload(r22, (row2 && c2) ? xoff[i] : 0xffffffffu);
+                    } else {
+                        sy[i][0] = bload(q00, yoff[i]);
+                        if constexpr (NC == 2) sy[i][1] = bload(q01, yoff[i]);
+                        if constexpr (NR == 2) {
+                            sy[i][NC] = bload(q10, yoff[i]);
+                            if constexpr (NC == 2) sy[i][NC + 1] = bload(q11, yoff[i]);
+                        }
+                    }
+                };
+            };
+            using TX = std::integral_constant<bool, true>;
+            using TY = std::integral_constant<bool, false>;
+            auto put_x = [&](unsigned char* img, int i) {
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    v[e] = (xv[i][0][e] + xsc * xv[i][1][e]) + xsr * (xv[i][2][e] + xsc * xv[i][3][e]);
-                ww_store(Bs + i * 8 * WW_RSB, WW_BLIMB, v);
-            }
-        };
-        // dY items of one half (four items): NR x NC loads each ...
-        auto load_y = [&](auto nr_tag, auto nc_tag, int kt, int half, auto& yv) {
-            constexpr int NR = decltype(nr_tag)::value, NC = decltype(nc_tag)::value;
-            const int R0 = kt * a.rows_per_kt;
-            const float* yb = a.dy + ((long long)(2 * R0) * a.W) * a.lddy + co0;
-            const __amdgpu_buffer_rsrc_t r00 = brsrc(yb + (long long)(yr1 * a.W + yc1) * a.lddy), r01 = brsrc(yb + (long long)(yr1 * a.W + 1) * a.lddy),
-                                         r10 = brsrc(yb + (long long)(a.W + yc1) * a.lddy), r11 = brsrc(yb + (long long)(a.W + 1) * a.lddy);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const unsigned off = yoff[half * 4 + i];
-                yv[i][0] = bload(r00, off);
-                if constexpr (NC == 2) yv[i][1] = bload(r01, off);
-                if constexpr (NR == 2) {
-                    yv[i][NC] = bload(r10, off);
-                    if constexpr (NC == 2) yv[i][NC + 1] = bload(r11, off);
-                }
-            }
-        };
-        // ... combined, split and stored
-        auto store_y = [&](auto nr_tag, auto nc_tag, int half, unsigned char* img, const auto& yv) {
-            constexpr int NR = decltype(nr_tag)::value, NC = decltype(nc_tag)::value;
-            unsigned char* As = img + lds_y + half * 16 * WW_RSA;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
+                    v[e] = (sx[i][0][e] + xsc * sx[i][1][e]) + xsr * (sx[i][2][e] + xsc * sx[i][3][e]);
+                ww_store(img + 3 * WW_ALIMB + lds_x + i * 8 * WW_RSB, WW_BLIMB, v);
+            };
+            auto put_y = [&](unsigned char* img, int i) {
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float t = yv[i][0][e];
-                    if constexpr (NC == 2) t += ysc * yv[i][1][e];
+                    float t = sy[i][0][e];
+                    if constexpr (NC == 2) t += ysc * sy[i][1][e];
                     if constexpr (NR == 2) {
-                        float u = yv[i][NC][e];
-                        if constexpr (NC == 2) u += ysc * yv[i][NC + 1][e];
+                        float u = sy[i][NC][e];
+                        if constexpr (NC == 2) u += ysc * sy[i][NC + 1][e];
                         t += ysr * u;
                     }
                     v[e] = t;
                 }
-                ww_store(As + i * 4 * WW_RSA, WW_ALIMB, v);
-            }
-        };
-        auto stage_tile = [&](int kt, int buf, bool more) {
-            unsigned char* img = smem + buf * WW_IMG;
-            // Every group of loads has one group's worth of combine + split work to land: the x values of this tile are in
-            // flight since the previous call; dY half 0 is asked for before they are combined, dY half 1 before half 0 is
-            // combined, the next tile's x values before half 1 is.
-            auto both = [&](auto nr_tag, auto nc_tag) {
-                constexpr int NL = decltype(nr_tag)::value * decltype(nc_tag)::value;
-                f32x4 ya[4][NL], yb[4][NL];
-                load_y(nr_tag, nc_tag, kt, 0, ya);
-                store_x(img);
-                load_y(nr_tag, nc_tag, kt, 1, yb);
-                store_y(nr_tag, nc_tag, 0, img, ya);
-                if (more) load_x(kt + 1);
-                store_y(nr_tag, nc_tag, 1, img, yb);
+                ww_store(img + lds_y + i * 4 * WW_RSA, WW_ALIMB, v);
             };
-            using I1 = std::integral_constant<int, 1>;
-            using I2 = std::integral_constant<int, 2>;
-            if (ynr == 2) {
-                if (ync == 2) both(I2{}, I2{}); else both(I2{}, I1{});
-            } else {
-                if (ync == 2) both(I1{}, I2{}); else both(I1{}, I1{});
+            {
+                auto ld = load_tile(kt_beg);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ld(TX{}, i);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ld(TY{}, i);
             }
+            for (int t = 0; t < nkt; ++t) {
+                unsigned char* img = smem + (t & 1) * WW_IMG;
+                if (t + 1 < nkt) {
+                    auto ld = load_tile(kt_beg + t + 1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        put_x(img, i);
+                        __builtin_amdgcn_sched_barrier(0);      // hipcc otherwise gathers the 48 loads at the end of the iteration
+                        ld(TX{}, i);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        put_y(img, i);
+                        __builtin_amdgcn_sched_barrier(0);
+                        ld(TY{}, i);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) put_x(img, i);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) put_y(img, i);
+                }
+                __syncthreads();        // tile t is in its image; everyone has left the other image (tile t - 1)
+            }
+            __syncthreads();            // the consumers' last barrier
         };
-        load_x(kt_beg);
-        stage_tile(kt_beg, 0, nkt > 1);
-        __syncthreads();
-        for (int i = 0; i < nkt; ++i) {
-            if (i + 1 < nkt) stage_tile(kt_beg + i + 1, (i + 1) & 1, i + 2 < nkt);      // everyone left that image at the last barrier
-            __syncthreads();
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        if (ynr == 2) {
+            if (ync == 2) stage(I2{}, I2{}); else stage(I2{}, I1{});
+        } else {
+            if (ync == 2) stage(I1{}, I2{}); else stage(I1{}, I1{});
         }
         return;
     }

@@ -7,7 +7,7 @@ steps = int(sys.argv[2])
 pats = sys.argv[3:]
 tot = sum(float(r["TotalDurationNs"]) for r in rows) / steps / 1e6
 calls = sum(int(r["Calls"]) for r in rows) / steps
-mfma = ("wino_conv", "dwgrad", "pw8_kernel", "pwgrad", "dconv", "bgemm", "attn_fwd", "tile_kernel")
+mfma = ("wino_conv", "dwgrad", "wwgrad_ws", "pw8_kernel", "pwgrad", "dconv", "bgemm", "attn_fwd", "tile_kernel")
 m = sum(float(r["TotalDurationNs"]) for r in rows if any(k in r["Name"] for k in mfma)) / steps / 1e6
 print(f"{tot:.2f} ms/step of kernels, {calls:.0f} launches/step; MFMA kernels {m:.2f} ms, the rest {tot - m:.2f} ms")
 for p in pats:
