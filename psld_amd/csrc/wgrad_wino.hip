@@ -64,6 +64,7 @@ struct WWgradArgs {
     int ktiles, ktiles_per_split;       // the last split may be shorter (never empty)
     float* slabs;           // [split][16][cout][cin_total]
     int cout, cin_total;
+    int pos_override;       // ablation library only (PSLD_WWGRAD_POS): every workgroup takes this position (-1: its own)
 };
 
 // rows / columns of the 4x4 input patch that position index i combines: V_i = d[r1] + s * d[r2]  (B^T rows)
@@ -79,10 +80,32 @@ __device__ __forceinline__ void y_combo(int i, int& r1, int& n, float& s) {
     s = i == 2 ? -1.f : 1.f;
 }
 
+// limb.h's split3 with the conversion written as a vector cast instead of inline asm: after every inline-asm
+// v_cvt_pk_bf16_f32 hipcc pads an `s_nop 0` (64 of them per staged K tile pair here); in this kernel the cast form compiles
+// to exactly three conversions per pair (checked in the ISA: 11 instructions per pair, no nop).  Same values bit for bit.
+typedef __attribute__((ext_vector_type(2))) float ww_f32x2;
+__device__ __forceinline__ unsigned ww_cvt_pk(float a, float b) {
+    const ww_f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ void ww_split3(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = ww_cvt_pk(x0, x1);
+    const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+    mid = ww_cvt_pk(r0, r1);
+    const float s0 = r0 - __uint_as_float(mid << 16), s1 = r1 - __uint_as_float(mid & 0xffff0000u);
+    lo = ww_cvt_pk(s0, s1);
+}
+
+template <int ABL = 0>
 __device__ __forceinline__ void ww_store(unsigned char* d, int limb_stride, const f32x4& v) {
     unsigned h0, m0, l0, h1, m1, l1;
-    split3(v[0], v[1], h0, m0, l0);
-    split3(v[2], v[3], h1, m1, l1);
+    if constexpr ((ABL & 1) != 0) {
+        h0 = m0 = l0 = __float_as_uint(v[0]) ^ __float_as_uint(v[1]);
+        h1 = m1 = l1 = __float_as_uint(v[2]) ^ __float_as_uint(v[3]);
+    } else {
+        ww_split3(v[0], v[1], h0, m0, l0);
+        ww_split3(v[2], v[3], h1, m1, l1);
+    }
     *reinterpret_cast<u32x2*>(d) = u32x2{h0, h1};
     *reinterpret_cast<u32x2*>(d + limb_stride) = u32x2{m0, m1};
     *reinterpret_cast<u32x2*>(d + 2 * limb_stride) = u32x2{l0, l1};
@@ -95,6 +118,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t brsrc(const float* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x7fffffff, 0x00020000);
 }
 
+// ABL: timing-only ablations (wrong results; libpsld_hip_abl.so only, PSLD_WWGRAD_ABL, tools/bench_wwgrad.py): 1 = no limb split
+// (raw halves stored), 2 = no global loads (the slots keep their first contents), 4 = no MFMAs, 8 = no fragment reads, 16 = the
+// product kernel with PSLD_WWGRAD_POS honoured, 32 = consumers only keep the barriers, 64 = producers only keep the barriers
+// after the first tile.  Measured (profiles/r06/wwgrad_ablations.txt, 256->256 @32 B=128, kernel + reduction 381 us): consumers
+// alone 298, producers alone 277, no split 326, no global loads 274; s_setprio(3) for the consumers 377-382 (nothing): the two
+// roles share each SIMD's vector issue port, and what the producers cost beyond the consumers' own pace is that sharing.
+template <int ABL = 0>
 __global__ void __launch_bounds__(512) wwgrad_ws_kernel(const WWgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -105,7 +135,10 @@ __global__ void __launch_bounds__(512) wwgrad_ws_kernel(const WWgradArgs a) {
     const int vid = xcd_remap(blockIdx.x, gridDim.x);
     const int split = vid / units;
     int rest = vid - split * units;
-    const int pos = rest & 15;
+    int pos = rest & 15;
+    if constexpr (ABL != 0) {
+        if (a.pos_override >= 0) pos = a.pos_override;
+    }
     rest >>= 4;
     const int ci_tile = rest % a.cin_tiles, co_tile = rest / a.cin_tiles;
     const int pi = pos >> 2, pj = pos & 3;
@@ -194,7 +227,7 @@ __global__ void __launch_bounds__(512) wwgrad_ws_kernel(const WWgradArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     v[e] = (sx[i][0][e] + xsc * sx[i][1][e]) + xsr * (sx[i][2][e] + xsc * sx[i][3][e]);
-                ww_store(img + 3 * WW_ALIMB + lds_x + i * 8 * WW_RSB, WW_BLIMB, v);
+                ww_store<ABL>(img + 3 * WW_ALIMB + lds_x + i * 8 * WW_RSB, WW_BLIMB, v);
             };
             auto put_y = [&](unsigned char* img, int i) {
                 f32x4 v;
@@ -209,7 +242,7 @@ __global__ void __launch_bounds__(512) wwgrad_ws_kernel(const WWgradArgs a) {
                     }
                     v[e] = t;
                 }
-                ww_store(img + lds_y + i * 4 * WW_RSA, WW_ALIMB, v);
+                ww_store<ABL>(img + lds_y + i * 4 * WW_RSA, WW_ALIMB, v);
             };
             {
                 auto ld = load_tile(kt_beg);
@@ -220,7 +253,13 @@ __global__ void __launch_bounds__(512) wwgrad_ws_kernel(const WWgradArgs a) {
             }
             for (int t = 0; t < nkt; ++t) {
                 unsigned char* img = smem + (t & 1) * WW_IMG;
-                if (t + 1 < nkt) {
+                if constexpr ((ABL & 64) != 0) {
+                    if (t > 0) {
+                        __syncthreads();
+                        continue;
+                    }
+                }
+                if (t + 1 < nkt && (ABL & 2) == 0) {
                     auto ld = load_tile(kt_beg + t + 1);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -277,7 +316,25 @@ __global__ void __launch_bounds__(512) wwgrad_ws_kernel(const WWgradArgs a) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     for (int i = 0; i < nkt; ++i) {
-        const unsigned char* img = smem + (i & 1) * WW_IMG;
+        const unsigned char* img = smem + (((ABL & 8) != 0 ? 0 : i) & 1) * WW_IMG;
+        if constexpr ((ABL & 32) != 0) {
+            __syncthreads();
+            continue;
+        }
+        if constexpr ((ABL & 8) != 0) {
+            if (i > 0) {            // fragments of the first tile, read once: the MFMAs below run on whatever the registers hold
+                u32x4 f = frag(img, a_base, 0);
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+                    for (int u = 0; u < 6; ++u)
+#pragma unroll
+                        for (int nb = 0; nb < 4; ++nb)
+                            acc[cb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, f), __builtin_bit_cast(bf16x8, f), acc[cb][nb], 0, 0, 0);
+                __syncthreads();
+                continue;
+            }
+        }
         u32x4 fb[4][3];
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
@@ -293,12 +350,21 @@ __global__ void __launch_bounds__(512) wwgrad_ws_kernel(const WWgradArgs a) {
                 for (int l = 0; l < 3; ++l) fa[(cb + 1) & 1][l] = frag(img, a_base, l * WW_ALIMB + (cb + 1) * 32);
             }
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-            for (int u = 0; u < 6; ++u)
+            if constexpr ((ABL & 4) != 0) {
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb)
-                    acc[cb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8, fa[cb & 1][PA[u]]), __builtin_bit_cast(bf16x8, fb[nb][PB[u]]), acc[cb][nb], 0, 0, 0);
+#pragma unroll
+                    for (int l = 0; l < 3; ++l)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[cb][nb][e] += __uint_as_float(fa[cb & 1][l][e] ^ fb[nb][l][e]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 6; ++u)
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb)
+                        acc[cb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, fa[cb & 1][PA[u]]), __builtin_bit_cast(bf16x8, fb[nb][PB[u]]), acc[cb][nb], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
@@ -319,16 +385,23 @@ __global__ void __launch_bounds__(512) wwgrad_ws_kernel(const WWgradArgs a) {
 // dg[co][ci][ky][kx] = sum_ij Gs[i][ky] Gs[j][kx] sum_split slabs[split][4 i + j][co][ci],  Gs = diag(1, 1, 1, -1) G
 // (the -1: the dY-side transform of the positions with i = 3 / j = 3 was formed without A's sign).  One thread per (co, ci):
 // 16 x nsplit coalesced reads, nine values written as one contiguous 36-byte run of the OIHW gradient.
-__global__ void __launch_bounds__(256) wwgrad_reduce_kernel(const float* __restrict__ slabs, int nsplit, long long n, float* __restrict__ dw,
-                                                            int accumulate, float alpha) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+__global__ void __launch_bounds__(64) wwgrad_reduce_kernel(const float* __restrict__ slabs, int nsplit, long long n, float* __restrict__ dw,
+                                                           int accumulate, float alpha) {
+    const long long idx = (long long)blockIdx.x * 64 + threadIdx.x;
     if (idx >= n) return;
+    // splits in order (a fixed sum per position); the 16 positions of a split are 16 independent loads in flight per thread,
+    // one-wave workgroups so that the ~1000 of them cover every CU several times (the first form - 256-thread blocks, one
+    // position at a time - moved its 33 MB at 1.1 TB/s: 30 us per layer, 2.2 ms per step)
     float m[16];
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {
-        float s = 0.f;
-        for (int sp = 0; sp < nsplit; ++sp) s += slabs[((long long)sp * 16 + p) * n + idx];
-        m[p] = s;
+    for (int p = 0; p < 16; ++p) m[p] = 0.f;
+    const float* src = slabs + idx;
+    for (int sp = 0; sp < nsplit; ++sp) {
+        float v[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) v[p] = __builtin_nontemporal_load(src + ((long long)sp * 16 + p) * n);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) m[p] += v[p];
     }
     // t[i][kx] = sum_j Gs[j][kx] m[i][j]:  kx=0: m0 + (m1 + m2)/2;  kx=1: (m1 - m2)/2;  kx=2: (m1 + m2)/2 - m3
     float t[4][3];
@@ -407,19 +480,42 @@ extern "C" int psld_conv3x3_wgrad_wino_f32(const float* dy, int lddy, int cout, 
     a.cout_tiles = cout / WW_CO; a.cin_tiles = (cin + cin2) / WW_CI;
     a.ktiles = (int)ktiles; a.ktiles_per_split = (int)per_split;
     a.slabs = slabs; a.cout = cout; a.cin_total = cin + cin2;
+    a.pos_override = -1;
+    const dim3 grid((unsigned)(16 * a.cout_tiles * a.cin_tiles * nsplit));
+#ifdef PSLD_ABLATIONS      // timing-only variants (wrong results): libpsld_hip_abl.so only (make abl), never the product library
+    static const int abl = [] { const char* v = getenv("PSLD_WWGRAD_ABL"); return v ? atoi(v) : 0; }();
+    static const int pos_ov = [] { const char* v = getenv("PSLD_WWGRAD_POS"); return v ? atoi(v) : -1; }();
+    a.pos_override = pos_ov;
+#define WW_ABL_CASE(N)                                                                                                              \
+    case N:                                                                                                                         \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wwgrad_ws_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WW_LDS); \
+        hipLaunchKernelGGL(wwgrad_ws_kernel<N>, grid, dim3(512), WW_LDS, stream, a);                                                \
+        PSLD_CHECK_LAUNCH("wwgrad_ws_kernel (ablation)");                                                                           \
+        launched = true;                                                                                                            \
+        break;
+    bool launched = false;
+    switch (abl) {
+        WW_ABL_CASE(1) WW_ABL_CASE(2) WW_ABL_CASE(3) WW_ABL_CASE(4) WW_ABL_CASE(8) WW_ABL_CASE(12) WW_ABL_CASE(16) WW_ABL_CASE(32) WW_ABL_CASE(64)
+        default: break;
+    }
+#undef WW_ABL_CASE
+    if (!launched)
+#endif
+    {
     static PsldPerDeviceFlag configured_; bool& configured = configured_.here();
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wwgrad_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WW_LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wwgrad_ws_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WW_LDS);
         if (e != hipSuccess) {
             psld_set_error("psld_conv3x3_wgrad_wino_f32: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return PSLD_ERR_LAUNCH;
         }
         configured = true;
     }
-    hipLaunchKernelGGL(wwgrad_ws_kernel, dim3((unsigned)(16 * a.cout_tiles * a.cin_tiles * nsplit)), dim3(512), WW_LDS, stream, a);
+    hipLaunchKernelGGL(wwgrad_ws_kernel<0>, grid, dim3(512), WW_LDS, stream, a);
     PSLD_CHECK_LAUNCH("wwgrad_ws_kernel");
+    }
     const long long n = (long long)cout * a.cin_total;
-    hipLaunchKernelGGL(wwgrad_reduce_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, slabs, nsplit, n, dw_oihw, accumulate, alpha);
+    hipLaunchKernelGGL(wwgrad_reduce_kernel, dim3((unsigned)cdiv(n, 64)), dim3(64), 0, stream, slabs, nsplit, n, dw_oihw, accumulate, alpha);
     PSLD_CHECK_LAUNCH("wwgrad_reduce_kernel");
     return PSLD_OK;
 }
