@@ -232,7 +232,8 @@ int psld_conv3x3_wgrad_xlimb_f32(const float* dy, int lddy, int cout, const void
  * accumulate, exact three-limb operands like every limb kernel.  slabs: workspace of psld_conv3x3_wgrad_wino_ws_bytes;
  * nsplit: K splits of ceil(batch*h*w/128 / nsplit) 32-tile K tiles, none empty (psld_conv3x3_wgrad_wino_nsplit fills the chip
  * with one round of one-workgroup-per-CU tiles).
- * Shapes: cout % 256 == 0, cin % 128 == 0, cin2 % 128 == 0 (second source of a channel concatenation; 0 / null for none),
+ * Shapes: cout % 128 == 0 (a workgroup owns 256 output channels of one position, 128 when cout is not a multiple of 256),
+ * cin % 128 == 0, cin2 % 128 == 0 (second source of a channel concatenation; 0 / null for none),
  * h == w in {8,16,32,64}, batch*h*w % 128 == 0; dy rows of lddy floats. */
 int psld_conv3x3_wgrad_wino_supported(int cout, int cin, int cin2, int batch, int h, int w);
 int psld_conv3x3_wgrad_wino_nsplit(int cout, int cin_total, int batch, int h, int w);

@@ -43,12 +43,18 @@ __device__ __forceinline__ u32x2 lds_tr16(const unsigned char* p) {
     return __builtin_bit_cast(u32x2, v);
 }
 
-constexpr int WW_CO = 256, WW_CI = 128;          // workgroup tile of one position's GEMM
-constexpr int WW_RSA = WW_CO * 2 + 32;           // 544: dY-side row stride (bytes per tile row and limb); 32 mod 256 like the
-constexpr int WW_RSB = WW_CI * 2 + 32;           // 288 of pwgrad_kernel: eight consecutive rows cover all 64 banks
-constexpr int WW_ALIMB = 32 * WW_RSA, WW_BLIMB = 32 * WW_RSB;
-constexpr int WW_IMG = 3 * (WW_ALIMB + WW_BLIMB);            // 79 872 bytes
-constexpr size_t WW_LDS = 2 * (size_t)WW_IMG;                // 159 744
+constexpr int WW_CI = 128;                       // c_in per workgroup; c_out per workgroup CO = 256 (128 for layers of 128 output channels)
+constexpr int WW_RSB = WW_CI * 2 + 32;           // 288: x-side row stride (bytes per tile row and limb); 32 mod 256 like pwgrad_kernel's:
+constexpr int WW_BLIMB = 32 * WW_RSB;            // eight consecutive rows cover all 64 banks
+template <int CO>
+struct WWGeom {
+    static constexpr int RSA = CO * 2 + 32;      // 544 / 288: dY-side row stride
+    static constexpr int ALIMB = 32 * RSA;
+    static constexpr int IMG = 3 * (ALIMB + WW_BLIMB);           // 79 872 / 55 296 bytes
+    static constexpr size_t LDS = 2 * (size_t)IMG;               // 159 744 / 110 592
+    static constexpr int NY = CO / 32;           // dY items per producer thread and K tile (8 / 4)
+    static constexpr int CB = CO / 32;           // 16-channel c_out blocks per consumer wave (wave tile CO/2 x 64)
+};
 
 struct WWgradArgs {
     const float* dy;
@@ -124,8 +130,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t brsrc(const float* p) {
 // after the first tile.  Measured (profiles/r06/wwgrad_ablations.txt, 256->256 @32 B=128, kernel + reduction 381 us): consumers
 // alone 298, producers alone 277, no split 326, no global loads 274; s_setprio(3) for the consumers 377-382 (nothing): the two
 // roles share each SIMD's vector issue port, and what the producers cost beyond the consumers' own pace is that sharing.
-template <int ABL = 0>
+template <int ABL = 0, int CO = 256>
 __global__ void __launch_bounds__(512) wwgrad_ws_kernel(const WWgradArgs a) {
+    using G = WWGeom<CO>;
+    constexpr int WW_CO = CO, WW_RSA = G::RSA, WW_ALIMB = G::ALIMB, WW_IMG = G::IMG, NY = G::NY, CB = G::CB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -173,12 +181,13 @@ __global__ void __launch_bounds__(512) wwgrad_ws_kernel(const WWgradArgs a) {
             xdr[i] = dr;
             xcol[i] = ((xc1 == 0 && tx == 0) ? 0u : 1u) | ((xc2 == 3 && tx == a.tw_mask) ? 0u : 2u);
         }
-        // dY items: channel quad pt & 63, tile row k = (pt >> 6) + 4 i
-        const int qy = pt & 63, ky0 = pt >> 6;
-        unsigned yoff[8];
+        // dY items: channel quad pt & (CO / 4 - 1), tile row k = pt / (CO / 4) + (32 / NY) i
+        constexpr int QY = CO / 4, KSTEP = 32 / NY;
+        const int qy = pt & (QY - 1), ky0 = pt / QY;
+        unsigned yoff[NY];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int k = ky0 + 4 * i;
+        for (int i = 0; i < NY; ++i) {
+            const int k = ky0 + KSTEP * i;
             const int tx = k & a.tw_mask, dr = k >> a.lg_tw;
             yoff[i] = (unsigned)((((2 * dr) * a.W + 2 * tx) * a.lddy + qy * 4) * 4);
         }
@@ -191,7 +200,7 @@ __global__ void __launch_bounds__(512) wwgrad_ws_kernel(const WWgradArgs a) {
         auto stage = [&](auto nr_tag, auto nc_tag) {
             constexpr int NR = decltype(nr_tag)::value, NC = decltype(nc_tag)::value, NL = NR * NC;
             f32x4 sx[4][4];         // [item][r1c1, r1c2, r2c1, r2c2]
-            f32x4 sy[8][NL];
+            f32x4 sy[NY][NL];
             auto load_tile = [&](int kt) {
                 const int R0 = kt * a.rows_per_kt;                   // global tile row (image * tile rows + ty) of the K tile
                 // pixel row 2 R0 - 1 + r, column -1 + c of the first tile: may lie before the tensor; never dereferenced there
@@ -242,14 +251,14 @@ __global__ void __launch_bounds__(512) wwgrad_ws_kernel(const WWgradArgs a) {
                     }
                     v[e] = t;
                 }
-                ww_store<ABL>(img + lds_y + i * 4 * WW_RSA, WW_ALIMB, v);
+                ww_store<ABL>(img + lds_y + i * KSTEP * WW_RSA, WW_ALIMB, v);
             };
             {
                 auto ld = load_tile(kt_beg);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) ld(TX{}, i);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) ld(TY{}, i);
+                for (int i = 0; i < NY; ++i) ld(TY{}, i);
             }
             for (int t = 0; t < nkt; ++t) {
                 unsigned char* img = smem + (t & 1) * WW_IMG;
@@ -269,7 +278,7 @@ __global__ void __launch_bounds__(512) wwgrad_ws_kernel(const WWgradArgs a) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
+                    for (int i = 0; i < NY; ++i) {
                         put_y(img, i);
                         __builtin_amdgcn_sched_barrier(0);
                         ld(TY{}, i);
@@ -279,7 +288,7 @@ __global__ void __launch_bounds__(512) wwgrad_ws_kernel(const WWgradArgs a) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) put_x(img, i);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) put_y(img, i);
+                    for (int i = 0; i < NY; ++i) put_y(img, i);
                 }
                 __syncthreads();        // tile t is in its image; everyone has left the other image (tile t - 1)
             }
@@ -302,16 +311,16 @@ __global__ void __launch_bounds__(512) wwgrad_ws_kernel(const WWgradArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int k = 4 * g + 16 * j + q;              // tile (K slot) of this lane's row in read j
-        a_base[j] = k * WW_RSA + (wr * 128 + 4 * p4) * 2;
+        a_base[j] = k * WW_RSA + (wr * (CO / 2) + 4 * p4) * 2;
         b_base[j] = 3 * WW_ALIMB + k * WW_RSB + (wc * 64 + 4 * p4) * 2;
     }
     auto frag = [&](const unsigned char* img, const int (&base)[2], int off) -> u32x4 {
         const u32x2 lo = lds_tr16(img + base[0] + off), hi = lds_tr16(img + base[1] + off);
         return u32x4{lo[0], lo[1], hi[0], hi[1]};
     };
-    f32x4v acc[8][4];
+    f32x4v acc[CB][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < CB; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
@@ -325,7 +334,7 @@ __global__ void __launch_bounds__(512) wwgrad_ws_kernel(const WWgradArgs a) {
             if (i > 0) {            // fragments of the first tile, read once: the MFMAs below run on whatever the registers hold
                 u32x4 f = frag(img, a_base, 0);
 #pragma unroll
-                for (int cb = 0; cb < 8; ++cb)
+                for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
                     for (int u = 0; u < 6; ++u)
 #pragma unroll
@@ -344,8 +353,8 @@ __global__ void __launch_bounds__(512) wwgrad_ws_kernel(const WWgradArgs a) {
 #pragma unroll
         for (int l = 0; l < 3; ++l) fa[0][l] = frag(img, a_base, l * WW_ALIMB);
 #pragma unroll
-        for (int cb = 0; cb < 8; ++cb) {
-            if (cb + 1 < 8) {
+        for (int cb = 0; cb < CB; ++cb) {
+            if (cb + 1 < CB) {
 #pragma unroll
                 for (int l = 0; l < 3; ++l) fa[(cb + 1) & 1][l] = frag(img, a_base, l * WW_ALIMB + (cb + 1) * 32);
             }
@@ -372,12 +381,12 @@ __global__ void __launch_bounds__(512) wwgrad_ws_kernel(const WWgradArgs a) {
     // C/D layout of the 16x16 MFMA: col (ci) = lane & 15, row (co) = 4*(lane >> 4) + v
     float* S = a.slabs + ((long long)split * 16 + pos) * a.cout * a.cin_total;
 #pragma unroll
-    for (int cb = 0; cb < 8; ++cb)
+    for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const int co = co0 + wr * 128 + cb * 16 + 4 * g + v;
+                const int co = co0 + wr * (CO / 2) + cb * 16 + 4 * g + v;
                 S[(long long)co * a.cin_total + ci_out + wc * 64 + nb * 16 + i16] = acc[cb][nb][v];
             }
 }
@@ -425,6 +434,8 @@ __global__ void __launch_bounds__(64) wwgrad_reduce_kernel(const float* __restri
     for (int e = 0; e < 9; ++e) out[e] = accumulate ? out[e] + alpha * o[e] : alpha * o[e];
 }
 
+inline int ww_co_tile(int cout) { return cout % 256 ? 128 : 256; }     // c_out per workgroup
+
 int ilog2(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;
@@ -434,15 +445,15 @@ int ilog2(int v) {
 }  // namespace
 
 extern "C" int psld_conv3x3_wgrad_wino_supported(int cout, int cin, int cin2, int batch, int h, int w) {
-    if (cout <= 0 || cin <= 0 || cin2 < 0 || batch <= 0 || cout % WW_CO || cin % WW_CI || cin2 % WW_CI) return 0;
+    if (cout <= 0 || cin <= 0 || cin2 < 0 || batch <= 0 || cout % 128 || cin % WW_CI || cin2 % WW_CI) return 0;
     if (h != w || !(w == 8 || w == 16 || w == 32 || w == 64)) return 0;
     return ((long long)batch * h * w / 4) % 32 == 0;
 }
 
 // K splits that fill the chip with one round of one-workgroup-per-CU tiles (0: shape not taken)
 extern "C" int psld_conv3x3_wgrad_wino_nsplit(int cout, int cin_total, int batch, int h, int w) {
-    if (cout % WW_CO || cin_total % WW_CI) return 0;
-    const int units = 16 * (cout / WW_CO) * (cin_total / WW_CI);
+    if (cout % 128 || cin_total % WW_CI) return 0;
+    const int units = 16 * (cout / ww_co_tile(cout)) * (cin_total / WW_CI);
     const long long ktiles = (long long)batch * h * w / 4 / 32;
     static int cus[PSLD_MAX_DEVICES] = {};
     int& n = cus[psld_device_slot()];
@@ -477,7 +488,8 @@ extern "C" int psld_conv3x3_wgrad_wino_f32(const float* dy, int lddy, int cout, 
     a.H = h; a.W = w;
     a.lg_tw = ilog2(w / 2); a.tw_mask = w / 2 - 1; a.th_mask = h / 2 - 1;
     a.rows_per_kt = 32 >> a.lg_tw;
-    a.cout_tiles = cout / WW_CO; a.cin_tiles = (cin + cin2) / WW_CI;
+    const int co_tile = ww_co_tile(cout);
+    a.cout_tiles = cout / co_tile; a.cin_tiles = (cin + cin2) / WW_CI;
     a.ktiles = (int)ktiles; a.ktiles_per_split = (int)per_split;
     a.slabs = slabs; a.cout = cout; a.cin_total = cin + cin2;
     a.pos_override = -1;
@@ -488,13 +500,13 @@ extern "C" int psld_conv3x3_wgrad_wino_f32(const float* dy, int lddy, int cout, 
     a.pos_override = pos_ov;
 #define WW_ABL_CASE(N)                                                                                                              \
     case N:                                                                                                                         \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wwgrad_ws_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WW_LDS); \
-        hipLaunchKernelGGL(wwgrad_ws_kernel<N>, grid, dim3(512), WW_LDS, stream, a);                                                \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wwgrad_ws_kernel<N, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WWGeom<256>::LDS); \
+        hipLaunchKernelGGL((wwgrad_ws_kernel<N, 256>), grid, dim3(512), WWGeom<256>::LDS, stream, a);                                \
         PSLD_CHECK_LAUNCH("wwgrad_ws_kernel (ablation)");                                                                           \
         launched = true;                                                                                                            \
         break;
     bool launched = false;
-    switch (abl) {
+    switch (co_tile == 256 ? abl : 0) {
         WW_ABL_CASE(1) WW_ABL_CASE(2) WW_ABL_CASE(3) WW_ABL_CASE(4) WW_ABL_CASE(8) WW_ABL_CASE(12) WW_ABL_CASE(16) WW_ABL_CASE(32) WW_ABL_CASE(64)
         default: break;
     }
@@ -504,14 +516,19 @@ extern "C" int psld_conv3x3_wgrad_wino_f32(const float* dy, int lddy, int cout, 
     {
     static PsldPerDeviceFlag configured_; bool& configured = configured_.here();
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wwgrad_ws_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WW_LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wwgrad_ws_kernel<0, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WWGeom<256>::LDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wwgrad_ws_kernel<0, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WWGeom<128>::LDS);
         if (e != hipSuccess) {
             psld_set_error("psld_conv3x3_wgrad_wino_f32: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
             return PSLD_ERR_LAUNCH;
         }
         configured = true;
     }
-    hipLaunchKernelGGL(wwgrad_ws_kernel<0>, grid, dim3(512), WW_LDS, stream, a);
+    if (co_tile == 256)
+        hipLaunchKernelGGL((wwgrad_ws_kernel<0, 256>), grid, dim3(512), WWGeom<256>::LDS, stream, a);
+    else
+        hipLaunchKernelGGL((wwgrad_ws_kernel<0, 128>), grid, dim3(512), WWGeom<128>::LDS, stream, a);
     PSLD_CHECK_LAUNCH("wwgrad_ws_kernel");
     }
     const long long n = (long long)cout * a.cin_total;

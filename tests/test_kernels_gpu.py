@@ -521,6 +521,8 @@ def test_wave_specialised_wgrad_on_short_k_ranges(ops, per):
     dict(b=1, c1=128, c2=0, co=256, h=64, w=64, nsplit=4),         # K tile = one tile row
     dict(b=3, c1=256, c2=128, co=256, h=32, w=32, nsplit=3),       # two sources of a concatenation, odd batch
     dict(b=2, c1=128, c2=128, co=512, h=16, w=16, nsplit=None),    # two c_out tiles
+    dict(b=1, c1=128, c2=0, co=128, h=64, w=64, nsplit=None),      # 128 output channels (CelebA-64's first level): 128 x 128 tiles
+    dict(b=2, c1=128, c2=128, co=384, h=32, w=32, nsplit=2),       # ... three of them, two sources
 ])
 def test_conv3x3_wgrad_winograd_domain(ops, cfg):
     """psld_conv3x3_wgrad_wino_f32 (wgrad_wino.hip): dU = sum over 2x2 tiles of (A dY A^T) (x) (B^T d B) on limb MFMAs, dw =

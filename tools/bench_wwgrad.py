@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--no-ref", action="store_true")
-    ap.add_argument("--shapes", default="256:0:256:32,256:256:256:32,256:0:256:16,256:256:256:16,128:0:256:32,256:128:256:32")
+    ap.add_argument("--shapes", default="256:0:256:32,256:256:256:32,256:0:256:16,256:256:256:16,128:0:256:32,256:128:256:32,128:0:128:64,128:128:128:64")
     args = ap.parse_args()
     B = args.batch
     ops.lib()
