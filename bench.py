@@ -421,6 +421,9 @@ def config_block(name, dev, batch, probe, steps=10, warmup=5):
     (CelebA-64: 6x64x64, ch_mult [1,2,2,2], 4 blocks per level) at the per-GPU batch, `warmup` + `steps` steps timed like the
     headline pass (wall clock between device fences, nothing inside), then the same steps with the 3x3 limb convolutions
     bracketed by HIP events for its own roofline fraction."""
+    from psld_amd import config as C, ops
+    from psld_amd.optim import EMAWeightUpdate
+    from psld_amd.registry import get_module
     cfg = getattr(C, name)()
     cfg.training.batch_size = batch
     size = cfg.data.image_size
