@@ -566,7 +566,7 @@ def psld_env():
 
 
 def refuse_ablations():
-    """Timing-only ablation modes compute wrong results by construction.  They exist only in libpsld_hip_abl.so (make abl),
+    """Timing-only ablation modes compute wrong results by construction.  They exist only in libpsld_hip_abl.so (make -C tools/abl),
     which tools/ab_*.sh load through PSLD_HIP_LIB; a benchmark line is never produced with them."""
     bad = [k for k in os.environ if k.startswith("PSLD_") and k.endswith("_ABL")]
     if "abl" in os.path.basename(os.environ.get("PSLD_HIP_LIB", "")):

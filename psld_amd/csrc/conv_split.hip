@@ -1905,7 +1905,7 @@ extern "C" int psld_conv3x3_wgrad_split_f32(const float* dy, int lddy, int cout,
     a.slab_stride = (long long)cout * 9 * cin_total;
     a.hw_w = (w < 32 ? w : 32) + 2;
     a.hrows = w >= 32 ? 1 : 32 / w;
-#ifdef PSLD_ABLATIONS      // timing-only variants (wrong results): libpsld_hip_abl.so only (make abl), never the product library
+#ifdef PSLD_ABLATIONS      // timing-only variants (wrong results): libpsld_hip_abl.so only (make -C tools/abl), never the product library
     static const int ws = [] { const char* v = getenv("PSLD_DWGRAD_WS"); return v ? atoi(v) : 1; }();
     if (!ws && co_tile == 128) return launch_dwgrad<4, false>(a, nsplit, stream);     // round 3's kernel, for A/B
     static const int abl = [] { const char* v = getenv("PSLD_DWGRAD_ABL"); return v ? atoi(v) : 0; }();

@@ -494,7 +494,7 @@ extern "C" int psld_conv3x3_wgrad_wino_f32(const float* dy, int lddy, int cout, 
     a.slabs = slabs; a.cout = cout; a.cin_total = cin + cin2;
     a.pos_override = -1;
     const dim3 grid((unsigned)(16 * a.cout_tiles * a.cin_tiles * nsplit));
-#ifdef PSLD_ABLATIONS      // timing-only variants (wrong results): libpsld_hip_abl.so only (make abl), never the product library
+#ifdef PSLD_ABLATIONS      // timing-only variants (wrong results): libpsld_hip_abl.so only (make -C tools/abl), never the product library
     static const int abl = [] { const char* v = getenv("PSLD_WWGRAD_ABL"); return v ? atoi(v) : 0; }();
     static const int pos_ov = [] { const char* v = getenv("PSLD_WWGRAD_POS"); return v ? atoi(v) : -1; }();
     a.pos_override = pos_ov;

@@ -12,4 +12,10 @@ wgrad)      # weight gradients of the 3x3 convolutions: direct limb kernels (rou
     echo "direct weight gradients (PSLD_WGRAD_WINOGRAD=0)"; step PSLD_WGRAD_WINOGRAD=0
     echo "Winograd-domain weight gradients (default)"; step PSLD_WGRAD_WINOGRAD=1
   done ;;
+level8)     # the 8x8 level in Winograd form (forward / data gradient and, with fp32 activations, the weight gradient)
+  for r in 1 2 3; do
+    echo "default policies"; step PSLD_X=1
+    echo "8x8 level forward / dgrad in Winograd form, its weight gradients direct (PSLD_WINOGRAD=2)"; step PSLD_WINOGRAD=2
+    echo "8x8 level forward / dgrad AND weight gradients in Winograd form (PSLD_WINOGRAD=2 PSLD_WGRAD_WINOGRAD=2)"; step PSLD_WINOGRAD=2 PSLD_WGRAD_WINOGRAD=2
+  done ;;
 esac

@@ -1,5 +1,5 @@
 """Diagnostic (libpsld_hip_abl.so): time stamps inside gn_bwd_fused_kernel and its timing-only modes.
-    PSLD_HIP_LIB=psld_amd/libpsld_hip_abl.so python tools/gnb_stamps.py [B size C [mode]]
+    PSLD_HIP_LIB=tools/abl/libpsld_hip_abl.so python tools/gnb_stamps.py [B size C [mode]]
 mode: bit 0 delay odd workgroups by (mode >> 8) x 3.4 us, bit 1 no reduction, bit 2 no stores."""
 import ctypes
 import os

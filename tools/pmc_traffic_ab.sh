@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the Winograd launch under both tile orders (PSLD_WINO_NMAJOR=1 default | 0): two counter-only passes each
 set -u
-export PSLD_HIP_LIB=${GRAFT_REPO_ROOT:-/root/repo}/psld_amd/libpsld_hip_abl.so   # PSLD_WINO_NMAJOR exists only in the ablation library (make abl)
+export PSLD_HIP_LIB=${GRAFT_REPO_ROOT:-/root/repo}/tools/abl/libpsld_hip_abl.so   # PSLD_WINO_NMAJOR exists only in the ablation library (make -C tools/abl)
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/r03
 mkdir -p $OUT

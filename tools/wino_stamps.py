@@ -1,6 +1,6 @@
 """Diagnostic (libpsld_hip_abl.so, PSLD_WINO_ABL=64): s_memtime stamps inside chunk 3 of wino_conv8s_kernel - how long a
 wave spends in its transform block, its MFMA block and at the two barriers of a chunk.
-    PSLD_HIP_LIB=psld_amd/libpsld_hip_abl.so PSLD_WINO_ABL=64 python tools/wino_stamps.py [cin cout size batch]"""
+    PSLD_HIP_LIB=tools/abl/libpsld_hip_abl.so PSLD_WINO_ABL=64 python tools/wino_stamps.py [cin cout size batch]"""
 import ctypes
 import os
 import sys
