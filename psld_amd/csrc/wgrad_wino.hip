@@ -130,6 +130,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t brsrc(const float* p) {
 // after the first tile.  Measured (profiles/r06/wwgrad_ablations.txt, 256->256 @32 B=128, kernel + reduction 381 us): consumers
 // alone 298, producers alone 277, no split 326, no global loads 274; s_setprio(3) for the consumers 377-382 (nothing): the two
 // roles share each SIMD's vector issue port, and what the producers cost beyond the consumers' own pace is that sharing.
+// A form of the consumers on v_mfma_f32_32x32x16_bf16 (half as many MFMAs to issue; unpadded rows with the 64-byte granules
+// swizzled by row & 3 for its 4-row transposed reads) was built and was bitwise-level correct on the eight test shapes:
+// 372.5 -> 364.8 us on 256->256 @32, 713 -> 712 on 512->256 @32, 461 -> 437 on 128->128 @64, +-0 on the 16x16 level
+// (profiles/r06/wwgrad_mfma32.txt) - not the lever; removed again.
 template <int ABL = 0, int CO = 256>
 __global__ void __launch_bounds__(512) wwgrad_ws_kernel(const WWgradArgs a) {
     using G = WWGeom<CO>;
