@@ -19,6 +19,7 @@ tested in this container (tests/test_ddp_cpu.py).
 from __future__ import annotations
 
 import collections
+import datetime
 
 import os
 from typing import List, Optional, Tuple
@@ -71,16 +72,21 @@ def _rendezvous(rank: int, world: int, timeout_s: float):
 
 
 def init_distributed(backend: Optional[str] = None, force: bool = False,
-                     timeout_s: Optional[float] = None) -> Tuple[int, int, int]:
+                     timeout_s: Optional[float] = None, pg_timeout_s: Optional[float] = None) -> Tuple[int, int, int]:
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun); returns (rank, local_rank, world).
     ``force`` creates the process group even for world size 1.  ``timeout_s`` (default PSLD_DIST_TIMEOUT_S or 180)
-    bounds the rendezvous - a rank that never joins raises ``RendezvousTimeout`` naming it - and every later collective
-    (the process group's watchdog aborts a rank stuck in one)."""
+    bounds the RENDEZVOUS - a rank that never joins raises ``RendezvousTimeout`` naming it.  ``pg_timeout_s`` (default
+    PSLD_PG_TIMEOUT_S or 600, never below the rendezvous timeout) is the process group's watchdog for every later
+    collective: its own, more generous value (rank-0-only work such as a checkpoint on a slow filesystem, or
+    uneven sampling shards in front of a barrier, must not trip a 3-minute watchdog)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if timeout_s is None:
         timeout_s = float(os.environ.get("PSLD_DIST_TIMEOUT_S", "180"))
+    if pg_timeout_s is None:
+        pg_timeout_s = float(os.environ.get("PSLD_PG_TIMEOUT_S", "600"))
+    pg_timeout_s = max(pg_timeout_s, timeout_s)
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
@@ -99,7 +105,7 @@ def init_distributed(backend: Optional[str] = None, force: bool = False,
             # Work._get_duration(): BucketReducer(profile=True) reads the time each collective occupied the process
             # group's stream from it (start / end events the group records itself)
             os.environ.setdefault("TORCH_NCCL_ENABLE_TIMING", "1")
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout,
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=pg_timeout_s),
                                 store=dist.PrefixStore("psld/pg", store))
     return rank, local, world
 

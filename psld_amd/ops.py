@@ -794,11 +794,13 @@ class Arena:
         self.off = 0
         self.high = 0
         self.retired = []       # outgrown buffers: alive until the next reset (pending tables hold raw pointers into them)
+        self.pinned = False     # a captured hipGraph holds raw pointers into buf: outgrown buffers then stay alive for good
 
     def reset(self):
         self.high = max(self.high, self.off)
         self.off = 0
-        self.retired = []
+        if not self.pinned:
+            self.retired = []
 
     def alloc(self, nbytes: int) -> Tensor:
         nbytes = (int(nbytes) + 255) & ~255
@@ -825,13 +827,17 @@ class TableCache:
     def __init__(self, limit: int = 64):
         self.limit = limit
         self.tabs = {}
+        self.pinned = False     # a captured hipGraph holds raw pointers to these tables: no eviction from then on
 
     def get(self, rows, device) -> Tensor:
         key = hash(tuple(rows))
         ent = self.tabs.get(key)
         if ent is not None and ent[0] == rows:
             return ent[1]
-        if len(self.tabs) >= self.limit:
+        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("psld_amd: a job table is missing while a hipGraph is being captured (its upload is a synchronous "
+                               "copy); run the eager warm-up steps on the same shapes first")
+        if len(self.tabs) >= self.limit and not self.pinned:
             self.tabs.pop(next(iter(self.tabs)))
         t = torch.tensor(rows, dtype=torch.int64, device=device)
         self.tabs[key] = (list(rows), t)

@@ -34,7 +34,8 @@ class FusedAdam(torch.optim.Optimizer):
             self._m = torch.zeros_like(flat)
             self._v = torch.zeros_like(flat)
             self._norm = torch.zeros(1, dtype=torch.float64, device=flat.device)
-            ops.gn_team_sync(flat.device)      # the error word the kernels are guarded by: exists before any capture
+            if flat.is_cuda:
+                ops.gn_team_sync(flat.device)      # the error word the kernels are guarded by: exists before any capture
         return flat
 
     @property

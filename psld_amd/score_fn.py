@@ -385,7 +385,10 @@ class _Exec:
             ops.copy_batch(net._tables.get(rows, dwcat.device), len(pend), first)
         else:
             for o, c, d0 in pend:
-                ops.gemm_tn_split(c, kd, b, dtp_all[:, o:o + c], total, act, kd, self.g(d0.weight), kd, 1)
+                if o % 4 == 0 and ops.gemm_tn_split_supported(c, kd, b):          # 16-byte aligned column slice
+                    ops.gemm_tn_split(c, kd, b, dtp_all[:, o:o + c], total, act, kd, self.g(d0.weight), kd, 1)
+                else:
+                    ops.gemm_raw(1, 0, c, kd, b, dtp_all[:, o:o + c], total, 0, act, kd, 0, self.g(d0.weight), kd, 0)
 
     def flush_deferred(self):
         self.on_side(self.flush_slabs)
@@ -1623,6 +1626,13 @@ class NCSNpp(nn.Module):
         self._conv_by_weight = {}
         self._side = None
 
+    def pin_scratch(self):
+        """A captured hipGraph replays raw pointers into the parameter / slab arenas and the cached job tables: keep every
+        buffer they ever pointed to alive (outgrown arena buffers are retained, tables are not evicted)."""
+        self._param_arena().pinned = True
+        self._slab_arena().pinned = True
+        self._tables.pinned = True
+
     def _param_arena(self) -> "ops.Arena":
         dev = self._params()[0].device
         if self._parena is None or self._parena.device != dev:
@@ -2124,6 +2134,7 @@ class NCSNpp(nn.Module):
             with torch.cuda.graph(graph), torch.no_grad():
                 sy = _Exec(self, record=False).run(sx, st)
             ent = self._graphs[key] = [graph, sx, st, sy, None]
+            self.pin_scratch()       # the graph holds raw pointers into arenas / job tables: no eviction, no freeing from now on
         graph, sx, st, sy, stamp = ent
         now = (self._epoch, self._flat._version)
         if stamp != now:

@@ -187,6 +187,9 @@ class SDEWrapper(_Base):
                 sde.check_nan = check_nan
                 net._dropout_seed_dev = None
             ent["graph"], ent["loss"] = graph, loss.detach()
+            # the graph holds raw pointers into the network's arenas and job tables: from now on an arena
+            # that has to grow keeps its old buffer alive and the table cache does not evict
+            net.pin_scratch()
         optim._step += 1                    # after a successful capture: a failed one leaves the step count alone
         ent["graph"].replay()
         optim._after_step()

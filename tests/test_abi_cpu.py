@@ -88,7 +88,7 @@ def test_product_switches_are_the_documented_ones():
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     listed = set(re.findall(r"^\| `(PSLD_[A-Z0-9_]+)`", doc, flags=re.M))
     assert found == listed, (sorted(found - listed), sorted(listed - found))
-    kernel_or_policy = found - {"PSLD_HIP_LIB", "PSLD_DIST_TIMEOUT_S", "PSLD_GRAPHS"}
+    kernel_or_policy = found - {"PSLD_HIP_LIB", "PSLD_DIST_TIMEOUT_S", "PSLD_PG_TIMEOUT_S", "PSLD_GRAPHS"}
     assert len(kernel_or_policy) <= 10, sorted(kernel_or_policy)
     n_getenv = sum(open(f).read().count("getenv(") for f in glob.glob(os.path.join(ROOT, "psld_amd", "csrc", "*.hip")))
     assert n_getenv <= 12, n_getenv

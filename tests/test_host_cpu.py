@@ -215,6 +215,18 @@ def test_arena_and_table_cache_keep_addresses_stable():
     t2 = t.get([5, 6], dev)
     t.get([7, 8], dev)                                                      # evicts the oldest entry
     assert len(t.tabs) == 2 and t.get([5, 6], dev) is t2 and t.get(rows, dev) is not t1
+    # once a hipGraph holds raw pointers into them (NCSNpp.pin_scratch): outgrown arena buffers stay alive, tables are not evicted
+    a.pinned = True
+    old = a.buf
+    a.alloc(4 * a.buf.numel())
+    a.reset()
+    assert a.retired and a.retired[0] is old
+    t.pinned = True
+    kept = [t.get([5, 6], dev), t.get(rows, dev)]
+    n0 = len(t.tabs)
+    t.get([9, 9], dev)
+    t.get([10, 10], dev)
+    assert len(t.tabs) == n0 + 2 > t.limit and t.get([5, 6], dev) is kept[0] and t.get(rows, dev) is kept[1]
     # job rows: pointer arithmetic and the float bit pattern of alpha
     src = torch.zeros(8, 6)
     dst = torch.zeros(6)
