@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 
-#define PSLD_ABI_VERSION 14 /* 2: limb-MFMA convolutions, math mode, bias-gradient / batched-copy entry points; 3: pointwise weight gradient and batched activation GEMM on limb kernels; 4: GroupNorm statistics from the limb kernels' epilogue; 5: per-sample-time reverse SDE, ScoreLoss nll / l1; 6: limb-plane activations; 7: device-resident dropout seed / Adam scalars (captured training step), GroupNorm-backward sums from the producing epilogue; 8: Winograd F(2x2,3x3) limb convolution; 9: launch tape; 10: GroupNorm apply (+SiLU) fused into the Winograd convolution's input staging; 11: GroupNorm backward kernel selector; 12: column sums of dx from the GroupNorm backward; 13: GroupNorm backward returns per-image sums (dgamma / dbeta / bias gradients and split-K slab reductions of a whole backward pass in batched launches), the GroupNorm-backward by-product of the limb epilogue and the launch tape (9) removed; 14: the optimiser kernels take the device error word (a refused step is a no-op + NaN loss) */
+#define PSLD_ABI_VERSION 14 /* 2: limb-MFMA convolutions, math mode, bias-gradient / batched-copy entry points; 3: pointwise weight gradient and batched activation GEMM on limb kernels; 4: GroupNorm statistics from the limb kernels' epilogue; 5: per-sample-time reverse SDE, ScoreLoss nll / l1; 6: limb-plane activations; 7: device-resident dropout seed / Adam scalars (captured training step), GroupNorm-backward sums from the producing epilogue; 8: Winograd F(2x2,3x3) limb convolution; 9: launch tape; 10: GroupNorm apply (+SiLU) fused into the Winograd convolution's input staging; 11: GroupNorm backward kernel selector; 12: column sums of dx from the GroupNorm backward; 13: GroupNorm backward returns per-image sums (dgamma / dbeta / bias gradients and split-K slab reductions of a whole backward pass in batched launches), the GroupNorm-backward by-product of the limb epilogue and the launch tape (9) removed; 14: the optimiser kernels take the device error word (a refused step is a no-op + NaN loss), Winograd-domain 3x3 weight gradient (psld_conv3x3_wgrad_wino_*) */
 #define PSLD_COEFF_STRIDE 12
 
 int psld_version(void);
