@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 
 PEAK = 8.0e12
 SOURCES = ["psld_amd/csrc/norm_act.hip", "psld_amd/csrc/resample.hip", "psld_amd/csrc/pointwise.hip", "psld_amd/csrc/optim.hip",
-           "psld_amd/csrc/sde.hip", "psld_amd/csrc/common.h", "psld_amd/score_fn.py"]
+           "psld_amd/csrc/sde.hip", "psld_amd/csrc/wgrad_wino.hip", "psld_amd/csrc/common.h", "psld_amd/score_fn.py"]
 
 # entry point -> (family, bytes(args))
 def _b(fam, fn):
@@ -47,6 +47,8 @@ BYTES = {
     "psld_colsum_f32": _b("bias_grad", lambda a: 4 * a[2] * a[3] * a[4]),
     "psld_bias_grad_f32": _b("bias_grad", lambda a: 4 * a[2] * a[3] * a[4]),
     "psld_reduce_slabs_f32": _b("reduce_slabs", lambda a: 4 * a[2] * (a[1] + 1)),
+    # Winograd-domain weight gradient: only its reduction kernel is bandwidth-bound (16 positions x nsplit slabs in, OIHW out)
+    "psld_conv3x3_wgrad_wino_f32": _b("reduce_slabs", lambda a: 4 * a[2] * (a[4] + a[6]) * (16 * a[11] + 9)),
     "psld_copy2d_f32": _b("copy2d", lambda a: (8 + (4 if a[6] else 0)) * a[4] * a[5]),
     "psld_scale_copy2d_f32": _b("copy2d", lambda a: 8 * a[4] * a[5]),
     "psld_softmax_rows_f32": _b("softmax", lambda a: 8 * a[2] * a[3]),
@@ -65,7 +67,7 @@ BYTES = {
 KERNELS = [
     ("gn_apply_limb_kernel", "gn_apply_limb"), ("gn_apply_kernel", "gn_apply"), ("gn_partial_kernel", "gn_stats"),
     ("gn_finalize_kernel", "gn_stats"), ("gn_bwd_", "gn_bwd"), ("upfirdn", "fir"), ("axpby_kernel", "axpby"),
-    ("silu_", "silu"), ("colsum", "bias_grad"), ("bias_grad", "bias_grad"), ("reduce_slabs", "reduce_slabs"), ("param_reduce", "param_reduce"),
+    ("silu_", "silu"), ("colsum", "bias_grad"), ("bias_grad", "bias_grad"), ("reduce_slabs", "reduce_slabs"), ("wwgrad_reduce", "reduce_slabs"), ("param_reduce", "param_reduce"),
     ("scale_copy2d", "copy2d"), ("copy2d_kernel", "copy2d"), ("softmax_rows", "softmax"), ("nchw_to_nhwc", "layout"),
     ("nhwc_to_nchw", "layout"), ("perturb_kernel", "perturb"), ("perturb_coeffs", "perturb"), ("sqerr", "sqerr"),
     ("adam_ema_kernel", "adam"), ("ema_kernel", "ema"), ("sumsq", "grad_norm"), ("f32_to_limb", "limb_convert"),

@@ -1,4 +1,4 @@
-"""HBM traffic per launch of the dominant convolution from rocprofv3 PMC passes -> profiles/r05/pmc_traffic.json
+"""HBM traffic per launch of the dominant convolution from rocprofv3 PMC passes -> profiles/r06/pmc_traffic.json
 (read by bench.py for roofline.traffic, which refuses it once the kernel sources change).  Round 3: the dominant launch
 is the Winograd kernel (wino_conv8s_kernel); the direct kernel and the weight gradient are recorded next to it.
 
@@ -81,7 +81,7 @@ def main():
                        ("dwgrad", "dwgrad_kernel<4> 256->256 @32x32 B=128")):
         if tag in fetch and tag in write:
             rec[label] = {"fetch_bytes_corrected": fetch[tag][0] * 2048, "write_bytes": write[tag][0] * 1024}
-    path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r05", "pmc_traffic.json")
+    path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r06", "pmc_traffic.json")
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "w") as fh:
         json.dump(rec, fh, indent=1)
