@@ -1,0 +1,10 @@
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+step() { env "$@" python3 bench.py --steps 30 --warmup 5 --sample-batch 0 --no-cpu-baseline --no-probe --no-forward --no-config-block $EXTRA 2> /dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.readlines()[-1]); print('  %.1f img/s %.2f ms/step' % (d['value'], d['ms_per_step']))"; }
+for b in 16 32 64; do
+for r in 1 2; do
+  echo "B=$b direct"; EXTRA="--batch $b" step PSLD_WGRAD_WINOGRAD=0
+  echo "B=$b winograd-domain (policy)"; EXTRA="--batch $b" step PSLD_WGRAD_WINOGRAD=1
+  echo "B=$b winograd-domain (forced)"; EXTRA="--batch $b" step PSLD_WGRAD_WINOGRAD=2
+done; done

@@ -34,7 +34,7 @@ rm -rf $OUT/hbm_prof_f
 cp $OUT/hbm_in_situ.json $OUT/hbm_in_situ.md $OUT/hbm_in_situ_forward.json $OUT/hbm_in_situ_forward.md $OUT/hbm_step_kernel_stats.csv $OUT/hbm_forward_kernel_stats.csv $P/ 2>/dev/null
 if [ "$MODE" != "hbm" ]; then
 # 4. per-kernel totals of the bench's training steps (headline pass + probed pass: 2 + 6 + 6 steps) and of the sampling forward
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_step -o step -- python3 $ROOT/bench.py --steps 6 --warmup 2 --sample-batch 0 --no-cpu-baseline --no-forward > $OUT/bench_train_b128_profiled_run.json 2> $OUT/prof_step.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_step -o step -- python3 $ROOT/bench.py --steps 6 --warmup 2 --sample-batch 0 --no-cpu-baseline --no-forward --no-config-block > $OUT/bench_train_b128_profiled_run.json 2> $OUT/prof_step.err
 find $OUT/prof_step -name "*kernel_stats.csv" -exec cp {} $OUT/bench_train_b128_kernel_stats.csv \;
 rm -rf $OUT/prof_step
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_sample -o sample -- python3 $ROOT/tools/profile_sample.py > $OUT/prof_sample.log 2>&1
