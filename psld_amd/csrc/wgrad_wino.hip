@@ -21,8 +21,8 @@
 // Shape of the kernel (the skeleton of dwgrad_ws_kernel, conv_split.hip):
 //   512 threads, one workgroup per CU, 156 KB of LDS = two images of { dY-side [3 limbs][32 tiles][256 ch], x-side [3][32][128] };
 //   waves 4-7 (producers): per K tile of 32 Winograd tiles, thread = (tile, channel quad) items - 4 x-items of 4 loads, 8
-//     dY-items of 1 / 2 / 4 loads - combine, split3, ds_write_b64 per limb into the NEXT image; the loads of the next group of
-//     items are in flight while a group is combined and split;
+//     dY-items of 1 / 2 / 4 loads - combine, split3, ds_write_b64 per limb into the NEXT image; every item has a register slot
+//     that is refilled with the same item of the tile after as soon as it is consumed (a whole K tile for a load to land);
 //   waves 0-3 (consumers): 128 (c_out) x 64 (c_in) each = 8 x 4 blocks of v_mfma_f32_16x16x32_bf16 x 6 limb products = 192 MFMAs
 //     per K tile on transposed fragment reads (ds_read_b64_tr_b16, k slot = tile 4g + 16j + q as in dwgrad_kernel), 128
 //     accumulator registers;
@@ -128,12 +128,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t brsrc(const float* p) {
 // (raw halves stored), 2 = no global loads (the slots keep their first contents), 4 = no MFMAs, 8 = no fragment reads, 16 = the
 // product kernel with PSLD_WWGRAD_POS honoured, 32 = consumers only keep the barriers, 64 = producers only keep the barriers
 // after the first tile.  Measured (profiles/r06/wwgrad_ablations.txt, 256->256 @32 B=128, kernel + reduction 381 us): consumers
-// alone 298, producers alone 277, no split 326, no global loads 274; s_setprio(3) for the consumers 377-382 (nothing): the two
-// roles share each SIMD's vector issue port, and what the producers cost beyond the consumers' own pace is that sharing.
-// A form of the consumers on v_mfma_f32_32x32x16_bf16 (half as many MFMAs to issue; unpadded rows with the 64-byte granules
-// swizzled by row & 3 for its 4-row transposed reads) was built and was bitwise-level correct on the eight test shapes:
-// 372.5 -> 364.8 us on 256->256 @32, 713 -> 712 on 512->256 @32, 461 -> 437 on 128->128 @64, +-0 on the 16x16 level
-// (profiles/r06/wwgrad_mfma32.txt) - not the lever; removed again.
+// alone 298, producers alone 277, no split 326, no global loads 274; s_setprio(3) for the consumers 377-382 (nothing).  Either
+// role alone runs near its own floor (the consumers at the clock the chip holds under MFMA load, the producers at their VALU +
+// the 64 B/clk L2->L1 path: 192 KB of loads per K tile for a centre position); together they share each SIMD's issue port, the
+// LDS and one barrier per K tile.  A form of the consumers on v_mfma_f32_32x32x16_bf16 (half as many MFMAs to issue; unpadded
+// rows with the 64-byte granules swizzled by row & 3 for its 4-row transposed reads) passed the parity tests on the eight
+// shapes: 372.5 -> 364.8 us on 256->256 @32, 713 -> 712 on 512->256 @32, 461 -> 437 on 128->128 @64, +-0 on the 16x16 level
+// (profiles/r06/wwgrad_mfma32.txt) - the issue port alone is not the lever; removed again.
 template <int ABL = 0, int CO = 256>
 __global__ void __launch_bounds__(512) wwgrad_ws_kernel(const WWgradArgs a) {
     using G = WWGeom<CO>;
