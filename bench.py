@@ -72,10 +72,10 @@ class ConvProbe:
             flops = 2.0 * x1.shape[0] * x1.shape[1] * x1.shape[2] * cout * 9 * cin
             timed("split", flops, lambda: probe.orig_split(x1, x2, wfrag, cout, y, epi, ldy))
 
-        def wino(x1, x2, ufrag, cout, y, epi=None, ldy=None):
+        def wino(x1, x2, ufrag, cout, y, epi=None, ldy=None, **kw):
             cin = x1.shape[-1] + (x2.shape[-1] if x2 is not None else 0)
             flops = 2.0 * x1.shape[0] * x1.shape[1] * x1.shape[2] * cout * 9 * cin      # direct-convolution (algorithmic) count
-            timed("wino", flops, lambda: probe.orig_wino(x1, x2, ufrag, cout, y, epi, ldy))
+            timed("wino", flops, lambda: probe.orig_wino(x1, x2, ufrag, cout, y, epi, ldy, **kw))
 
         def tile(x1, x2, w, cout, kh, kw, stride, pad, tstride, oh, ow, y, epi=None, ldy=None):
             cin = x1.shape[-1] + (x2.shape[-1] if x2 is not None else 0)

@@ -157,6 +157,16 @@ int psld_pack_wino_batch(const long long* table_dev, int entries, long long tota
 int psld_conv3x3_wino_f32(const float* x1, int c1, const float* x2, int c2, int batch, int h, int w,
                           const void* ufrag, int cout, float* y, int ldy, const psld_epilogue_t* epi,
                           hipStream_t stream);
+/* The same with a workspace for small grids (one workgroup per CU: a launch below half a round - the 8x8 level at training
+ * batches - leaves CUs idle): the channel chunks are split over psld_conv3x3_wino_ksplit workgroups per tile, plain partial
+ * outputs go to the workspace (psld_conv3x3_wino_ws_bytes) and one reduction pass applies the epilogue, as
+ * psld_conv3x3_split_f32 does for such shapes.  Without a workspace, with ksplit == 1 or with epi->gn_part set it is
+ * psld_conv3x3_wino_f32. */
+int psld_conv3x3_wino_ksplit(int c1, int c2, int batch, int h, int w, int cout);
+long long psld_conv3x3_wino_ws_bytes(int c1, int c2, int batch, int h, int w, int cout);
+int psld_conv3x3_wino_ws_f32(const float* x1, int c1, const float* x2, int c2, int batch, int h, int w,
+                             const void* ufrag, int cout, float* y, int ldy, const psld_epilogue_t* epi,
+                             void* workspace, long long ws_bytes, hipStream_t stream);
 /* The same convolution applied to act(GroupNorm(x)) without materialising it: x1 / x2 are the RAW tensors, scale* /
  * shift* the per-(image, channel) rows psld_gn_stats_nhwc_f32 / psld_gn_stats_from_partials_f32 produce ([batch][c1],
  * [batch][c2]; a two-source input is normalised per source, as the executor's concat-free up path does), act = 1: SiLU.

@@ -93,6 +93,9 @@ SIGNATURES = {
     "psld_pack_conv3x3_wino": (I, [P, P, I, I, I, P]),
     "psld_pack_wino_batch": (I, [P, I, LL, P]),
     "psld_conv3x3_wino_f32": (I, [P, I, P, I, I, I, I, P, I, P, I, EP, P]),
+    "psld_conv3x3_wino_ksplit": (I, [I, I, I, I, I, I]),
+    "psld_conv3x3_wino_ws_bytes": (LL, [I, I, I, I, I, I]),
+    "psld_conv3x3_wino_ws_f32": (I, [P, I, P, I, I, I, I, P, I, P, I, EP, P, LL, P]),
     "psld_conv3x3_wino_gn_supported": (I, [I, I, I, I, I, I]),
     "psld_conv3x3_wino_gn_f32": (I, [P, I, P, P, P, I, P, P, I, I, I, I, P, I, P, I, EP, P]),
     "psld_gn_apply_limb_nhwc": (I, [P, P, P, P, I, I, I, I, F, C.c_ulonglong, P, P]),

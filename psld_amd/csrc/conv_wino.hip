@@ -61,6 +61,10 @@ struct WinoArgs {
     int gn_act;
     unsigned long long* dbg;    // ablation library: s_memtime stamps of one chunk (ABL & 64), [workgroup][wave][8]
     int lg_tiles_x, lg_tps; // wino_conv8p_kernel: log2 of the tiles per tile row (cw / 2) and per image segment
+    // wino_conv8s_kernel, small grids (round 6): the channel chunks split over ksplit workgroups per tile, each writing its plain
+    // partial output to C + split * slab_stride (no epilogue); psld_detail_conv_reduce_epilogue sums them.  ksplit = 0 / 1: off
+    int ksplit;
+    long long slab_stride;
 };
 
 // raw halo image: pixel hp, 16-byte slot q (4 channels) -> byte offset.  Pixels sit pairwise in 256-byte rows and the
@@ -184,8 +188,14 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArg
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_n = a.N >> 7;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tiles_m = (int)gridDim.x / tiles_n;
+    const int nsp = a.ksplit > 1 ? a.ksplit : 1;
+    const int per_range = (int)gridDim.x / nsp;                  // workgroups of one channel-chunk range
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = vb / per_range;
+    const int bid = vb - split * per_range;
+    const int kch = a.chunks / nsp, ch0 = split * kch;           // this workgroup's chunks [ch0, ch0 + kch)
+    float* const Cw = a.C + split * a.slab_stride;
+    const int tiles_m = per_range / tiles_n;
     const int tile_n = a.nmajor ? bid / tiles_m : bid % tiles_n;
     const int tile_m = a.nmajor ? bid - tile_n * tiles_m : bid / tiles_n;
     const int n0 = tile_n * 128;
@@ -302,7 +312,7 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArg
         aoff[tb] = row * ROWB + ((kq ^ lds_swz(row)) << 4);
     }
     // ABL & 128 (timing only, wrong results): SIMD partners w, w + 4 stream the SAME fragments - what the L1 merges
-    const u32x4* ub = a.ufrag + ((long long)(tile_n * 8 + ((ABL & 128) ? (wave & 3) : wave)) * a.chunks) * (16 * 3 * 64);      // wave-uniform
+    const u32x4* ub = a.ufrag + ((long long)(tile_n * 8 + ((ABL & 128) ? (wave & 3) : wave)) * a.chunks + ch0) * (16 * 3 * 64);      // wave-uniform
     u32x4 bq[4][3];
     auto load_b = [&](int sigma, u32x4 (&dst)[3]) {
         const u32x4* p = ub + (long long)sigma * (3 * 64);
@@ -360,12 +370,12 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArg
     // "Two waves per SIMD" item 4): 454 -> 443 us on 256->256 @32x32, 206 -> 201 us on 512->256 @16x16 (ABL & 4 switches it off).
     if constexpr ((ABL & 4) == 0 && (ABL & 256) == 0) { if (vr != 0) __builtin_amdgcn_s_setprio(1); }
 
-    load_raw(0);
+    load_raw(ch0);
     load_b(0, bq[0]);
     load_b(1, bq[1]);
     if (LA > 2) load_b(2, bq[2]);
-    store_raw(0, 0);
-    if constexpr (ERAW) load_raw(min(1, a.chunks - 1));
+    store_raw(0, ch0);
+    if constexpr (ERAW) load_raw(ch0 + min(1, kch - 1));
     __syncthreads();
     if (vr == 0) transform(I0{}, I0{}, 0); else transform(I0{}, I1{}, 0);      // V rows 0,1 of chunk 0
     __syncthreads();
@@ -381,10 +391,10 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArg
             }
         }
     };
-    for (int c = 0; c < a.chunks; ++c) {
+    for (int c = 0; c < kch; ++c) {
         // HP0: MFMAs on V rows 0,1 of chunk c || V rows 2,3 of chunk c (raw image c & 1)
         stamp(c, 0);
-        if constexpr (!ERAW) load_raw(min(c + 1, a.chunks - 1));
+        if constexpr (!ERAW) load_raw(ch0 + min(c + 1, kch - 1));
         if (vr == 0 && !(ABL & 1)) transform(I1{}, I0{}, c & 1);             // waves 0-3: transform, then MFMAs
         __builtin_amdgcn_sched_barrier(0);
         if (vr == 0) stamp(c, 1);
@@ -393,7 +403,7 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArg
         if (vr != 0) stamp(c, 1);
         if (vr != 0 && !(ABL & 1)) transform(I1{}, I1{}, c & 1);             // waves 4-7: MFMAs, then transform
         stamp(c, 2);
-        store_raw((c + 1) & 1, min(c + 1, a.chunks - 1));
+        store_raw((c + 1) & 1, ch0 + min(c + 1, kch - 1));
         stamp(c, 3);
         __syncthreads();
         // HP1: MFMAs on V rows 2,3 of chunk c || V rows 0,1 of chunk c + 1 (raw image (c + 1) & 1; stale for the last chunk)
@@ -404,7 +414,7 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArg
         mfma_half(I1{}, c);
         __builtin_amdgcn_sched_barrier(0);
         if (vr != 0) stamp(c, 5);
-        if constexpr (ERAW) load_raw(min(c + 2, a.chunks - 1));
+        if constexpr (ERAW) load_raw(ch0 + min(c + 2, kch - 1));
         if (vr != 0 && !(ABL & 1)) transform(I0{}, I1{}, (c + 1) & 1);
         stamp(c, 6);
         __syncthreads();
@@ -444,7 +454,7 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArg
             for (int xb = 0; xb < 2; ++xb) {
                 const int gm = gmc + ya * a.W + xb;
                 rv[ya][xb] = e.res ? *reinterpret_cast<const f32x4v*>(e.res + (long long)gm * e.ldres + cn) : zero4;
-                cv[ya][xb] = e.accumulate ? *reinterpret_cast<const f32x4v*>(a.C + (long long)gm * a.ldc + cn) : zero4;
+                cv[ya][xb] = e.accumulate ? *reinterpret_cast<const f32x4v*>(Cw + (long long)gm * a.ldc + cn) : zero4;
                 tbv[ya][xb] = e.rowbias ? *reinterpret_cast<const f32x4v*>(e.rowbias + (long long)(gm / e.rows_per_img) * e.ld_rowbias + cn)
                                         : zero4;
             }
@@ -458,7 +468,7 @@ __global__ void __launch_bounds__(WINO_THREADS) wino_conv8s_kernel(const WinoArg
                 o *= e.out_scale;
                 if (e.accumulate) o += cv[ya][xb];
                 if (ok && !((ABL & 8) && gm != 0)) {
-                    *reinterpret_cast<f32x4v*>(a.C + (long long)gm * a.ldc + cn) = o;
+                    *reinterpret_cast<f32x4v*>(Cw + (long long)gm * a.ldc + cn) = o;
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         gs += o[v];
@@ -514,7 +524,7 @@ int launch_wino8s(const WinoArgs& a, hipStream_t stream, const char* name) {
         }
         configured = true;
     }
-    dim3 grid((unsigned)(cdiv(a.M, 128) * (a.N / 128)));
+    dim3 grid((unsigned)(cdiv(a.M, 128) * (a.N / 128) * (a.ksplit > 1 ? a.ksplit : 1)));
     hipLaunchKernelGGL((wino_conv8s_kernel<ABL, GNF, ERAW, LA>), grid, dim3(WINO_THREADS), LDS, stream, a);
     PSLD_CHECK_LAUNCH(name);
     return PSLD_OK;
@@ -598,13 +608,34 @@ struct WinoGn {
     int act;
 };
 int wino_conv(const float* x1, int c1, const float* x2, int c2, int batch, int h, int w, const void* ufrag, int cout, float* y,
-              int ldy, const psld_epilogue_t* epi, const WinoGn* gn, hipStream_t stream);
+              int ldy, const psld_epilogue_t* epi, const WinoGn* gn, void* workspace, long long ws_bytes, hipStream_t stream);
 }  // namespace
 
 extern "C" int psld_conv3x3_wino_f32(const float* x1, int c1, const float* x2, int c2, int batch, int h, int w,
                                      const void* ufrag, int cout, float* y, int ldy, const psld_epilogue_t* epi,
                                      hipStream_t stream) {
-    return wino_conv(x1, c1, x2, c2, batch, h, w, ufrag, cout, y, ldy, epi, nullptr, stream);
+    return wino_conv(x1, c1, x2, c2, batch, h, w, ufrag, cout, y, ldy, epi, nullptr, nullptr, 0, stream);
+}
+
+// K splits a launch of this shape takes when it is given a workspace (1: none) and the bytes that workspace needs
+extern "C" int psld_conv3x3_wino_ksplit(int c1, int c2, int batch, int h, int w, int cout) {
+    if (!psld_conv3x3_wino_supported(c1, c2, batch, h, w, cout)) return 1;
+    const int tiles = cdiv((long long)batch * h * w, 128) * (cout / 128), chunks = (c1 + c2) / 32;
+    const int cus = wino_cu_count();
+    int ks = 1;
+    // one workgroup per CU: a grid below half a round leaves CUs idle - split the channel chunks so that it fills one round
+    while (tiles * ks * 2 <= cus && chunks % (ks * 2) == 0 && chunks / (ks * 2) >= 2) ks *= 2;
+    return ks;
+}
+extern "C" long long psld_conv3x3_wino_ws_bytes(int c1, int c2, int batch, int h, int w, int cout) {
+    const int ks = psld_conv3x3_wino_ksplit(c1, c2, batch, h, w, cout);
+    return ks > 1 ? (long long)ks * batch * h * w * cout * 4 : 0;
+}
+
+extern "C" int psld_conv3x3_wino_ws_f32(const float* x1, int c1, const float* x2, int c2, int batch, int h, int w,
+                                        const void* ufrag, int cout, float* y, int ldy, const psld_epilogue_t* epi,
+                                        void* workspace, long long ws_bytes, hipStream_t stream) {
+    return wino_conv(x1, c1, x2, c2, batch, h, w, ufrag, cout, y, ldy, epi, nullptr, workspace, ws_bytes, stream);
 }
 
 extern "C" int psld_conv3x3_wino_gn_supported(int c1, int c2, int batch, int h, int w, int cout) {
@@ -621,12 +652,12 @@ extern "C" int psld_conv3x3_wino_gn_f32(const float* x1, int c1, const float* sc
     PSLD_CHECK_ARG(aligned16(scale1) && aligned16(shift1) && (c2 == 0 || (aligned16(scale2) && aligned16(shift2))),
                    "psld_conv3x3_wino_gn_f32: unaligned scale / shift");
     const WinoGn gn{scale1, shift1, scale2, shift2, act};
-    return wino_conv(x1, c1, x2, c2, batch, h, w, ufrag, cout, y, ldy, epi, &gn, stream);
+    return wino_conv(x1, c1, x2, c2, batch, h, w, ufrag, cout, y, ldy, epi, &gn, nullptr, 0, stream);
 }
 
 namespace {
 int wino_conv(const float* x1, int c1, const float* x2, int c2, int batch, int h, int w, const void* ufrag, int cout, float* y,
-              int ldy, const psld_epilogue_t* epi, const WinoGn* gn, hipStream_t stream) {
+              int ldy, const psld_epilogue_t* epi, const WinoGn* gn, void* workspace, long long ws_bytes, hipStream_t stream) {
     PSLD_CHECK_ARG(x1 && ufrag && y && (c2 == 0 || x2), "psld_conv3x3_wino_f32: null pointer");
     PSLD_CHECK_ARG(psld_conv3x3_wino_supported(c1, c2, batch, h, w, cout),
                    "psld_conv3x3_wino_f32: unsupported shape c1=%d c2=%d %dx%d cout=%d", c1, c2, h, w, cout);
@@ -659,6 +690,21 @@ int wino_conv(const float* x1, int c1, const float* x2, int c2, int batch, int h
     if (gn) {
         a.gsc1 = gn->sc1; a.gsh1 = gn->sh1; a.gsc2 = gn->sc2; a.gsh2 = gn->sh2; a.gn_act = gn->act;
         return launch_wino8s<0, true>(a, stream, "psld_conv3x3_wino_gn_f32");
+    }
+    // Small grids (the 8x8 level at training batches: 128 workgroups for 256 CUs): split the channel chunks over ksplit
+    // workgroups per tile, plain partial outputs into the workspace, summed + the whole epilogue by conv_reduce_epilogue -
+    // what the direct kernels do for the same shapes.  GroupNorm partial sums are not formed on this route.
+    const int ks = workspace ? psld_conv3x3_wino_ksplit(c1, c2, batch, h, w, cout) : 1;
+    if (ks > 1 && !e.gn_part && ws_bytes >= (long long)ks * a.M * cout * 4 && aligned16(workspace)) {
+        WinoArgs s = a;
+        s.ksplit = ks;
+        s.slab_stride = (long long)a.M * cout;
+        s.C = reinterpret_cast<float*>(workspace);
+        s.ldc = cout;
+        s.e = make_epilogue(nullptr);
+        const int rc = launch_wino8s<0>(s, stream, name);
+        if (rc != PSLD_OK) return rc;
+        return psld_detail_conv_reduce_epilogue(s.C, ks, a.M, cout, y, ldy, e, stream);
     }
 #ifdef PSLD_ABLATIONS      // libpsld_hip_abl.so only: the variants of conv_wino_abl.inc and the timing-only ablations (wrong results)
 #include "conv_wino_abl_dispatch.inc"

@@ -220,12 +220,13 @@ def set_winograd(mode: Optional[int]):
 
 
 @functools.lru_cache(maxsize=None)
-def conv3x3_wino_wanted(c1: int, c2: int, b: int, h: int, w: int, cout: int) -> bool:
+def conv3x3_wino_wanted(c1: int, c2: int, b: int, h: int, w: int, cout: int, split_ok: bool = False) -> bool:
     """Policy (limb-MFMA math mode only - the caller checks that): does a 3x3 stride-1 convolution of this shape run in
     Winograd F(2x2, 3x3) form?  By default (``PSLD_WINOGRAD=1``) when the kernel takes the shape and the grid has at least
-    384 workgroups (smaller grids - the 8x8 level at training batch sizes, everything at batch 16 - run faster on the
-    direct kernels, which can split their K range and leave room for a second resident workgroup); ``PSLD_WINOGRAD=0`` restores the direct limb kernels everywhere, ``=2`` takes every supported
-    shape (parity tests at small batches).  The environment is read once; set_winograd() overrides it."""
+    384 workgroups, or - ``split_ok``: a training pass with no weight-gradient side stream beside it - when splitting the
+    channel chunks makes it one full round (round 6: the 8x8 level at B=128; conv3x3_wino(allow_split=True));
+    ``PSLD_WINOGRAD=0`` restores the direct limb kernels everywhere, ``=2`` takes every supported shape (parity tests at small
+    batches).  The environment is read once; set_winograd() overrides it."""
     mode = _WINO_MODE if _WINO_MODE is not None else int(os.environ.get("PSLD_WINOGRAD", "1"))
     if mode == 0 or not conv3x3_wino_supported(c1, c2, b, h, w, cout):
         return False
@@ -233,8 +234,17 @@ def conv3x3_wino_wanted(c1: int, c2: int, b: int, h: int, w: int, cout: int) -> 
     # (32x32 level, batch 16) the step is 3 % SLOWER than with the direct kernels - a workgroup per CU leaves no room
     # for the weight-gradient kernels of the side stream that small batches overlap with - from 512 on it is 7-16 % faster;
     # the 8x8 level at batch 128 (128 workgroups, no side stream there): 213 vs 184-192 TFLOP/s per launch, but the step is
-    # 0.5 % slower (985.5 / 988.9 / 987.4 vs 993.0 / 992.2 / 992.0 images/s: its weight gradients lose the limb-plane input)
-    return mode == 2 or (b * h * w // 128) * (cout // 128) >= 384
+    # 0.5 % slower (985.5 / 988.9 / 987.4 vs 993.0 / 992.2 / 992.0 images/s: its weight gradients lose the limb-plane input).
+    # Round 6: with the chunks of such a launch split over two workgroups per tile (256 workgroups: one full round) and the
+    # weight gradients of fp32 activations in the Winograd domain the 8x8 level in Winograd form is +1.6-2.2 % on the step
+    # (profiles/r06/ab_level8_winograd_split.txt).
+    tiles = (b * h * w // 128) * (cout // 128)
+    if mode == 2 or tiles >= 384:
+        return True
+    if not split_ok:
+        return False
+    ks = int(lib().psld_conv3x3_wino_ksplit(c1, c2, b, h, w, cout))
+    return ks > 1 and tiles * ks >= 256
 
 
 @functools.lru_cache(maxsize=None)
@@ -281,13 +291,29 @@ def conv3x3_wino_gn(x1: Tensor, st1: "GNStats", x2: Optional[Tensor], st2: Optio
 
 
 def conv3x3_wino(x1: Tensor, x2: Optional[Tensor], ufrag: Tensor, cout: int, y: Tensor,
-                 epi: Optional[Epilogue] = None, ldy: Optional[int] = None):
-    """conv3x3_split in Winograd F(2x2, 3x3) form (fp32 NHWC input(s), fragments of conv3x3_wino_frag)."""
+                 epi: Optional[Epilogue] = None, ldy: Optional[int] = None, allow_split: bool = False):
+    """conv3x3_split in Winograd F(2x2, 3x3) form (fp32 NHWC input(s), fragments of conv3x3_wino_frag).  ``allow_split``: a launch
+    whose grid leaves CUs idle may split its channel chunks over workgroups (another summation order: the training pass asks
+    for it, the inference forward - bitwise the GroupNorm-fused kernel - does not)."""
     b, h, w, c1 = x1.shape
     c2 = x2.shape[-1] if x2 is not None else 0
+    wsb = conv3x3_wino_ws_bytes(c1, c2, b, h, w, cout) if allow_split else 0
+    if wsb and (epi is None or not epi.gn_part):
+        # a small grid (the 8x8 level at training batches): channel chunks split over workgroups, one reduction + epilogue pass
+        ws = workspace(wsb, x1.device)
+        check(lib().psld_conv3x3_wino_ws_f32(x1.data_ptr(), c1, _p(x2), c2, b, h, w, ufrag.data_ptr(), cout, y.data_ptr(),
+                                             ldy if ldy is not None else cout, C.byref(epi) if epi is not None else None,
+                                             ws.data_ptr(), wsb, _stream()), "psld_conv3x3_wino_ws_f32")
+        return
     check(lib().psld_conv3x3_wino_f32(x1.data_ptr(), c1, _p(x2), c2, b, h, w, ufrag.data_ptr(), cout, y.data_ptr(),
                                       ldy if ldy is not None else cout, C.byref(epi) if epi is not None else None,
                                       _stream()), "psld_conv3x3_wino_f32")
+
+
+@functools.lru_cache(maxsize=None)
+def conv3x3_wino_ws_bytes(c1: int, c2: int, b: int, h: int, w: int, cout: int) -> int:
+    """Workspace of the split-chunk route of conv3x3_wino for this shape (0: the launch fills the chip by itself)."""
+    return int(lib().psld_conv3x3_wino_ws_bytes(c1, c2, b, h, w, cout))
 
 
 class LimbPlanes:
@@ -441,7 +467,8 @@ def set_wgrad_winograd(mode: Optional[int]):
 def conv3x3_wgrad_wino_wanted(cout: int, cin: int, cin2: int, b: int, h: int, w: int) -> bool:
     """Policy (limb-MFMA math mode, fp32 x - the caller checks both): does the weight gradient of a 3x3 stride-1 convolution
     run in the Winograd domain (wgrad_wino.hip)?  ``PSLD_WGRAD_WINOGRAD=1`` (default): when the kernel takes the shape and
-    every K split holds at least 16 K tiles (measured on MI355X, tools/bench_wwgrad.py: x1.40-1.47 on the 32x32 level, x1.23-
+    every K split holds at least 8 K tiles (at B=128 that is every layer of the 32x32 / 16x16 levels, and of the 8x8 level now
+    that its activations are fp32: forced on there the step gains another 0.6 %) (measured on MI355X, tools/bench_wwgrad.py: x1.40-1.47 on the 32x32 level, x1.23-
     1.37 on the 16x16 level at B=128; short K ranges are prologue + epilogue); ``=0``: the direct limb kernels everywhere;
     ``=2``: every supported shape (parity tests at small batches)."""
     mode = _WGRAD_WINO_MODE if _WGRAD_WINO_MODE is not None else int(os.environ.get("PSLD_WGRAD_WINOGRAD", "1"))
@@ -450,7 +477,7 @@ def conv3x3_wgrad_wino_wanted(cout: int, cin: int, cin2: int, b: int, h: int, w:
     if mode == 2:
         return True
     ns, _ = conv3x3_wgrad_wino_plan(cout, cin + cin2, b, h, w)
-    return h >= 16 and (b * h * w // 128) // ns >= 16
+    return (b * h * w // 128) // ns >= 8
 
 
 @functools.lru_cache(maxsize=None)

@@ -543,13 +543,18 @@ class _Exec:
         ops.colsum(tmp, c, 1, b, c, out, alpha)
         return tmp
 
+    def wino_wanted(self, c1: int, c2: int, b: int, h: int, w: int, cout: int) -> bool:
+        """ops.conv3x3_wino_wanted for this pass: a training pass without a weight-gradient side stream may also take the launches
+        that fill the chip only with their channel chunks split over workgroups (the 8x8 level at B=128)."""
+        return ops.conv3x3_wino_wanted(c1, c2, b, h, w, cout, bool(self.record and self.side is None))
+
     def conv3(self, x: Tensor, conv: _Affine, out: Tensor, epi, x2: Optional[Tensor] = None):
         """3x3 stride-1 pad-1 convolution of an NHWC tensor (or of the channel concatenation of x and x2)."""
         b, h, w, c = x.shape
         c2 = x2.shape[-1] if x2 is not None else 0
         cout = conv.weight.shape[0]
-        if self.split and not isinstance(x, ops.LimbPlanes) and ops.conv3x3_wino_wanted(c, c2, b, h, w, cout):
-            ops.conv3x3_wino(x, x2, self.net._wfrag(conv, False), cout, out, epi)       # Winograd F(2x2, 3x3)
+        if self.split and not isinstance(x, ops.LimbPlanes) and self.wino_wanted(c, c2, b, h, w, cout):
+            ops.conv3x3_wino(x, x2, self.net._wfrag(conv, False), cout, out, epi, allow_split=self.record)   # Winograd F(2x2, 3x3)
         elif self.split and ops.conv3x3_split_supported(c, c2, b, h, w, cout):
             ops.conv3x3_split(x, x2, self.net._frag(conv, False), cout, out, epi)
         else:
@@ -616,8 +621,8 @@ class _Exec:
         cin = conv.weight.shape[1]
         epi = ops.epilogue(alpha=alpha, accumulate=accumulate) if (alpha != 1.0 or accumulate) else None
         if self.split and k == 3 and stride == 1 and pad == 1 and \
-                ops.conv3x3_wino_wanted(dy.shape[-1], 0, dy.shape[0], ih, iw, cin):
-            ops.conv3x3_wino(dy, None, self.net._wfrag(conv, True), cin, out, epi)      # Winograd F(2x2, 3x3)
+                self.wino_wanted(dy.shape[-1], 0, dy.shape[0], ih, iw, cin):
+            ops.conv3x3_wino(dy, None, self.net._wfrag(conv, True), cin, out, epi, allow_split=True)     # Winograd F(2x2, 3x3)
             return
         if self.split and k == 3 and stride == 1 and pad == 1 and \
                 ops.conv3x3_split_supported(dy.shape[-1], 0, dy.shape[0], ih, iw, cin):
@@ -756,11 +761,11 @@ class _Exec:
         ho_, wo_ = (h // 2, w // 2) if down else ((h * 2, w * 2) if up else (h, w))
         c2_ = cin - c1
         # (a convolution that runs in Winograd form transforms fp32 input itself: its producer writes plain fp32)
-        lp0 = self.split and self.limb_planes and not (up or down) and not ops.conv3x3_wino_wanted(c1, c2_, b, h, w, cout) and \
+        lp0 = self.split and self.limb_planes and not (up or down) and not self.wino_wanted(c1, c2_, b, h, w, cout) and \
             ops.conv3x3_split_supported(c1, c2_, b, h, w, cout) and \
             (not self.record or (ops.conv3x3_wgrad_split_supported(cout, c1, b, h, w) and
                                  (c2_ == 0 or ops.conv3x3_wgrad_split_supported(cout, c2_, b, h, w))))
-        lp1 = self.split and self.limb_planes and not ops.conv3x3_wino_wanted(cout, 0, b, ho_, wo_, cout) and \
+        lp1 = self.split and self.limb_planes and not self.wino_wanted(cout, 0, b, ho_, wo_, cout) and \
             ops.conv3x3_split_supported(cout, 0, b, ho_, wo_, cout) and \
             (not self.record or ops.conv3x3_wgrad_split_supported(cout, cout, b, ho_, wo_))
         apply0 = ops.gn_apply_limb if lp0 else ops.gn_apply
@@ -959,8 +964,8 @@ class _Exec:
         m = b * h * w
         c1 = xa.v.shape[-1]
         cin = c1 + xb.v.shape[-1]
-        wino = self.split and ops.conv3x3_wino_wanted(cout, 0, b, h, w, c1) and \
-            ops.conv3x3_wino_wanted(cout, 0, b, h, w, cin - c1)
+        wino = self.split and self.wino_wanted(cout, 0, b, h, w, c1) and \
+            self.wino_wanted(cout, 0, b, h, w, cin - c1)
         # [cin/128 tiles][...]: data gradient of the 3x3 (Winograd fragments carry 16 KB of read-ahead padding at the end)
         f3 = net._wfrag(mod.Conv_0, True) if wino else net._frag(mod.Conv_0, True)
         f1 = net._pfrag(c2.weight, "dgrad", cin, cout, 1, cin)  # same for the shortcut
@@ -974,7 +979,7 @@ class _Exec:
             ops.gemm_split(dout, None, m, fr1, c, xg, ops.epilogue(alpha=s, accumulate=acc))
             da0 = torch.empty_like(node.v)
             if wino:
-                ops.conv3x3_wino(dh1, None, fr3, c, da0)
+                ops.conv3x3_wino(dh1, None, fr3, c, da0, allow_split=True)
             else:
                 ops.conv3x3_split(dh1, None, fr3, c, da0)
             self.gn_backward(da0, node.v, st, gam[lo:hi], bet[lo:hi], dgam[lo:hi], dbet[lo:hi], True, xg,

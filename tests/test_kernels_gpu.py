@@ -277,6 +277,44 @@ WINO_FWD = [
 ]
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(b=128, c1=256, c2=0, co=256, h=8, w=8),     # the 8x8 level at the training batch: 128 tiles -> 2 chunk ranges
+    dict(b=64, c1=256, c2=256, co=256, h=8, w=8),    # two sources, 64 tiles -> 4 ranges
+    dict(b=3, c1=256, c2=256, co=256, h=16, w=16),   # 12 tiles -> 8 ranges of two chunks
+    dict(b=7, c1=256, c2=0, co=256, h=32, w=32),     # 112 tiles -> 2 ranges
+])
+def test_conv3x3_wino_split_chunks(ops, cfg):
+    """psld_conv3x3_wino_ws_f32 (round 6): a launch whose grid leaves CUs idle splits its channel chunks over workgroups (plain
+    partial outputs + one reduction pass with the whole epilogue) - against fp64 with the full epilogue at the unsplit kernel's
+    tolerance, next to the unsplit launch on the same inputs (another summation order: close, not bitwise), with `accumulate`,
+    and repeatable bit for bit."""
+    b, c1, c2, co, h, w_ = (cfg[n] for n in ("b", "c1", "c2", "co", "h", "w"))
+    assert ops.conv3x3_wino_ws_bytes(c1, c2, b, h, w_, co) > 0
+    x = gen(b, c1 + c2, h, w_, seed=40)
+    w = gen(co, c1 + c2, 3, 3, seed=41, scale=0.1)
+    bias, res, temb = gen(co, seed=42), gen(b, co, h, w_, seed=43), gen(b, co, seed=44)
+    ref = (F.conv2d(x.double(), w.double(), bias.double(), padding=1) + temb.double()[:, :, None, None] + res.double()) * 0.7
+    x1 = _nhwc(x[:, :c1]).to(DEV)
+    x2 = _nhwc(x[:, c1:]).to(DEV) if c2 else None
+    uf = ops.conv3x3_wino_frag(w.to(DEV), False)
+    epi = ops.epilogue(bias=bias.to(DEV), rowbias=temb.to(DEV), rows_per_img=h * w_, residual=_nhwc(res).to(DEV),
+                       ld_residual=co, out_scale=0.7)
+    y0 = torch.full((b, h, w_, co), float("nan"), device=DEV)
+    ops.conv3x3_wino(x1, x2, uf, co, y0, epi)
+    y1 = torch.full_like(y0, float("nan"))
+    ops.conv3x3_wino(x1, x2, uf, co, y1, epi, allow_split=True)
+    e0, e1 = rel_l2(y0.permute(0, 3, 1, 2), ref), rel_l2(y1.permute(0, 3, 1, 2), ref)
+    print(f"unsplit {e0:.2e} split {e1:.2e}")
+    assert e1 < 3e-6 and e1 < 2.0 * max(e0, 2e-7) and not torch.equal(y0, y1)
+    y2 = torch.full_like(y0, float("nan"))
+    ops.conv3x3_wino(x1, x2, uf, co, y2, epi, allow_split=True)
+    assert torch.equal(y1, y2)
+    acc = torch.ones_like(y0)
+    ops.conv3x3_wino(x1, x2, uf, co, acc, ops.epilogue(alpha=0.5, accumulate=True), allow_split=True)
+    plain = F.conv2d(x.double(), w.double(), padding=1) * 0.5 + 1.0
+    assert rel_l2(acc.permute(0, 3, 1, 2), plain) < 3e-6
+
+
 @pytest.mark.parametrize("cfg", WINO_FWD)
 def test_conv3x3_wino_forward(ops, cfg):
     """psld_conv3x3_wino_f32 against fp64 torch with the full epilogue (bias, time-embedding row bias, residual, scale),
