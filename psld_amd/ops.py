@@ -222,29 +222,25 @@ def set_winograd(mode: Optional[int]):
 @functools.lru_cache(maxsize=None)
 def conv3x3_wino_wanted(c1: int, c2: int, b: int, h: int, w: int, cout: int, split_ok: bool = False) -> bool:
     """Policy (limb-MFMA math mode only - the caller checks that): does a 3x3 stride-1 convolution of this shape run in
-    Winograd F(2x2, 3x3) form?  By default (``PSLD_WINOGRAD=1``) when the kernel takes the shape and the grid has at least
-    384 workgroups, or - ``split_ok``: a training pass with no weight-gradient side stream beside it - when splitting the
-    channel chunks makes it one full round (round 6: the 8x8 level at B=128; conv3x3_wino(allow_split=True));
-    ``PSLD_WINOGRAD=0`` restores the direct limb kernels everywhere, ``=2`` takes every supported shape (parity tests at small
-    batches).  The environment is read once; set_winograd() overrides it."""
+    Winograd F(2x2, 3x3) form?  By default (``PSLD_WINOGRAD=1``) when the kernel takes the shape and the launch is at least
+    ONE full round of its one-workgroup-per-CU grid - counting, in a training pass (``split_ok``), the workgroups its channel
+    chunks can be split over (conv3x3_wino(allow_split=True); the inference forward does not split: it stays bitwise the
+    GroupNorm-fused kernel).  ``PSLD_WINOGRAD=0`` restores the direct limb kernels everywhere, ``=2`` takes every supported
+    shape (parity tests at small batches).  The environment is read once; set_winograd() overrides it.
+
+    History of the threshold: rounds 3-5 asked for 384 workgroups - at 256 (32x32 level, batch 16) the step was 3 % slower than
+    with the direct kernels, because a workgroup per CU left no room for the direct weight-gradient kernels that small batches
+    overlap on the side stream.  Round 6 moved the weight gradients into the Winograd domain (one workgroup per CU themselves)
+    and split small launches over their chunks; re-measured on MI355X (profiles/r06/ab_small_batches_*.txt): every shape in
+    Winograd form against the old rule +16 % at B=16, +4 % at B=32, +8 % at B=64, +2 % at B=128 (the 8x8 level)."""
     mode = _WINO_MODE if _WINO_MODE is not None else int(os.environ.get("PSLD_WINOGRAD", "1"))
     if mode == 0 or not conv3x3_wino_supported(c1, c2, b, h, w, cout):
         return False
-    # >= 384 workgroups (one per CU, 160 KB of LDS each: 1.5 rounds).  Measured (tools/ab_wino_batches.sh): at 256 workgroups
-    # (32x32 level, batch 16) the step is 3 % SLOWER than with the direct kernels - a workgroup per CU leaves no room
-    # for the weight-gradient kernels of the side stream that small batches overlap with - from 512 on it is 7-16 % faster;
-    # the 8x8 level at batch 128 (128 workgroups, no side stream there): 213 vs 184-192 TFLOP/s per launch, but the step is
-    # 0.5 % slower (985.5 / 988.9 / 987.4 vs 993.0 / 992.2 / 992.0 images/s: its weight gradients lose the limb-plane input).
-    # Round 6: with the chunks of such a launch split over two workgroups per tile (256 workgroups: one full round) and the
-    # weight gradients of fp32 activations in the Winograd domain the 8x8 level in Winograd form is +1.6-2.2 % on the step
-    # (profiles/r06/ab_level8_winograd_split.txt).
-    tiles = (b * h * w // 128) * (cout // 128)
-    if mode == 2 or tiles >= 384:
+    if mode == 2:
         return True
-    if not split_ok:
-        return False
-    ks = int(lib().psld_conv3x3_wino_ksplit(c1, c2, b, h, w, cout))
-    return ks > 1 and tiles * ks >= 256
+    tiles = (b * h * w // 128) * (cout // 128)
+    ks = int(lib().psld_conv3x3_wino_ksplit(c1, c2, b, h, w, cout)) if split_ok else 1
+    return tiles * ks >= 256
 
 
 @functools.lru_cache(maxsize=None)
@@ -596,9 +592,10 @@ def gn_part_width(c: int) -> int:
 @functools.lru_cache(maxsize=None)
 def gn_part_supported(b: int, hw: int, c: int) -> bool:
     """Can a limb kernel's epilogue produce the GroupNorm partial sums of its [b, hw, c] output?  (Whole 64-row
-    runs per image, groups made of 4- or 8-channel fine groups, and a grid large enough that the kernel does not split
-    its K range.)"""
-    return hw % 64 == 0 and c % 128 == 0 and (c // gn_groups(c)) % 4 == 0 and ((b * hw + 127) // 128) * (c // 128) >= 384
+    runs per image, groups made of 4- or 8-channel fine groups, and a grid of at least one full round of workgroups: such a
+    launch runs unsplit - in Winograd form by conv3x3_wino_wanted's rule - whereas smaller ones split their K range and finish
+    through a reduction pass that forms no sums.)"""
+    return hw % 64 == 0 and c % 128 == 0 and (c // gn_groups(c)) % 4 == 0 and ((b * hw + 127) // 128) * (c // 128) >= 256
 
 
 def gn_part_buffer(b: int, hw: int, c: int, device) -> Tensor:

@@ -544,9 +544,9 @@ class _Exec:
         return tmp
 
     def wino_wanted(self, c1: int, c2: int, b: int, h: int, w: int, cout: int) -> bool:
-        """ops.conv3x3_wino_wanted for this pass: a training pass without a weight-gradient side stream may also take the launches
-        that fill the chip only with their channel chunks split over workgroups (the 8x8 level at B=128)."""
-        return ops.conv3x3_wino_wanted(c1, c2, b, h, w, cout, bool(self.record and self.side is None))
+        """ops.conv3x3_wino_wanted for this pass: a training pass also takes the launches that fill the chip only with their
+        channel chunks split over workgroups (the 8x8 level at B=128, the 16x16 level at B=16)."""
+        return ops.conv3x3_wino_wanted(c1, c2, b, h, w, cout, bool(self.record))
 
     def conv3(self, x: Tensor, conv: _Affine, out: Tensor, epi, x2: Optional[Tensor] = None):
         """3x3 stride-1 pad-1 convolution of an NHWC tensor (or of the channel concatenation of x and x2)."""
