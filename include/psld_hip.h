@@ -180,6 +180,12 @@ int psld_conv3x3_wino_gn_f32(const float* x1, int c1, const float* scale1, const
                              const float* scale2, const float* shift2, int act, int batch, int h, int w,
                              const void* ufrag, int cout, float* y, int ldy, const psld_epilogue_t* epi,
                              hipStream_t stream);
+/* ... with the workspace of psld_conv3x3_wino_ws_f32: small grids split their channel chunks the same way (bitwise the
+ * unfused psld_gn_apply + psld_conv3x3_wino_ws_f32 pair). */
+int psld_conv3x3_wino_gn_ws_f32(const float* x1, int c1, const float* scale1, const float* shift1, const float* x2,
+                                int c2, const float* scale2, const float* shift2, int act, int batch, int h, int w,
+                                const void* ufrag, int cout, float* y, int ldy, const psld_epilogue_t* epi,
+                                void* workspace, long long ws_bytes, hipStream_t stream);
 
 /* "Limb planes": an NHWC activation [rows][c] (c a multiple of 32) stored already decomposed, as bf16
  * [rows][c/32 chunks][3 limbs hi|mid|lo][32 channels] (6 bytes per element; hi + mid + lo == x bit for bit).  The

@@ -98,6 +98,7 @@ SIGNATURES = {
     "psld_conv3x3_wino_ws_f32": (I, [P, I, P, I, I, I, I, P, I, P, I, EP, P, LL, P]),
     "psld_conv3x3_wino_gn_supported": (I, [I, I, I, I, I, I]),
     "psld_conv3x3_wino_gn_f32": (I, [P, I, P, P, P, I, P, P, I, I, I, I, P, I, P, I, EP, P]),
+    "psld_conv3x3_wino_gn_ws_f32": (I, [P, I, P, P, P, I, P, P, I, I, I, I, P, I, P, I, EP, P, LL, P]),
     "psld_gn_apply_limb_nhwc": (I, [P, P, P, P, I, I, I, I, F, C.c_ulonglong, P, P]),
     "psld_limb_bytes": (LL, [LL, I]),
     "psld_f32_to_limb": (I, [P, LL, I, P, P]),

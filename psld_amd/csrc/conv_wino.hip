@@ -655,6 +655,19 @@ extern "C" int psld_conv3x3_wino_gn_f32(const float* x1, int c1, const float* sc
     return wino_conv(x1, c1, x2, c2, batch, h, w, ufrag, cout, y, ldy, epi, &gn, nullptr, 0, stream);
 }
 
+extern "C" int psld_conv3x3_wino_gn_ws_f32(const float* x1, int c1, const float* scale1, const float* shift1, const float* x2,
+                                           int c2, const float* scale2, const float* shift2, int act, int batch, int h, int w,
+                                           const void* ufrag, int cout, float* y, int ldy, const psld_epilogue_t* epi,
+                                           void* workspace, long long ws_bytes, hipStream_t stream) {
+    PSLD_CHECK_ARG(scale1 && shift1 && (c2 == 0 || (scale2 && shift2)), "psld_conv3x3_wino_gn_ws_f32: null scale / shift");
+    PSLD_CHECK_ARG(psld_conv3x3_wino_gn_supported(c1, c2, batch, h, w, cout),
+                   "psld_conv3x3_wino_gn_ws_f32: unsupported shape c1=%d c2=%d %dx%d cout=%d (needs h*w >= 128)", c1, c2, h, w, cout);
+    PSLD_CHECK_ARG(aligned16(scale1) && aligned16(shift1) && (c2 == 0 || (aligned16(scale2) && aligned16(shift2))),
+                   "psld_conv3x3_wino_gn_ws_f32: unaligned scale / shift");
+    const WinoGn gn{scale1, shift1, scale2, shift2, act};
+    return wino_conv(x1, c1, x2, c2, batch, h, w, ufrag, cout, y, ldy, epi, &gn, workspace, ws_bytes, stream);
+}
+
 namespace {
 int wino_conv(const float* x1, int c1, const float* x2, int c2, int batch, int h, int w, const void* ufrag, int cout, float* y,
               int ldy, const psld_epilogue_t* epi, const WinoGn* gn, void* workspace, long long ws_bytes, hipStream_t stream) {
@@ -689,11 +702,11 @@ int wino_conv(const float* x1, int c1, const float* x2, int c2, int batch, int h
     }
     if (gn) {
         a.gsc1 = gn->sc1; a.gsh1 = gn->sh1; a.gsc2 = gn->sc2; a.gsh2 = gn->sh2; a.gn_act = gn->act;
-        return launch_wino8s<0, true>(a, stream, "psld_conv3x3_wino_gn_f32");
     }
     // Small grids (the 8x8 level at training batches: 128 workgroups for 256 CUs): split the channel chunks over ksplit
     // workgroups per tile, plain partial outputs into the workspace, summed + the whole epilogue by conv_reduce_epilogue -
-    // what the direct kernels do for the same shapes.  GroupNorm partial sums are not formed on this route.
+    // what the direct kernels do for the same shapes.  GroupNorm partial sums are not formed on this route.  The GroupNorm-
+    // fused form splits the same way (same chunk ranges, same reduction: bitwise the unfused pair).
     const int ks = workspace ? psld_conv3x3_wino_ksplit(c1, c2, batch, h, w, cout) : 1;
     if (ks > 1 && !e.gn_part && ws_bytes >= (long long)ks * a.M * cout * 4 && aligned16(workspace)) {
         WinoArgs s = a;
@@ -702,10 +715,11 @@ int wino_conv(const float* x1, int c1, const float* x2, int c2, int batch, int h
         s.C = reinterpret_cast<float*>(workspace);
         s.ldc = cout;
         s.e = make_epilogue(nullptr);
-        const int rc = launch_wino8s<0>(s, stream, name);
+        const int rc = gn ? launch_wino8s<0, true>(s, stream, "psld_conv3x3_wino_gn_f32") : launch_wino8s<0>(s, stream, name);
         if (rc != PSLD_OK) return rc;
         return psld_detail_conv_reduce_epilogue(s.C, ks, a.M, cout, y, ldy, e, stream);
     }
+    if (gn) return launch_wino8s<0, true>(a, stream, "psld_conv3x3_wino_gn_f32");
 #ifdef PSLD_ABLATIONS      // libpsld_hip_abl.so only: the variants of conv_wino_abl.inc and the timing-only ablations (wrong results)
 #include "conv_wino_abl_dispatch.inc"
 #endif

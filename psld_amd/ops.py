@@ -223,9 +223,8 @@ def set_winograd(mode: Optional[int]):
 def conv3x3_wino_wanted(c1: int, c2: int, b: int, h: int, w: int, cout: int, split_ok: bool = False) -> bool:
     """Policy (limb-MFMA math mode only - the caller checks that): does a 3x3 stride-1 convolution of this shape run in
     Winograd F(2x2, 3x3) form?  By default (``PSLD_WINOGRAD=1``) when the kernel takes the shape and the launch is at least
-    ONE full round of its one-workgroup-per-CU grid - counting, in a training pass (``split_ok``), the workgroups its channel
-    chunks can be split over (conv3x3_wino(allow_split=True); the inference forward does not split: it stays bitwise the
-    GroupNorm-fused kernel).  ``PSLD_WINOGRAD=0`` restores the direct limb kernels everywhere, ``=2`` takes every supported
+    ONE full round of its one-workgroup-per-CU grid - counting (``split_ok``: what the executor passes) the workgroups its
+    channel chunks can be split over (conv3x3_wino / conv3x3_wino_gn with allow_split=True).  ``PSLD_WINOGRAD=0`` restores the direct limb kernels everywhere, ``=2`` takes every supported
     shape (parity tests at small batches).  The environment is read once; set_winograd() overrides it.
 
     History of the threshold: rounds 3-5 asked for 384 workgroups - at 256 (32x32 level, batch 16) the step was 3 % slower than
@@ -272,12 +271,22 @@ def conv3x3_wino_gn_wanted(c1: int, c2: int, b: int, h: int, w: int, cout: int) 
 
 
 def conv3x3_wino_gn(x1: Tensor, st1: "GNStats", x2: Optional[Tensor], st2: Optional["GNStats"], act: bool, ufrag: Tensor,
-                    cout: int, y: Tensor, epi: Optional[Epilogue] = None):
+                    cout: int, y: Tensor, epi: Optional[Epilogue] = None, allow_split: bool = False):
     """conv3x3_wino applied to act(GroupNorm(x)) with the apply pass inside the kernel's input staging: x1 / x2 are the
     raw tensors, st1 / st2 their statistics (gn_stats / gn_stats_from_part).  Inference forward only (no dropout, the
     activated tensor is not kept)."""
     b, h, w, c1 = x1.shape
     c2 = x2.shape[-1] if x2 is not None else 0
+    wsb = conv3x3_wino_ws_bytes(c1, c2, b, h, w, cout) if allow_split else 0
+    if wsb and (epi is None or not epi.gn_part):       # a small grid: channel chunks split like conv3x3_wino(allow_split=True)
+        ws = workspace(wsb, x1.device)
+        check(lib().psld_conv3x3_wino_gn_ws_f32(x1.data_ptr(), c1, st1.scale.data_ptr(), st1.shift.data_ptr(), _p(x2), c2,
+                                                st2.scale.data_ptr() if st2 is not None else None,
+                                                st2.shift.data_ptr() if st2 is not None else None, 1 if act else 0, b, h, w,
+                                                ufrag.data_ptr(), cout, y.data_ptr(), y.shape[-1],
+                                                C.byref(epi) if epi is not None else None, ws.data_ptr(), wsb, _stream()),
+              "psld_conv3x3_wino_gn_ws_f32")
+        return
     check(lib().psld_conv3x3_wino_gn_f32(x1.data_ptr(), c1, st1.scale.data_ptr(), st1.shift.data_ptr(), _p(x2), c2,
                                          st2.scale.data_ptr() if st2 is not None else None,
                                          st2.shift.data_ptr() if st2 is not None else None, 1 if act else 0, b, h, w,
@@ -289,8 +298,9 @@ def conv3x3_wino_gn(x1: Tensor, st1: "GNStats", x2: Optional[Tensor], st2: Optio
 def conv3x3_wino(x1: Tensor, x2: Optional[Tensor], ufrag: Tensor, cout: int, y: Tensor,
                  epi: Optional[Epilogue] = None, ldy: Optional[int] = None, allow_split: bool = False):
     """conv3x3_split in Winograd F(2x2, 3x3) form (fp32 NHWC input(s), fragments of conv3x3_wino_frag).  ``allow_split``: a launch
-    whose grid leaves CUs idle may split its channel chunks over workgroups (another summation order: the training pass asks
-    for it, the inference forward - bitwise the GroupNorm-fused kernel - does not)."""
+    whose grid leaves CUs idle may split its channel chunks over workgroups (another summation order than the unsplit launch;
+    the executor always asks for it - conv3x3_wino_gn splits the same way, so the fused and unfused inference forwards stay
+    bitwise equal)."""
     b, h, w, c1 = x1.shape
     c2 = x2.shape[-1] if x2 is not None else 0
     wsb = conv3x3_wino_ws_bytes(c1, c2, b, h, w, cout) if allow_split else 0

@@ -544,9 +544,9 @@ class _Exec:
         return tmp
 
     def wino_wanted(self, c1: int, c2: int, b: int, h: int, w: int, cout: int) -> bool:
-        """ops.conv3x3_wino_wanted for this pass: a training pass also takes the launches that fill the chip only with their
-        channel chunks split over workgroups (the 8x8 level at B=128, the 16x16 level at B=16)."""
-        return ops.conv3x3_wino_wanted(c1, c2, b, h, w, cout, bool(self.record))
+        """ops.conv3x3_wino_wanted counting the launches that fill the chip only with their channel chunks split over workgroups
+        (the 8x8 level at B=128, the 16x16 level at B=16)."""
+        return ops.conv3x3_wino_wanted(c1, c2, b, h, w, cout, True)
 
     def conv3(self, x: Tensor, conv: _Affine, out: Tensor, epi, x2: Optional[Tensor] = None):
         """3x3 stride-1 pad-1 convolution of an NHWC tensor (or of the channel concatenation of x and x2)."""
@@ -554,7 +554,7 @@ class _Exec:
         c2 = x2.shape[-1] if x2 is not None else 0
         cout = conv.weight.shape[0]
         if self.split and not isinstance(x, ops.LimbPlanes) and self.wino_wanted(c, c2, b, h, w, cout):
-            ops.conv3x3_wino(x, x2, self.net._wfrag(conv, False), cout, out, epi, allow_split=self.record)   # Winograd F(2x2, 3x3)
+            ops.conv3x3_wino(x, x2, self.net._wfrag(conv, False), cout, out, epi, allow_split=True)   # Winograd F(2x2, 3x3)
         elif self.split and ops.conv3x3_split_supported(c, c2, b, h, w, cout):
             ops.conv3x3_split(x, x2, self.net._frag(conv, False), cout, out, epi)
         else:
@@ -799,7 +799,7 @@ class _Exec:
         epi0 = ops.epilogue(bias=mod.Conv_0.bias, rowbias=tp, rows_per_img=ho * wo, ld_rowbias=tp_ld, gn_part=h1p, gn_hw=ho * wo)
         if fuse0:
             ops.conv3x3_wino_gn(x.v, st0, xb.v if xb is not None else None, st0b, True, net._wfrag(mod.Conv_0, False), cout,
-                                h1, epi0)
+                                h1, epi0, allow_split=True)
         else:
             self.conv3(a0r, mod.Conv_0, h1, epi0, x2=a0b)
         st1 = self.node_stats(_Node(h1, h1p), gn1.weight, gn1.bias)
@@ -826,7 +826,7 @@ class _Exec:
         outp = self.part_for(b, ho * wo, cout, out.device, ops.conv3x3_split_supported(cout, 0, b, ho, wo, cout))
         epi1 = ops.epilogue(bias=mod.Conv_1.bias, residual=res, ld_residual=cout, out_scale=s, gn_part=outp, gn_hw=ho * wo)
         if fuse1:
-            ops.conv3x3_wino_gn(h1, st1, None, None, True, net._wfrag(mod.Conv_1, False), cout, out, epi1)
+            ops.conv3x3_wino_gn(h1, st1, None, None, True, net._wfrag(mod.Conv_1, False), cout, out, epi1, allow_split=True)
         else:
             self.conv3(a1, mod.Conv_1, out, epi1)
         on = _Node(out, outp, want_gsum=True)       # Conv_1.bias (and Conv_2.bias) = s * column sums of its gradient

@@ -313,6 +313,20 @@ def test_conv3x3_wino_split_chunks(ops, cfg):
     ops.conv3x3_wino(x1, x2, uf, co, acc, ops.epilogue(alpha=0.5, accumulate=True), allow_split=True)
     plain = F.conv2d(x.double(), w.double(), padding=1) * 0.5 + 1.0
     assert rel_l2(acc.permute(0, 3, 1, 2), plain) < 3e-6
+    if ops.conv3x3_wino_gn_supported(c1, c2, b, h, w_, co):
+        # the GroupNorm-fused form splits the same way: bitwise the apply pass + split convolution (the inference forward's pair)
+        g1, b1 = (gen(c1, seed=74) * 0.2 + 1.0).to(DEV), (gen(c1, seed=75) * 0.1).to(DEV)
+        st1 = ops.gn_stats(x1, g1, b1)
+        st2 = a2 = None
+        if c2:
+            g2, b2 = (gen(c2, seed=76) * 0.2 + 1.0).to(DEV), (gen(c2, seed=77) * 0.1).to(DEV)
+            st2 = ops.gn_stats(x2, g2, b2)
+            a2 = ops.gn_apply(x2, st2, True)
+        ya = torch.full_like(y0, float("nan"))
+        ops.conv3x3_wino(ops.gn_apply(x1, st1, True), a2, uf, co, ya, epi, allow_split=True)
+        yf = torch.full_like(y0, float("nan"))
+        ops.conv3x3_wino_gn(x1, st1, x2, st2, True, uf, co, yf, epi, allow_split=True)
+        assert torch.equal(yf, ya)
 
 
 @pytest.mark.parametrize("cfg", WINO_FWD)
