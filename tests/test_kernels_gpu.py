@@ -575,6 +575,10 @@ def test_wave_specialised_wgrad_on_short_k_ranges(ops, per):
     dict(b=2, c1=128, c2=128, co=512, h=16, w=16, nsplit=None),    # two c_out tiles
     dict(b=1, c1=128, c2=0, co=128, h=64, w=64, nsplit=None),      # 128 output channels (CelebA-64's first level): 128 x 128 tiles
     dict(b=2, c1=128, c2=128, co=384, h=32, w=32, nsplit=2),       # ... three of them, two sources
+    dict(b=4, c1=128, c2=256, co=256, h=8, w=8, nsplit=None),      # sources of different widths on 8x8 maps (two K tiles)
+    dict(b=6, c1=384, c2=0, co=128, h=16, w=16, nsplit=None),      # three c_in tiles, 12 K tiles in uneven splits
+    dict(b=2, c1=128, c2=0, co=640, h=16, w=16, nsplit=None),      # five 128-channel c_out tiles
+    dict(b=10, c1=256, c2=0, co=256, h=32, w=32, nsplit=7),        # 80 K tiles in 7 splits: the last one shorter
 ])
 def test_conv3x3_wgrad_winograd_domain(ops, cfg):
     """psld_conv3x3_wgrad_wino_f32 (wgrad_wino.hip): dU = sum over 2x2 tiles of (A dY A^T) (x) (B^T d B) on limb MFMAs, dw =
