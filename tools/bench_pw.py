@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--rounds", type=int, default=1, help="ignored (pmc_wait.sh passes it)")
     ap.add_argument("--only", type=int, default=-1, help="index of the one shape to run")
+    ap.add_argument("--check", action="store_true", help="also print rel-L2 vs an fp64 GEMM and a CRC of the output bytes (A/B of two kernels: equal CRCs = bitwise equal)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     b = args.batch
@@ -42,6 +43,15 @@ def main():
         for _ in range(3):
             ops.gemm_split(a1, a2, m, frag, n, y, epi)
         torch.cuda.synchronize()
+        chk = ""
+        if args.check:
+            import zlib
+            rows = min(m, 4096)
+            af = torch.cat([a1[:rows], a2[:rows]], 1) if a2 is not None else a1[:rows]
+            ref = af.double() @ w.double().t() + bias.double()
+            rel = float((y[:rows].double() - ref).norm() / ref.norm())
+            tail = float((y[m - 128:].double() - ((torch.cat([a1[m - 128:], a2[m - 128:]], 1) if a2 is not None else a1[m - 128:]).double() @ w.double().t() + bias.double())).abs().max())
+            chk = f"  rel-L2 {rel:.2e} tail-maxabs {tail:.1e} crc {zlib.crc32(y.cpu().numpy().tobytes()):08x}"
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.iters):
@@ -52,7 +62,7 @@ def main():
         flops = 2.0 * m * (k1 + k2) * n
         mb = (m * (k1 + k2) + m * n) * 4 / 1e6
         total += us * per_step
-        print(f"{name:44s} M={m:7d}  {us:8.1f} us  {flops / us / 1e6:6.1f} TF  {mb / us:5.2f} TB/s  x{per_step}/step = {us * per_step / 1e3:.2f} ms")
+        print(f"{name:44s} M={m:7d}  {us:8.1f} us  {flops / us / 1e6:6.1f} TF  {mb / us:5.2f} TB/s  x{per_step}/step = {us * per_step / 1e3:.2f} ms{chk}")
     print(f"sum over a step: {total / 1e3:.2f} ms")
 
 
