@@ -1672,7 +1672,7 @@ int launch_dconv_lp(const DConvArgs& a, int nsplit, hipStream_t stream, const ch
 int plan_split(DConvArgs& a, const PsldEpilogue& e, float* y, int ldy, void* workspace, long long ws_bytes, int mt = 128) {
     const long long tiles = (long long)cdiv(a.M, mt) * (a.N / 128);
     int ns = 1;
-    if (workspace && tiles < 384 && !e.gn_part && ldy % 4 == 0 && aligned16(y) && (!e.bias || aligned16(e.bias)) &&
+    if (workspace && tiles < 384 && (!e.gn_part || psld_detail_conv_reduce_gn_ok(a.M, a.N, e)) && ldy % 4 == 0 && aligned16(y) && (!e.bias || aligned16(e.bias)) &&
         (!e.rowbias || (aligned16(e.rowbias) && e.ld_rowbias % 4 == 0)) && (!e.res || (aligned16(e.res) && e.ldres % 4 == 0))) {
         ns = (int)(512 / tiles);
         if (ns > 8) ns = 8;

@@ -705,10 +705,10 @@ int wino_conv(const float* x1, int c1, const float* x2, int c2, int batch, int h
     }
     // Small grids (the 8x8 level at training batches: 128 workgroups for 256 CUs): split the channel chunks over ksplit
     // workgroups per tile, plain partial outputs into the workspace, summed + the whole epilogue by conv_reduce_epilogue -
-    // what the direct kernels do for the same shapes.  GroupNorm partial sums are not formed on this route.  The GroupNorm-
+    // what the direct kernels do for the same shapes (GroupNorm partial sums of the output: formed by that pass).  The GroupNorm-
     // fused form splits the same way (same chunk ranges, same reduction: bitwise the unfused pair).
     const int ks = workspace ? psld_conv3x3_wino_ksplit(c1, c2, batch, h, w, cout) : 1;
-    if (ks > 1 && !e.gn_part && ws_bytes >= (long long)ks * a.M * cout * 4 && aligned16(workspace)) {
+    if (ks > 1 && (!e.gn_part || psld_detail_conv_reduce_gn_ok(a.M, cout, e)) && ws_bytes >= (long long)ks * a.M * cout * 4 && aligned16(workspace)) {
         WinoArgs s = a;
         s.ksplit = ks;
         s.slab_stride = (long long)a.M * cout;

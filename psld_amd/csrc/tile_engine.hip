@@ -773,6 +773,77 @@ __global__ void conv_reduce_epilogue_kernel(const float* __restrict__ slabs, int
     }
 }
 
+// The same pass when the consumer of the output is a GroupNorm (round 6): it also leaves the partial sums of what it stores,
+// in the layout the limb kernels' epilogues write (psld_epilogue_t.gn_part: [64-row run][fine group of gn_fine channels][sum,
+// sum of squares], float64) - so a split launch no longer costs its GroupNorm a pass over the tensor (gn_partial_kernel: 54
+// launches of the B=128 step, every GroupNorm of the 8x8 level).  Workgroup = one 64-row run x 64 channels; thread = float4
+// column q of the slab, rows rg + 16 i.  Fixed order: rows and components in the thread, the four row groups of a wave by two
+// shuffles, the four waves through LDS - bitwise repeatable.
+__global__ void __launch_bounds__(256) conv_reduce_epilogue_gn_kernel(const float* __restrict__ slabs, int nsplit, int M, int N,
+                                                                        float* __restrict__ out, int ldc, const Epilogue e) {
+    __shared__ float red[4][16][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane & 15, rg = 4 * wave + (lane >> 4);
+    const int run = blockIdx.x, n0 = blockIdx.y * 64 + q * 4;
+    const long long slab = (long long)M * N;
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f};
+    if (e.bias) bias = *reinterpret_cast<const f32x4*>(e.bias + n0);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = run * 64 + rg + 16 * i;
+        const long long off = (long long)m * N + n0;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(slabs + off);
+        int s = 1;
+        for (; s + 3 < nsplit; s += 4) {        // the plain kernel's order
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(slabs + s * slab + off);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(slabs + (s + 1) * slab + off);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(slabs + (s + 2) * slab + off);
+            const f32x4 v3 = *reinterpret_cast<const f32x4*>(slabs + (s + 3) * slab + off);
+            acc += v0;
+            acc += v1;
+            acc += v2;
+            acc += v3;
+        }
+        for (; s < nsplit; ++s) acc += *reinterpret_cast<const f32x4*>(slabs + s * slab + off);
+        acc *= e.alpha;
+        acc += bias;
+        if (e.rowbias) acc += *reinterpret_cast<const f32x4*>(e.rowbias + (long long)(m / e.rows_per_img) * e.ld_rowbias + n0);
+        if (e.res) acc += *reinterpret_cast<const f32x4*>(e.res + (long long)m * e.ldres + n0);
+        acc *= e.out_scale;
+        *reinterpret_cast<f32x4*>(out + (long long)m * ldc + n0) = acc;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            s1 += acc[v];
+            s2 += acc[v] * acc[v];
+        }
+    }
+    s1 += __shfl_xor(s1, 16, 64);
+    s2 += __shfl_xor(s2, 16, 64);
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (lane < 16) {
+        red[wave][lane][0] = s1;
+        red[wave][lane][1] = s2;
+    }
+    __syncthreads();
+    if (tid < 16) {
+        float t1 = ((red[0][tid][0] + red[1][tid][0]) + red[2][tid][0]) + red[3][tid][0];
+        float t2 = ((red[0][tid][1] + red[1][tid][1]) + red[2][tid][1]) + red[3][tid][1];
+        const int c0 = blockIdx.y * 64 + tid * 4;
+        if (e.gn_fine == 4) {
+            double* pp = e.gn_part + ((long long)run * (N >> 2) + (c0 >> 2)) * 2;
+            pp[0] = (double)t1;
+            pp[1] = (double)t2;
+        } else if ((tid & 1) == 0) {
+            const float u1 = ((red[0][tid + 1][0] + red[1][tid + 1][0]) + red[2][tid + 1][0]) + red[3][tid + 1][0];
+            const float u2 = ((red[0][tid + 1][1] + red[1][tid + 1][1]) + red[2][tid + 1][1]) + red[3][tid + 1][1];
+            double* pp = e.gn_part + ((long long)run * (N >> 3) + (c0 >> 3)) * 2;
+            pp[0] = (double)(t1 + u1);
+            pp[1] = (double)(t2 + u2);
+        }
+    }
+}
 
 }  // namespace
 
@@ -790,8 +861,20 @@ const float* psld_detail_zero_page(const char* name) {
     return zero_dev;
 }
 
+bool psld_detail_conv_reduce_gn_ok(int M, int N, const PsldEpilogue& e) {
+    return M % 64 == 0 && N % 64 == 0 && e.gn_hw > 0 && e.gn_hw % 64 == 0 && !e.accumulate;
+}
+
 int psld_detail_conv_reduce_epilogue(const float* slabs, int nsplit, int M, int N, float* y, int ldy,
                                      const PsldEpilogue& e, hipStream_t stream) {
+    if (e.gn_part) {
+        // callers split a launch whose epilogue forms GroupNorm sums only when psld_detail_conv_reduce_gn_ok says so
+        PSLD_CHECK_ARG(psld_detail_conv_reduce_gn_ok(M, N, e), "conv_reduce_epilogue: GroupNorm sums need M, N, gn_hw %% 64 == 0, 16-byte rows and no accumulation");
+        hipLaunchKernelGGL(conv_reduce_epilogue_gn_kernel, dim3((unsigned)(M / 64), (unsigned)(N / 64)), dim3(256), 0, stream, slabs, nsplit, M, N,
+                           y, ldy, e);
+        PSLD_CHECK_LAUNCH("conv_reduce_epilogue_gn_kernel");
+        return PSLD_OK;
+    }
     const long long total = (long long)M * (N / 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;

@@ -42,6 +42,8 @@ const float* psld_detail_zero_page(const char* name);
 // out = epilogue(sum_s slabs[s][M][N]) (float4 along N)
 int psld_detail_conv_reduce_epilogue(const float* slabs, int nsplit, int M, int N, float* y, int ldy,
                                      const PsldEpilogue& e, hipStream_t stream);
+// ... which also forms the GroupNorm partial sums of the output (e.gn_part) when this holds
+bool psld_detail_conv_reduce_gn_ok(int M, int N, const PsldEpilogue& e);
 
 // XCD-aware block remap: workgroups are dealt round-robin over the 8 XCDs (private L2 each); give every XCD a
 // contiguous run of logical tiles.  Bijective for any grid size.

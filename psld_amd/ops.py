@@ -278,7 +278,7 @@ def conv3x3_wino_gn(x1: Tensor, st1: "GNStats", x2: Optional[Tensor], st2: Optio
     b, h, w, c1 = x1.shape
     c2 = x2.shape[-1] if x2 is not None else 0
     wsb = conv3x3_wino_ws_bytes(c1, c2, b, h, w, cout) if allow_split else 0
-    if wsb and (epi is None or not epi.gn_part):       # a small grid: channel chunks split like conv3x3_wino(allow_split=True)
+    if wsb:       # a small grid: channel chunks split like conv3x3_wino(allow_split=True)
         ws = workspace(wsb, x1.device)
         check(lib().psld_conv3x3_wino_gn_ws_f32(x1.data_ptr(), c1, st1.scale.data_ptr(), st1.shift.data_ptr(), _p(x2), c2,
                                                 st2.scale.data_ptr() if st2 is not None else None,
@@ -304,8 +304,9 @@ def conv3x3_wino(x1: Tensor, x2: Optional[Tensor], ufrag: Tensor, cout: int, y: 
     b, h, w, c1 = x1.shape
     c2 = x2.shape[-1] if x2 is not None else 0
     wsb = conv3x3_wino_ws_bytes(c1, c2, b, h, w, cout) if allow_split else 0
-    if wsb and (epi is None or not epi.gn_part):
+    if wsb:
         # a small grid (the 8x8 level at training batches): channel chunks split over workgroups, one reduction + epilogue pass
+        # (which also forms the GroupNorm partial sums an epilogue asks for)
         ws = workspace(wsb, x1.device)
         check(lib().psld_conv3x3_wino_ws_f32(x1.data_ptr(), c1, _p(x2), c2, b, h, w, ufrag.data_ptr(), cout, y.data_ptr(),
                                              ldy if ldy is not None else cout, C.byref(epi) if epi is not None else None,
@@ -602,10 +603,11 @@ def gn_part_width(c: int) -> int:
 @functools.lru_cache(maxsize=None)
 def gn_part_supported(b: int, hw: int, c: int) -> bool:
     """Can a limb kernel's epilogue produce the GroupNorm partial sums of its [b, hw, c] output?  (Whole 64-row
-    runs per image, groups made of 4- or 8-channel fine groups, and a grid of at least one full round of workgroups: such a
-    launch runs unsplit - in Winograd form by conv3x3_wino_wanted's rule - whereas smaller ones split their K range and finish
-    through a reduction pass that forms no sums.)"""
-    return hw % 64 == 0 and c % 128 == 0 and (c // gn_groups(c)) % 4 == 0 and ((b * hw + 127) // 128) * (c // 128) >= 256
+    runs per image and groups made of 4- or 8-channel fine groups.  Any grid: a launch too small to fill the chip splits
+    its K range and finishes through a reduction + epilogue pass, which since round 6 forms the sums as well -
+    conv_reduce_epilogue_gn_kernel; before, every GroupNorm behind such a launch - the whole 8x8 level at B=128 - paid a
+    statistics pass over the tensor.)"""
+    return hw % 64 == 0 and c % 128 == 0 and (c // gn_groups(c)) % 4 == 0
 
 
 def gn_part_buffer(b: int, hw: int, c: int, device) -> Tensor:

@@ -710,6 +710,69 @@ def test_gn_partials_from_conv_epilogue(ops, b, c, co, h):
     assert rel_l2(got.rstd, ref.rstd) < 2e-6 and rel_l2(got.scale, ref.scale) < 2e-6 and (got.shift - ref.shift).abs().max() < 1e-5
 
 
+@pytest.mark.parametrize("b,c,co,h", [(16, 256, 256, 8), (128, 256, 256, 8), (6, 128, 256, 16), (8, 128, 128, 8), (3, 512, 256, 8)])
+def test_gn_partials_from_split_launches(ops, b, c, co, h):
+    """A launch too small to fill the chip splits its K range over workgroups and finishes through the reduction + epilogue
+    pass; since round 6 that pass forms the GroupNorm partial sums of what it stores (conv_reduce_epilogue_gn_kernel), so the
+    consumer's statistics cost no pass over the tensor: direct limb kernel, Winograd form (allow_split, plain and
+    GroupNorm-fused input), pointwise form.  The output is bit for bit the one of the same launch without the sums."""
+    x = gen(b, c, h, h, seed=210)
+    w = gen(co, c, 3, 3, seed=211, scale=0.1)
+    bias, res, temb = gen(co, seed=212), gen(b, h, h, co, seed=213), gen(b, co, seed=214)
+    gamma, beta = (1 + 0.2 * gen(co, seed=215)).to(DEV), (0.1 * gen(co, seed=216)).to(DEV)
+    xd = _nhwc(x).to(DEV)
+    assert ops.gn_part_supported(b, h * h, co)
+    part = ops.gn_part_buffer(b, h * h, co, DEV)
+
+    def epis():
+        kw = dict(bias=bias.to(DEV), rowbias=temb.to(DEV), rows_per_img=h * h, residual=res.to(DEV), ld_residual=co, out_scale=0.7)
+        return ops.epilogue(gn_part=part, gn_hw=h * h, **kw), ops.epilogue(**kw)
+
+    def check_stats(y):
+        for groups in (None, ops.gn_groups(2 * co) // 2):
+            ref = ops.gn_stats(y, gamma, beta, groups=groups)
+            got = ops.gn_stats_from_part(part, y.shape, gamma, beta, groups=groups)
+            assert (got.mean - ref.mean).abs().max() < 2e-6 * ref.mean.abs().max() + 1e-7
+            assert rel_l2(got.rstd, ref.rstd) < 2e-6 and rel_l2(got.scale, ref.scale) < 2e-6
+            assert (got.shift - ref.shift).abs().max() < 1e-5
+
+    # direct limb kernel (splits below 384 tiles when it is handed a workspace: ops.conv3x3_split does)
+    e_gn, e_plain = epis()
+    y, y_ref = torch.empty(b, h, h, co, device=DEV), torch.empty(b, h, h, co, device=DEV)
+    part.fill_(float("nan"))
+    wf = ops.conv3x3_frag(w.to(DEV), False)
+    ops.conv3x3_split(xd, None, wf, co, y, e_gn)
+    ops.conv3x3_split(xd, None, wf, co, y_ref, e_plain)
+    assert torch.equal(y, y_ref) and not torch.isnan(part).any()
+    check_stats(y)
+    # Winograd form with its channel chunks split over workgroups
+    if ops.conv3x3_wino_supported(c, 0, b, h, h, co) and ops.conv3x3_wino_ws_bytes(c, 0, b, h, h, co) > 0:
+        uf = ops.conv3x3_wino_frag(w.to(DEV), False)
+        part.fill_(float("nan"))
+        ops.conv3x3_wino(xd, None, uf, co, y, e_gn, allow_split=True)
+        ops.conv3x3_wino(xd, None, uf, co, y_ref, e_plain, allow_split=True)
+        assert torch.equal(y, y_ref) and not torch.isnan(part).any()
+        check_stats(y)
+        if ops.conv3x3_wino_gn_supported(c, 0, b, h, h, co):      # GroupNorm + SiLU of the INPUT inside the staging
+            gin, bin_ = (1 + 0.2 * gen(c, seed=217)).to(DEV), (0.1 * gen(c, seed=218)).to(DEV)
+            st_in = ops.gn_stats(xd, gin, bin_)
+            part.fill_(float("nan"))
+            ops.conv3x3_wino_gn(xd, st_in, None, None, True, uf, co, y, e_gn, allow_split=True)
+            ops.conv3x3_wino_gn(xd, st_in, None, None, True, uf, co, y_ref, e_plain, allow_split=True)
+            assert torch.equal(y, y_ref) and not torch.isnan(part).any()
+            check_stats(y)
+    # pointwise form (splits below 128 tiles of 128 x 256)
+    m = b * h * h
+    wmat = gen(co, c, seed=219, scale=0.1)
+    part.fill_(float("nan"))
+    y2, y2_ref = torch.empty(m, co, device=DEV), torch.empty(m, co, device=DEV)
+    gf = ops.gemm_frag(wmat.to(DEV), co, c, c, 1)
+    ops.gemm_split(xd.view(m, c), None, m, gf, co, y2, ops.epilogue(bias=bias.to(DEV), gn_part=part, gn_hw=h * h))
+    ops.gemm_split(xd.view(m, c), None, m, gf, co, y2_ref, ops.epilogue(bias=bias.to(DEV)))
+    assert torch.equal(y2, y2_ref) and not torch.isnan(part).any()
+    check_stats(y2.view(b, h, h, co))
+
+
 def test_two_source_weight_gradients(ops):
     """dwgrad / pwgrad reading the input of the convolution from two tensors (unmaterialised concatenation)."""
     b, c1, c2, co, h, w_ = 2, 128, 256, 128, 16, 16
