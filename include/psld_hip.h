@@ -61,8 +61,9 @@ typedef struct psld_epilogue {
     long long residual_stride_batch;
     float out_scale;
     int accumulate;
-    /* Optional (limb kernels psld_conv3x3_split_f32 / psld_gemm_split_f32 only; the call then never splits its K
-     * range): GroupNorm statistics of the OUTPUT as a by-product, for the GroupNorm that reads it next
+    /* Optional (limb kernels psld_conv3x3_split_f32 / _limb_f32 / _wino_f32 / psld_gemm_split_f32 only; a call that splits
+     * its K range over workgroups forms them in its reduction + epilogue pass instead: rows, N and gn_hw multiples of 64):
+     * GroupNorm statistics of the OUTPUT as a by-product, for the GroupNorm that reads it next
      * (layerspp.py:258,264 GroupNorm_0/1; :77 of the attention block).  gn_part[((img*chunks + chunk)*(N/8) + f)*2 + {0,1}]
      * = sum / sum of squares of the 8 channels 8f..8f+7 over the chunk-th run of 64 rows of image img
      * (chunks = gn_hw / 64, gn_hw = rows per image, a multiple of 64; N a multiple of 128).  gn_fine = 4: sums of FOUR
@@ -160,8 +161,8 @@ int psld_conv3x3_wino_f32(const float* x1, int c1, const float* x2, int c2, int 
 /* The same with a workspace for small grids (one workgroup per CU: a launch below half a round - the 8x8 level at training
  * batches - leaves CUs idle): the channel chunks are split over psld_conv3x3_wino_ksplit workgroups per tile, plain partial
  * outputs go to the workspace (psld_conv3x3_wino_ws_bytes) and one reduction pass applies the epilogue, as
- * psld_conv3x3_split_f32 does for such shapes.  Without a workspace, with ksplit == 1 or with epi->gn_part set it is
- * psld_conv3x3_wino_f32. */
+ * psld_conv3x3_split_f32 does for such shapes (epi->gn_part: formed by that pass).  Without a workspace or with ksplit == 1
+ * it is psld_conv3x3_wino_f32. */
 int psld_conv3x3_wino_ksplit(int c1, int c2, int batch, int h, int w, int cout);
 long long psld_conv3x3_wino_ws_bytes(int c1, int c2, int batch, int h, int w, int cout);
 int psld_conv3x3_wino_ws_f32(const float* x1, int c1, const float* x2, int c2, int batch, int h, int w,
